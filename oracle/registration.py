@@ -1,0 +1,85 @@
+"""Registration loop, oracle restatement of reference PointCloud/mlp_reg.py:17-237 (torch CPU).
+
+``train``            mlp_reg.py:17-152  Adam + ReduceLROnPlateau over <=300 epochs of
+                     pose repr -> MLP -> pose -> calculate_pc -> L1 Chamfer, best-loss tracking
+                     (strict ``<`` on ``loss.item()``, min_loss starts at 1000), early stop when
+                     the non-improving count exceeds ``stop`` (checked BEFORE that epoch's update).
+``calculate_pc``     mlp_reg.py:155-170
+``resample_cluster`` mlp_reg.py:172-237 (non-``normal`` branch)
+The module-global ROT of the reference is an explicit ``rot`` argument here; ``epochs`` (300 in
+the reference, mlp_reg.py:60) is exposed so parity tests can pin short trajectories.
+"""
+import numpy as np
+import torch
+
+from . import dq as DQ
+from . import transforms as T
+from .chamfer import chamfer_distance
+from .kmeans import k_means
+
+
+def calculate_pc(local_clusters, matrices):
+    return [c @ M[:3, :3].T + M[:3, 3] for c, M in zip(local_clusters, matrices)]
+
+
+def pose_forward(m, model, rot):
+    """One pass pose -> representation -> model -> pose (mlp_reg.py:62-90). Returns (K,4,4)."""
+    m2 = m.clone()
+    if rot == "dq":
+        return DQ.dualquat_to_transform(model(DQ.transform_to_dualquat(m2)))
+    R, t = m2[:, :3, :3], m2[:, :3, 3]
+    if rot == "q":
+        t2, r2 = model(torch.cat([t, T.matrix_to_quaternion(R)], 1))
+        R2 = T.quaternion_to_matrix(r2)
+    elif rot == "rpy":
+        t2, r2 = model(torch.cat([t, T.matrix_to_euler_angles(R, "XYZ")], 1))
+        R2 = T.euler_angles_to_matrix(r2, "XYZ")
+    elif rot == "6d":
+        t2, r2 = model(torch.cat([t, T.matrix_to_rotation_6d(R)], 1))
+        R2 = T.rotation_6d_to_matrix(r2)
+    else:
+        raise ValueError(rot)
+    m2[:, :3, :3] = R2
+    m2[:, :3, 3] = t2
+    return m2
+
+
+def train(m, y, model, clusters, stop=200, learning_rate=0.0002, scheduler_patience=5,
+          scheduler_factor=0.7, rot="q", epochs=300):
+    opt = torch.optim.Adam(model.parameters(), lr=learning_rate)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=scheduler_factor,
+                                                       patience=scheduler_patience)
+    min_loss, best_pcd, best_m, count = 1000, None, None, 0
+    losses, lrs = [], []
+    for epoch in range(epochs):
+        m2 = pose_forward(m, model, rot)
+        pred_list = calculate_pc(clusters, m2)
+        loss, _ = chamfer_distance(torch.cat(pred_list, 0).unsqueeze(0), y.unsqueeze(0), norm=1)
+        lv = loss.item()
+        losses.append(lv)
+        lrs.append(opt.param_groups[0]["lr"])
+        if lv < min_loss:
+            min_loss, best_pcd, best_m, count = lv, pred_list, m2, 0
+        else:
+            count += 1
+            if count > stop:
+                break
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sched.step(loss)
+    pred_np = [p.detach().cpu().numpy() for p in best_pcd]
+    return pred_np, best_m, min_loss, {"loss": losses, "lr": lrs}
+
+
+def resample_cluster(pc_np, n_clusters, matrices):
+    """pc_np (N,3) f64 world points of the next frame, matrices (K,4,4): -> (list of K local (M_k,3) f64, labels)."""
+    pc_np = np.asarray(pc_np, np.float64)
+    matrices = np.asarray(matrices)
+    _, labels, _, _ = k_means(pc_np, init=matrices[:, :3, 3], n_clusters=n_clusters, n_init=1)
+    out = []
+    for i in range(n_clusters):
+        pts = pc_np[labels == i]
+        inv = np.linalg.inv(matrices[i])
+        out.append((inv @ np.hstack([pts, np.ones((len(pts), 1))]).T)[:3].T)
+    return out, labels

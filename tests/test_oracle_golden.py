@@ -1,0 +1,211 @@
+"""CPU: pin the oracle against the golden vectors minted from the reference (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chamfer, dq, icp, kmeans, models, registration
+from oracle import transforms as T
+
+
+def _split(flat, offsets):
+    return [flat[offsets[i]:offsets[i + 1]] for i in range(len(offsets) - 1)]
+
+
+@pytest.mark.parametrize("tag,tol", [("f32", 1e-6), ("f64", 1e-14)])
+def test_dq_functions_match_reference(golden, tag, tol):
+    g = golden("dq_reference.npz")
+    t = lambda k: torch.from_numpy(g[f"{tag}_{k}"])
+    M, d, db, noisy = t("M"), t("dq"), t("dq_b"), t("noisy")
+    close = lambda a, k: np.testing.assert_allclose(a.numpy(), g[f"{tag}_{k}"], rtol=0, atol=tol)
+    close(dq.transform_to_dualquat(M), "dq")
+    close(dq.dualquat_to_transform(noisy), "to_transform")
+    q, tr = dq.dualquat_to_quat_trans(noisy)
+    close(q, "qt_q"); close(tr, "qt_t")
+    R, tr = dq.dualquat_to_rot_trans(noisy)
+    close(R, "rt_R"); close(tr, "rt_t")
+    close(dq.dualquat_multiply(d, db), "mul")
+    close(dq.dualquat_invert(noisy), "inv")
+    close(dq.quaternion_conjugate(d[:, :4]), "conj")
+    close(dq.quat_trans_to_dualquat(d[:, :4], M[:, :3, 3]), "from_qt")
+    close(dq.rot_trans_to_dualquat(M[:, :3, :3], M[:, :3, 3]), "from_rt")
+    close(dq.transform_from_rot_trans(M[:, :3, :3], M[:, :3, 3]), "assemble")
+    close(dq.point_to_dualquat(M[:, :3, 3]), "point")
+
+
+def test_dq_identities():
+    g = torch.Generator().manual_seed(0)
+    from scipy.spatial.transform import Rotation
+    M = torch.eye(4, dtype=torch.float64).repeat(32, 1, 1)
+    M[:, :3, :3] = torch.from_numpy(Rotation.random(32, random_state=3).as_matrix())
+    M[:, :3, 3] = torch.randn(32, 3, generator=g, dtype=torch.float64)
+    d = dq.transform_to_dualquat(M)
+    assert (dq.dualquat_to_transform(d) - M).abs().max() < 1e-12
+    ident = dq.dualquat_multiply(d, dq.dualquat_invert(d))
+    assert (ident - torch.tensor([1., 0, 0, 0, 0, 0, 0, 0], dtype=torch.float64)).abs().max() < 1e-12
+
+
+def test_transforms_against_scipy():
+    from scipy.spatial.transform import Rotation
+    rot = Rotation.random(200, random_state=5)
+    R = torch.from_numpy(rot.as_matrix())
+    q = T.matrix_to_quaternion(R)
+    qs = rot.as_quat()[:, [3, 0, 1, 2]]
+    qs = np.where(qs[:, :1] < 0, -qs, qs)
+    np.testing.assert_allclose(q.numpy(), qs, atol=1e-14)
+    np.testing.assert_allclose(T.quaternion_to_matrix(3.0 * q).numpy(), rot.as_matrix(), atol=1e-14)
+    e = T.matrix_to_euler_angles(R, "XYZ")
+    np.testing.assert_allclose(T.euler_angles_to_matrix(e, "XYZ").numpy(), rot.as_matrix(), atol=1e-13)
+    np.testing.assert_allclose(T.rotation_6d_to_matrix(T.matrix_to_rotation_6d(R)).numpy(),
+                               rot.as_matrix(), atol=1e-14)
+    a, b = Rotation.random(50, random_state=6), Rotation.random(50, random_state=7)
+    qa = torch.from_numpy(a.as_quat()[:, [3, 0, 1, 2]])
+    qb = torch.from_numpy(b.as_quat()[:, [3, 0, 1, 2]])
+    np.testing.assert_allclose(T.quaternion_to_matrix(T.quaternion_raw_multiply(qa, qb)).numpy(),
+                               (a * b).as_matrix(), atol=1e-14)
+
+
+def _load_sd(g, prefix):
+    return {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+
+
+def test_models_match_reference(golden):
+    g = golden("models_reference.npz")
+    q = models.QRegMLP(True, hidden_dim=32)
+    q.load_state_dict(_load_sd(g, "q."))
+    t, r = q(torch.from_numpy(g["q_in"]))
+    np.testing.assert_allclose(t.detach().numpy(), g["q_out_t"], atol=1e-7)
+    np.testing.assert_allclose(r.detach().numpy(), g["q_out_r"], atol=1e-7)
+    d = models.DQRegMLP(hidden_dim=32)
+    d.load_state_dict(_load_sd(g, "dq."))
+    np.testing.assert_allclose(d(torch.from_numpy(g["dq_in"])).detach().numpy(), g["dq_out"], atol=1e-7)
+
+
+def test_model_parameter_count():
+    assert sum(p.numel() for p in models.QRegMLP(True, 512).parameters()) == 425991
+
+
+def test_calculate_pc_matches_reference(golden):
+    g = golden("calculate_pc.npz")
+    out = registration.calculate_pc([torch.from_numpy(c) for c in _split(g["local"], g["offsets"])],
+                                    torch.from_numpy(g["mats"]))
+    np.testing.assert_array_equal(np.concatenate([o.numpy() for o in out]), g["world"])
+
+
+@pytest.mark.parametrize("rot,ctor", [("q", lambda: models.QRegMLP(True, 32)), ("dq", lambda: models.DQRegMLP(32))])
+def test_train_matches_reference_full_300_epochs(golden, rot, ctor):
+    g = golden("train_reference.npz")
+    model = ctor()
+    model.load_state_dict(_load_sd(g, f"{rot}.sd."))
+    clusters = [torch.from_numpy(c) for c in _split(g[f"{rot}_local"], g[f"{rot}_offsets"])]
+    pred, best_m, min_loss, hist = registration.train(
+        torch.from_numpy(g[f"{rot}_m"]), torch.from_numpy(g[f"{rot}_y"]), model, clusters, rot=rot)
+    # same torch build, same op sequence: the trajectory is reproduced to rounding
+    assert abs(min_loss - float(g[f"{rot}_min_loss"])) < 1e-7
+    np.testing.assert_allclose(best_m.detach().numpy(), g[f"{rot}_best_m"], atol=1e-6)
+    np.testing.assert_allclose(np.concatenate(pred), g[f"{rot}_best_pred"], atol=1e-6)
+    sd_sum = sum(float(v.double().abs().sum()) for v in model.state_dict().values())
+    assert abs(sd_sum - float(g[f"{rot}_final_sd_sum"])) < 1e-3 * sd_sum
+    assert len(hist["loss"]) == 300
+
+
+def test_resample_matches_reference_and_live_sklearn(golden):
+    g = golden("resample_reference.npz")
+    local, labels = registration.resample_cluster(g["frame"], len(g["mats"]), g["mats"])
+    np.testing.assert_array_equal(np.cumsum([0] + [len(c) for c in local]), g["offsets"])
+    np.testing.assert_allclose(np.concatenate(local), g["local"], atol=1e-12)
+
+
+def test_masked_icp_matches_reference(golden):
+    g = golden("masked_icp_reference.npz")
+    local = _split(g["local"], g["offsets"])
+    world = _split(g["world_pred"], g["offsets"])
+    w, m = icp.masked_icp(local, world, g["frame"], g["mats"])
+    np.testing.assert_allclose(m, g["new_mats"], atol=1e-12)
+    np.testing.assert_allclose(np.concatenate(w), g["new_world"], atol=1e-12)
+
+
+def test_kabsch_known_motion_reflection_and_planar():
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(0)
+    src = rng.normal(size=(100, 3))
+    R, t = Rotation.random(random_state=1).as_matrix(), np.array([0.3, -0.2, 0.5])
+    Tm = icp.kabsch(src, src @ R.T + t)
+    np.testing.assert_allclose(Tm[:3, :3], R, atol=1e-12)
+    np.testing.assert_allclose(Tm[:3, 3], t, atol=1e-12)
+    refl = src * np.array([1, 1, -1])                      # det < 0 target: still a proper rotation
+    assert abs(np.linalg.det(icp.kabsch(src, refl)[:3, :3]) - 1) < 1e-12
+    planar = src * np.array([1, 1, 0])
+    Tp = icp.kabsch(planar, planar @ R.T + t)
+    np.testing.assert_allclose(planar @ Tp[:3, :3].T + Tp[:3, 3], planar @ R.T + t, atol=1e-12)
+    np.testing.assert_array_equal(icp.kabsch(src[:0], src[:0]), np.eye(4))
+
+
+@pytest.mark.parametrize("tag", ["small", "c1"])
+def test_kmeans_matches_live_sklearn_golden(golden, tag):
+    g = golden("kmeans_sklearn.npz")
+    c, lab, inertia, n_iter = kmeans.k_means(g[f"{tag}_X"], g[f"{tag}_init"])
+    np.testing.assert_array_equal(lab, g[f"{tag}_labels"])           # bit-exact assignments
+    np.testing.assert_allclose(c, g[f"{tag}_centers"], atol=1e-13)
+    assert abs(inertia - float(g[f"{tag}_inertia"])) < 1e-10 * max(1.0, inertia)
+
+
+def test_kmeans_against_sklearn_live_random_and_duplicates():
+    sk = pytest.importorskip("sklearn.cluster")
+    rng = np.random.default_rng(2)
+    for n, k in ((300, 5), (2000, 16), (64, 8)):
+        X = rng.normal(size=(n, 3))
+        if n == 64:
+            X[32:] = X[:32]                                          # duplicates
+        init = X[rng.choice(n, k, replace=False)] + 1e-3
+        c, lab, inertia, _ = kmeans.k_means(X, init)
+        c2, lab2, in2 = sk.k_means(X.copy(), init=init.copy(), n_clusters=k, n_init=1)
+        np.testing.assert_array_equal(lab, lab2)
+        np.testing.assert_allclose(c, c2, atol=1e-12)
+
+
+def test_kmeans_empty_cluster_relocation_keeps_k_clusters():
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(200, 3))
+    init = np.vstack([X[:3], [[50., 50, 50]]])                      # 4th seed owns nothing
+    c, lab, _, _ = kmeans.k_means(X, init)
+    assert len(np.unique(lab)) == 4
+
+
+def test_chamfer_golden_and_dense_crosscheck(golden):
+    g = golden("chamfer_l1.npz")
+    x, y = g["x"], g["y"]
+    dx, ix = chamfer.nn_l1(x, y)
+    dy, iy = chamfer.nn_l1(y, x)
+    np.testing.assert_array_equal(ix, g["ix"]); np.testing.assert_array_equal(iy, g["iy"])
+    np.testing.assert_array_equal(dx, g["dx"]); np.testing.assert_array_equal(dy, g["dy"])
+    xt = torch.from_numpy(x).requires_grad_(True)
+    loss, _ = chamfer.chamfer_distance(xt[None], torch.from_numpy(y)[None], norm=1)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-7
+    np.testing.assert_allclose(xt.grad.numpy(), g["grad"], atol=1e-9)
+    dense, ix2, iy2 = chamfer.chamfer_l1_dense(torch.from_numpy(x), torch.from_numpy(y))
+    np.testing.assert_array_equal(ix2.numpy(), ix); np.testing.assert_array_equal(iy2.numpy(), iy)
+    # autograd through the dense form agrees except at exact zeros (pytorch3d's sign rule gives -1)
+    xd = torch.from_numpy(x).requires_grad_(True)
+    chamfer.chamfer_l1_dense(xd, torch.from_numpy(y))[0].backward()
+    nz = np.abs(x[:, None, :] - y[None, :, :]).min(1).min(1) > 0
+    np.testing.assert_allclose(xd.grad.numpy()[nz], xt.grad.numpy()[nz], atol=1e-7)
+
+
+def test_chamfer_first_min_tie_break_and_ragged():
+    x = np.zeros((3, 3), np.float32)
+    y = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 0]], np.float32)   # all at L1 distance 1
+    d, i = chamfer.nn_l1(x, y)
+    assert (i == 0).all() and (d == 1).all()
+    d, i = chamfer.nn_l1(y[:1], x[:2])
+    assert i[0] == 0
+
+
+def test_fps_is_a_permutation_prefix_and_spreads():
+    rng = np.random.default_rng(1)
+    X = rng.normal(size=(500, 3))
+    sel = kmeans.farthest_point_sample(X, 64)
+    assert sel[0] == 0 and len(set(sel.tolist())) == 64
+    d_sel = np.sqrt(((X[sel][:, None] - X[sel][None]) ** 2).sum(-1) + np.eye(64) * 1e9).min()
+    d_rnd = np.sqrt(((X[:64][:, None] - X[:64][None]) ** 2).sum(-1) + np.eye(64) * 1e9).min()
+    assert d_sel > d_rnd
