@@ -1,0 +1,83 @@
+"""ctypes binding of libcreg.so (include/creg.h).  There is no CPU fallback: a missing library, a
+missing GPU or a non-gfx950 device raises immediately."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcreg.so")
+
+vp, i64, i32, f32, f64, sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
+                              ctypes.c_double, ctypes.c_size_t)
+
+
+class TrainShape(ctypes.Structure):
+    _fields_ = [("rot", i32), ("k", i32), ("hidden", i32), ("epochs", i32), ("n_pred", i64),
+                ("n_tgt", i64), ("use_graph", i32), ("reserved", i32)]
+
+
+class TrainArgs(ctypes.Structure):
+    _fields_ = [("m", vp), ("y", vp), ("local_pts", vp), ("seg_offsets", vp),
+                ("params", ctypes.POINTER(vp)), ("lr", f32), ("sched_factor", f32),
+                ("sched_patience", i32), ("stop", i32), ("best_m", vp), ("best_pred", vp),
+                ("loss_hist", vp), ("lr_hist", vp), ("result", vp)]
+
+
+# name -> (restype, argtypes); every symbol include/creg.h declares
+SIGNATURES = {
+    "creg_version": (ctypes.c_int, []),
+    "creg_last_error": (ctypes.c_char_p, []),
+    "creg_device_check": (ctypes.c_int, []),
+    "creg_nn_l1_bidir_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, vp]),
+    "creg_nn_l1_bwd_scratch_bytes": (sz, [i64]),
+    "creg_nn_l1_bwd_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, f32, f32, vp, vp, vp]),
+    "creg_chamfer_l1_reduce_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, vp]),
+    "creg_cluster_transform_f32": (ctypes.c_int, [vp, i64, vp, i32, vp, vp, vp]),
+    "creg_cluster_transform_bwd_f32": (ctypes.c_int, [vp, vp, i32, vp, vp, vp]),
+    "creg_kmeans_workspace_bytes": (sz, [i64, i32]),
+    "creg_kmeans_lloyd_f64": (ctypes.c_int, [vp, i64, vp, i32, i32, f64, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "creg_kmeans_assign_f64": (ctypes.c_int, [vp, i64, vp, i32, i32, vp, vp]),
+    "creg_group_to_local_f64": (ctypes.c_int, [vp, i64, vp, i32, vp, vp, vp, vp]),
+    "creg_se3_to_dq_f32": (ctypes.c_int, [vp, i32, vp, vp]),
+    "creg_dq_to_se3_f32": (ctypes.c_int, [vp, i32, vp, vp]),
+    "creg_dq_to_se3_bwd_f32": (ctypes.c_int, [vp, vp, i32, vp, vp]),
+    "creg_dq_multiply_f32": (ctypes.c_int, [vp, vp, i32, vp, vp]),
+    "creg_dq_invert_f32": (ctypes.c_int, [vp, i32, vp, vp]),
+    "creg_dq_to_quat_trans_f32": (ctypes.c_int, [vp, i32, vp, vp, vp]),
+    "creg_quat_trans_to_dq_f32": (ctypes.c_int, [vp, vp, i32, vp, vp]),
+    "creg_matrix_to_quat_f32": (ctypes.c_int, [vp, i32, vp, vp]),
+    "creg_quat_to_matrix_f32": (ctypes.c_int, [vp, i32, vp, vp]),
+    "creg_icp_workspace_bytes": (sz, [i64, i64, i32]),
+    "creg_masked_icp_f64": (ctypes.c_int, [vp, vp, vp, i32, vp, i64, vp, f64, f64, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "creg_train_workspace_bytes": (sz, [ctypes.POINTER(TrainShape)]),
+    "creg_train_plan_create": (ctypes.c_int, [ctypes.POINTER(TrainShape), vp, sz, ctypes.POINTER(vp)]),
+    "creg_train_plan_run": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), vp]),
+    "creg_train_plan_probe": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), vp, vp, vp, vp, vp]),
+    "creg_train_plan_destroy": (ctypes.c_int, [vp]),
+}
+
+_lib = None
+
+
+def load(check_device: bool = True) -> ctypes.CDLL:
+    """dlopen libcreg.so and bind every entry point.  Raises RuntimeError when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m autourdf_amd.build` "
+                "(hipcc --offload-arch=gfx950). autourdf_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)            # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    if check_device:
+        rc = _lib.creg_device_check()
+        if rc != 0:
+            raise RuntimeError("libcreg needs an MI355X (gfx950): " + _lib.creg_last_error().decode())
+    return _lib
+
+
+def check(rc: int, what: str = "libcreg call"):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {_lib.creg_last_error().decode()}")

@@ -1,0 +1,189 @@
+"""Frame loading, frame-0 segmentation and masked per-cluster ICP on the MI355X -- drop-in for
+reference PointCloud/cluster_icp.py (``xyzrpy_to_matrix_scipy`` :7-12, ``Segments`` :14-115,
+``masked_icp`` :118-191): same names, positional order, defaults, attributes and return values.
+
+Open3D is not a dependency: ``robot.ply`` files are parsed here (ascii / binary little- or
+big-endian, float or double vertices) and clouds are handed around as ``PointCloud`` objects
+exposing ``.points`` like ``open3d.geometry.PointCloud`` does.  GUI calls of the reference
+(``draw_geometries``, cluster_icp.py:106,183) are not reproduced.
+"""
+from glob import glob
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation as R
+
+from . import _lib, ops
+from .synthetic import kmeans_plusplus
+
+
+def xyzrpy_to_matrix_scipy(xyz, rpy):
+    T = np.eye(4)
+    T[:3, 3] = xyz
+    T[:3, :3] = R.from_euler("xyz", rpy).as_matrix()
+    return T
+
+
+class PointCloud:
+    """Minimal stand-in for open3d.geometry.PointCloud: ``.points`` is an (N,3) float64 array."""
+
+    def __init__(self, points=None):
+        self.points = np.zeros((0, 3)) if points is None else np.asarray(points, np.float64).reshape(-1, 3)
+        self.colors = None
+
+    def paint_uniform_color(self, c):
+        self.colors = np.tile(np.asarray(c, np.float64), (len(self.points), 1))
+        return self
+
+    def transform(self, T):
+        T = np.asarray(T, np.float64)
+        self.points = self.points @ T[:3, :3].T + T[:3, 3]
+        return self
+
+    def farthest_point_down_sample(self, num_samples):
+        from .fps import farthest_point_sample
+        return PointCloud(self.points[farthest_point_sample(self.points, num_samples)])
+
+
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2",
+              "ushort": "u2", "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4",
+              "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def read_point_cloud(path) -> PointCloud:
+    """Vertex x/y/z of a PLY file as float64 (what o3d.io.read_point_cloud yields, cluster_icp.py:41)."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise IOError(f"{path}: not a PLY file")
+        fmt, n_vert, props, in_vertex = None, 0, [], False
+        while True:
+            line = f.readline()
+            if not line:
+                raise IOError(f"{path}: truncated PLY header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok:
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                in_vertex = tok[1] == "vertex"
+                if in_vertex:
+                    n_vert = int(tok[2])
+            elif tok[0] == "property" and in_vertex:
+                if tok[1] == "list":
+                    raise IOError(f"{path}: list property on vertices is not supported")
+                props.append((tok[2], _PLY_TYPES[tok[1]]))
+            elif tok[0] == "end_header":
+                break
+        names = [p[0] for p in props]
+        if not all(a in names for a in "xyz"):
+            raise IOError(f"{path}: vertex element lacks x/y/z")
+        if fmt == "ascii":
+            data = np.loadtxt(f, max_rows=n_vert, ndmin=2)
+            pts = np.stack([data[:, names.index(a)] for a in "xyz"], 1)
+        else:
+            order = "<" if fmt == "binary_little_endian" else ">"
+            dt = np.dtype([(n, order + t) for n, t in props])
+            rec = np.frombuffer(f.read(dt.itemsize * n_vert), dtype=dt, count=n_vert)
+            pts = np.stack([rec[a].astype(np.float64) for a in "xyz"], 1)
+    return PointCloud(pts)
+
+
+class Segments:
+    """Frames of one sequence + the frame-0 segmentation (reference cluster_icp.py:14-115)."""
+
+    def __init__(self, data_path, sample_size=None) -> None:
+        self.pc_path = data_path
+        self.pc_list = []
+        self.init_coord_list = []
+        self.init_matrix_list = []
+        self.init_segment_list = []
+        self.data_size = 0
+        self.sample_size = sample_size
+        self._load_pc()
+
+    def _load_pc(self):
+        sub_path = sorted(glob(self.pc_path + "*/"))
+        self.data_size = len(sub_path)
+        print(f"Found {self.data_size} sub path")
+        for path in sub_path:
+            pc = read_point_cloud(path + "robot.ply")
+            if self.sample_size is not None:
+                pc = pc.farthest_point_down_sample(self.sample_size)
+            self.pc_list.append(pc)
+
+    @classmethod
+    def from_arrays(cls, frames):
+        """Build from in-memory (N,3) arrays (synthetic sequences) instead of a directory of PLYs."""
+        self = cls.__new__(cls)
+        self.pc_path, self.sample_size = None, None
+        self.pc_list = [PointCloud(f) for f in frames]
+        self.init_coord_list, self.init_matrix_list, self.init_segment_list = [], [], []
+        self.data_size = len(self.pc_list)
+        return self
+
+    def k_means_cluster(self, pc_id=0, num=30, normal=False, colors=None, seed=None):
+        """k-means++ seeding (host RNG, as sklearn does it) + Lloyd on the GPU (K2); then per
+        cluster a frame with R = I at the centroid and the points in that frame
+        (cluster_icp.py:86-99).  ``seed`` pins the otherwise unseeded k-means++ draw."""
+        if normal:
+            raise NotImplementedError("--normal needs Open3D normal estimation (out of scope, SURVEY.md 8)")
+        _lib.load()
+        dev = torch.device("cuda")
+        pc_np = np.asarray(self.pc_list[pc_id].points)
+        init = kmeans_plusplus(pc_np, num, np.random.default_rng(seed))
+        X = torch.as_tensor(pc_np, dtype=torch.float64, device=dev)
+        _, labels, _, _ = ops.kmeans_lloyd(X, torch.as_tensor(init, dtype=torch.float64, device=dev))
+        lab = labels.long()
+        counts = torch.zeros(num, dtype=torch.float64, device=dev).index_add_(0, lab, torch.ones_like(X[:, 0]))
+        # np.mean over the cluster's own points (cluster_icp.py:86), not the Lloyd centre
+        grouped, off = ops.group_to_local(X, labels, torch.eye(4, dtype=torch.float64, device=dev).repeat(num, 1, 1))
+        off_h = off.cpu().numpy()
+        grouped_h = grouped.cpu().numpy()
+        new_pcd = []
+        for i in range(num):
+            pts = grouped_h[off_h[i]:off_h[i + 1]]
+            center = np.mean(pts, axis=0)
+            xyzrpy = np.array([center[0], center[1], center[2], 0.0, 0.0, 0.0])
+            matrix = xyzrpy_to_matrix_scipy(xyzrpy[:3], xyzrpy[3:])
+            self.init_coord_list.append(xyzrpy)
+            self.init_matrix_list.append(matrix)
+            inv = np.linalg.inv(matrix)
+            self.init_segment_list.append((inv @ np.hstack([pts, np.ones((len(pts), 1))]).T)[:3].T)
+            pcd = PointCloud(pts)
+            pcd.paint_uniform_color(colors[i] if colors is not None else np.random.rand(3))
+            new_pcd.append(pcd)
+        return new_pcd
+
+    def visualize(self, pcs):
+        raise NotImplementedError("visualisation needs Open3D's GUI (out of scope)")
+
+
+def masked_icp(clusters_local, clusters_world, step_pc_np, matrices, visual=False, ori=False, scale=1.2, th=1,
+               colors=None, max_iteration=10000):
+    """Per-cluster AABB-masked point-to-point ICP on the GPU (K4): one launch for all clusters.
+    Returns (list of world-frame clusters (M_k,3) f64, new matrices (K,4,4) f64) like the reference."""
+    if visual:
+        raise NotImplementedError("visual=True needs Open3D's GUI (out of scope)")
+    L = _lib.load()
+    dev = torch.device("cuda")
+    k = len(clusters_local)
+    local, off = ops.pack_clusters(clusters_local, dev, torch.float64)
+    world, off_w = ops.pack_clusters(clusters_world, dev, torch.float32)
+    if not torch.equal(off, off_w):
+        raise ValueError("clusters_local and clusters_world must have matching sizes")
+    frame = torch.as_tensor(np.asarray(step_pc_np), dtype=torch.float64, device=dev).contiguous()
+    M = torch.as_tensor(np.asarray(matrices), dtype=torch.float64, device=dev).contiguous()
+    n, nf = local.shape[0], frame.shape[0]
+    ws_bytes = L.creg_icp_workspace_bytes(n, nf, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    M_out = torch.empty(k, 4, 4, dtype=torch.float64, device=dev)
+    w_out = torch.empty(n, 3, dtype=torch.float64, device=dev)
+    n_it = torch.empty(k, dtype=torch.int32, device=dev)
+    p = ops._p
+    _lib.check(L.creg_masked_icp_f64(p(local), p(world), p(off), k, p(frame), nf, p(M), float(scale), float(th),
+                                     int(max_iteration), int(bool(ori)), p(M_out), p(w_out), p(n_it), p(ws), ws_bytes,
+                                     ops._stream()), "creg_masked_icp_f64")
+    off_h = off.cpu().numpy()
+    w_h = w_out.cpu().numpy()
+    return [w_h[off_h[i]:off_h[i + 1]] for i in range(k)], M_out.cpu().numpy()

@@ -1,0 +1,159 @@
+// creg_dev.h -- device-side math shared by the kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace creg {
+
+constexpr int WAVE = 64;
+
+// ---- wave / block reductions with a fixed combination order (deterministic) ------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+// (value, index) lexicographic minimum across the wave: smallest value, then smallest index.
+__device__ __forceinline__ void wave_argmin(float& v, int& i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float ov = __shfl_xor(v, off, WAVE);
+        int oi = __shfl_xor(i, off, WAVE);
+        bool take = (ov < v) || (ov == v && oi < i);
+        v = take ? ov : v;
+        i = take ? oi : i;
+    }
+}
+
+// Sum `v` over a block of NT threads; result valid in thread 0. `scratch` >= NT/64 entries.
+template <typename T, int NT>
+__device__ __forceinline__ T block_sum(T v, T* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    T r = T(0);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) r += scratch[i];
+    }
+    return r;
+}
+
+// ---- L1 distance in the canonical order (pytorch3d knn: dist += |diff| for d = 0,1,2) ---------
+__device__ __forceinline__ float l1_dist(float ax, float ay, float az, float bx, float by, float bz) {
+    float d = fabsf(ax - bx);
+    d = d + fabsf(ay - by);
+    d = d + fabsf(az - bz);
+    return d;
+}
+
+// ---- quaternion helpers, pytorch3d.transforms conventions (real first) -----------------------
+template <typename T>
+__device__ __forceinline__ void quat_to_matrix(const T q[4], T R[9]) {
+    const T w = q[0], x = q[1], y = q[2], z = q[3];
+    const T s = T(2) / (w * w + x * x + y * y + z * z);
+    R[0] = T(1) - s * (y * y + z * z); R[1] = s * (x * y - z * w); R[2] = s * (x * z + y * w);
+    R[3] = s * (x * y + z * w); R[4] = T(1) - s * (x * x + z * z); R[5] = s * (y * z - x * w);
+    R[6] = s * (x * z - y * w); R[7] = s * (y * z + x * w); R[8] = T(1) - s * (x * x + y * y);
+}
+
+// vector-Jacobian product of quat_to_matrix: G = dL/dR (row-major 3x3) -> gq = dL/dq.
+template <typename T>
+__device__ __forceinline__ void quat_to_matrix_vjp(const T q[4], const T G[9], T gq[4]) {
+    const T w = q[0], x = q[1], y = q[2], z = q[3];
+    const T n = w * w + x * x + y * y + z * z;
+    const T s = T(2) / n;
+    // R = diag-part + s*N(q); dL/ds = sum G_ij N_ij
+    const T N00 = -(y * y + z * z), N01 = x * y - z * w, N02 = x * z + y * w;
+    const T N10 = x * y + z * w, N11 = -(x * x + z * z), N12 = y * z - x * w;
+    const T N20 = x * z - y * w, N21 = y * z + x * w, N22 = -(x * x + y * y);
+    const T gs = G[0] * N00 + G[1] * N01 + G[2] * N02 + G[3] * N10 + G[4] * N11 + G[5] * N12 +
+                 G[6] * N20 + G[7] * N21 + G[8] * N22;
+    const T dw = -z * G[1] + y * G[2] + z * G[3] - x * G[5] - y * G[6] + x * G[7];
+    const T dx = y * (G[1] + G[3]) + z * (G[2] + G[6]) - T(2) * x * (G[4] + G[8]) + w * (G[7] - G[5]);
+    const T dy = -T(2) * y * (G[0] + G[8]) + x * (G[1] + G[3]) + w * (G[2] - G[6]) + z * (G[5] + G[7]);
+    const T dz = -T(2) * z * (G[0] + G[4]) + w * (G[3] - G[1]) + x * (G[2] + G[6]) + y * (G[5] + G[7]);
+    const T k = -gs * s * s;     // ds/dq_c = -s^2 q_c
+    gq[0] = s * dw + k * w; gq[1] = s * dx + k * x; gq[2] = s * dy + k * y; gq[3] = s * dz + k * z;
+}
+
+template <typename T>
+__device__ __forceinline__ T sqrt_pos(T v) { return v > T(0) ? sqrt(v) : T(0); }
+
+// R row-major 3x3 -> q (w >= 0), best-conditioned of the four candidates (first max on ties).
+template <typename T>
+__device__ __forceinline__ void matrix_to_quat(const T R[9], T q[4]) {
+    const T m00 = R[0], m01 = R[1], m02 = R[2], m10 = R[3], m11 = R[4], m12 = R[5], m20 = R[6],
+            m21 = R[7], m22 = R[8];
+    T qa[4] = {sqrt_pos(T(1) + m00 + m11 + m22), sqrt_pos(T(1) + m00 - m11 - m22),
+               sqrt_pos(T(1) - m00 + m11 - m22), sqrt_pos(T(1) - m00 - m11 + m22)};
+    int c = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (qa[i] > qa[c]) c = i;
+    T cand[4];
+    if (c == 0) { cand[0] = qa[0] * qa[0]; cand[1] = m21 - m12; cand[2] = m02 - m20; cand[3] = m10 - m01; }
+    else if (c == 1) { cand[0] = m21 - m12; cand[1] = qa[1] * qa[1]; cand[2] = m10 + m01; cand[3] = m02 + m20; }
+    else if (c == 2) { cand[0] = m02 - m20; cand[1] = m10 + m01; cand[2] = qa[2] * qa[2]; cand[3] = m12 + m21; }
+    else { cand[0] = m10 - m01; cand[1] = m20 + m02; cand[2] = m21 + m12; cand[3] = qa[3] * qa[3]; }
+    const T den = T(2) * (qa[c] > T(0.1) ? qa[c] : T(0.1));
+    const bool neg = (cand[0] / den) < T(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { T v = cand[i] / den; q[i] = neg ? -v : v; }
+}
+
+// Hamilton product a (x) b, real first.
+template <typename T>
+__device__ __forceinline__ void quat_mul(const T a[4], const T b[4], T o[4]) {
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+
+// (R,t) -> dual quaternion, dq_func.py:72-98: q = m2q(R) / max(|q|, eps); dual = 0.5 (0,t) (x) q.
+template <typename T>
+__device__ __forceinline__ void se3_to_dq(const T R[9], const T t[3], T dq[8], T eps) {
+    T q[4];
+    matrix_to_quat(R, q);
+    T n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    n = n > eps ? n : eps;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq[i] = q[i] / n;
+    const T p[4] = {T(0), t[0], t[1], t[2]};
+    T d[4];
+    quat_mul(p, dq, d);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq[4 + i] = T(0.5) * d[i];
+}
+
+// dual quaternion -> (R,t), dq_func.py:148-168: R = q2m(real); t = (2 dual (x) conj(real))[1:].
+template <typename T>
+__device__ __forceinline__ void dq_to_se3(const T dq[8], T R[9], T t[3]) {
+    quat_to_matrix(dq, R);
+    const T c[4] = {dq[0], -dq[1], -dq[2], -dq[3]};
+    T o[4];
+    quat_mul(dq + 4, c, o);
+    t[0] = T(2) * o[1]; t[1] = T(2) * o[2]; t[2] = T(2) * o[3];
+}
+
+// VJP of dq_to_se3: (G = dL/dR, gt = dL/dt) -> gdq (8).
+template <typename T>
+__device__ __forceinline__ void dq_to_se3_vjp(const T dq[8], const T G[9], const T gt[3], T gdq[8]) {
+    quat_to_matrix_vjp(dq, G, gdq);
+    const T rw = dq[0], rx = dq[1], ry = dq[2], rz = dq[3];
+    const T dw = dq[4], dx = dq[5], dy = dq[6], dz = dq[7];
+    const T a = gt[0], b = gt[1], c = gt[2];
+    gdq[4] = T(2) * (-rx * a - ry * b - rz * c);
+    gdq[5] = T(2) * (rw * a + rz * b - ry * c);
+    gdq[6] = T(2) * (-rz * a + rw * b + rx * c);
+    gdq[7] = T(2) * (ry * a - rx * b + rw * c);
+    gdq[0] += T(2) * (dx * a + dy * b + dz * c);
+    gdq[1] += T(2) * (-dw * a - dz * b + dy * c);
+    gdq[2] += T(2) * (dz * a - dw * b - dx * c);
+    gdq[3] += T(2) * (-dy * a + dx * b - dw * c);
+}
+
+}  // namespace creg

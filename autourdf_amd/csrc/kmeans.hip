@@ -1,0 +1,479 @@
+// kmeans.hip -- K2: Lloyd k-means in fp64 for 3-D points, sklearn.cluster.k_means(init=array,
+// n_init=1) semantics (reference mlp_reg.py:204, cluster_icp.py:67), plus the stable grouping /
+// change-of-frame step that follows it (mlp_reg.py:208-217).
+//
+// Per Lloyd iteration three small launches, all with fixed reduction orders (bit-reproducible):
+//   k_assign[_mfma]  labels = first argmin_k fma(x2,b2,fma(x1,b1,fma(x0,b0,|c|^2))),  b = -2c
+//   k_accumulate     grid (k, S): per-cluster sums over a segment of the points, strided + tree
+//   k_finalize       1 block: reduce segments, relocate empty clusters, average (x 1/w), centre
+//                    shift, convergence (strict label equality first, then tol), next b/|c|^2
+// The host enqueues iterations in batches and reads the `done` word between batches; kernels of
+// iterations after convergence return immediately.
+#include "creg_common.h"
+#include "creg_dev.h"
+
+namespace creg {
+
+struct KmFlags {
+    int changed;      // points whose label differs from the previous iteration (this iteration)
+    int done;         // convergence reached; later iterations are no-ops
+    int strict;       // converged by label equality (no final E-step needed)
+    int n_iter;       // iterations executed (i + 1 of the breaking iteration)
+    int cur;          // which centre buffer holds the current centres
+    int pad[3];
+    double mean[3];
+    double tol;
+    double shift_tot;
+    double inertia;
+};
+
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+// B rows: (-2cx, -2cy, -2cz, |c|^2)
+__device__ __forceinline__ void make_b(const double* c, double* b) {
+    b[0] = -2.0 * c[0]; b[1] = -2.0 * c[1]; b[2] = -2.0 * c[2];
+    b[3] = fma(c[2], c[2], fma(c[1], c[1], c[0] * c[0]));
+}
+
+__global__ __launch_bounds__(1024) void k_km_stats(const double* __restrict__ X, int n, double tol_rel,
+                                                   KmFlags* __restrict__ f) {
+    __shared__ double sc[16];
+    __shared__ double mean[3];
+    for (int d = 0; d < 3; ++d) {
+        double s = 0;
+        for (int i = threadIdx.x; i < n; i += 1024) s += X[3 * (size_t)i + d];
+        s = block_sum<double, 1024>(s, sc);
+        if (threadIdx.x == 0) mean[d] = s / (double)n;
+    }
+    __syncthreads();
+    double var = 0;
+    for (int d = 0; d < 3; ++d) {
+        double s = 0;
+        for (int i = threadIdx.x; i < n; i += 1024) { const double t = X[3 * (size_t)i + d] - mean[d]; s = fma(t, t, s); }
+        s = block_sum<double, 1024>(s, sc);
+        if (threadIdx.x == 0) var += s / (double)n;
+    }
+    if (threadIdx.x == 0) {
+        f->mean[0] = mean[0]; f->mean[1] = mean[1]; f->mean[2] = mean[2];
+        f->tol = (var / 3.0) * tol_rel;
+        f->changed = 0; f->done = 0; f->strict = 0; f->n_iter = 0; f->cur = 0;
+        f->shift_tot = 0; f->inertia = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_km_center(const double* __restrict__ X, int n,
+                                                   const double* __restrict__ init, int k,
+                                                   const KmFlags* __restrict__ f, double* __restrict__ Xc,
+                                                   double* __restrict__ C, double* __restrict__ B,
+                                                   int* __restrict__ labels_prev) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) Xc[3 * (size_t)i + d] = X[3 * (size_t)i + d] - f->mean[d];
+        labels_prev[i] = -1;
+    }
+    if (i < k) {
+        double c[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { c[d] = init[3 * i + d] - f->mean[d]; C[3 * i + d] = c[d]; }
+        make_b(c, B + 4 * i);
+    }
+}
+
+// E-step, VALU form: one thread per point, centres broadcast from LDS.
+__global__ __launch_bounds__(256) void k_km_assign(const double* __restrict__ X, int n,
+                                                   const double* __restrict__ B, int k,
+                                                   int* __restrict__ labels, const int* __restrict__ prev,
+                                                   KmFlags* __restrict__ f) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sB = (double*)smem;
+    if (f && f->done) return;
+    for (int i = threadIdx.x; i < 4 * k; i += 256) sB[i] = B[i];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int diff = 0;
+    if (i < n) {
+        const double x0 = X[3 * (size_t)i], x1 = X[3 * (size_t)i + 1], x2 = X[3 * (size_t)i + 2];
+        double best = fma(x2, sB[2], fma(x1, sB[1], fma(x0, sB[0], sB[3])));
+        int lab = 0;
+        for (int j = 1; j < k; ++j) {
+            const double d = fma(x2, sB[4 * j + 2], fma(x1, sB[4 * j + 1], fma(x0, sB[4 * j], sB[4 * j + 3])));
+            if (d < best) { best = d; lab = j; }
+        }
+        labels[i] = lab;
+        if (prev) diff = (prev[i] != lab);
+    }
+    if (prev && f) {
+        const unsigned long long m = __ballot(diff);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&f->changed, __popcll(m));
+    }
+}
+
+// E-step, matrix-core form: v_mfma_f64_16x16x4_f64 evaluates a 16-point x 16-centre tile of
+// |c|^2 - 2 x.c as D = C + A.B with A = [x0 x1 x2 0], B = [b0;b1;b2;0], C = |c|^2 per column; the
+// k-ordered fma chain of the instruction is the same chain the VALU form spells out.
+// Layout (gfx950 f64 MFMA): A[i=l&15][kk=l>>4], B[kk=l>>4][j=l&15], D[i=(l>>4)+4r][j=l&15].
+__global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict__ X, int n,
+                                                        const double* __restrict__ B, int k,
+                                                        int* __restrict__ labels, const int* __restrict__ prev,
+                                                        KmFlags* __restrict__ f) {
+    if (f && f->done) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i0 = wave * 16;
+    if (i0 >= n) return;
+    const int kk = lane >> 4, col = lane & 15;
+    const int pi = min(i0 + col, n - 1);
+    const double a = (kk < 3) ? X[3 * (size_t)pi + kk] : 0.0;
+    double best[4];
+    int lab[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { best[r] = INFINITY; lab[r] = 0x7fffffff; }
+    for (int j0 = 0; j0 < k; j0 += 16) {
+        const int j = j0 + col;
+        const bool ok = j < k;
+        const double b = (ok && kk < 3) ? B[4 * j + kk] : 0.0;
+        const double csq = ok ? B[4 * j + 3] : INFINITY;
+        double4v c = {csq, csq, csq, csq};
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = c[r];
+            int idx = ok ? j : 0x7fffffff;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {      // first-min across the 16 centres of the tile
+                const double ov = __shfl_xor(v, off, 64);
+                const int oi = __shfl_xor(idx, off, 64);
+                const bool take = (ov < v) || (ov == v && oi < idx);
+                v = take ? ov : v; idx = take ? oi : idx;
+            }
+            if (v < best[r]) { best[r] = v; lab[r] = idx; }     // tiles ascend: strict < keeps the first
+        }
+    }
+    int diff = 0;
+    if (col == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + kk + 4 * r;
+            if (i < n) { labels[i] = lab[r]; if (prev) diff += (prev[i] != lab[r]); }
+        }
+    }
+    if (prev && f) {
+        diff = wave_sum(diff);
+        if (lane == 0 && diff) atomicAdd(&f->changed, diff);
+    }
+}
+
+// grid (k, S): block (j, s) sums the points of cluster j inside segment s.
+__global__ __launch_bounds__(256) void k_km_accumulate(const double* __restrict__ X, int n,
+                                                       const int* __restrict__ labels, int k, int S,
+                                                       double* __restrict__ part, const KmFlags* __restrict__ f) {
+    __shared__ double sc[4];
+    if (f->done) return;
+    const int j = blockIdx.x, s = blockIdx.y;
+    const int seg = (n + S - 1) / S, b = s * seg, e = min(n, b + seg);
+    double a0 = 0, a1 = 0, a2 = 0, w = 0;
+    for (int i = b + threadIdx.x; i < e; i += 256) {
+        if (labels[i] == j) { a0 += X[3 * (size_t)i]; a1 += X[3 * (size_t)i + 1]; a2 += X[3 * (size_t)i + 2]; w += 1.0; }
+    }
+    a0 = block_sum<double, 256>(a0, sc); a1 = block_sum<double, 256>(a1, sc);
+    a2 = block_sum<double, 256>(a2, sc); w = block_sum<double, 256>(w, sc);
+    if (threadIdx.x == 0) {
+        double* p = part + 4 * ((size_t)s * k + j);
+        p[0] = a0; p[1] = a1; p[2] = a2; p[3] = w;
+    }
+}
+
+// single block.  Cw: (k,4) scratch for sums / weights.  C[2]: double-buffered centres.
+__global__ __launch_bounds__(1024) void k_km_finalize(const double* __restrict__ X, int n,
+                                                      const int* __restrict__ labels, int k, int S,
+                                                      const double* __restrict__ part, double* __restrict__ C2,
+                                                      double* __restrict__ B, double* __restrict__ Cw,
+                                                      double* __restrict__ far_d, KmFlags* __restrict__ f) {
+    __shared__ double sc[16];
+    __shared__ int s_nempty, s_argmax, s_far;
+    __shared__ double s_dmax;
+    if (f->done) return;
+    const int cur = f->cur;
+    const double* Cold = C2 + (size_t)cur * 3 * k;
+    double* Cnew = C2 + (size_t)(cur ^ 1) * 3 * k;
+    for (int j = threadIdx.x; j < k; j += 1024) {
+        double a[4] = {0, 0, 0, 0};
+        for (int s = 0; s < S; ++s)
+            for (int d = 0; d < 4; ++d) a[d] += part[4 * ((size_t)s * k + j) + d];
+        for (int d = 0; d < 4; ++d) Cw[4 * j + d] = a[d];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ne = 0;
+        for (int j = 0; j < k; ++j) ne += (Cw[4 * j + 3] == 0.0);
+        s_nempty = ne;
+    }
+    __syncthreads();
+    if (s_nempty > 0) {
+        // _relocate_empty_clusters_dense: farthest points (descending distance, ties to the lower
+        // index) seed the empty clusters and leave their old ones.  Rare path, whole block scans.
+        double dmax = 0;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const double* c = Cold + 3 * labels[i];
+            const double a = X[3 * (size_t)i] - c[0], b = X[3 * (size_t)i + 1] - c[1], e = X[3 * (size_t)i + 2] - c[2];
+            const double d = (a * a + b * b) + e * e;
+            far_d[i] = d;
+            dmax = fmax(dmax, d);
+        }
+        for (int off = 32; off >= 1; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = dmax;
+        __syncthreads();
+        if (threadIdx.x == 0) { double m = 0; for (int i = 0; i < 16; ++i) m = fmax(m, sc[i]); s_dmax = m; }
+        __syncthreads();
+        if (s_dmax > 0) {
+            for (int j = 0; j < k; ++j) {
+                if (Cw[4 * j + 3] != 0.0) continue;            // uniform: Cw only changes under barriers
+                double bv = -1; int bi = 0x7fffffff;
+                for (int i = threadIdx.x; i < n; i += 1024) if (far_d[i] > bv) { bv = far_d[i]; bi = i; }
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const double ov = __shfl_xor(bv, off, 64); const int oi = __shfl_xor(bi, off, 64);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                __shared__ double s_v[16]; __shared__ int s_i[16];
+                __syncthreads();
+                if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = bv; s_i[threadIdx.x >> 6] = bi; }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    for (int w = 0; w < 16; ++w) if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) { bv = s_v[w]; bi = s_i[w]; }
+                    s_far = bi;
+                    far_d[bi] = -2;
+                    const int old = labels[bi];
+                    for (int d = 0; d < 3; ++d) { Cw[4 * old + d] -= X[3 * (size_t)bi + d]; Cw[4 * j + d] = X[3 * (size_t)bi + d]; }
+                    Cw[4 * j + 3] = 1.0; Cw[4 * old + 3] -= 1.0;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        int am = 0;
+        for (int j = 1; j < k; ++j) if (Cw[4 * j + 3] > Cw[4 * am + 3]) am = j;
+        s_argmax = am;
+    }
+    __syncthreads();
+    double shift = 0;
+    for (int j = threadIdx.x; j < k; j += 1024) {
+        const double w = Cw[4 * j + 3];
+        double c[3];
+        if (w > 0) { const double alpha = 1.0 / w; for (int d = 0; d < 3; ++d) c[d] = Cw[4 * j + d] * alpha; }
+        else { const double wa = Cw[4 * s_argmax + 3]; const double alpha = 1.0 / wa;
+               for (int d = 0; d < 3; ++d) c[d] = Cw[4 * s_argmax + d] * alpha; }
+        double s = 0;
+        for (int d = 0; d < 3; ++d) { Cnew[3 * j + d] = c[d]; const double t = c[d] - Cold[3 * j + d]; s += t * t; }
+        const double sh = sqrt(s);
+        shift += sh * sh;
+        make_b(c, B + 4 * j);
+    }
+    // fixed order: per-thread value for j = tid (k <= 1024), summed by thread 0 in index order
+    __shared__ double s_shift[1024];
+    s_shift[threadIdx.x] = shift;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0;
+        for (int j = 0; j < min(k, 1024); ++j) tot += s_shift[j];
+        f->shift_tot = tot;
+        f->cur = cur ^ 1;
+        f->n_iter += 1;
+        if (f->changed == 0) { f->strict = 1; f->done = 1; }
+        else if (tot <= f->tol) { f->done = 1; }
+        f->changed = 0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_km_finish(const double* __restrict__ X, int n,
+                                                    const int* __restrict__ labels, int k,
+                                                    const double* __restrict__ C2, KmFlags* __restrict__ f,
+                                                    double* __restrict__ centers, double* __restrict__ inertia,
+                                                    int* __restrict__ n_iter) {
+    __shared__ double sc[16];
+    const double* C = C2 + (size_t)f->cur * 3 * k;
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const double* c = C + 3 * labels[i];
+        const double a = X[3 * (size_t)i] - c[0], b = X[3 * (size_t)i + 1] - c[1], e = X[3 * (size_t)i + 2] - c[2];
+        s += (a * a + b * b) + e * e;
+    }
+    s = block_sum<double, 1024>(s, sc);
+    if (threadIdx.x == 0) { inertia[0] = s; n_iter[0] = f->n_iter; }
+    for (int j = threadIdx.x; j < 3 * k; j += 1024) centers[j] = C[j] + f->mean[j % 3];
+}
+
+__global__ __launch_bounds__(256) void k_make_b(const double* __restrict__ C, int k, double* __restrict__ B) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < k) make_b(C + 3 * j, B + 4 * j);
+}
+
+// ---- grouping by label + inverse-pose change of frame ------------------------------------------
+__device__ void inv4x4(const double* M, double* I) {      // Gauss-Jordan, partial pivoting
+    double a[4][8];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { a[r][c] = M[4 * r + c]; a[r][4 + c] = (r == c) ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 4; ++r) if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
+        if (p != c) for (int q = 0; q < 8; ++q) { const double t = a[c][q]; a[c][q] = a[p][q]; a[p][q] = t; }
+        const double inv = 1.0 / a[c][c];
+        for (int q = 0; q < 8; ++q) a[c][q] *= inv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            const double fct = a[r][c];
+            for (int q = 0; q < 8; ++q) a[r][q] = fma(-fct, a[c][q], a[r][q]);
+        }
+    }
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) I[4 * r + c] = a[r][4 + c];
+}
+
+__global__ __launch_bounds__(1024) void k_group_offsets(const int* __restrict__ labels, int n, int k,
+                                                        int* __restrict__ off, const double* __restrict__ M,
+                                                        double* __restrict__ Minv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* cnt = (int*)smem;
+    for (int j = threadIdx.x; j <= k; j += 1024) cnt[j] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) atomicAdd(&cnt[labels[i]], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int j = 0; j < k; ++j) { const int c = cnt[j]; off[j] = run; run += c; }
+        off[k] = run;
+    }
+    for (int j = threadIdx.x; j < k; j += 1024) inv4x4(M + 16 * j, Minv + 16 * j);
+}
+
+// one wave per cluster walks the labels in order: ballot + prefix popcount gives the stable slot
+__global__ __launch_bounds__(64) void k_group_scatter(const double* __restrict__ X, int n,
+                                                      const int* __restrict__ labels,
+                                                      const int* __restrict__ off,
+                                                      const double* __restrict__ Minv,
+                                                      double* __restrict__ out) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const double* I = Minv + 16 * j;
+    int pos = off[j];
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool mine = (i < n) && (labels[i] == j);
+        const unsigned long long m = __ballot(mine);
+        if (mine) {
+            const int slot = pos + __popcll(m & ((1ull << lane) - 1ull));
+            const double p0 = X[3 * (size_t)i], p1 = X[3 * (size_t)i + 1], p2 = X[3 * (size_t)i + 2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                out[3 * (size_t)slot + a] = fma(I[4 * a + 2], p2, fma(I[4 * a + 1], p1, I[4 * a] * p0)) + I[4 * a + 3];
+        }
+        pos += __popcll(m);
+    }
+}
+
+static int seg_count(int64_t n) { int s = (int)((n + 16383) / 16384); return s < 1 ? 1 : (s > 64 ? 64 : s); }
+
+struct KmLayout { size_t xc, c2, b, cw, part, far, prev, lab2, flags, total; };
+static KmLayout km_layout(int64_t n, int k) {
+    KmLayout L; size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    L.xc = take(sizeof(double) * 3 * n); L.c2 = take(sizeof(double) * 6 * k); L.b = take(sizeof(double) * 4 * k);
+    L.cw = take(sizeof(double) * 4 * k); L.part = take(sizeof(double) * 4 * k * seg_count(n));
+    L.far = take(sizeof(double) * n); L.prev = take(sizeof(int) * n); L.lab2 = take(sizeof(int) * n);
+    L.flags = take(sizeof(KmFlags)); L.total = o;
+    return L;
+}
+
+static void launch_assign(const double* X, int n, const double* B, int k, int* labels, const int* prev,
+                          KmFlags* f, int use_mfma, hipStream_t s) {
+    if (use_mfma)
+        hipLaunchKernelGGL(k_km_assign_mfma, dim3(cdiv(cdiv(n, 16), 4)), dim3(256), 0, s, X, n, B, k, labels, prev, f);
+    else
+        hipLaunchKernelGGL(k_km_assign, dim3(cdiv(n, 256)), dim3(256), sizeof(double) * 4 * k, s, X, n, B, k, labels, prev, f);
+}
+
+}  // namespace creg
+using namespace creg;
+
+extern "C" size_t creg_kmeans_workspace_bytes(int64_t n, int32_t k) {
+    if (n < 1 || k < 1) return 0;
+    return km_layout(n, k).total;
+}
+
+extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* init, int32_t k,
+                                     int32_t max_iter, double tol_rel, int32_t use_mfma, double* centers,
+                                     int32_t* labels, double* inertia, int32_t* n_iter, void* workspace,
+                                     size_t workspace_bytes, creg_stream_t stream) {
+    CREG_REQUIRE(X && init && centers && labels && inertia && n_iter && workspace, "creg_kmeans_lloyd_f64: null pointer");
+    CREG_REQUIRE(n >= 1 && n < (1ll << 31) && k >= 1 && k <= 1024 && max_iter >= 1,
+                 "creg_kmeans_lloyd_f64: need 1 <= n < 2^31, 1 <= k <= 1024, max_iter >= 1");
+    const KmLayout L = km_layout(n, k);
+    CREG_REQUIRE(workspace_bytes >= L.total, "creg_kmeans_lloyd_f64: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+    hipStream_t s = (hipStream_t)stream;
+    char* w = (char*)workspace;
+    double* Xc = (double*)(w + L.xc); double* C2 = (double*)(w + L.c2); double* B = (double*)(w + L.b);
+    double* Cw = (double*)(w + L.cw); double* part = (double*)(w + L.part); double* far_d = (double*)(w + L.far);
+    int* lab[2] = {labels, (int*)(w + L.lab2)};
+    int* prev0 = (int*)(w + L.prev);
+    KmFlags* f = (KmFlags*)(w + L.flags);
+    const int S = seg_count(n), ni = (int)n;
+
+    hipLaunchKernelGGL(k_km_stats, dim3(1), dim3(1024), 0, s, X, ni, tol_rel, f);
+    hipLaunchKernelGGL(k_km_center, dim3(cdiv(n > k ? n : k, 256)), dim3(256), 0, s, X, ni, init, k, f, Xc, C2, B, prev0);
+    CREG_LAUNCH_CHECK();
+    // labels ping-pong between the caller's buffer and lab2 so "previous labels" needs no copy;
+    // iteration `it` writes lab[it & 1] and compares with the buffer written by it - 1.
+    int it = 0, done = 0;
+    KmFlags host;
+    while (it < max_iter && !done) {
+        const int batch = (max_iter - it) < 8 ? (max_iter - it) : 8;
+        for (int b = 0; b < batch; ++b, ++it) {
+            int* cur = lab[it & 1];
+            const int* prev = it == 0 ? prev0 : lab[(it - 1) & 1];
+            launch_assign(Xc, ni, B, k, cur, prev, f, use_mfma, s);
+            hipLaunchKernelGGL(k_km_accumulate, dim3(k, S), dim3(256), 0, s, Xc, ni, cur, k, S, part, f);
+            hipLaunchKernelGGL(k_km_finalize, dim3(1), dim3(1024), 0, s, Xc, ni, cur, k, S, part, C2, B, Cw, far_d, f);
+        }
+        CREG_LAUNCH_CHECK();
+        CREG_HIP(hipMemcpyAsync(&host, f, sizeof(KmFlags), hipMemcpyDeviceToHost, s));
+        CREG_HIP(hipStreamSynchronize(s));
+        done = host.done;
+    }
+    // which buffer holds the labels of the last executed iteration
+    int* last = lab[(host.n_iter - 1) & 1];
+    if (!host.strict) {      // rerun the E-step so labels match the final centres (_kmeans.py:736-748)
+        launch_assign(Xc, ni, B, k, last, nullptr, nullptr, use_mfma, s);
+    }
+    if (last != labels) CREG_HIP(hipMemcpyAsync(labels, last, sizeof(int) * n, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_km_finish, dim3(1), dim3(1024), 0, s, Xc, ni, labels, k, C2, f, centers, inertia, n_iter);
+    CREG_LAUNCH_CHECK();
+    return CREG_OK;
+}
+
+extern "C" int creg_kmeans_assign_f64(const double* X, int64_t n, const double* C, int32_t k, int32_t use_mfma,
+                                      int32_t* labels, creg_stream_t stream) {
+    CREG_REQUIRE(X && C && labels && n >= 1 && n < (1ll << 31) && k >= 1 && k <= 1024, "creg_kmeans_assign_f64: bad argument");
+    // B is built in a small device buffer carved from the tail of `labels`? No: keep the ABI honest
+    // and stage it in a static per-stream-ordered allocation instead.
+    double* B = nullptr;
+    CREG_HIP(hipMallocAsync((void**)&B, sizeof(double) * 4 * k, (hipStream_t)stream));
+    hipLaunchKernelGGL(k_make_b, dim3(cdiv(k, 256)), dim3(256), 0, (hipStream_t)stream, C, k, B);
+    launch_assign(X, (int)n, B, k, labels, nullptr, nullptr, use_mfma, (hipStream_t)stream);
+    CREG_HIP(hipFreeAsync(B, (hipStream_t)stream));
+    CREG_LAUNCH_CHECK();
+    return CREG_OK;
+}
+
+extern "C" int creg_group_to_local_f64(const double* X, int64_t n, const int32_t* labels, int32_t k,
+                                       const double* M, double* out_local, int32_t* seg_offsets,
+                                       creg_stream_t stream) {
+    CREG_REQUIRE(X && labels && M && out_local && seg_offsets && n >= 1 && n < (1ll << 31) && k >= 1 && k <= 4096,
+                 "creg_group_to_local_f64: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    double* Minv = nullptr;
+    CREG_HIP(hipMallocAsync((void**)&Minv, sizeof(double) * 16 * k, s));
+    hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(1024), sizeof(int) * (k + 1), s, labels, (int)n, k, seg_offsets, M, Minv);
+    hipLaunchKernelGGL(k_group_scatter, dim3(k), dim3(64), 0, s, X, (int)n, labels, seg_offsets, Minv, out_local);
+    CREG_HIP(hipFreeAsync(Minv, s));
+    CREG_LAUNCH_CHECK();
+    return CREG_OK;
+}

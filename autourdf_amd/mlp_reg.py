@@ -1,0 +1,225 @@
+"""Per-sequence cluster registration on the MI355X -- drop-in for reference PointCloud/mlp_reg.py.
+
+Same public surface (``train`` :17, ``calculate_pc`` :155, ``resample_cluster`` :172, ``match`` :240,
+the CLI flags :394-404 and the module globals the ``__main__`` block sets :390-426), same files
+written (``matrix/{t:04}.npy``, ``cluster/{t:04}.npz``, ``loss.txt``).  What changed is where the
+work runs:
+
+* ``train``            one device-resident plan in libcreg.so (A1): 300 epochs of pose MLP,
+                       calculate_pc, L1 Chamfer forward/backward, Adam and ReduceLROnPlateau with
+                       no host round trip (the reference syncs on ``loss.item()`` every epoch).
+* ``calculate_pc``     HIP kernel K3 (differentiable).
+* ``resample_cluster`` fp64 Lloyd k-means + stable grouping + inverse-pose change of frame, K2.
+* ``masked_icp``       (``--mlp_icp``) one launch for all clusters, K4.
+
+There is no CPU path: without libcreg.so / an MI355X every entry point raises.
+Run as ``python -m autourdf_amd.mlp_reg --robot wx200_5`` from a directory holding
+``parameters.json`` and ``data/raw/...`` (what scripts/registration.sh does).
+"""
+import argparse
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .cluster_icp import PointCloud, Segments, masked_icp
+from .helper_functions import load_pc_npz, save_pc_npz
+from .model_utils import DQRegMLP, QRegMLP, RegMLP, RRegMLP
+
+# module globals, set by main() exactly like the reference's __main__ block; ROT has a default so
+# that `import mlp_reg; mlp_reg.train(...)` works without NameError.
+ROT = "q"
+DEVICE = None
+EPOCHS = 300            # mlp_reg.py:60
+USE_GRAPH = True
+_PLANS = {}
+
+
+def _plan(rot, k, hidden, n_pred, n_tgt, device):
+    key = (rot, k, hidden, n_pred, n_tgt, EPOCHS, USE_GRAPH, str(device))
+    if key not in _PLANS:
+        _PLANS[key] = ops.TrainPlan(rot, k, hidden, n_pred, n_tgt, epochs=EPOCHS, use_graph=USE_GRAPH, device=device)
+    return _PLANS[key]
+
+
+def _model_params(model):
+    if isinstance(model, QRegMLP):
+        rot, order = "q", ops.Q_PARAM_ORDER
+    elif isinstance(model, DQRegMLP):
+        rot, order = "dq", ops.DQ_PARAM_ORDER
+    else:
+        raise NotImplementedError(f"train(): no HIP plan for {type(model).__name__}; use QRegMLP (--r q) or DQRegMLP (--r dq)")
+    named = dict(model.named_parameters())
+    params = [named[n].data for n in order]
+    return rot, params, model.encoder[0].out_features
+
+
+def train(m, y, model, clusters, stop=200, learning_rate=0.0002, scheduler_patience=5, scheduler_factor=0.7):
+    """The reference's Adam loop (mlp_reg.py:17-152) as one asynchronous device plan.
+
+    Args as in the reference: m (K,4,4) fp32 poses, y (N,3) fp32 target cloud, model (QRegMLP /
+    DQRegMLP, updated in place), clusters (list of K (M_k,3) fp32 local clouds).
+    Returns (pred_pcd_np, pred_pcd, best_m, min_loss) like the reference.
+    """
+    rot, params, hidden = _model_params(model)
+    if rot != ROT:
+        raise ValueError(f"model {type(model).__name__} does not match ROT={ROT!r}")
+    dev = m.device
+    pts, off = ops.pack_clusters(clusters, dev)
+    plan = _plan(rot, m.shape[0], hidden, pts.shape[0], y.shape[0], dev)
+    best_m, best_pred, result, _, _ = plan.run(m, y, pts, off, params, lr=learning_rate, factor=scheduler_factor,
+                                               patience=scheduler_patience, stop=stop)
+    res = result.cpu()                                   # the one host sync of the whole loop
+    min_loss, epochs_run = float(res[0]), int(res[1])
+    if epochs_run < EPOCHS:
+        print(f"Early stopping triggered after {epochs_run - 1} epochs")
+    off_h = off.cpu().numpy()
+    pred_h = best_pred.cpu().numpy()
+    pred_pcd_np = [pred_h[off_h[i]:off_h[i + 1]] for i in range(len(clusters))]
+    pred_pcd = [PointCloud(p) for p in pred_pcd_np]
+    print("Best Loss:", min_loss)
+    return pred_pcd_np, pred_pcd, best_m, min_loss
+
+
+def calculate_pc(local_clusters, matrices):
+    """list of (M_k,3) local clusters, (K,4,4) poses -> list of world-frame clusters (mlp_reg.py:155-170)."""
+    dev = matrices.device
+    pts, off = ops.pack_clusters(local_clusters, dev)
+    out = ops.cluster_transform(pts, off, matrices.to(torch.float32))
+    sizes = [int(c.shape[0]) for c in local_clusters]
+    return list(torch.split(out, sizes, dim=0))
+
+
+def resample_cluster(segments, idx, n_clusters, matrices, normal=False, visual=False):
+    """Re-segment frame ``idx`` around the current poses and express each cluster in its pose frame
+    (mlp_reg.py:172-237): k_means(init = pose translations, n_init=1) -> labels -> inv(M_k).[p;1]."""
+    if normal or visual:
+        raise NotImplementedError("normal / visual branches need Open3D (out of scope)")
+    dev = torch.device("cuda")
+    pc_np = np.asarray(segments.pc_list[idx].points)
+    X = torch.as_tensor(pc_np, dtype=torch.float64, device=dev).contiguous()
+    M = torch.as_tensor(np.asarray(matrices), device=dev).to(torch.float64).contiguous()
+    if M.shape[0] != n_clusters:
+        raise ValueError("matrices must hold n_clusters poses")
+    _, labels, _, _ = ops.kmeans_lloyd(X, M[:, :3, 3].contiguous())
+    local, off = ops.group_to_local(X, labels, M)
+    off_h, local_h = off.cpu().numpy(), local.cpu().numpy()
+    if (np.diff(off_h) == 0).any():
+        import warnings
+        warnings.warn(f"Number of distinct clusters ({int((np.diff(off_h) > 0).sum())}) found smaller than "
+                      f"n_clusters ({n_clusters}). Possibly due to duplicate points in X.")
+    return [local_h[off_h[i]:off_h[i + 1]] for i in range(n_clusters)]
+
+
+def _make_models():
+    if ROT == "dq":
+        print("Using DQRegMLP")
+        return DQRegMLP(hidden_dim=512).to(DEVICE), DQRegMLP(hidden_dim=512).to(DEVICE)
+    if ROT == "q":
+        print("Using QRegMLP")
+        return QRegMLP(True, hidden_dim=512).to(DEVICE), QRegMLP(True, hidden_dim=512).to(DEVICE)
+    if ROT == "rpy":
+        return RegMLP(6, 3), RegMLP(6, 3)              # raises: out of scope
+    return RRegMLP(hidden_dim=512), RRegMLP(hidden_dim=512)
+
+
+def register_sequence(seg, step_matrices, step_cluster_np, save_dir=None, mlp_icp=False, models=None, loss_log=None):
+    """Frames 1..T-1 of one sequence (the loop body of ``match``, mlp_reg.py:293-378), on arrays.
+    Returns (list of (K,4,4) poses per frame incl. frame 0, best losses)."""
+    K = len(step_cluster_np)
+    m_t = torch.tensor(np.asarray(step_matrices), dtype=torch.float32).to(DEVICE)
+    cl_t = [torch.tensor(step_cluster_np[i], dtype=torch.float32).to(DEVICE) for i in range(K)]
+    cl_init = [c.clone() for c in cl_t]
+    model, model_rf = models if models is not None else _make_models()
+    poses, best_losses = [np.asarray(step_matrices)], []
+    for i in range(0, seg.data_size - 1):
+        target_np = np.array(seg.pc_list[i + 1].points)
+        target = torch.tensor(target_np, dtype=torch.float32).to(DEVICE)
+        if mlp_icp:
+            pred_np, _, step_m, best_loss = train(m=m_t, y=target, model=model, clusters=cl_t)
+            best_losses.append(best_loss)
+            step_m_np = step_m.detach().cpu().numpy()
+            _, matrices = masked_icp(step_cluster_np, pred_np, target_np, step_m_np, False, ori=False)
+            new_seg_np = resample_cluster(seg, i + 1, K, matrices)
+            m_t = torch.tensor(matrices, dtype=torch.float32).to(DEVICE)
+            out_m = matrices
+        else:
+            _, _, step_m, _ = train(m=m_t, y=target, model=model, clusters=cl_t)                 # "Step"
+            m_t = step_m.detach().clone().to(DEVICE)
+            _, _, step_m, best_loss = train(m=m_t, y=target, model=model_rf, clusters=cl_init,
+                                            learning_rate=0.0001)                                 # "Anchor"
+            m_t = step_m.detach().clone().to(DEVICE)
+            best_losses.append(best_loss)
+            out_m = step_m.detach().cpu().numpy()
+            new_seg_np = resample_cluster(seg, i + 1, K, out_m)
+        step_cluster_np = new_seg_np
+        cl_t = [torch.tensor(new_seg_np[j], dtype=torch.float32).to(DEVICE) for j in range(K)]
+        poses.append(out_m)
+        if save_dir is not None:
+            np.save(save_dir + f"matrix/{(i + 1):04}.npy", out_m)
+            save_pc_npz(new_seg_np, save_dir + f"cluster/{(i + 1):04}.npz")
+    return poses, best_losses
+
+
+def match(data_dir, idx):
+    """One sequence ("video"): frame-0 state (fresh k-means++ for the very first sequence, otherwise
+    reloaded from the first output directory, mlp_reg.py:242-253), then frames 1..T-1."""
+    save_dir_list = sorted(glob.glob(f"data/part/{ROBOT}_{NUM_SEG}_seg/{STEP_SZIE}_deg_{NUM_CAMERAS}_cams/*/"))
+    if len(save_dir_list) == 0:
+        seg0 = Segments(RAW_PATH_LIST[0])
+        seg0.k_means_cluster(0, NUM_SEG, NORMAL)
+        step_matrices = np.array(seg0.init_matrix_list)
+        step_cluster_np = seg0.init_segment_list
+    else:
+        first_dir = save_dir_list[0]
+        step_matrices = np.load(first_dir + "matrix/0000.npy")
+        step_cluster_np = load_pc_npz(first_dir + "cluster/0000.npz")
+    sub_dir = data_dir.split("/")[-2]
+    save_dir = f"data/part/{ROBOT}_{NUM_SEG}_seg/{STEP_SZIE}_deg_{NUM_CAMERAS}_cams/{sub_dir}/"
+    os.makedirs(save_dir + "cluster", exist_ok=True)
+    os.makedirs(save_dir + "matrix", exist_ok=True)
+    np.save(save_dir + "matrix/0000.npy", step_matrices)
+    save_pc_npz(step_cluster_np, save_dir + "cluster/0000.npz")
+    seg = Segments(data_dir)
+    _, best_losses = register_sequence(seg, step_matrices, step_cluster_np, save_dir, mlp_icp=MLP_ICP)
+    if LOSS:
+        np.savetxt(save_dir + "loss.txt", best_losses)
+
+
+def main(argv=None):
+    global DEVICE, ROBOT, NUM_SEG, DOF, STEP_SZIE, NUM_CAMERAS, MLP_ICP, VIS, ROT, LOSS, NORMAL, RAW_PATH_LIST
+    if not torch.cuda.is_available():
+        raise RuntimeError("autourdf_amd.mlp_reg needs an MI355X: no GPU is visible and there is no CPU path")
+    DEVICE = torch.device("cuda")
+    print("Using device:", DEVICE)
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--robot", type=str, default="nao")
+    parser.add_argument("--mlp_icp", action="store_true")
+    parser.add_argument("--visual", action="store_true")
+    parser.add_argument("--loss", action="store_true")
+    parser.add_argument("--normal", action="store_true")
+    parser.add_argument("--num_cameras", type=int, default=20)
+    parser.add_argument("--step_size", type=int, default=4)
+    parser.add_argument("--num_video", type=int, default=5)
+    parser.add_argument("--r", type=str, default="q", choices=["q", "rpy", "dq", "6d"])
+    args = parser.parse_args(argv)
+    with open("parameters.json") as f:
+        robot_params = json.load(f)[args.robot]
+    ROBOT, NUM_SEG, DOF = args.robot, robot_params["num_seg"], robot_params["dof"]
+    STEP_SZIE, NUM_CAMERAS = args.step_size, args.num_cameras
+    MLP_ICP, VIS, ROT, LOSS, NORMAL = args.mlp_icp, args.visual, args.r, args.loss, args.normal
+    if VIS:
+        raise NotImplementedError("--visual needs Open3D's GUI (out of scope)")
+    RAW_PATH_LIST = sorted(glob.glob(f"data/raw/{ROBOT}/{STEP_SZIE}_deg_{NUM_CAMERAS}_cams/*/"))
+    if len(RAW_PATH_LIST) == 0:
+        RAW_PATH_LIST = sorted(glob.glob(f"data/raw/{ROBOT}/*/"))
+    print(f"Found {len(RAW_PATH_LIST)} raw data directories")
+    for i, data_dir in enumerate(RAW_PATH_LIST[: args.num_video]):
+        match(data_dir, i)
+
+
+if __name__ == "__main__":
+    main()

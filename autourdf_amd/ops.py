@@ -1,0 +1,263 @@
+"""torch-facing wrappers over the C ABI: tensors in, tensors out, current CUDA(HIP) stream.
+
+Only plumbing lives here (pointer extraction, output allocation, autograd glue); all arithmetic is
+in libcreg.so.  Every function requires CUDA tensors and raises otherwise -- no CPU path exists.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor on the MI355X (autourdf_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# ------------------------------------------------------------------------------ K1 nearest neighbour
+def nn_l1_bidir(x: torch.Tensor, y: torch.Tensor):
+    """x (nx,3), y (ny,3) fp32 -> (dx, ix, dy, iy): L1 nearest neighbour both ways, first min wins."""
+    L = _lib.load()
+    x, y = _need(x, torch.float32, "x"), _need(y, torch.float32, "y")
+    nx, ny = x.shape[0], y.shape[0]
+    if nx == 0 or ny == 0:
+        raise ValueError("nn_l1_bidir: empty point cloud")      # pytorch3d rejects it as well
+    dx = torch.empty(nx, dtype=torch.float32, device=x.device)
+    dy = torch.empty(ny, dtype=torch.float32, device=x.device)
+    ix = torch.empty(nx, dtype=torch.int64, device=x.device)
+    iy = torch.empty(ny, dtype=torch.int64, device=x.device)
+    _lib.check(L.creg_nn_l1_bidir_f32(_p(x), nx, _p(y), ny, _p(dx), _p(ix), _p(dy), _p(iy), _stream()),
+               "creg_nn_l1_bidir_f32")
+    return dx, ix, dy, iy
+
+
+class _ChamferL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        L = _lib.load()
+        dx, ix, dy, iy = nn_l1_bidir(x, y)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        _lib.check(L.creg_chamfer_l1_reduce_f32(_p(dx), dx.numel(), _p(dy), dy.numel(), _p(loss), _stream()),
+                   "creg_chamfer_l1_reduce_f32")
+        ctx.save_for_backward(x.detach().contiguous(), y.detach().contiguous(), ix, iy)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.load()
+        x, y, ix, iy = ctx.saved_tensors
+        nx, ny = x.shape[0], y.shape[0]
+        grad = torch.empty_like(x)
+        scratch = torch.empty(L.creg_nn_l1_bwd_scratch_bytes(nx), dtype=torch.uint8, device=x.device)
+        one = torch.tensor(1.0, dtype=torch.float32)
+        gx, gy = float(one / nx), float(one / ny)
+        _lib.check(L.creg_nn_l1_bwd_f32(_p(x), nx, _p(y), ny, _p(ix), _p(iy), gx, gy, _p(grad), _p(scratch),
+                                        _stream()), "creg_nn_l1_bwd_f32")
+        return grad * g, None
+
+
+def chamfer_distance(x: torch.Tensor, y: torch.Tensor, norm: int = 1):
+    """pytorch3d.loss.chamfer_distance(x, y, norm=1) for the reference's call (mlp_reg.py:96):
+    x (1,P1,3) with grad, y (1,P2,3); returns (loss, None)."""
+    if norm != 1:
+        raise NotImplementedError("only norm=1 is on the registration path")
+    if x.dim() != 3 or x.shape[0] != 1 or y.shape[0] != 1:
+        raise NotImplementedError("batch of 1 only (as the reference calls it)")
+    return _ChamferL1.apply(_need(x[0], torch.float32, "x"), _need(y[0], torch.float32, "y")), None
+
+
+# ------------------------------------------------------------------------------ K3 cluster transform
+class _ClusterTransform(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, offsets, M):
+        L = _lib.load()
+        out = torch.empty_like(pts)
+        k = M.shape[0]
+        _lib.check(L.creg_cluster_transform_f32(_p(pts), pts.shape[0], _p(offsets), k, _p(M), _p(out), _stream()),
+                   "creg_cluster_transform_f32")
+        ctx.save_for_backward(pts, offsets)
+        ctx.k = k
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.load()
+        pts, offsets = ctx.saved_tensors
+        gM = torch.empty(ctx.k, 4, 4, dtype=torch.float32, device=pts.device)
+        _lib.check(L.creg_cluster_transform_bwd_f32(_p(pts), _p(offsets), ctx.k, _p(g.contiguous()), _p(gM), _stream()),
+                   "creg_cluster_transform_bwd_f32")
+        return None, None, gM
+
+
+def cluster_transform(pts: torch.Tensor, offsets: torch.Tensor, M: torch.Tensor) -> torch.Tensor:
+    """pts (n,3) fp32 clusters back to back, offsets (k+1) int32, M (k,4,4) fp32 -> world points."""
+    return _ClusterTransform.apply(_need(pts, torch.float32, "pts"), _need(offsets, torch.int32, "offsets"),
+                                   _need(M, torch.float32, "M"))
+
+
+def pack_clusters(clusters, device, dtype=torch.float32):
+    """list of (M_k,3) tensors/arrays -> (flat (n,3) tensor, offsets (k+1) int32 tensor), on `device`."""
+    ts = [torch.as_tensor(c, dtype=dtype).reshape(-1, 3) for c in clusters]
+    sizes = [t.shape[0] for t in ts]
+    off = torch.zeros(len(ts) + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(torch.tensor(sizes, dtype=torch.int64), 0).to(torch.int32)
+    flat = torch.cat([t.to(device) for t in ts], 0) if ts else torch.zeros(0, 3, dtype=dtype, device=device)
+    return flat.contiguous(), off.to(device)
+
+
+# ------------------------------------------------------------------------------ K2 k-means
+def kmeans_lloyd(X: torch.Tensor, init: torch.Tensor, max_iter: int = 300, tol: float = 1e-4,
+                 use_mfma: bool = False):
+    """sklearn.cluster.k_means(X, init=init, n_init=1): returns (centers (k,3) f64, labels (n) int32,
+    inertia (1) f64, n_iter (1) int32), all on the device."""
+    L = _lib.load()
+    X, init = _need(X, torch.float64, "X"), _need(init, torch.float64, "init")
+    n, k = X.shape[0], init.shape[0]
+    ws_bytes = L.creg_kmeans_workspace_bytes(n, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
+    centers = torch.empty(k, 3, dtype=torch.float64, device=X.device)
+    labels = torch.empty(n, dtype=torch.int32, device=X.device)
+    inertia = torch.empty(1, dtype=torch.float64, device=X.device)
+    n_iter = torch.empty(1, dtype=torch.int32, device=X.device)
+    _lib.check(L.creg_kmeans_lloyd_f64(_p(X), n, _p(init), k, max_iter, tol, int(use_mfma), _p(centers), _p(labels),
+                                       _p(inertia), _p(n_iter), _p(ws), ws_bytes, _stream()), "creg_kmeans_lloyd_f64")
+    return centers, labels, inertia, n_iter
+
+
+def kmeans_assign(X: torch.Tensor, C: torch.Tensor, use_mfma: bool = False) -> torch.Tensor:
+    L = _lib.load()
+    X, C = _need(X, torch.float64, "X"), _need(C, torch.float64, "C")
+    labels = torch.empty(X.shape[0], dtype=torch.int32, device=X.device)
+    _lib.check(L.creg_kmeans_assign_f64(_p(X), X.shape[0], _p(C), C.shape[0], int(use_mfma), _p(labels), _stream()),
+               "creg_kmeans_assign_f64")
+    return labels
+
+
+def group_to_local(X: torch.Tensor, labels: torch.Tensor, M: torch.Tensor):
+    """Stable grouping by label and inv(M_k) change of frame: returns (local (n,3) f64, offsets (k+1) int32)."""
+    L = _lib.load()
+    X, labels, M = _need(X, torch.float64, "X"), _need(labels, torch.int32, "labels"), _need(M, torch.float64, "M")
+    k = M.shape[0]
+    out = torch.empty_like(X)
+    off = torch.empty(k + 1, dtype=torch.int32, device=X.device)
+    _lib.check(L.creg_group_to_local_f64(_p(X), X.shape[0], _p(labels), k, _p(M), _p(out), _p(off), _stream()),
+               "creg_group_to_local_f64")
+    return out, off
+
+
+# ------------------------------------------------------------------------------ K5 row conversions
+def _rows(fn_name, a, out_shape, b=None, out2_shape=None):
+    L = _lib.load()
+    a = _need(a, torch.float32, "input")
+    k = a.shape[0]
+    out = torch.empty((k,) + out_shape, dtype=torch.float32, device=a.device)
+    fn = getattr(L, fn_name)
+    if out2_shape is not None:
+        out2 = torch.empty((k,) + out2_shape, dtype=torch.float32, device=a.device)
+        _lib.check(fn(_p(a), k, _p(out), _p(out2), _stream()), fn_name)
+        return out, out2
+    if b is not None:
+        b = _need(b, torch.float32, "input")
+        _lib.check(fn(_p(a), _p(b), k, _p(out), _stream()), fn_name)
+    else:
+        _lib.check(fn(_p(a), k, _p(out), _stream()), fn_name)
+    return out
+
+
+def se3_to_dq(M): return _rows("creg_se3_to_dq_f32", M, (8,))
+def dq_to_se3(dq): return _rows("creg_dq_to_se3_f32", dq, (4, 4))
+def dq_to_se3_bwd(dq, gM): return _rows("creg_dq_to_se3_bwd_f32", dq, (8,), b=gM)
+def dq_multiply(a, b): return _rows("creg_dq_multiply_f32", a, (8,), b=b)
+def dq_invert(dq): return _rows("creg_dq_invert_f32", dq, (8,))
+def dq_to_quat_trans(dq): return _rows("creg_dq_to_quat_trans_f32", dq, (4,), out2_shape=(3,))
+def quat_trans_to_dq(q, t): return _rows("creg_quat_trans_to_dq_f32", q, (8,), b=t)
+def matrix_to_quat(R): return _rows("creg_matrix_to_quat_f32", R, (4,))
+def quat_to_matrix(q): return _rows("creg_quat_to_matrix_f32", q, (3, 3))
+
+
+# ------------------------------------------------------------------------------ A1 train plan
+Q_PARAM_ORDER = ["encoder.0.weight", "encoder.0.bias", "decoder_1.0.weight", "decoder_1.0.bias",
+                 "decoder_1.2.weight", "decoder_1.2.bias", "decoder_2.0.weight", "decoder_2.0.bias",
+                 "decoder_2.2.weight", "decoder_2.2.bias"]
+DQ_PARAM_ORDER = ["encoder.0.weight", "encoder.0.bias", "decoder.0.weight", "decoder.0.bias",
+                  "decoder.2.weight", "decoder.2.bias"]
+
+
+class TrainPlan:
+    """Device-resident `train` loop (mlp_reg.py:17-152) for one (rot, K, hidden, N) shape."""
+
+    def __init__(self, rot: str, k: int, hidden: int, n_pred: int, n_tgt: int, epochs: int = 300,
+                 use_graph: bool = True, device=None):
+        self.L = _lib.load()
+        self.rot = {"q": 0, "dq": 1}[rot]
+        self.device = torch.device(device if device is not None else "cuda")
+        self.shape = _lib.TrainShape(self.rot, k, hidden, epochs, n_pred, n_tgt, int(use_graph), 0)
+        need = self.L.creg_train_workspace_bytes(ctypes.byref(self.shape))
+        if need == 0:
+            raise ValueError("unsupported train shape")
+        self.ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        base = (self.ws.data_ptr() + 255) // 256 * 256
+        self.plan = ctypes.c_void_p()
+        _lib.check(self.L.creg_train_plan_create(ctypes.byref(self.shape), ctypes.c_void_p(base), need,
+                                                 ctypes.byref(self.plan)), "creg_train_plan_create")
+        self.k, self.n_pred, self.n_tgt, self.epochs = k, n_pred, n_tgt, epochs
+
+    def __del__(self):
+        if getattr(self, "plan", None) and self.plan.value:
+            self.L.creg_train_plan_destroy(self.plan)
+            self.plan = ctypes.c_void_p()
+
+    def _args(self, m, y, pts, offsets, params, lr, factor, patience, stop, outs):
+        n = 10 if self.rot == 0 else 6
+        if len(params) != n:
+            raise ValueError(f"expected {n} parameter tensors, got {len(params)}")
+        self._keep = [_need(m, torch.float32, "m"), _need(y, torch.float32, "y"), _need(pts, torch.float32, "pts"),
+                      _need(offsets, torch.int32, "offsets")]
+        for p in params:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise TypeError("model parameters must be contiguous fp32 CUDA tensors")
+        arr = (ctypes.c_void_p * n)(*[p.data_ptr() for p in params])
+        self._arr = arr
+        a = _lib.TrainArgs()
+        a.m, a.y, a.local_pts, a.seg_offsets = [t.data_ptr() for t in self._keep]
+        a.params = ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
+        a.lr, a.sched_factor, a.sched_patience, a.stop = lr, factor, patience, stop
+        a.best_m, a.best_pred, a.loss_hist, a.lr_hist, a.result = [o.data_ptr() if o is not None else None for o in outs]
+        return a
+
+    def run(self, m, y, pts, offsets, params, lr=2e-4, factor=0.7, patience=5, stop=200):
+        """Returns (best_m (k,4,4), best_pred (n_pred,3), result (4) = [min_loss, epochs_run, lr,
+        best_epoch], loss_hist (epochs), lr_hist (epochs)); all device tensors, stream-ordered."""
+        dev = self.device
+        best_m = torch.empty(self.k, 4, 4, dtype=torch.float32, device=dev)
+        best_pred = torch.empty(self.n_pred, 3, dtype=torch.float32, device=dev)
+        result = torch.empty(4, dtype=torch.float32, device=dev)
+        lh = torch.empty(self.epochs, dtype=torch.float32, device=dev)
+        lrh = torch.empty(self.epochs, dtype=torch.float32, device=dev)
+        a = self._args(m, y, pts, offsets, params, lr, factor, patience, stop, (best_m, best_pred, lh, lrh, result))
+        _lib.check(self.L.creg_train_plan_run(self.plan, ctypes.byref(a), _stream()), "creg_train_plan_run")
+        return best_m, best_pred, result, lh, lrh
+
+    def probe(self, m, y, pts, offsets, params):
+        """One forward + pose-gradient evaluation (test hook): (m2, pred, loss, grad_m2)."""
+        dev = self.device
+        m2 = torch.empty(self.k, 4, 4, dtype=torch.float32, device=dev)
+        pred = torch.empty(self.n_pred, 3, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        gm = torch.empty(self.k, 4, 4, dtype=torch.float32, device=dev)
+        a = self._args(m, y, pts, offsets, params, 2e-4, 0.7, 5, 200, (None, None, None, None, None))
+        _lib.check(self.L.creg_train_plan_probe(self.plan, ctypes.byref(a), _p(m2), _p(pred), _p(loss), _p(gm),
+                                                _stream()), "creg_train_plan_probe")
+        return m2, pred, loss, gm

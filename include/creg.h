@@ -1,0 +1,200 @@
+/*
+ * creg.h -- C ABI of libcreg.so: MI355X (gfx950) kernels for AutoURDF's cluster-registration path.
+ *
+ * The reference (jl6017/AutoURDF) is pure Python and has no FFI layer of its own; the boundary
+ * that `match()` / scripts/registration.sh exercise is the Python module surface of
+ * PointCloud/{mlp_reg,cluster_icp,dq_func}.py.  Each entry point below names the
+ * reference interface (file:line under /root/reference) whose arithmetic it replaces; the
+ * same-named Python modules in autourdf_amd/ bind these through ctypes (autourdf_amd/_lib.py),
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - Every data pointer is a DEVICE pointer on the current HIP device unless marked HOST.
+ *   - Row-major, xyz interleaved (N,3) exactly as the reference stores clouds (mlp_reg.py:296).
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *     All work is enqueued asynchronously on it; nothing synchronises unless documented.
+ *   - The library never allocates caller-visible memory and keeps no pointer after return,
+ *     except inside an explicit plan object (creg_train_plan_*), which owns only the workspace
+ *     the caller handed it.
+ *   - Return 0 on success, a negative creg_status otherwise; creg_last_error() gives the
+ *     thread-local message.  No exception crosses the boundary.
+ *   - Quaternions are real-first (w,x,y,z); dual quaternions are [real | dual] (8 floats).
+ */
+#ifndef CREG_H
+#define CREG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* creg_stream_t;
+
+enum creg_status {
+    CREG_OK = 0,
+    CREG_EINVAL = -1,       /* bad argument (null pointer, negative size, unsupported option) */
+    CREG_EHIP = -2,         /* a HIP runtime call failed */
+    CREG_ENOTCONVERGED = -3,
+    CREG_EARCH = -4         /* current device is not gfx950 */
+};
+
+int creg_version(void);                 /* 10000*major + 100*minor + patch */
+const char* creg_last_error(void);
+/* 0 when the current device is a gfx950 part; CREG_EARCH / CREG_EHIP otherwise. */
+int creg_device_check(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  L1 nearest neighbour (K=1), both directions of the Chamfer term.
+ * Replaces pytorch3d knn_points as reached by chamfer_distance(pred, y, norm=1) at
+ * mlp_reg.py:96 (and Sim/evaluation.py:81).  d = (|dx|+|dy|)+|dz| in fp32, FIRST minimum wins.
+ * x (nx,3), y (ny,3) fp32.  dx (nx) / ix (nx): distance / index of the nearest y for every x;
+ * dy (ny) / iy (ny): the same for every y among x.  Either direction may be skipped by passing
+ * NULL for both of its outputs.  nx, ny >= 1. */
+int creg_nn_l1_bidir_f32(const float* x, int64_t nx, const float* y, int64_t ny,
+                         float* dx, int64_t* ix, float* dy, int64_t* iy, creg_stream_t stream);
+
+/* Backward of  gx_scale * sum_i |x_i - y[ix_i]|_1 + gy_scale * sum_j |y_j - x[iy_j]|_1  w.r.t. x
+ * with pytorch3d's sign rule (p1 > p2 ? +1 : -1).  grad_x (nx,3) is overwritten.
+ * `scratch` must hold creg_nn_l1_bwd_scratch_bytes(nx) bytes. */
+size_t creg_nn_l1_bwd_scratch_bytes(int64_t nx);
+int creg_nn_l1_bwd_f32(const float* x, int64_t nx, const float* y, int64_t ny,
+                       const int64_t* ix, const int64_t* iy, float gx_scale, float gy_scale,
+                       float* grad_x, void* scratch, creg_stream_t stream);
+
+/* mean_i dx_i + mean_j dy_j  -> *loss (one float, device).  Replaces the reduction half of
+ * chamfer_distance (point_reduction = batch_reduction = "mean", batch 1). */
+int creg_chamfer_l1_reduce_f32(const float* dx, int64_t nx, const float* dy, int64_t ny,
+                               float* loss, creg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3  per-cluster rigid transform.  Replaces calculate_pc (mlp_reg.py:155-170):
+ * out[i] = R_k pts[i] + t_k for i in [seg_offsets[k], seg_offsets[k+1]), n = seg_offsets[k_last+1].
+ * pts/out (n,3) fp32, M (k,4,4) fp32 row-major, seg_offsets (k+1) int32 DEVICE. */
+int creg_cluster_transform_f32(const float* pts, int64_t n, const int32_t* seg_offsets, int32_t k,
+                               const float* M, float* out, creg_stream_t stream);
+/* grad_M (k,4,4): rows 0..2 get [sum g (x) p | sum g], row 3 is zero. */
+int creg_cluster_transform_bwd_f32(const float* pts, const int32_t* seg_offsets, int32_t k,
+                                   const float* grad_out, float* grad_M, creg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  Lloyd k-means, fp64, 3-D.  Replaces sklearn.cluster.k_means(X, init=<array>, n_init=1)
+ * as called by resample_cluster (mlp_reg.py:204) and Segments.k_means_cluster
+ * (cluster_icp.py:67, after k-means++ seeding on the host).
+ *   distance  d = fma(x2,b2, fma(x1,b1, fma(x0,b0, |c|^2))),  b = -2c   (first minimum wins)
+ * X (n,3) fp64 is read only (centring happens on an internal copy), init (k,3) fp64.
+ * Outputs: centers (k,3) fp64, labels (n) int32, inertia (1) fp64, n_iter (1) int32 -- device.
+ * use_mfma != 0 selects the v_mfma_f64_16x16x4_f64 assignment kernel (bit-identical results).
+ * This call synchronises the stream periodically to read the convergence flag. */
+size_t creg_kmeans_workspace_bytes(int64_t n, int32_t k);
+int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* init, int32_t k,
+                          int32_t max_iter, double tol_rel, int32_t use_mfma,
+                          double* centers, int32_t* labels, double* inertia, int32_t* n_iter,
+                          void* workspace, size_t workspace_bytes, creg_stream_t stream);
+/* E-step only: labels[i] = argmin_k d(X_i, C_k) (no centring).  Asynchronous. */
+int creg_kmeans_assign_f64(const double* X, int64_t n, const double* C, int32_t k,
+                           int32_t use_mfma, int32_t* labels, creg_stream_t stream);
+
+/* Stable grouping of points by label + change of frame, fp64.  Replaces the per-cluster mask /
+ * inv(M_k) . [p;1] loop of resample_cluster (mlp_reg.py:208-217) and Segments.k_means_cluster
+ * (cluster_icp.py:86-99).  M (k,4,4) fp64 local->world; out_local (n,3) holds the clusters
+ * back to back in label order, each keeping the original point order; seg_offsets (k+1) int32. */
+int creg_group_to_local_f64(const double* X, int64_t n, const int32_t* labels, int32_t k,
+                            const double* M, double* out_local, int32_t* seg_offsets,
+                            creg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5  SE(3) <-> dual quaternion.  Replace transform_to_dualquat (dq_func.py:100-124) and
+ * dualquat_to_transform (dq_func.py:170-186) incl. the pytorch3d matrix_to_quaternion /
+ * quaternion_to_matrix they call.  M (k,4,4), dq (k,8) fp32.  The *_bwd forms give the vector-
+ * Jacobian products used when these sit inside autograd (mlp_reg.py:78-84). */
+int creg_se3_to_dq_f32(const float* M, int32_t k, float* dq, creg_stream_t stream);
+int creg_dq_to_se3_f32(const float* dq, int32_t k, float* M, creg_stream_t stream);
+int creg_dq_to_se3_bwd_f32(const float* dq, const float* grad_M, int32_t k, float* grad_dq,
+                           creg_stream_t stream);
+/* Remaining dq_func.py algebra on (k,8)/(k,4) rows (dq_func.py:29,47,126,148,188,213,238). */
+int creg_dq_multiply_f32(const float* a, const float* b, int32_t k, float* out, creg_stream_t stream);
+int creg_dq_invert_f32(const float* dq, int32_t k, float* out, creg_stream_t stream);
+int creg_dq_to_quat_trans_f32(const float* dq, int32_t k, float* q, float* t, creg_stream_t stream);
+int creg_quat_trans_to_dq_f32(const float* q, const float* t, int32_t k, float* dq, creg_stream_t stream);
+/* pytorch3d.transforms rows used on the path (mlp_reg.py:65,68). */
+int creg_matrix_to_quat_f32(const float* R, int32_t k, float* q, creg_stream_t stream);   /* R (k,3,3) */
+int creg_quat_to_matrix_f32(const float* q, int32_t k, float* R, creg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4  masked point-to-point ICP per cluster, fp64.  Replaces masked_icp (cluster_icp.py:118-191)
+ * including open3d registration_icp (TransformationEstimationPointToPoint, max_iteration,
+ * relative_fitness = relative_rmse = 1e-6).
+ * local (n,3) fp64 clusters back to back, world (n,3) fp32 predicted clusters (AABB source),
+ * frame (nf,3) fp64 target, M (k,4,4) fp64 initial poses.  M_out (k,4,4) fp64,
+ * world_out (n,3) fp64 = M_out applied to local.  keep_translation mirrors `ori`.
+ * workspace: creg_icp_workspace_bytes(n, nf, k). */
+size_t creg_icp_workspace_bytes(int64_t n, int64_t nf, int32_t k);
+int creg_masked_icp_f64(const double* local, const float* world, const int32_t* seg_offsets,
+                        int32_t k, const double* frame, int64_t nf, const double* M,
+                        double scale, double th, int32_t max_iteration, int32_t keep_translation,
+                        double* M_out, double* world_out, int32_t* n_iter_out,
+                        void* workspace, size_t workspace_bytes, creg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A1  the whole `train` loop (mlp_reg.py:17-152) as one device-resident plan: per epoch
+ * pose -> sin/cos features -> MLP -> pose -> calculate_pc -> L1 Chamfer -> backward -> Adam ->
+ * ReduceLROnPlateau, best-loss tracking and early stop, with no host round trip per epoch
+ * (the reference syncs on loss.item() every epoch, mlp_reg.py:102).
+ *
+ * rot = 0: ROT == 'q'  with QRegMLP(True, hidden)  (model_utils.py:101-159)
+ * rot = 1: ROT == 'dq' with DQRegMLP(hidden)       (model_utils.py:65-99)
+ * Parameter order in `params` (torch nn.Linear layout, weight (out,in) row-major):
+ *   rot 0: encoder.0.{weight,bias}, decoder_1.0.{w,b}, decoder_1.2.{w,b}, decoder_2.0.{w,b},
+ *          decoder_2.2.{w,b}                                        (10 tensors)
+ *   rot 1: encoder.0.{w,b}, decoder.0.{w,b}, decoder.2.{w,b}        (6 tensors)
+ */
+typedef struct creg_train_shape {
+    int32_t rot;          /* 0 'q', 1 'dq' */
+    int32_t k;            /* clusters (poses) */
+    int32_t hidden;       /* hidden_dim, multiple of 64, <= 1024 */
+    int32_t epochs;       /* 300 in the reference (mlp_reg.py:60) */
+    int64_t n_pred;       /* sum of cluster sizes */
+    int64_t n_tgt;        /* points in the target frame */
+    int32_t use_graph;    /* replay the epoch as a captured hipGraph instead of eager launches */
+    int32_t reserved;
+} creg_train_shape;
+
+typedef struct creg_train_args {
+    const float* m;             /* (k,4,4) current poses */
+    const float* y;             /* (n_tgt,3) target frame */
+    const float* local_pts;     /* (n_pred,3) clusters in local frames, back to back */
+    const int32_t* seg_offsets; /* (k+1) int32, DEVICE */
+    float* const* params;       /* HOST array of 10 (rot 0) / 6 (rot 1) device pointers; updated in place */
+    float lr;                   /* 2e-4 (Step) / 1e-4 (Anchor), mlp_reg.py:17,354 */
+    float sched_factor;         /* 0.7 */
+    int32_t sched_patience;     /* 5 */
+    int32_t stop;               /* 200 */
+    float* best_m;              /* (k,4,4) out */
+    float* best_pred;           /* (n_pred,3) out: clusters at the best epoch, back to back */
+    float* loss_hist;           /* (epochs) out, entries after an early stop are NaN; may be NULL */
+    float* lr_hist;             /* (epochs) out (lr used by that epoch's Adam step); may be NULL */
+    float* result;              /* (4) out: [min_loss, epochs_run, final_lr, best_epoch] */
+} creg_train_args;
+
+typedef struct creg_train_plan creg_train_plan;
+
+size_t creg_train_workspace_bytes(const creg_train_shape* shape);
+/* `workspace` (device, 256-byte aligned) must stay valid until creg_train_plan_destroy. */
+int creg_train_plan_create(const creg_train_shape* shape, void* workspace, size_t workspace_bytes,
+                           creg_train_plan** plan);
+/* Enqueues the whole loop on `stream`; asynchronous (outputs are ready when the stream is). */
+int creg_train_plan_run(creg_train_plan* plan, const creg_train_args* args, creg_stream_t stream);
+int creg_train_plan_destroy(creg_train_plan* plan);
+
+/* Test / profiling hook: run exactly one epoch's forward and return intermediates.
+ * m2 (k,4,4), pred (n_pred,3), loss (1), grad_m2 (k,4,4: [dL/dR | dL/dt]); any may be NULL. */
+int creg_train_plan_probe(creg_train_plan* plan, const creg_train_args* args, float* m2,
+                          float* pred, float* loss, float* grad_m2, creg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CREG_H */

@@ -1,0 +1,126 @@
+"""CPU: host logic and the C-ABI surface (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_build_produces_library_and_every_declared_symbol_resolves():
+    from autourdf_amd.build import build_lib
+    lib_path = build_lib()
+    assert os.path.exists(lib_path)
+    header = open(os.path.join(ROOT, "include", "creg.h")).read()
+    declared = set(re.findall(r"\b(creg_[a-z0-9_]+)\s*\(", header))
+    declared -= {"creg_status"}
+    from autourdf_amd import _lib
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = ctypes.CDLL(lib_path)
+    for name in declared:
+        assert getattr(L, name) is not None
+    lib = _lib.load(check_device=False)
+    assert lib.creg_version() >= 100
+
+
+def test_product_path_has_no_cpu_fallback_and_never_imports_the_oracle():
+    import torch
+    from autourdf_amd import dq_func, ops
+    with pytest.raises(RuntimeError):
+        ops.nn_l1_bidir(torch.zeros(4, 3), torch.zeros(4, 3))
+    with pytest.raises(RuntimeError):
+        dq_func.transform_to_dualquat(torch.eye(4)[None])
+    pkg = os.path.join(ROOT, "autourdf_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+            assert "/root/reference" not in src, fn
+
+
+def test_drop_in_signatures_match_the_reference_surface():
+    import inspect
+    from autourdf_amd import cluster_icp, dq_func, helper_functions, mlp_reg, model_utils
+    sig = lambda f: list(inspect.signature(f).parameters)
+    assert sig(mlp_reg.train) == ["m", "y", "model", "clusters", "stop", "learning_rate", "scheduler_patience",
+                                  "scheduler_factor"]
+    d = inspect.signature(mlp_reg.train).parameters
+    assert (d["stop"].default, d["learning_rate"].default, d["scheduler_patience"].default,
+            d["scheduler_factor"].default) == (200, 0.0002, 5, 0.7)
+    assert sig(mlp_reg.calculate_pc) == ["local_clusters", "matrices"]
+    assert sig(mlp_reg.resample_cluster) == ["segments", "idx", "n_clusters", "matrices", "normal", "visual"]
+    assert sig(mlp_reg.match) == ["data_dir", "idx"]
+    assert sig(cluster_icp.masked_icp)[:9] == ["clusters_local", "clusters_world", "step_pc_np", "matrices", "visual",
+                                               "ori", "scale", "th", "colors"]
+    assert sig(cluster_icp.Segments.__init__) == ["self", "data_path", "sample_size"]
+    assert sig(cluster_icp.Segments.k_means_cluster)[:5] == ["self", "pc_id", "num", "normal", "colors"]
+    for name in ("transform_from_rot_trans", "quaternion_conjugate", "quat_trans_to_dualquat", "rot_trans_to_dualquat",
+                 "transform_to_dualquat", "dualquat_to_quat_trans", "dualquat_to_rot_trans", "dualquat_to_transform",
+                 "dualquat_multiply", "dualquat_invert", "point_to_dualquat"):
+        assert callable(getattr(dq_func, name))
+    assert callable(helper_functions.save_pc_npz) and callable(helper_functions.load_pc_npz)
+    q = model_utils.QRegMLP(True, hidden_dim=512)
+    assert sum(p.numel() for p in q.parameters()) == 425991
+    from oracle import models
+    assert list(q.state_dict()) and set(q.state_dict()) == set(models.QRegMLP(True, 512).state_dict())
+    assert set(model_utils.DQRegMLP(512).state_dict()) == set(models.DQRegMLP(512).state_dict())
+
+
+def test_models_forward_match_reference_golden(golden):
+    import torch
+    from autourdf_amd import model_utils
+    g = golden("models_reference.npz")
+    q = model_utils.QRegMLP(True, hidden_dim=32)
+    q.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("q.")})
+    t, r = q(torch.from_numpy(g["q_in"]))
+    np.testing.assert_allclose(t.detach().numpy(), g["q_out_t"], atol=1e-7)
+    np.testing.assert_allclose(r.detach().numpy(), g["q_out_r"], atol=1e-7)
+    d = model_utils.DQRegMLP(hidden_dim=32)
+    d.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("dq.")})
+    np.testing.assert_allclose(d(torch.from_numpy(g["dq_in"])).detach().numpy(), g["dq_out"], atol=1e-7)
+
+
+def test_npz_roundtrip_keeps_order_and_dtype(tmp_path):
+    from autourdf_amd.helper_functions import load_pc_npz, save_pc_npz
+    rng = np.random.default_rng(0)
+    segs = [rng.normal(size=(n, 3)) for n in (5, 0, 12, 3, 7, 1, 9, 2, 4, 6, 8, 10)]     # > 10: '10' sorts after '1'
+    save_pc_npz(segs, str(tmp_path / "c.npz"))
+    back = load_pc_npz(str(tmp_path / "c.npz"))
+    assert len(back) == len(segs)
+    for a, b in zip(segs, back):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_ply_reader_ascii_and_binary(tmp_path):
+    from autourdf_amd.cluster_icp import read_point_cloud
+    pts = np.random.default_rng(1).normal(size=(17, 3))
+    p1 = tmp_path / "a.ply"
+    with open(p1, "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment x\nelement vertex 17\nproperty double x\nproperty double y\n"
+                "property double z\nend_header\n")
+        for r in pts:
+            f.write("%.17g %.17g %.17g\n" % tuple(r))
+    np.testing.assert_array_equal(read_point_cloud(str(p1)).points, pts)
+    p2 = tmp_path / "b.ply"
+    rec = np.zeros(17, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    rec["x"], rec["y"], rec["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+    with open(p2, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 17\nproperty float x\nproperty float y\n"
+                b"property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n")
+        f.write(rec.tobytes())
+    np.testing.assert_array_equal(read_point_cloud(str(p2)).points, pts.astype(np.float32).astype(np.float64))
+
+
+def test_synthetic_sequences_are_seeded_and_sized():
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    a = make_sequence("wx200_5", 2, 3, 4096)
+    b = make_sequence("wx200_5", 2, 3, 4096)
+    assert all(x.shape == (4096, 3) and x.dtype == np.float64 for x in a)
+    assert all((x == y).all() for x, y in zip(a, b))
+    assert not (a[0] == make_sequence("wx200_5", 3, 1, 4096)[0]).all()
+    mats, clusters, lab = initial_segmentation(a[0], 20, seed=0)
+    assert mats.shape == (20, 4, 4) and sum(len(c) for c in clusters) == 4096 and lab.dtype == np.int32
+    for r in ("franka", "allegro", "chain32"):
+        assert make_sequence(r, 0, 1, 512)[0].shape == (512, 3)
