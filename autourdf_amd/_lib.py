@@ -3,6 +3,9 @@ missing GPU or a non-gfx950 device raises immediately."""
 import ctypes
 import os
 
+import torch  # noqa: F401  -- FIRST: brings torch's bundled libamdhip64 (SONAME libamdhip64.so.7) into the
+#                 process so libcreg.so binds to the same HIP runtime instead of a second copy from /opt/rocm
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcreg.so")
 
@@ -66,6 +69,9 @@ def load(check_device: bool = True) -> ctypes.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m autourdf_amd.build` "
                 "(hipcc --offload-arch=gfx950). autourdf_amd has no CPU fallback.")
+        hip = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(hip):
+            ctypes.CDLL(hip, mode=ctypes.RTLD_GLOBAL)
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError if the .so lacks a declared symbol

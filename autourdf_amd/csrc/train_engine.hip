@@ -618,17 +618,20 @@ extern "C" int creg_train_plan_run(creg_train_plan* plan, const creg_train_args*
     int e = 0;
     if (P->shape.use_graph && D.epochs >= 2) {
         if (!P->graph_ready) {
-            // capture one even + one odd epoch; epoch numbers only enter the kernels through their
-            // parity and through loss_hist[epoch], so the captured pair carries a device-side
-            // epoch base instead: we keep it simple and capture with explicit epoch 0/1 kernels
-            // whose hist index is taken from state.epochs_run (see k_ctrl) -- hence parity only.
+            // capture one even + one odd epoch: the epoch number enters the kernels only through its
+            // parity (the history index comes from the device-side counter state.epochs_run).
+            // captured on a private stream (torch's current stream is usually the null stream, which
+            // cannot be captured); the instantiated graph is then launched on the caller's stream.
             hipGraph_t g;
-            CREG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            enqueue_epoch(P, 0, s);
-            enqueue_epoch(P, 1, s);
-            CREG_HIP(hipStreamEndCapture(s, &g));
+            hipStream_t cs;
+            CREG_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            CREG_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+            enqueue_epoch(P, 0, cs);
+            enqueue_epoch(P, 1, cs);
+            CREG_HIP(hipStreamEndCapture(cs, &g));
             CREG_HIP(hipGraphInstantiate(&P->gexec, g, nullptr, nullptr, 0));
             CREG_HIP(hipGraphDestroy(g));
+            CREG_HIP(hipStreamDestroy(cs));
             P->graph_ready = true;
         }
         for (; e + 2 <= D.epochs; e += 2) CREG_HIP(hipGraphLaunch(P->gexec, s));
