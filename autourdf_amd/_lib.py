@@ -55,6 +55,7 @@ SIGNATURES = {
     "creg_train_plan_create": (ctypes.c_int, [ctypes.POINTER(TrainShape), vp, sz, ctypes.POINTER(vp)]),
     "creg_train_plan_run": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), vp]),
     "creg_train_plan_probe": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), vp, vp, vp, vp, vp]),
+    "creg_train_plan_profile": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), i32, ctypes.POINTER(f32), vp]),
     "creg_train_plan_destroy": (ctypes.c_int, [vp]),
 }
 

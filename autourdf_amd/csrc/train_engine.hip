@@ -528,18 +528,21 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     return o;
 }
 
-static void enqueue_epoch(Plan* P, int epoch, hipStream_t s) {
+// `ev` (optional): 9 events recorded before kernel 0 and after each of the 8 kernels.
+static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nullptr) {
     const Dims& D = P->D; const Ws& W = P->W;
     const int par = epoch & 1;
-    hipLaunchKernelGGL(k_l2, dim3(cdiv(D.H2, 4)), dim3(256), 0, s, D, W, par);
-    hipLaunchKernelGGL(k_head, dim3(cdiv(D.NP, 1024)), dim3(1024), P->smem_head, s, D, W);
+    auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], s); };
+    mark(0);
+    hipLaunchKernelGGL(k_l2, dim3(cdiv(D.H2, 4)), dim3(256), 0, s, D, W, par); mark(1);
+    hipLaunchKernelGGL(k_head, dim3(cdiv(D.NP, 1024)), dim3(1024), P->smem_head, s, D, W); mark(2);
     launch_nn_l1_bidir<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, W.dist_x, W.idx_x, W.dist_y,
-                            W.idx_y, s);
-    hipLaunchKernelGGL(k_post, dim3(D.nblk_post), dim3(256), 0, s, D, W);
-    hipLaunchKernelGGL(k_ctrl, dim3(cdiv(D.NP, 1024)), dim3(256), 0, s, D, W, epoch);
-    hipLaunchKernelGGL(k_gradc, dim3(D.K), dim3(256), 0, s, D, W, epoch);
-    hipLaunchKernelGGL(k_bwd2, dim3(cdiv(D.H, 256), D.OC), dim3(256), P->smem_bwd2, s, D, W, epoch);
-    hipLaunchKernelGGL(k_dw, dim3(cdiv(D.H2 + D.OA + D.OB + D.H, 4)), dim3(256), P->smem_dw, s, D, W, epoch);
+                            W.idx_y, s); mark(3);
+    hipLaunchKernelGGL(k_post, dim3(D.nblk_post), dim3(256), 0, s, D, W); mark(4);
+    hipLaunchKernelGGL(k_ctrl, dim3(cdiv(D.NP, 1024)), dim3(256), 0, s, D, W, epoch); mark(5);
+    hipLaunchKernelGGL(k_gradc, dim3(D.K), dim3(256), 0, s, D, W, epoch); mark(6);
+    hipLaunchKernelGGL(k_bwd2, dim3(cdiv(D.H, 256), D.OC), dim3(256), P->smem_bwd2, s, D, W, epoch); mark(7);
+    hipLaunchKernelGGL(k_dw, dim3(cdiv(D.H2 + D.OA + D.OB + D.H, 4)), dim3(256), P->smem_dw, s, D, W, epoch); mark(8);
 }
 
 struct ParamMap { int off, count; };
@@ -670,6 +673,31 @@ extern "C" int creg_train_plan_probe(creg_train_plan* plan, const creg_train_arg
     if (pred) CREG_HIP(hipMemcpyAsync(pred, W.best_pred, sizeof(float) * 3 * D.NP, hipMemcpyDeviceToDevice, s));
     if (loss) CREG_HIP(hipMemcpyAsync(loss, W.loss_hist, sizeof(float), hipMemcpyDeviceToDevice, s));
     if (grad_m2) CREG_HIP(hipMemcpyAsync(grad_m2, W.gm2, sizeof(float) * 16 * D.K, hipMemcpyDeviceToDevice, s));
+    return CREG_OK;
+}
+
+extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_args* a, int32_t n_epochs,
+                                       float* us_out, creg_stream_t stream) {
+    Plan* P = (Plan*)plan;
+    CREG_REQUIRE(P && a && a->m && a->y && a->local_pts && a->seg_offsets && a->params && us_out && n_epochs >= 1,
+                 "creg_train_plan_profile: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = stage_inputs(P, a, s);
+    if (rc) return rc;
+    std::vector<hipEvent_t> ev((size_t)9 * n_epochs);
+    for (auto& e : ev) CREG_HIP(hipEventCreate(&e));
+    for (int e = 0; e < n_epochs; ++e) enqueue_epoch(P, e, s, ev.data() + 9 * e);
+    CREG_LAUNCH_CHECK();
+    CREG_HIP(hipStreamSynchronize(s));
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = 0; e < n_epochs; ++e)
+        for (int k = 0; k < 8; ++k) {
+            float ms = 0.f;
+            CREG_HIP(hipEventElapsedTime(&ms, ev[9 * e + k], ev[9 * e + k + 1]));
+            acc[k] += ms;
+        }
+    for (int k = 0; k < 8; ++k) us_out[k] = (float)(acc[k] * 1000.0 / n_epochs);
+    for (auto& e : ev) (void)hipEventDestroy(e);
     return CREG_OK;
 }
 

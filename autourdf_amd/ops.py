@@ -261,3 +261,13 @@ class TrainPlan:
         _lib.check(self.L.creg_train_plan_probe(self.plan, ctypes.byref(a), _p(m2), _p(pred), _p(loss), _p(gm),
                                                 _stream()), "creg_train_plan_probe")
         return m2, pred, loss, gm
+
+    KERNELS = ("l2", "head", "nn_l1", "post", "ctrl", "gradc", "bwd2", "dw")
+
+    def profile(self, m, y, pts, offsets, params, n_epochs=50):
+        """Average event-bracketed microseconds of each of the 8 epoch kernels (synchronises)."""
+        out = (ctypes.c_float * 8)()
+        a = self._args(m, y, pts, offsets, params, 2e-4, 0.7, 5, 200, (None, None, None, None, None))
+        _lib.check(self.L.creg_train_plan_profile(self.plan, ctypes.byref(a), n_epochs, out, _stream()),
+                   "creg_train_plan_profile")
+        return dict(zip(self.KERNELS, [float(v) for v in out]))

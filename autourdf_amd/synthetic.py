@@ -69,12 +69,16 @@ def make_sequence(robot: str = "wx200_5", seq: int = 0, n_frames: int = 10, n_po
     """Returns a list of ``n_frames`` float64 (n_points, 3) world-frame clouds of one moving robot."""
     links = robot_links(robot)
     L = len(links)
-    srng = np.random.default_rng(977 * seq + 13)
+    # geometry and the start configuration belong to the ROBOT (every sequence of the reference
+    # starts from the same rest pose, which is why match() may reuse sequence 0's frame-0
+    # clustering, mlp_reg.py:242-253); the joint directions belong to the SEQUENCE.
+    grng = np.random.default_rng(sum(map(ord, robot)))
     axes = [np.array([1.0, 0, 0]) if i % 2 else np.array([0, 1.0, 0]) for i in range(L)]
-    tilt = [_rot(srng.normal(size=3), srng.uniform(-0.3, 0.3)) for _ in range(L)]
-    sign = srng.choice([-1.0, 1.0], size=L)
-    ang = srng.uniform(-0.6, 0.6, size=L)
+    tilt = [_rot(grng.normal(size=3), grng.uniform(-0.3, 0.3)) for _ in range(L)]
+    ang = grng.uniform(-0.6, 0.6, size=L)
     ang[0] = 0.0
+    srng = np.random.default_rng(977 * seq + 13)
+    sign = srng.choice([-1.0, 1.0], size=L)
     area = np.array([2 * np.pi * r * ln + 4 * np.pi * r * r for _, ln, r in links])
     quota = np.floor(area / area.sum() * n_points).astype(int)
     quota[np.argsort(-(area / area.sum() * n_points - quota))[: n_points - quota.sum()]] += 1

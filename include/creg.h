@@ -194,6 +194,13 @@ int creg_train_plan_destroy(creg_train_plan* plan);
 int creg_train_plan_probe(creg_train_plan* plan, const creg_train_args* args, float* m2,
                           float* pred, float* loss, float* grad_m2, creg_stream_t stream);
 
+/* Measurement hook: run n_epochs eagerly with a HIP event before / after each of the eight kernels
+ * of an epoch (order: l2, head, nn_l1, post, ctrl, gradc, bwd2, dw) on `stream`, synchronise, and
+ * write the average microseconds per kernel to us_out (HOST, 8 floats).  Event-bracketed times
+ * include the dispatch latency of the launch, i.e. they are an upper bound of the kernel time. */
+int creg_train_plan_profile(creg_train_plan* plan, const creg_train_args* args, int32_t n_epochs,
+                            float* us_out, creg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
