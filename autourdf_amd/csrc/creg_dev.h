@@ -14,6 +14,34 @@ __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
+// DPP row reductions (gfx9 family): 4 intra-row steps + row_bcast15/31; total lands in lane 63.
+// ~6 VALU ops instead of 6 LDS-crossbar bpermutes; the combination order is fixed.
+#define CREG_DPP_STEP(v, ctrl, mask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, mask, 0xF, false))
+// sum over the wave, result broadcast to every lane (wave-uniform)
+__device__ __forceinline__ float wave_sum_fast(float v) {
+    CREG_DPP_STEP(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+    CREG_DPP_STEP(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+    CREG_DPP_STEP(v, 0x141, 0xF);   // row_half_mirror
+    CREG_DPP_STEP(v, 0x140, 0xF);   // row_mirror      -> every lane holds its row's sum
+    CREG_DPP_STEP(v, 0x142, 0xA);   // row_bcast15 into rows 1,3
+    CREG_DPP_STEP(v, 0x143, 0xC);   // row_bcast31 into rows 2,3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Cooperative global -> LDS copy of n float4 by NT threads with B loads in flight per thread.
+// (A plain `for (i = tid; i < n; i += NT) dst[i] = src[i]` costs one full memory round trip per
+// iteration: hipcc does not software-pipeline it, and on MI355X a dependent round trip is ~1 us.)
+template <int NT, int B>
+__device__ __forceinline__ void stage_f4(float4* __restrict__ dst, const float4* __restrict__ src, int n) {
+    for (int base = 0; base < n; base += NT * B) {
+        float4 v[B];
+#pragma unroll
+        for (int q = 0; q < B; ++q) v[q] = src[min(base + q * NT + (int)threadIdx.x, n - 1)];
+#pragma unroll
+        for (int q = 0; q < B; ++q) { const int i = base + q * NT + (int)threadIdx.x; if (i < n) dst[i] = v[q]; }
+    }
+}
+
 // (value, index) lexicographic minimum across the wave: smallest value, then smallest index.
 __device__ __forceinline__ void wave_argmin(float& v, int& i) {
 #pragma unroll

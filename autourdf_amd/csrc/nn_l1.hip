@@ -63,7 +63,8 @@ extern "C" int creg_nn_l1_bidir_f32(const float* x, int64_t nx, const float* y, 
                  "creg_nn_l1_bidir_f32: sizes must be in [1, 2^31)");
     CREG_REQUIRE((dx != nullptr) == (ix != nullptr) && (dy != nullptr) == (iy != nullptr),
                  "creg_nn_l1_bidir_f32: pass both or neither output of a direction");
-    launch_nn_l1_bidir<int64_t>(x, (int)nx, 3, y, (int)ny, 3, dx, ix, dy, iy, (hipStream_t)stream);
+    launch_nn_l1<int64_t>(x, (int)nx, 3, y, (int)ny, 3, dx, ix, dy, iy, dx != nullptr, dy != nullptr, NnEpilogueNone{},
+                          (hipStream_t)stream);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }

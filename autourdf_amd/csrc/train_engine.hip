@@ -1,12 +1,13 @@
 // train_engine.hip -- A1: the whole `train` loop of the reference (PointCloud/mlp_reg.py:17-152)
-// as a device-resident plan.  One epoch = eight small launches, no host round trip:
+// as a device-resident plan.  One epoch = six small launches, no host round trip:
 //
 //   k_l2      hidden layer(s) of the pose MLP            (model_utils.py:152-159 / :94-99)
-//   k_head    output layer(s) + residual + pose assembly + calculate_pc (mlp_reg.py:62-94,155-170)
-//   k_nn      L1 nearest neighbour both ways             (chamfer_distance, mlp_reg.py:96)
-//   k_post    loss partial sums + sign scatter of the y->x term (integer atomics: exact)
-//   k_ctrl    loss, best tracking (mlp_reg.py:102-111), ReduceLROnPlateau, Adam scalars, early stop
-//   k_gradc   per-cluster reduction to dL/dR, dL/dt, backward through the pose head
+//   k_head    output layer(s) + residual + pose assembly + calculate_pc (mlp_reg.py:62-94,155-170),
+//             one workgroup per pose row / cluster
+//   k_nn_l1   L1 nearest neighbour both ways (chamfer_distance, mlp_reg.py:96); its epilogue emits
+//             the loss partials and the sign scatter of the y->x term (integer atomics: exact)
+//   k_gradc   loss, best tracking (mlp_reg.py:102-111), ReduceLROnPlateau, Adam scalars, early stop;
+//             per-cluster reduction to dL/dR, dL/dt and backward through the pose head
 //   k_bwd2    backward through the output / hidden layers to the encoder activation
 //   k_dw      weight gradients fused with the Adam update (no gradient buffer), and -- for the
 //             encoder rows -- the NEXT epoch's encoder activation from the just-updated weights
@@ -30,7 +31,7 @@ struct Dims {
     // flat parameter offsets
     int oW1, ob1, oW2, ob2, oW3A, ob3A, oW3B, ob3B, NPAR;
     int OC;        // o-chunks of k_bwd2
-    int nblk_post; // blocks of k_post (= loss partial count)
+    int nbx, nby;  // NN blocks per direction (= loss partial counts)
 };
 
 struct Hyper {      // uploaded per run
@@ -51,8 +52,7 @@ struct Ws {         // device pointers into the caller's workspace
     float *P, *AM, *AV;
     float *pose_in, *enc, *x1[2], *h2, *head_save, *m_in, *m2, *gm2;
     float4 *pts4, *y4, *pred4;
-    float *dist_x, *dist_y;
-    int *idx_x, *idx_y;
+    int* sgn_x;
     int4* cnt4;
     float *lossp_x, *lossp_y;
     float *g_out, *g_h2, *gx1_part;
@@ -135,65 +135,85 @@ __global__ __launch_bounds__(256) void k_l1(Dims D, Ws W, int par) {
     const int lane = threadIdx.x & 63;
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o >= D.H) return;
-    const float* w = W.P + D.oW1 + (size_t)o * D.IN;
+    const float w = lane < D.IN ? W.P[D.oW1 + (size_t)o * D.IN + lane] : 0.f;
     const float b = W.P[D.ob1 + o];
     for (int r = 0; r < D.K; ++r) {
-        const float v = wave_dot(w, W.enc + (size_t)r * D.IN, D.IN, lane) + b;
+        const float v = wave_sum_fast(lane < D.IN ? w * W.enc[(size_t)r * D.IN + lane] : 0.f) + b;
         if (lane == 0) W.x1[par][(size_t)r * D.H + o] = act_f(v, D.slope);
     }
 }
 
+// rows of the K-row activation matrix staged per LDS chunk (<= 64 KB)
+__host__ __device__ inline int rows_per_chunk(int K, int width) {
+    int rc = 16384 / width;
+    return rc < K ? rc : K;
+}
+
 // ------------------------------------------------------------------------------------------ layer 2
+// One wave per hidden unit; the block stages the encoder activation in LDS with one round trip
+// (all threads loading) instead of K dependent global reads per wave.
 __global__ __launch_bounds__(256) void k_l2(Dims D, Ws W, int par) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = (float*)smem;                      // [rc][H]
     const int lane = threadIdx.x & 63;
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (o >= D.H2) return;
-    const float* w = W.P + D.oW2 + (size_t)o * D.H;
-    const float b = W.P[D.ob2 + o];
-    // weights of this row stay in registers (H/64 per lane), activations stream from L2
+    const bool active = o < D.H2;
+    const int nc = D.H / 64;
     float wr[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) wr[c] = (c * 64 + lane < D.H) ? w[c * 64 + lane] : 0.f;
-    const int nc = D.H / 64;
-    for (int r = 0; r < D.K; ++r) {
-        const float* a = W.x1[par] + (size_t)r * D.H;
-        float s = 0.f;
+    for (int c = 0; c < 16; ++c) wr[c] = (active && c < nc) ? W.P[D.oW2 + (size_t)o * D.H + c * 64 + lane] : 0.f;
+    const float b = active ? W.P[D.ob2 + o] : 0.f;
+    const int rc = rows_per_chunk(D.K, D.H);
+    for (int r0 = 0; r0 < D.K; r0 += rc) {
+        const int nr = min(rc, D.K - r0);
+        if (r0) __syncthreads();
+        stage_f4<256, 10>((float4*)xs, (const float4*)(W.x1[par] + (size_t)r0 * D.H), nr * D.H / 4);
+        __syncthreads();
+        if (!active) continue;
+        for (int r = 0; r < nr; ++r) {
+            const float* a = xs + r * D.H + lane;
+            float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) if (c < nc) s = fmaf(wr[c], a[c * 64 + lane], s);
-        s = wave_sum(s) + b;
-        if (lane == 0) W.h2[(size_t)r * D.H2 + o] = act_f(s, D.slope);
+            for (int c = 0; c < 16; ++c) if (c < nc) s = fmaf(wr[c], a[c * 64], s);
+            s = wave_sum_fast(s) + b;
+            if (lane == 0) W.h2[(size_t)(r0 + r) * D.H2 + o] = act_f(s, D.slope);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------ head + transform
-// Every block recomputes the K-row output layer (tiny) so the transformed cloud can follow in the
-// same launch; block 0 publishes m2 / head_save.
-__global__ __launch_bounds__(1024) void k_head(Dims D, Ws W) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* outs = (float*)smem;              // [K][8]  raw output-layer values
-    float* m2s = outs + 8 * D.K;             // [K][12] rows of [R|t]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Block r: output layer for pose row r (one wave per output unit), pose assembly, then the rigid
+// transform of cluster r's points (clusters are stored back to back) -- calculate_pc needs no
+// launch of its own and nothing is recomputed.
+__global__ __launch_bounds__(512) void k_head(Dims D, Ws W) {
+    __shared__ float outs[8];
+    __shared__ float m2s[12];
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NO = D.OA + D.OB;
-    for (int id = wave; id < D.K * NO; id += 16) {
-        const int r = id / NO, o = id % NO;
-        float v;
-        if (o < D.OA)
-            v = wave_dot(W.P + D.oW3A + (size_t)o * D.HA, W.h2 + (size_t)r * D.H2, D.HA, lane) + W.P[D.ob3A + o];
-        else
-            v = wave_dot(W.P + D.oW3B + (size_t)(o - D.OA) * D.HB, W.h2 + (size_t)r * D.H2 + D.HA, D.HB, lane) +
-                W.P[D.ob3B + (o - D.OA)];
-        if (lane == 0) outs[8 * r + o] = v;
+    if (wave < NO) {
+        const int o = wave;
+        const float *w, *a; int n; float bias;
+        if (o < D.OA) { w = W.P + D.oW3A + (size_t)o * D.HA; a = W.h2 + (size_t)r * D.H2; n = D.HA; bias = W.P[D.ob3A + o]; }
+        else { w = W.P + D.oW3B + (size_t)(o - D.OA) * D.HB; a = W.h2 + (size_t)r * D.H2 + D.HA; n = D.HB; bias = W.P[D.ob3B + o - D.OA]; }
+        float wv[16], av[16];                      // n <= 1024: every load of the dot in flight at once
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { const int i = min(c * 64 + lane, n - 1); wv[c] = w[i]; av[c] = a[i]; }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) if (c * 64 + lane < n) s = fmaf(wv[c], av[c], s);
+        s = wave_sum_fast(s) + bias;
+        if (lane == 0) outs[o] = s;
     }
     __syncthreads();
-    for (int r = threadIdx.x; r < D.K; r += 1024) {
+    if (threadIdx.x == 0) {
         const float* in = W.pose_in + 8 * r;
         float R[9], t[3], save[16];
         for (int i = 0; i < 16; ++i) save[i] = 0.f;
         if (D.rot == 0) {
             // xyz + orig[:, :3] ; normalize(q + orig[:, 3:])   model_utils.py:159
-            for (int i = 0; i < 3; ++i) t[i] = outs[8 * r + i] + in[i];
+            for (int i = 0; i < 3; ++i) t[i] = outs[i] + in[i];
             float v[4], n2 = 0.f;
-            for (int i = 0; i < 4; ++i) { v[i] = outs[8 * r + 3 + i] + in[3 + i]; n2 = fmaf(v[i], v[i], n2); }
+            for (int i = 0; i < 4; ++i) { v[i] = outs[3 + i] + in[3 + i]; n2 = fmaf(v[i], v[i], n2); }
             const float nrm = sqrtf(n2), den = fmaxf(nrm, 1e-12f);
             float u[4];
             for (int i = 0; i < 4; ++i) u[i] = v[i] / den;
@@ -202,139 +222,152 @@ __global__ __launch_bounds__(1024) void k_head(Dims D, Ws W) {
             save[4] = nrm;
         } else {
             float dq[8];
-            for (int i = 0; i < 8; ++i) dq[i] = outs[8 * r + i] + in[i];     // x + orig  model_utils.py:99
+            for (int i = 0; i < 8; ++i) dq[i] = outs[i] + in[i];              // x + orig  model_utils.py:99
             dq_to_se3(dq, R, t);
             for (int i = 0; i < 8; ++i) save[i] = dq[i];
         }
-        for (int a = 0; a < 3; ++a) { m2s[12 * r + 4 * a] = R[3 * a]; m2s[12 * r + 4 * a + 1] = R[3 * a + 1];
-                                      m2s[12 * r + 4 * a + 2] = R[3 * a + 2]; m2s[12 * r + 4 * a + 3] = t[a]; }
-        if (blockIdx.x == 0) {
-            for (int i = 0; i < 12; ++i) W.m2[16 * r + i] = m2s[12 * r + i];
-            W.m2[16 * r + 12] = 0.f; W.m2[16 * r + 13] = 0.f; W.m2[16 * r + 14] = 0.f; W.m2[16 * r + 15] = 1.f;
-            for (int i = 0; i < 16; ++i) W.head_save[16 * r + i] = save[i];
-        }
+        for (int a = 0; a < 3; ++a) { m2s[4 * a] = R[3 * a]; m2s[4 * a + 1] = R[3 * a + 1]; m2s[4 * a + 2] = R[3 * a + 2]; m2s[4 * a + 3] = t[a]; }
+        for (int i = 0; i < 12; ++i) W.m2[16 * r + i] = m2s[i];
+        W.m2[16 * r + 12] = 0.f; W.m2[16 * r + 13] = 0.f; W.m2[16 * r + 14] = 0.f; W.m2[16 * r + 15] = 1.f;
+        for (int i = 0; i < 16; ++i) W.head_save[16 * r + i] = save[i];
     }
     __syncthreads();
-    const int n = blockIdx.x * 1024 + threadIdx.x;
-    if (n < D.NP) {
+    const int b = W.off[r], e = W.off[r + 1];
+    for (int n = b + threadIdx.x; n < e; n += 512) {
         const float4 p = W.pts4[n];
-        const float* T = m2s + 12 * __float_as_int(p.w);
         float o[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) o[a] = fmaf(p.z, T[4 * a + 2], fmaf(p.y, T[4 * a + 1], p.x * T[4 * a])) + T[4 * a + 3];
+        for (int a = 0; a < 3; ++a) o[a] = fmaf(p.z, m2s[4 * a + 2], fmaf(p.y, m2s[4 * a + 1], p.x * m2s[4 * a])) + m2s[4 * a + 3];
         W.pred4[n] = make_float4(o[0], o[1], o[2], 0.f);
         W.cnt4[n] = make_int4(0, 0, 0, 0);
     }
 }
 
-// ------------------------------------------------------------------------------------------ post-NN
-__global__ __launch_bounds__(256) void k_post(Dims D, Ws W) {
-    __shared__ float sc[4];
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const float a = t < D.NP ? W.dist_x[t] : 0.f;
-    const float b = t < D.NT ? W.dist_y[t] : 0.f;
-    if (t < D.NT) {
-        const int i = W.idx_y[t];
-        const float4 yv = W.y4[t], xv = W.pred4[i];
-        // knn(p1=y, p2=x) backward: grad_p2 -= g * sign, sign = (p1 > p2 ? 1 : -1)
-        atomicAdd(&W.cnt4[i].x, (yv.x > xv.x) ? -1 : 1);
-        atomicAdd(&W.cnt4[i].y, (yv.y > xv.y) ? -1 : 1);
-        atomicAdd(&W.cnt4[i].z, (yv.z > xv.z) ? -1 : 1);
+// ------------------------------------------------------------------------------------------ NN epilogue
+// Runs inside the nearest-neighbour launch (results are final there): sign bits of the x->y term,
+// integer sign scatter of the y->x term (exact, order independent), per-block loss partials.
+struct EngineEpi {
+    const float4* pred4; const float4* y4; int* sgn_x; int4* cnt4; float* lossp_x; float* lossp_y;
+    __device__ __forceinline__ void operator()(int dir, int q, int, float d, int idx, float& acc) const {
+        if (dir == 0) {          // query pred[q], nearest y[idx]: knn(p1=x,p2=y) grad_p1 sign = (p1 > p2 ? +1 : -1)
+            const float4 xv = pred4[q], yv = y4[idx];
+            sgn_x[q] = (xv.x > yv.x ? 1 : 0) | (xv.y > yv.y ? 2 : 0) | (xv.z > yv.z ? 4 : 0);
+        } else {                 // query y[q], nearest pred[idx]: knn(p1=y,p2=x) grad_p2 -= sign
+            const float4 yv = y4[q], xv = pred4[idx];
+            atomicAdd(&cnt4[idx].x, (yv.x > xv.x) ? -1 : 1);
+            atomicAdd(&cnt4[idx].y, (yv.y > xv.y) ? -1 : 1);
+            atomicAdd(&cnt4[idx].z, (yv.z > xv.z) ? -1 : 1);
+        }
+        acc += d;
     }
-    const float sa = block_sum<float, 256>(a, sc);
-    const float sb = block_sum<float, 256>(b, sc);
-    if (threadIdx.x == 0) { W.lossp_x[blockIdx.x] = sa; W.lossp_y[blockIdx.x] = sb; }
+    __device__ __forceinline__ void finish(int dir, int blk, float s, float*) const { (dir == 0 ? lossp_x : lossp_y)[blk] = s; }
+};
+
+// ------------------------------------------------------------------------------------------ control + cluster grads
+// K blocks.  Every block derives the same loss and the same decisions from the same inputs; block 0
+// advances the double-buffered state.  Then block k reduces cluster k's point gradients to
+// [dL/dR | dL/dt] in a fixed order and thread 0 pulls them back through the pose head.
+__device__ __forceinline__ TrainState advance_state(const TrainState& S, float loss, const Hyper& hy) {
+    TrainState N = S;
+    const bool improved = loss < S.min_loss;
+    N.last_loss = loss;
+    N.epochs_run = S.epochs_run + 1;
+    if (improved) { N.min_loss = loss; N.count = 0; N.best_epoch = S.epochs_run; }
+    else { N.count = S.count + 1; if (N.count > hy.stop) N.stopped = 1; }            // mlp_reg.py:107-111
+    if (!N.stopped) {
+        // optimizer.step() of this epoch uses S.lr (torch.optim.Adam, betas (0.9, 0.999), eps 1e-8)
+        N.step = S.step + 1;
+        const double bc1 = 1.0 - pow(0.9, (double)N.step), bc2 = 1.0 - pow(0.999, (double)N.step);
+        N.step_size = (float)(S.lr / bc1);
+        N.bc2_sqrt = (float)sqrt(bc2);
+        // scheduler.step(loss): ReduceLROnPlateau(mode='min', threshold 1e-4 rel, cooldown 0, min_lr 0, eps 1e-8)
+        const double cur = (double)loss;
+        if (cur < S.sched_best * (1.0 - 1e-4)) { N.sched_best = cur; N.sched_bad = 0; }
+        else N.sched_bad = S.sched_bad + 1;
+        if (N.sched_bad > hy.patience) {
+            const double nl = fmax(S.lr * (double)hy.factor, 0.0);
+            if (S.lr - nl > 1e-8) N.lr = nl;
+            N.sched_bad = 0;
+        }
+    }
+    return N;
 }
 
-// ------------------------------------------------------------------------------------------ control
-// Every block derives the same loss / decision; block 0 advances the state, all blocks copy their
-// slice of the prediction when the loss improved.
-__global__ __launch_bounds__(256) void k_ctrl(Dims D, Ws W, int epoch) {
-    __shared__ float sc[4];
+__global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W, int epoch, int nbx, int nby) {
+    __shared__ float red[4][14];
     __shared__ float s_loss;
     const TrainState S = W.state[epoch & 1];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (S.stopped) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) W.state[(epoch + 1) & 1] = S;
+        if (k == 0 && tid == 0) W.state[(epoch + 1) & 1] = S;
         return;
     }
+    // independent loads first (cluster bounds, this thread's first point, hyper-parameters) so they
+    // overlap the loss reduction instead of forming a chain of dependent round trips
+    const int b0 = W.off[k], e0 = W.off[k + 1];
+    const Hyper hy = *W.hyper;
+    const int n_first = min(b0 + tid, D.NP - 1);
+    const float4 p_first = W.pts4[n_first];
+    const int4 c_first = W.cnt4[n_first];
+    const int s_first = W.sgn_x[n_first];
+    // ---- loss = sum_x / NP + sum_y / NT from the NN launch's per-block partials (fixed order)
     float a = 0.f, b = 0.f;
-    for (int i = threadIdx.x; i < D.nblk_post; i += 256) { a += W.lossp_x[i]; b += W.lossp_y[i]; }
-    a = block_sum<float, 256>(a, sc);
-    b = block_sum<float, 256>(b, sc);
-    if (threadIdx.x == 0) s_loss = a / (float)D.NP + b / (float)D.NT;
+    for (int i = tid; i < nbx; i += 256) a += W.lossp_x[i];
+    for (int i = tid; i < nby; i += 256) b += W.lossp_y[i];
+    a = wave_sum_fast(a); b = wave_sum_fast(b);
+    if (lane == 0) { red[wv][0] = a; red[wv][1] = b; }
+    __syncthreads();
+    if (tid == 0) {
+        const float sa = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+        const float sb = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+        s_loss = sa / (float)D.NP + sb / (float)D.NT;
+    }
     __syncthreads();
     const float loss = s_loss;
+    const TrainState N = advance_state(S, loss, hy);
     const bool improved = loss < S.min_loss;
-    const int e = S.epochs_run;          // device-side epoch counter (the launch argument only carries parity)
-    if (improved) {
-        for (int n = blockIdx.x * 256 + threadIdx.x; n < D.NP; n += gridDim.x * 256) {
+    if (improved) {                                     // best_pcd / best_m  (mlp_reg.py:102-106)
+        for (int n = b0 + tid; n < e0; n += 256) {
             const float4 p = W.pred4[n];
             W.best_pred[3 * (size_t)n] = p.x; W.best_pred[3 * (size_t)n + 1] = p.y; W.best_pred[3 * (size_t)n + 2] = p.z;
         }
-        if (blockIdx.x == 0)
-            for (int i = threadIdx.x; i < 16 * D.K; i += 256) W.best_m[i] = W.m2[i];
+        if (tid < 16) W.best_m[16 * k + tid] = W.m2[16 * k + tid];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        TrainState N = S;
-        N.last_loss = loss;
-        N.epochs_run = e + 1;
-        W.loss_hist[e] = loss;
-        W.lr_hist[e] = (float)S.lr;
-        if (improved) { N.min_loss = loss; N.count = 0; N.best_epoch = e; }
-        else { N.count = S.count + 1; if (N.count > W.hyper->stop) N.stopped = 1; }   // mlp_reg.py:107-111
-        if (!N.stopped) {
-            // optimizer.step() of this epoch uses S.lr (torch.optim.Adam, betas (0.9, 0.999), eps 1e-8)
-            N.step = S.step + 1;
-            const double bc1 = 1.0 - pow(0.9, (double)N.step), bc2 = 1.0 - pow(0.999, (double)N.step);
-            N.step_size = (float)(S.lr / bc1);
-            N.bc2_sqrt = (float)sqrt(bc2);
-            // scheduler.step(loss): ReduceLROnPlateau(mode='min', threshold 1e-4 rel, cooldown 0, min_lr 0, eps 1e-8)
-            const double cur = (double)loss;
-            if (cur < S.sched_best * (1.0 - 1e-4)) { N.sched_best = cur; N.sched_bad = 0; }
-            else N.sched_bad = S.sched_bad + 1;
-            if (N.sched_bad > W.hyper->patience) {
-                const double nl = fmax(S.lr * (double)W.hyper->factor, 0.0);
-                if (S.lr - nl > 1e-8) N.lr = nl;
-                N.sched_bad = 0;
-            }
-        }
+    if (k == 0 && tid == 0) {
         W.state[(epoch + 1) & 1] = N;
-        W.result[0] = N.min_loss; W.result[1] = (float)N.epochs_run; W.result[2] = (float)N.lr;
-        W.result[3] = (float)N.best_epoch;
+        W.loss_hist[S.epochs_run] = loss;
+        W.lr_hist[S.epochs_run] = (float)S.lr;
+        W.result[0] = N.min_loss; W.result[1] = (float)N.epochs_run; W.result[2] = (float)N.lr; W.result[3] = (float)N.best_epoch;
     }
-}
-
-// ------------------------------------------------------------------------------------------ cluster grads + head backward
-__global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W, int epoch) {
-    __shared__ float sc[4];
-    __shared__ float red[12];
-    if (W.state[(epoch + 1) & 1].stopped) return;
-    const int k = blockIdx.x, b = W.off[k], e = W.off[k + 1];
+    if (N.stopped) return;                              // the reference breaks before backward()
+    // ---- per-cluster reduction of the point gradients
     const float gx = 1.0f / (float)D.NP, gy = 1.0f / (float)D.NT;
     float acc[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = 0.f;
-    for (int n = b + threadIdx.x; n < e; n += 256) {
-        const float4 xv = W.pred4[n], yv = W.y4[W.idx_x[n]], p = W.pts4[n];
-        const int4 c = W.cnt4[n];
-        const float g[3] = {((xv.x > yv.x) ? gx : -gx) + gy * (float)c.x,
-                            ((xv.y > yv.y) ? gx : -gx) + gy * (float)c.y,
-                            ((xv.z > yv.z) ? gx : -gx) + gy * (float)c.z};
+    for (int n = b0 + tid; n < e0; n += 256) {
+        const bool first = n == b0 + tid;
+        const float4 p = first ? p_first : W.pts4[n];
+        const int4 c = first ? c_first : W.cnt4[n];
+        const int sb = first ? s_first : W.sgn_x[n];
+        const float g[3] = {((sb & 1) ? gx : -gx) + gy * (float)c.x, ((sb & 2) ? gx : -gx) + gy * (float)c.y,
+                            ((sb & 4) ? gx : -gx) + gy * (float)c.z};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            acc[4 * a] = fmaf(g[a], p.x, acc[4 * a]); acc[4 * a + 1] = fmaf(g[a], p.y, acc[4 * a + 1]);
-            acc[4 * a + 2] = fmaf(g[a], p.z, acc[4 * a + 2]); acc[4 * a + 3] += g[a];
+        for (int q = 0; q < 3; ++q) {
+            acc[4 * q] = fmaf(g[q], p.x, acc[4 * q]); acc[4 * q + 1] = fmaf(g[q], p.y, acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(g[q], p.z, acc[4 * q + 2]); acc[4 * q + 3] += g[q];
         }
     }
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const float r = block_sum<float, 256>(acc[i], sc);
-        if (threadIdx.x == 0) red[i] = r;
-    }
-    if (threadIdx.x != 0) return;
-    for (int i = 0; i < 16; ++i) W.gm2[16 * k + i] = i < 12 ? red[i] : 0.f;
-    const float G[9] = {red[0], red[1], red[2], red[4], red[5], red[6], red[8], red[9], red[10]};
-    const float gt[3] = {red[3], red[7], red[11]};
+    for (int i = 0; i < 12; ++i) { const float r = wave_sum_fast(acc[i]); if (lane == 0) red[wv][i] = r; }
+    __syncthreads();
+    if (tid != 0) return;
+    float G12[12];
+    for (int i = 0; i < 12; ++i) G12[i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    for (int i = 0; i < 16; ++i) W.gm2[16 * k + i] = i < 12 ? G12[i] : 0.f;
+    const float G[9] = {G12[0], G12[1], G12[2], G12[4], G12[5], G12[6], G12[8], G12[9], G12[10]};
+    const float gt[3] = {G12[3], G12[7], G12[11]};
     float* go = W.g_out + 16 * k;          // [0..2] branch A, [4..11] branch B
     const float* sv = W.head_save + 16 * k;
     if (D.rot == 0) {
@@ -356,73 +389,133 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W, int epoch) {
 }
 
 // ------------------------------------------------------------------------------------------ backward to x1
-// grid (H/256, OC), 4 waves: wave = 64 columns of x1, block = one chunk of hidden rows.
-constexpr int RT = 32;      // rows of K handled per register tile
+// grid (H/256, OC): thread = one column of W2, block = one chunk of <= BW2_ROWS hidden rows.
+// Phase 1 builds the chunk's g_h2 = act'(h2) * (g_out . W3) in LDS from LDS-staged operands;
+// phase 2 keeps the column's weights of the chunk in registers (all loads in flight at once) and
+// walks the pose rows four at a time (one broadcast ds_read_b128 per weight).
+constexpr int BW2_ROWS = 48;
+constexpr int BW2_OC = 16;
 __global__ __launch_bounds__(256) void k_bwd2(Dims D, Ws W, int epoch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* gs = (float*)smem;                 // [rows][K]
+    const int KP = (D.K + 3) & ~3;
+    float* gs = (float*)smem;                  // [BW2_ROWS][KP]   g_h2 of the chunk (zero padded)
+    float* gos = gs + BW2_ROWS * KP;           // [K][16]          g_out
+    float* w3s = gos + 16 * D.K;               // [8][BW2_ROWS]    output-layer weights of the chunk's units
     if (W.state[(epoch + 1) & 1].stopped) return;
-    const int rows = D.H2 / D.OC, o0 = blockIdx.y * rows;
-    for (int id = threadIdx.x; id < rows * D.K; id += 256) {
-        const int ol = id / D.K, r = id % D.K, o = o0 + ol;
-        const float* go = W.g_out + 16 * r;
-        float s = 0.f;
-        if (o < D.HA) { for (int j = 0; j < D.OA; ++j) s = fmaf(go[j], W.P[D.oW3A + (size_t)j * D.HA + o], s); }
-        else { for (int j = 0; j < D.OB; ++j) s = fmaf(go[4 + j], W.P[D.oW3B + (size_t)j * D.HB + (o - D.HA)], s); }
-        s *= act_grad(W.h2[(size_t)r * D.H2 + o], D.slope);
-        gs[ol * D.K + r] = s;
-        if (blockIdx.x == 0) W.g_h2[(size_t)r * D.H2 + o] = s;
-    }
-    __syncthreads();
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= D.H) return;
-    for (int r0 = 0; r0 < D.K; r0 += RT) {
-        float acc[RT];
+    const int rows = D.H2 / BW2_OC, o0 = blockIdx.y * rows, tid = threadIdx.x;
+    stage_f4<256, 4>((float4*)gos, (const float4*)W.g_out, 4 * D.K);
+    {
+        float v[2] = {0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < RT; ++r) acc[r] = 0.f;
-        for (int ol = 0; ol < rows; ++ol) {
-            const float w = W.P[D.oW2 + (size_t)(o0 + ol) * D.H + col];
-            const float* g = gs + ol * D.K + r0;
-#pragma unroll
-            for (int r = 0; r < RT; ++r) if (r0 + r < D.K) acc[r] = fmaf(g[r], w, acc[r]);
+        for (int q = 0; q < 2; ++q) {                 // 8 * BW2_ROWS = 384 <= 512: both loads in flight
+            const int id = q * 256 + tid, j = id / BW2_ROWS, ol = id % BW2_ROWS, o = o0 + ol;
+            if (id < 8 * BW2_ROWS && ol < rows) {
+                if (o < D.HA) { if (j < D.OA) v[q] = W.P[D.oW3A + (size_t)j * D.HA + o]; }
+                else if (j < D.OB) v[q] = W.P[D.oW3B + (size_t)j * D.HB + (o - D.HA)];
+            }
         }
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
-            if (r0 + r < D.K) W.gx1_part[((size_t)blockIdx.y * D.K + r0 + r) * D.H + col] = acc[r];
+        for (int q = 0; q < 2; ++q) if (q * 256 + tid < 8 * BW2_ROWS) w3s[q * 256 + tid] = v[q];
+    }
+    for (int id = tid; id < BW2_ROWS * KP; id += 256) gs[id] = 0.f;
+    __syncthreads();
+    for (int base = 0; base < rows * D.K; base += 256 * 4) {
+        float hv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int id = min(base + q * 256 + tid, rows * D.K - 1);
+            hv[q] = W.h2[(size_t)(id / rows) * D.H2 + o0 + id % rows];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int id = base + q * 256 + tid;
+            if (id < rows * D.K) {
+                const int r = id / rows, ol = id % rows, o = o0 + ol;
+                const float* go = gos + 16 * r;
+                float sum = 0.f;
+                if (o < D.HA) { for (int j = 0; j < D.OA; ++j) sum = fmaf(go[j], w3s[j * BW2_ROWS + ol], sum); }
+                else { for (int j = 0; j < D.OB; ++j) sum = fmaf(go[4 + j], w3s[j * BW2_ROWS + ol], sum); }
+                sum *= act_grad(hv[q], D.slope);
+                gs[ol * KP + r] = sum;
+                if (blockIdx.x == 0) W.g_h2[(size_t)r * D.H2 + o] = sum;
+            }
+        }
+    }
+    __syncthreads();
+    const int col = blockIdx.x * 256 + tid;
+    if (col >= D.H) return;
+    float w[BW2_ROWS];
+#pragma unroll
+    for (int ol = 0; ol < BW2_ROWS; ++ol) {
+        const float v = W.P[D.oW2 + (size_t)(o0 + min(ol, rows - 1)) * D.H + col];
+        w[ol] = ol < rows ? v : 0.f;
+    }
+    for (int r0 = 0; r0 < D.K; r0 += 4) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int ol = 0; ol < BW2_ROWS; ++ol) {
+            const float4 g = *(const float4*)(gs + ol * KP + r0);
+            a0 = fmaf(g.x, w[ol], a0); a1 = fmaf(g.y, w[ol], a1); a2 = fmaf(g.z, w[ol], a2); a3 = fmaf(g.w, w[ol], a3);
+        }
+        float* out = W.gx1_part + ((size_t)blockIdx.y * D.K + r0) * D.H + col;
+        out[0] = a0;
+        if (r0 + 1 < D.K) out[D.H] = a1;
+        if (r0 + 2 < D.K) out[2 * (size_t)D.H] = a2;
+        if (r0 + 3 < D.K) out[3 * (size_t)D.H] = a3;
     }
 }
 
 // ------------------------------------------------------------------------------------------ dW + Adam (+ next x1)
-__device__ __forceinline__ void adam_update(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
-                                            float g, float step_size, float bc2_sqrt) {
+__device__ __forceinline__ float adam_value(float p, float& mm, float& vv, float g, float step_size, float bc2_sqrt) {
     // torch single-tensor Adam: exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2);
     // denom = sqrt(v)/sqrt(bc2) + eps; p.addcdiv_(exp_avg, denom, value=-step_size)
     const float b1w = (float)(1.0 - 0.9), b2 = 0.999f, b2w = (float)(1.0 - 0.999);
-    float mm = *m, vv = *v;
     mm = mm + b1w * (g - mm);
     vv = vv * b2 + (b2w * g) * g;
     const float denom = sqrtf(vv) / bc2_sqrt + 1e-8f;
-    *p = *p + (-step_size * mm) / denom;
-    *m = mm; *v = vv;
+    return p + (-step_size * mm) / denom;
 }
 
+// One wave per parameter row, 4 rows per block.  The block stages its rows' input activation matrix
+// ([K][H] encoder activation for hidden rows, [K][H2] hidden activation for output rows, [K][IN]
+// features for encoder rows) in LDS with batched loads; a row's parameter / Adam-state loads are all
+// issued together.  No loop over K contains a global load.
 __global__ __launch_bounds__(256) void k_dw(Dims D, Ws W, int epoch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const TrainState S = W.state[(epoch + 1) & 1];
     if (S.stopped) return;                          // block-uniform
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     float* g = (float*)smem + wib * D.K;            // per-wave gradient column g[r]
-    const int row = blockIdx.x * 4 + wib;
-    const int nrows = D.H2 + D.OA + D.OB + D.H;
-    const bool active = row < nrows;
+    float* as = (float*)smem + ((4 * D.K + 3) & ~3);   // staged activations [rc][width]
     const int par = epoch & 1;
-    // decode the row: 0: W2, 1: W3A, 2: W3B, 3: W1
-    int oW = 0, ob = 0, o = 0, n_in = 0, astride = 0, kind = 0; const float* act = nullptr;
-    if (row < D.H2) { kind = 0; o = row; oW = D.oW2 + o * D.H; ob = D.ob2 + o; n_in = D.H; act = W.x1[par]; astride = D.H; }
-    else if (row < D.H2 + D.OA) { kind = 1; o = row - D.H2; oW = D.oW3A + o * D.HA; ob = D.ob3A + o; n_in = D.HA; act = W.h2; astride = D.H2; }
-    else if (row < D.H2 + D.OA + D.OB) { kind = 2; o = row - D.H2 - D.OA; oW = D.oW3B + o * D.HB; ob = D.ob3B + o; n_in = D.HB; act = W.h2 + D.HA; astride = D.H2; }
-    else if (active) { kind = 3; o = row - D.H2 - D.OA - D.OB; oW = D.oW1 + o * D.IN; ob = D.ob1 + o; n_in = D.IN; act = W.enc; astride = D.IN; }
-    // gradient of this output unit for every pose row
+    // block -> row kind.  Blocks: [hidden rows /4][output rows /4][encoder rows /4]
+    const int nb2 = D.H2 / 4, nb3 = (D.OA + D.OB + 3) / 4;
+    int kind, row;
+    if ((int)blockIdx.x < nb2) { kind = 0; row = blockIdx.x * 4 + wib; }
+    else if ((int)blockIdx.x < nb2 + nb3) { row = (blockIdx.x - nb2) * 4 + wib; kind = row < D.OA ? 1 : 2; }
+    else { kind = 3; row = (blockIdx.x - nb2 - nb3) * 4 + wib; }
+    const int bkind = (int)blockIdx.x < nb2 ? 0 : ((int)blockIdx.x < nb2 + nb3 ? 1 : 3);   // block-uniform
+    bool active = true;
+    int oW = 0, ob = 0, o = 0, n_in = 0, aoff = 0;
+    if (kind == 0) { o = row; oW = D.oW2 + o * D.H; ob = D.ob2 + o; n_in = D.H; }
+    else if (kind == 3) { o = row; active = o < D.H; oW = D.oW1 + o * D.IN; ob = D.ob1 + o; n_in = D.IN; }
+    else if (row < D.OA) { o = row; oW = D.oW3A + o * D.HA; ob = D.ob3A + o; n_in = D.HA; }
+    else if (row < D.OA + D.OB) { o = row - D.OA; oW = D.oW3B + o * D.HB; ob = D.ob3B + o; n_in = D.HB; aoff = D.HA; }
+    else active = false;
+    const float* amat = bkind == 0 ? W.x1[par] : (bkind == 1 ? W.h2 : W.enc);
+    const int awidth = bkind == 0 ? D.H : (bkind == 1 ? D.H2 : D.IN);
+    // parameter, Adam state: all loads of the row in flight at once
+    const int nc = (n_in + 63) / 64;
+    float pw[16], pm[16], pv[16], acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int i = c * 64 + lane;
+        const bool ok = active && c < nc && i < n_in;
+        pw[c] = ok ? W.P[oW + i] : 0.f; pm[c] = ok ? W.AM[oW + i] : 0.f; pv[c] = ok ? W.AV[oW + i] : 0.f; acc[c] = 0.f;
+    }
+    float pb = 0.f, mb = 0.f, vb = 0.f;
+    if (active && lane == 0) { pb = W.P[ob]; mb = W.AM[ob]; vb = W.AV[ob]; }
+    // gradient of this output unit for every pose row (lane r <-> pose row r, K > 64 loops)
     if (active) {
         for (int r = lane; r < D.K; r += 64) {
             float v;
@@ -430,38 +523,58 @@ __global__ __launch_bounds__(256) void k_dw(Dims D, Ws W, int epoch) {
             else if (kind == 1) v = W.g_out[16 * r + o];
             else if (kind == 2) v = W.g_out[16 * r + 4 + o];
             else {
-                float s = 0.f;
-                for (int c = 0; c < D.OC; ++c) s += W.gx1_part[((size_t)c * D.K + r) * D.H + o];
-                v = s * act_grad(W.x1[par][(size_t)r * D.H + o], D.slope);
+                float part[BW2_OC];
+#pragma unroll
+                for (int c = 0; c < BW2_OC; ++c) part[c] = W.gx1_part[((size_t)c * D.K + r) * D.H + o];
+                const float post = W.x1[par][(size_t)r * D.H + o];
+                float sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < BW2_OC; ++c) sum += part[c];
+                v = sum * act_grad(post, D.slope);
             }
             g[r] = v;
         }
     }
-    __syncthreads();
-    if (!active) return;
-    // weights: lanes over the input index; the (single) chunk of an encoder row stays in a register
-    float wnew = 0.f;
-    for (int i = lane; i < n_in; i += 64) {
-        float s = 0.f;
-        for (int r = 0; r < D.K; ++r) s = fmaf(g[r], act[(size_t)r * astride + i], s);
-        adam_update(W.P + oW + i, W.AM + oW + i, W.AV + oW + i, s, S.step_size, S.bc2_sqrt);
-        wnew = W.P[oW + i];
+    // accumulate g[r] * act[r][i] over the pose rows from the LDS-staged activation matrix
+    const int rc = rows_per_chunk(D.K, awidth);
+    for (int r0 = 0; r0 < D.K; r0 += rc) {
+        const int nr = min(rc, D.K - r0);
+        __syncthreads();
+        if ((awidth & 3) == 0) stage_f4<256, 10>((float4*)as, (const float4*)(amat + (size_t)r0 * awidth), nr * awidth / 4);
+        else for (int i = threadIdx.x; i < nr * awidth; i += 256) as[i] = amat[(size_t)r0 * awidth + i];
+        __syncthreads();
+        if (active) {
+            for (int r = 0; r < nr; ++r) {
+                const float gr = g[r0 + r];
+                const float* a = as + r * awidth + aoff + lane;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) if (c < nc && c * 64 + lane < n_in) acc[c] = fmaf(gr, a[c * 64], acc[c]);
+            }
+        }
     }
-    float bnew = 0.f;
-    if (lane == 0) {
-        float s = 0.f;
-        for (int r = 0; r < D.K; ++r) s += g[r];
-        adam_update(W.P + ob, W.AM + ob, W.AV + ob, s, S.step_size, S.bc2_sqrt);
-        bnew = W.P[ob];
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int i = c * 64 + lane;
+            if (c < nc && i < n_in) {
+                pw[c] = adam_value(pw[c], pm[c], pv[c], acc[c], S.step_size, S.bc2_sqrt);
+                W.P[oW + i] = pw[c]; W.AM[oW + i] = pm[c]; W.AV[oW + i] = pv[c];
+            }
+        }
+        if (lane == 0) {
+            float sum = 0.f;
+            for (int r = 0; r < D.K; ++r) sum += g[r];
+            pb = adam_value(pb, mb, vb, sum, S.step_size, S.bc2_sqrt);
+            W.P[ob] = pb; W.AM[ob] = mb; W.AV[ob] = vb;
+        }
     }
-    if (kind == 3) {
+    if (bkind == 3 && active) {
         // next epoch's encoder activation from the updated row held in registers (IN <= 64: one
-        // weight per lane).  The MLP input is the same every epoch: m.clone() of the same m
-        // (mlp_reg.py:62), so only the weights moved.
-        bnew = __shfl(bnew, 0, 64);
+        // weight per lane) and the LDS-staged features (K * IN floats always fit one chunk).  The MLP
+        // input is the same every epoch: m.clone() of the same m (mlp_reg.py:62); only weights moved.
+        const float bnew = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pb)));
         for (int r = 0; r < D.K; ++r) {
-            float v = (lane < D.IN) ? wnew * W.enc[(size_t)r * D.IN + lane] : 0.f;
-            v = wave_sum(v) + bnew;
+            const float v = wave_sum_fast(lane < D.IN ? pw[0] * as[r * D.IN + lane] : 0.f) + bnew;
             if (lane == 0) W.x1[par ^ 1][(size_t)r * D.H + o] = act_f(v, D.slope);
         }
     }
@@ -476,11 +589,11 @@ struct Plan {
     size_t bytes;
     hipGraphExec_t gexec;     // two epochs (parity 0 then 1)
     bool graph_ready;
-    int smem_head, smem_bwd2, smem_dw;
+    int smem_l2, smem_bwd2, smem_dw;
 };
 
 static bool make_dims(const creg_train_shape* s, Dims* D) {
-    if (!s || (s->rot != 0 && s->rot != 1) || s->k < 1 || s->k > 4096 || s->hidden < 64 || s->hidden > 1024 ||
+    if (!s || (s->rot != 0 && s->rot != 1) || s->k < 1 || s->k > 256 || s->hidden < 64 || s->hidden > 1024 ||
         s->hidden % 64 || s->epochs < 1 || s->n_pred < 1 || s->n_tgt < 1 || s->n_pred >= (1ll << 31) ||
         s->n_tgt >= (1ll << 31))
         return false;
@@ -495,10 +608,10 @@ static bool make_dims(const creg_train_shape* s, Dims* D) {
     D->oW3A = o; o += D->OA * D->HA; D->ob3A = o; o += D->OA;
     D->oW3B = o; o += D->OB * D->HB; D->ob3B = o; o += D->OB;
     D->NPAR = o;
-    D->OC = 16;
-    while (D->H2 % D->OC) D->OC /= 2;
-    const int mx = D->NP > D->NT ? D->NP : D->NT;
-    D->nblk_post = (mx + 255) / 256;
+    D->OC = BW2_OC;
+    if (D->H2 % BW2_OC || D->H2 / BW2_OC > BW2_ROWS) return false;
+    const NnGrid g = nn_grid(D->NP, D->NT, true, true);
+    D->nbx = g.blocksA; D->nby = g.blocksB;
     return true;
 }
 
@@ -514,10 +627,9 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     w.m_in = (float*)take(f * 16 * D.K); w.m2 = (float*)take(f * 16 * D.K); w.gm2 = (float*)take(f * 16 * D.K);
     w.pts4 = (float4*)take(sizeof(float4) * D.NP); w.y4 = (float4*)take(sizeof(float4) * D.NT);
     w.pred4 = (float4*)take(sizeof(float4) * D.NP);
-    w.dist_x = (float*)take(f * D.NP); w.dist_y = (float*)take(f * D.NT);
-    w.idx_x = (int*)take(sizeof(int) * D.NP); w.idx_y = (int*)take(sizeof(int) * D.NT);
+    w.sgn_x = (int*)take(sizeof(int) * D.NP);
     w.cnt4 = (int4*)take(sizeof(int4) * D.NP);
-    w.lossp_x = (float*)take(f * D.nblk_post); w.lossp_y = (float*)take(f * D.nblk_post);
+    w.lossp_x = (float*)take(f * D.nbx); w.lossp_y = (float*)take(f * D.nby);
     w.g_out = (float*)take(f * 16 * D.K); w.g_h2 = (float*)take(f * D.K * D.H2);
     w.gx1_part = (float*)take(f * (size_t)D.OC * D.K * D.H);
     w.state = (TrainState*)take(sizeof(TrainState) * 2);
@@ -528,21 +640,20 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     return o;
 }
 
-// `ev` (optional): 9 events recorded before kernel 0 and after each of the 8 kernels.
+constexpr int NKERN = 6;
+// `ev` (optional): NKERN + 1 events recorded before kernel 0 and after each kernel.
 static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nullptr) {
     const Dims& D = P->D; const Ws& W = P->W;
     const int par = epoch & 1;
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], s); };
     mark(0);
-    hipLaunchKernelGGL(k_l2, dim3(cdiv(D.H2, 4)), dim3(256), 0, s, D, W, par); mark(1);
-    hipLaunchKernelGGL(k_head, dim3(cdiv(D.NP, 1024)), dim3(1024), P->smem_head, s, D, W); mark(2);
-    launch_nn_l1_bidir<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, W.dist_x, W.idx_x, W.dist_y,
-                            W.idx_y, s); mark(3);
-    hipLaunchKernelGGL(k_post, dim3(D.nblk_post), dim3(256), 0, s, D, W); mark(4);
-    hipLaunchKernelGGL(k_ctrl, dim3(cdiv(D.NP, 1024)), dim3(256), 0, s, D, W, epoch); mark(5);
-    hipLaunchKernelGGL(k_gradc, dim3(D.K), dim3(256), 0, s, D, W, epoch); mark(6);
-    hipLaunchKernelGGL(k_bwd2, dim3(cdiv(D.H, 256), D.OC), dim3(256), P->smem_bwd2, s, D, W, epoch); mark(7);
-    hipLaunchKernelGGL(k_dw, dim3(cdiv(D.H2 + D.OA + D.OB + D.H, 4)), dim3(256), P->smem_dw, s, D, W, epoch); mark(8);
+    hipLaunchKernelGGL(k_l2, dim3(cdiv(D.H2, 4)), dim3(256), P->smem_l2, s, D, W, par); mark(1);
+    hipLaunchKernelGGL(k_head, dim3(D.K), dim3(512), 0, s, D, W); mark(2);
+    launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
+                      true, true, EngineEpi{W.pred4, W.y4, W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y}, s); mark(3);
+    hipLaunchKernelGGL(k_gradc, dim3(D.K), dim3(256), 0, s, D, W, epoch, D.nbx, D.nby); mark(4);
+    hipLaunchKernelGGL(k_bwd2, dim3(cdiv(D.H, 256), D.OC), dim3(256), P->smem_bwd2, s, D, W, epoch); mark(5);
+    hipLaunchKernelGGL(k_dw, dim3(D.H2 / 4 + (D.OA + D.OB + 3) / 4 + cdiv(D.H, 4)), dim3(256), P->smem_dw, s, D, W, epoch); mark(6);
 }
 
 struct ParamMap { int off, count; };
@@ -599,11 +710,11 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     P->shape = *shape; P->D = D; P->base = (char*)workspace; P->bytes = workspace_bytes;
     carve(D, P->base, &P->W);
     P->gexec = nullptr; P->graph_ready = false;
-    P->smem_head = (int)(sizeof(float) * (8 + 12) * D.K);
-    P->smem_bwd2 = (int)(sizeof(float) * (D.H2 / D.OC) * D.K);
-    P->smem_dw = (int)(sizeof(float) * 4 * D.K);
-    if (P->smem_head > 65536)
-        CREG_HIP(hipFuncSetAttribute((const void*)k_head, hipFuncAttributeMaxDynamicSharedMemorySize, P->smem_head));
+    P->smem_l2 = (int)(sizeof(float) * rows_per_chunk(D.K, D.H) * D.H);
+    P->smem_bwd2 = (int)(sizeof(float) * (BW2_ROWS * ((D.K + 3) & ~3) + 16 * D.K + 8 * BW2_ROWS));
+    P->smem_dw = (int)(sizeof(float) * (((4 * D.K + 3) & ~3) + 16384 + 4));
+    if (P->smem_dw > 65536)
+        CREG_HIP(hipFuncSetAttribute((const void*)k_dw, hipFuncAttributeMaxDynamicSharedMemorySize, P->smem_dw));
     if (P->smem_bwd2 > 65536)
         CREG_HIP(hipFuncSetAttribute((const void*)k_bwd2, hipFuncAttributeMaxDynamicSharedMemorySize, P->smem_bwd2));
     *plan = (creg_train_plan*)P;
@@ -662,12 +773,11 @@ extern "C" int creg_train_plan_probe(creg_train_plan* plan, const creg_train_arg
     const Dims& D = P->D; const Ws& W = P->W;
     int rc = stage_inputs(P, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_l2, dim3(cdiv(D.H2, 4)), dim3(256), 0, s, D, W, 0);
-    hipLaunchKernelGGL(k_head, dim3(cdiv(D.NP, 1024)), dim3(1024), P->smem_head, s, D, W);
-    launch_nn_l1_bidir<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, W.dist_x, W.idx_x, W.dist_y, W.idx_y, s);
-    hipLaunchKernelGGL(k_post, dim3(D.nblk_post), dim3(256), 0, s, D, W);
-    hipLaunchKernelGGL(k_ctrl, dim3(cdiv(D.NP, 1024)), dim3(256), 0, s, D, W, 0);
-    hipLaunchKernelGGL(k_gradc, dim3(D.K), dim3(256), 0, s, D, W, 0);
+    hipLaunchKernelGGL(k_l2, dim3(cdiv(D.H2, 4)), dim3(256), P->smem_l2, s, D, W, 0);
+    hipLaunchKernelGGL(k_head, dim3(D.K), dim3(512), 0, s, D, W);
+    launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
+                      true, true, EngineEpi{W.pred4, W.y4, W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y}, s);
+    hipLaunchKernelGGL(k_gradc, dim3(D.K), dim3(256), 0, s, D, W, 0, D.nbx, D.nby);
     CREG_LAUNCH_CHECK();
     if (m2) CREG_HIP(hipMemcpyAsync(m2, W.m2, sizeof(float) * 16 * D.K, hipMemcpyDeviceToDevice, s));
     if (pred) CREG_HIP(hipMemcpyAsync(pred, W.best_pred, sizeof(float) * 3 * D.NP, hipMemcpyDeviceToDevice, s));
@@ -684,19 +794,19 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
     hipStream_t s = (hipStream_t)stream;
     int rc = stage_inputs(P, a, s);
     if (rc) return rc;
-    std::vector<hipEvent_t> ev((size_t)9 * n_epochs);
+    std::vector<hipEvent_t> ev((size_t)(NKERN + 1) * n_epochs);
     for (auto& e : ev) CREG_HIP(hipEventCreate(&e));
-    for (int e = 0; e < n_epochs; ++e) enqueue_epoch(P, e, s, ev.data() + 9 * e);
+    for (int e = 0; e < n_epochs; ++e) enqueue_epoch(P, e, s, ev.data() + (NKERN + 1) * e);
     CREG_LAUNCH_CHECK();
     CREG_HIP(hipStreamSynchronize(s));
-    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double acc[NKERN] = {0};
     for (int e = 0; e < n_epochs; ++e)
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < NKERN; ++k) {
             float ms = 0.f;
-            CREG_HIP(hipEventElapsedTime(&ms, ev[9 * e + k], ev[9 * e + k + 1]));
+            CREG_HIP(hipEventElapsedTime(&ms, ev[(NKERN + 1) * e + k], ev[(NKERN + 1) * e + k + 1]));
             acc[k] += ms;
         }
-    for (int k = 0; k < 8; ++k) us_out[k] = (float)(acc[k] * 1000.0 / n_epochs);
+    for (int k = 0; k < NKERN; ++k) us_out[k] = (float)(acc[k] * 1000.0 / n_epochs);
     for (auto& e : ev) (void)hipEventDestroy(e);
     return CREG_OK;
 }

@@ -262,10 +262,10 @@ class TrainPlan:
                                                 _stream()), "creg_train_plan_probe")
         return m2, pred, loss, gm
 
-    KERNELS = ("l2", "head", "nn_l1", "post", "ctrl", "gradc", "bwd2", "dw")
+    KERNELS = ("l2", "head", "nn_l1", "gradc", "bwd2", "dw")
 
     def profile(self, m, y, pts, offsets, params, n_epochs=50):
-        """Average event-bracketed microseconds of each of the 8 epoch kernels (synchronises)."""
+        """Average event-bracketed microseconds of each of the 6 epoch kernels (synchronises)."""
         out = (ctypes.c_float * 8)()
         a = self._args(m, y, pts, offsets, params, 2e-4, 0.7, 5, 200, (None, None, None, None, None))
         _lib.check(self.L.creg_train_plan_profile(self.plan, ctypes.byref(a), n_epochs, out, _stream()),

@@ -28,7 +28,10 @@ def cpu_baseline(seq0, mats0, clusters0, budget_s=12.0):
     from oracle import models, registration
     from oracle import kmeans as okm
     torch.manual_seed(0)
-    threads = os.cpu_count() or 1
+    # a 600-epoch frame is latency-sized work: more host threads than ~16 only add OpenMP / intra-op
+    # fork-join cost (256 threads ran 1000x slower than 16 on the GPU box), so cap the team size
+    threads = min(16, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     torch.set_num_threads(threads)
     model = models.QRegMLP(True, HIDDEN)
     m = torch.tensor(mats0, dtype=torch.float32)

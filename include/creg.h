@@ -153,8 +153,8 @@ int creg_masked_icp_f64(const double* local, const float* world, const int32_t* 
  */
 typedef struct creg_train_shape {
     int32_t rot;          /* 0 'q', 1 'dq' */
-    int32_t k;            /* clusters (poses) */
-    int32_t hidden;       /* hidden_dim, multiple of 64, <= 1024 */
+    int32_t k;            /* clusters (poses), <= 256 */
+    int32_t hidden;       /* hidden_dim, multiple of 64, <= 512 */
     int32_t epochs;       /* 300 in the reference (mlp_reg.py:60) */
     int64_t n_pred;       /* sum of cluster sizes */
     int64_t n_tgt;        /* points in the target frame */
@@ -194,9 +194,9 @@ int creg_train_plan_destroy(creg_train_plan* plan);
 int creg_train_plan_probe(creg_train_plan* plan, const creg_train_args* args, float* m2,
                           float* pred, float* loss, float* grad_m2, creg_stream_t stream);
 
-/* Measurement hook: run n_epochs eagerly with a HIP event before / after each of the eight kernels
- * of an epoch (order: l2, head, nn_l1, post, ctrl, gradc, bwd2, dw) on `stream`, synchronise, and
- * write the average microseconds per kernel to us_out (HOST, 8 floats).  Event-bracketed times
+/* Measurement hook: run n_epochs eagerly with a HIP event before / after each of the six kernels
+ * of an epoch (order: l2, head, nn_l1, gradc, bwd2, dw) on `stream`, synchronise, and write the
+ * average microseconds per kernel to us_out (HOST, 8 floats, first 6 used).  Event-bracketed times
  * include the dispatch latency of the launch, i.e. they are an upper bound of the kernel time. */
 int creg_train_plan_profile(creg_train_plan* plan, const creg_train_args* args, int32_t n_epochs,
                             float* us_out, creg_stream_t stream);

@@ -295,8 +295,11 @@ def test_train_is_bit_reproducible_and_graph_equals_eager(dev, golden):
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
 
 
-def test_train_early_stop_and_scheduler(dev, golden):
-    """stop=3 with a tiny lr: the loss plateaus, the scheduler cuts lr after patience, the loop stops."""
+@pytest.mark.parametrize("lr,stop,expect_stop", [(0.2, 3, True), (5e-2, 4, False)])
+def test_train_early_stop_and_scheduler(dev, golden, lr, stop, expect_stop):
+    """Large lr: the loss stops improving, ReduceLROnPlateau(patience=1) cuts lr, and with stop=3 the
+    loop breaks early (before that epoch's backward); with lr 5e-2 it runs all epochs through
+    several lr cuts.  Epoch count, lr trajectory and the NaN tail of the history must match."""
     from autourdf_amd import ops
     from oracle import models, registration
     g, _, _ = _train_case(golden, "q")
@@ -309,13 +312,17 @@ def test_train_early_stop_and_scheduler(dev, golden):
     pts, off = ops.pack_clusters(clusters, dev)
     params = [model.state_dict()[k].clone().to(dev) for k in ops.Q_PARAM_ORDER]
     plan = ops.TrainPlan("q", len(clusters), 64, pts.shape[0], y.shape[0], epochs=60, use_graph=True, device=dev)
-    _, _, res, lh, lrh = plan.run(m.to(dev), y.to(dev), pts, off, params, lr=5e-2, patience=1, stop=4)
-    _, _, o_min, hist = registration.train(m, y, model, clusters, rot="q", epochs=60, learning_rate=5e-2,
-                                           scheduler_patience=1, stop=4)
+    _, _, res, lh, lrh = plan.run(m.to(dev), y.to(dev), pts, off, params, lr=lr, patience=1, stop=stop)
+    _, _, o_min, hist = registration.train(m, y, model, clusters, rot="q", epochs=60, learning_rate=lr,
+                                           scheduler_patience=1, stop=stop)
     n = len(hist["loss"])
-    assert int(res[1].item()) == n                                 # same early-stop epoch
-    assert n < 60 and torch.isnan(lh[n:]).all()
+    assert (n < 60) == expect_stop
+    assert int(res[1].item()) == n                                 # same (early-)stop epoch
+    assert torch.isnan(lh[n:]).all() and not torch.isnan(lh[:n]).any()
+    assert len(set(np.round(hist["lr"], 9))) >= 2                  # the scheduler did cut the lr
     np.testing.assert_allclose(lrh.cpu().numpy()[:n], np.array(hist["lr"], np.float32), rtol=1e-6)
+    for k, p in zip(ops.Q_PARAM_ORDER, params):                    # no update after the break
+        np.testing.assert_allclose(p.cpu().numpy(), model.state_dict()[k].numpy(), rtol=5e-3, atol=1e-5)
 
 
 def test_train_300_epochs_golden_reference(dev, golden):
