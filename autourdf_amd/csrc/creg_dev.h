@@ -35,10 +35,12 @@ template <int NT, int B>
 __device__ __forceinline__ void stage_f4(float4* __restrict__ dst, const float4* __restrict__ src, int n) {
     for (int base = 0; base < n; base += NT * B) {
         float4 v[B];
+        // index clamped on BOTH sides: an `if (i < n)` around the store makes hipcc sink the load into
+        // the branch and wait on each one; the tail threads just rewrite element n-1 with itself.
 #pragma unroll
         for (int q = 0; q < B; ++q) v[q] = src[min(base + q * NT + (int)threadIdx.x, n - 1)];
 #pragma unroll
-        for (int q = 0; q < B; ++q) { const int i = base + q * NT + (int)threadIdx.x; if (i < n) dst[i] = v[q]; }
+        for (int q = 0; q < B; ++q) dst[min(base + q * NT + (int)threadIdx.x, n - 1)] = v[q];
     }
 }
 

@@ -151,30 +151,32 @@ __host__ __device__ inline int rows_per_chunk(int K, int width) {
 
 // ------------------------------------------------------------------------------------------ layer 2
 // One wave per hidden unit; the block stages the encoder activation in LDS with one round trip
-// (all threads loading) instead of K dependent global reads per wave.
+// (all threads loading) instead of K dependent global reads per wave.  NC = H / 64 is a template
+// parameter so the per-row dot is straight-line code (runtime bounds made hipcc emit a branch and an
+// lgkmcnt(0) per element).
+template <int NC>
 __global__ __launch_bounds__(256) void k_l2(Dims D, Ws W, int par) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = (float*)smem;                      // [rc][H]
+    constexpr int H = NC * 64;
     const int lane = threadIdx.x & 63;
-    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool active = o < D.H2;
-    const int nc = D.H / 64;
-    float wr[16];
+    const int o = min((int)(blockIdx.x * 4 + (threadIdx.x >> 6)), D.H2 - 1);     // grid covers H2 exactly (H2 % 4 == 0)
+    float wr[NC];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) wr[c] = (active && c < nc) ? W.P[D.oW2 + (size_t)o * D.H + c * 64 + lane] : 0.f;
-    const float b = active ? W.P[D.ob2 + o] : 0.f;
-    const int rc = rows_per_chunk(D.K, D.H);
+    for (int c = 0; c < NC; ++c) wr[c] = W.P[D.oW2 + (size_t)o * H + c * 64 + lane];
+    const float b = W.P[D.ob2 + o];
+    const int rc = rows_per_chunk(D.K, H);
     for (int r0 = 0; r0 < D.K; r0 += rc) {
         const int nr = min(rc, D.K - r0);
         if (r0) __syncthreads();
-        stage_f4<256, 10>((float4*)xs, (const float4*)(W.x1[par] + (size_t)r0 * D.H), nr * D.H / 4);
+        stage_f4<256, (NC * 5 + 3) / 4>((float4*)xs, (const float4*)(W.x1[par] + (size_t)r0 * H), nr * H / 4);
         __syncthreads();
-        if (!active) continue;
+#pragma unroll 4
         for (int r = 0; r < nr; ++r) {
-            const float* a = xs + r * D.H + lane;
+            const float* a = xs + r * H + lane;
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) if (c < nc) s = fmaf(wr[c], a[c * 64], s);
+            for (int c = 0; c < NC; ++c) s = fmaf(wr[c], a[c * 64], s);
             s = wave_sum_fast(s) + b;
             if (lane == 0) W.h2[(size_t)(r0 + r) * D.H2 + o] = act_f(s, D.slope);
         }
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(256) void k_l2(Dims D, Ws W, int par) {
 // Block r: output layer for pose row r (one wave per output unit), pose assembly, then the rigid
 // transform of cluster r's points (clusters are stored back to back) -- calculate_pc needs no
 // launch of its own and nothing is recomputed.
+template <int NC>
 __global__ __launch_bounds__(512) void k_head(Dims D, Ws W) {
     __shared__ float outs[8];
     __shared__ float m2s[12];
@@ -195,12 +198,12 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W) {
         const float *w, *a; int n; float bias;
         if (o < D.OA) { w = W.P + D.oW3A + (size_t)o * D.HA; a = W.h2 + (size_t)r * D.H2; n = D.HA; bias = W.P[D.ob3A + o]; }
         else { w = W.P + D.oW3B + (size_t)(o - D.OA) * D.HB; a = W.h2 + (size_t)r * D.H2 + D.HA; n = D.HB; bias = W.P[D.ob3B + o - D.OA]; }
-        float wv[16], av[16];                      // n <= 1024: every load of the dot in flight at once
+        float wv[NC], av[NC];                      // n <= 64 NC: every load of the dot in flight at once
 #pragma unroll
-        for (int c = 0; c < 16; ++c) { const int i = min(c * 64 + lane, n - 1); wv[c] = w[i]; av[c] = a[i]; }
+        for (int c = 0; c < NC; ++c) { const int i = min(c * 64 + lane, n - 1); wv[c] = w[i]; av[c] = a[i]; }
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) if (c * 64 + lane < n) s = fmaf(wv[c], av[c], s);
+        for (int c = 0; c < NC; ++c) s = fmaf(c * 64 + lane < n ? wv[c] : 0.f, av[c], s);
         s = wave_sum_fast(s) + bias;
         if (lane == 0) outs[o] = s;
     }
@@ -480,6 +483,7 @@ __device__ __forceinline__ float adam_value(float p, float& mm, float& vv, float
 // ([K][H] encoder activation for hidden rows, [K][H2] hidden activation for output rows, [K][IN]
 // features for encoder rows) in LDS with batched loads; a row's parameter / Adam-state loads are all
 // issued together.  No loop over K contains a global load.
+template <int NC>
 __global__ __launch_bounds__(256) void k_dw(Dims D, Ws W, int epoch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const TrainState S = W.state[(epoch + 1) & 1];
@@ -496,85 +500,75 @@ __global__ __launch_bounds__(256) void k_dw(Dims D, Ws W, int epoch) {
     else { kind = 3; row = (blockIdx.x - nb2 - nb3) * 4 + wib; }
     const int bkind = (int)blockIdx.x < nb2 ? 0 : ((int)blockIdx.x < nb2 + nb3 ? 1 : 3);   // block-uniform
     bool active = true;
-    int oW = 0, ob = 0, o = 0, n_in = 0, aoff = 0;
+    int oW = 0, ob = 0, o = 0, n_in = 64, aoff = 0;
     if (kind == 0) { o = row; oW = D.oW2 + o * D.H; ob = D.ob2 + o; n_in = D.H; }
-    else if (kind == 3) { o = row; active = o < D.H; oW = D.oW1 + o * D.IN; ob = D.ob1 + o; n_in = D.IN; }
+    else if (kind == 3) { o = min(row, D.H - 1); active = row < D.H; oW = D.oW1 + o * D.IN; ob = D.ob1 + o; n_in = D.IN; }
     else if (row < D.OA) { o = row; oW = D.oW3A + o * D.HA; ob = D.ob3A + o; n_in = D.HA; }
     else if (row < D.OA + D.OB) { o = row - D.OA; oW = D.oW3B + o * D.HB; ob = D.ob3B + o; n_in = D.HB; aoff = D.HA; }
-    else active = false;
+    else { active = false; oW = D.oW3B; ob = D.ob3B; n_in = D.HB; aoff = D.HA; }      // idle wave mirrors a valid row, stores nothing
     const float* amat = bkind == 0 ? W.x1[par] : (bkind == 1 ? W.h2 : W.enc);
     const int awidth = bkind == 0 ? D.H : (bkind == 1 ? D.H2 : D.IN);
-    // parameter, Adam state: all loads of the row in flight at once
-    const int nc = (n_in + 63) / 64;
-    float pw[16], pm[16], pv[16], acc[16];
+    // parameter, Adam state: all loads of the row in flight at once (indices clamped, not predicated)
+    float pw[NC], pm[NC], pv[NC], acc[NC];
+    int idx[NC];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const int i = c * 64 + lane;
-        const bool ok = active && c < nc && i < n_in;
-        pw[c] = ok ? W.P[oW + i] : 0.f; pm[c] = ok ? W.AM[oW + i] : 0.f; pv[c] = ok ? W.AV[oW + i] : 0.f; acc[c] = 0.f;
+    for (int c = 0; c < NC; ++c) {
+        idx[c] = min(c * 64 + lane, n_in - 1);
+        pw[c] = W.P[oW + idx[c]]; pm[c] = W.AM[oW + idx[c]]; pv[c] = W.AV[oW + idx[c]]; acc[c] = 0.f;
     }
-    float pb = 0.f, mb = 0.f, vb = 0.f;
-    if (active && lane == 0) { pb = W.P[ob]; mb = W.AM[ob]; vb = W.AV[ob]; }
+    float pb = W.P[ob], mb = W.AM[ob], vb = W.AV[ob];
     // gradient of this output unit for every pose row (lane r <-> pose row r, K > 64 loops)
-    if (active) {
-        for (int r = lane; r < D.K; r += 64) {
-            float v;
-            if (kind == 0) v = W.g_h2[(size_t)r * D.H2 + o];
-            else if (kind == 1) v = W.g_out[16 * r + o];
-            else if (kind == 2) v = W.g_out[16 * r + 4 + o];
-            else {
-                float part[BW2_OC];
+    for (int r = lane; r < D.K; r += 64) {
+        float v;
+        if (kind == 0) v = W.g_h2[(size_t)r * D.H2 + o];
+        else if (kind == 1) v = W.g_out[16 * r + o];
+        else if (kind == 2) v = W.g_out[16 * r + 4 + o];
+        else {
+            float part[BW2_OC];
 #pragma unroll
-                for (int c = 0; c < BW2_OC; ++c) part[c] = W.gx1_part[((size_t)c * D.K + r) * D.H + o];
-                const float post = W.x1[par][(size_t)r * D.H + o];
-                float sum = 0.f;
+            for (int c = 0; c < BW2_OC; ++c) part[c] = W.gx1_part[((size_t)c * D.K + r) * D.H + o];
+            const float post = W.x1[par][(size_t)r * D.H + o];
+            float sum = 0.f;
 #pragma unroll
-                for (int c = 0; c < BW2_OC; ++c) sum += part[c];
-                v = sum * act_grad(post, D.slope);
-            }
-            g[r] = v;
+            for (int c = 0; c < BW2_OC; ++c) sum += part[c];
+            v = sum * act_grad(post, D.slope);
         }
+        g[r] = v;
     }
     // accumulate g[r] * act[r][i] over the pose rows from the LDS-staged activation matrix
     const int rc = rows_per_chunk(D.K, awidth);
     for (int r0 = 0; r0 < D.K; r0 += rc) {
         const int nr = min(rc, D.K - r0);
         __syncthreads();
-        if ((awidth & 3) == 0) stage_f4<256, 10>((float4*)as, (const float4*)(amat + (size_t)r0 * awidth), nr * awidth / 4);
-        else for (int i = threadIdx.x; i < nr * awidth; i += 256) as[i] = amat[(size_t)r0 * awidth + i];
+        stage_f4<256, 10>((float4*)as, (const float4*)(amat + (size_t)r0 * awidth), nr * awidth / 4);
         __syncthreads();
-        if (active) {
-            for (int r = 0; r < nr; ++r) {
-                const float gr = g[r0 + r];
-                const float* a = as + r * awidth + aoff + lane;
+#pragma unroll 4
+        for (int r = 0; r < nr; ++r) {
+            const float gr = g[r0 + r];
+            const float* a = as + r * awidth + aoff;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) if (c < nc && c * 64 + lane < n_in) acc[c] = fmaf(gr, a[c * 64], acc[c]);
-            }
+            for (int c = 0; c < NC; ++c) acc[c] = fmaf(gr, a[idx[c]], acc[c]);
         }
     }
     if (active) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int i = c * 64 + lane;
-            if (c < nc && i < n_in) {
-                pw[c] = adam_value(pw[c], pm[c], pv[c], acc[c], S.step_size, S.bc2_sqrt);
-                W.P[oW + i] = pw[c]; W.AM[oW + i] = pm[c]; W.AV[oW + i] = pv[c];
-            }
+        for (int c = 0; c < NC; ++c) {
+            const float nw = adam_value(pw[c], pm[c], pv[c], acc[c], S.step_size, S.bc2_sqrt);
+            if (c * 64 + lane < n_in) { W.P[oW + idx[c]] = nw; W.AM[oW + idx[c]] = pm[c]; W.AV[oW + idx[c]] = pv[c]; }
+            pw[c] = nw;
         }
-        if (lane == 0) {
-            float sum = 0.f;
-            for (int r = 0; r < D.K; ++r) sum += g[r];
-            pb = adam_value(pb, mb, vb, sum, S.step_size, S.bc2_sqrt);
-            W.P[ob] = pb; W.AM[ob] = mb; W.AV[ob] = vb;
-        }
+        float sum = 0.f;
+        for (int r = 0; r < D.K; ++r) sum += g[r];
+        pb = adam_value(pb, mb, vb, sum, S.step_size, S.bc2_sqrt);
+        if (lane == 0) { W.P[ob] = pb; W.AM[ob] = mb; W.AV[ob] = vb; }
     }
     if (bkind == 3 && active) {
         // next epoch's encoder activation from the updated row held in registers (IN <= 64: one
         // weight per lane) and the LDS-staged features (K * IN floats always fit one chunk).  The MLP
         // input is the same every epoch: m.clone() of the same m (mlp_reg.py:62); only weights moved.
-        const float bnew = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pb)));
+#pragma unroll 4
         for (int r = 0; r < D.K; ++r) {
-            const float v = wave_sum_fast(lane < D.IN ? pw[0] * as[r * D.IN + lane] : 0.f) + bnew;
+            const float v = wave_sum_fast(lane < D.IN ? pw[0] * as[r * D.IN + lane] : 0.f) + pb;
             if (lane == 0) W.x1[par ^ 1][(size_t)r * D.H + o] = act_f(v, D.slope);
         }
     }
@@ -593,8 +587,7 @@ struct Plan {
 };
 
 static bool make_dims(const creg_train_shape* s, Dims* D) {
-    if (!s || (s->rot != 0 && s->rot != 1) || s->k < 1 || s->k > 256 || s->hidden < 64 || s->hidden > 1024 ||
-        s->hidden % 64 || s->epochs < 1 || s->n_pred < 1 || s->n_tgt < 1 || s->n_pred >= (1ll << 31) ||
+    if (!s || (s->rot != 0 && s->rot != 1) || s->k < 1 || s->k > 256 || (s->hidden != 64 && s->hidden != 128 && s->hidden != 256 && s->hidden != 512) || s->epochs < 1 || s->n_pred < 1 || s->n_tgt < 1 || s->n_pred >= (1ll << 31) ||
         s->n_tgt >= (1ll << 31))
         return false;
     memset(D, 0, sizeof(*D));
@@ -640,6 +633,30 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     return o;
 }
 
+template <typename F>
+static void by_nc(int H, F f) {            // H in {64, 128, 256, 512}
+    switch (H / 64) {
+        case 1: f(std::integral_constant<int, 1>{}); break;
+        case 2: f(std::integral_constant<int, 2>{}); break;
+        case 4: f(std::integral_constant<int, 4>{}); break;
+        default: f(std::integral_constant<int, 8>{}); break;
+    }
+}
+static void launch_l2(Plan* P, int par, hipStream_t s) {
+    const Dims& D = P->D; const Ws& W = P->W;
+    by_nc(D.H, [&](auto nc) {
+        hipLaunchKernelGGL((k_l2<decltype(nc)::value>), dim3(D.H2 / 4), dim3(256), P->smem_l2, s, D, W, par); });
+}
+static void launch_head(Plan* P, hipStream_t s) {
+    const Dims& D = P->D; const Ws& W = P->W;
+    by_nc(D.H, [&](auto nc) { hipLaunchKernelGGL((k_head<decltype(nc)::value>), dim3(D.K), dim3(512), 0, s, D, W); });
+}
+static void launch_dw(Plan* P, int epoch, hipStream_t s) {
+    const Dims& D = P->D; const Ws& W = P->W;
+    by_nc(D.H, [&](auto nc) {
+        hipLaunchKernelGGL((k_dw<decltype(nc)::value>), dim3(D.H2 / 4 + (D.OA + D.OB + 3) / 4 + cdiv(D.H, 4)), dim3(256),
+                           P->smem_dw, s, D, W, epoch); });
+}
 constexpr int NKERN = 6;
 // `ev` (optional): NKERN + 1 events recorded before kernel 0 and after each kernel.
 static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nullptr) {
@@ -647,13 +664,13 @@ static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nu
     const int par = epoch & 1;
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], s); };
     mark(0);
-    hipLaunchKernelGGL(k_l2, dim3(cdiv(D.H2, 4)), dim3(256), P->smem_l2, s, D, W, par); mark(1);
-    hipLaunchKernelGGL(k_head, dim3(D.K), dim3(512), 0, s, D, W); mark(2);
+    launch_l2(P, par, s); mark(1);
+    launch_head(P, s); mark(2);
     launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
                       true, true, EngineEpi{W.pred4, W.y4, W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y}, s); mark(3);
     hipLaunchKernelGGL(k_gradc, dim3(D.K), dim3(256), 0, s, D, W, epoch, D.nbx, D.nby); mark(4);
     hipLaunchKernelGGL(k_bwd2, dim3(cdiv(D.H, 256), D.OC), dim3(256), P->smem_bwd2, s, D, W, epoch); mark(5);
-    hipLaunchKernelGGL(k_dw, dim3(D.H2 / 4 + (D.OA + D.OB + 3) / 4 + cdiv(D.H, 4)), dim3(256), P->smem_dw, s, D, W, epoch); mark(6);
+    launch_dw(P, epoch, s); mark(6);
 }
 
 struct ParamMap { int off, count; };
@@ -713,8 +730,13 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     P->smem_l2 = (int)(sizeof(float) * rows_per_chunk(D.K, D.H) * D.H);
     P->smem_bwd2 = (int)(sizeof(float) * (BW2_ROWS * ((D.K + 3) & ~3) + 16 * D.K + 8 * BW2_ROWS));
     P->smem_dw = (int)(sizeof(float) * (((4 * D.K + 3) & ~3) + 16384 + 4));
-    if (P->smem_dw > 65536)
-        CREG_HIP(hipFuncSetAttribute((const void*)k_dw, hipFuncAttributeMaxDynamicSharedMemorySize, P->smem_dw));
+    int rc_attr = 0;
+    by_nc(D.H, [&](auto nc) {
+        if (P->smem_dw > 65536 &&
+            hipFuncSetAttribute((const void*)k_dw<decltype(nc)::value>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                P->smem_dw) != hipSuccess) rc_attr = 1;
+    });
+    CREG_REQUIRE(rc_attr == 0, "creg_train_plan_create: cannot raise the dynamic LDS limit of k_dw");
     if (P->smem_bwd2 > 65536)
         CREG_HIP(hipFuncSetAttribute((const void*)k_bwd2, hipFuncAttributeMaxDynamicSharedMemorySize, P->smem_bwd2));
     *plan = (creg_train_plan*)P;
@@ -773,8 +795,8 @@ extern "C" int creg_train_plan_probe(creg_train_plan* plan, const creg_train_arg
     const Dims& D = P->D; const Ws& W = P->W;
     int rc = stage_inputs(P, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_l2, dim3(cdiv(D.H2, 4)), dim3(256), P->smem_l2, s, D, W, 0);
-    hipLaunchKernelGGL(k_head, dim3(D.K), dim3(512), 0, s, D, W);
+    launch_l2(P, 0, s);
+    launch_head(P, s);
     launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
                       true, true, EngineEpi{W.pred4, W.y4, W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y}, s);
     hipLaunchKernelGGL(k_gradc, dim3(D.K), dim3(256), 0, s, D, W, 0, D.nbx, D.nby);
