@@ -44,6 +44,27 @@ __device__ __forceinline__ void stage_f4(float4* __restrict__ dst, const float4*
     }
 }
 
+// (value, index) lexicographic minimum over the wave with DPP moves instead of LDS-crossbar
+// bpermutes (same tree as wave_sum_fast); the result is returned wave-uniform.
+#define CREG_DPP_ARGMIN_STEP(ctrl, mask)                                                              \
+    {                                                                                                 \
+        const float ov = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, mask, 0xF, false)); \
+        const int oi = __builtin_amdgcn_update_dpp(i, i, ctrl, mask, 0xF, false);                      \
+        const bool take = (ov < v) || (ov == v && oi < i);                                            \
+        v = take ? ov : v;                                                                            \
+        i = take ? oi : i;                                                                            \
+    }
+__device__ __forceinline__ void wave_argmin_fast(float& v, int& i) {
+    CREG_DPP_ARGMIN_STEP(0xB1, 0xF)
+    CREG_DPP_ARGMIN_STEP(0x4E, 0xF)
+    CREG_DPP_ARGMIN_STEP(0x141, 0xF)
+    CREG_DPP_ARGMIN_STEP(0x140, 0xF)
+    CREG_DPP_ARGMIN_STEP(0x142, 0xA)
+    CREG_DPP_ARGMIN_STEP(0x143, 0xC)
+    v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    i = __builtin_amdgcn_readlane(i, 63);
+}
+
 // (value, index) lexicographic minimum across the wave: smallest value, then smallest index.
 __device__ __forceinline__ void wave_argmin(float& v, int& i) {
 #pragma unroll

@@ -2,24 +2,29 @@
 // (nn_l1.hip) and the fused train plan (train_engine.hip).
 //
 // Mapping (N=4096: 256 workgroups = one per CU, 8 waves each):
-//   * a workgroup stages the target cloud into LDS once (float4 per point, 64 KB per 4096 points,
-//     chunked for larger clouds) -- without that every wave streamed the whole cloud from L2
-//     (128 MB per launch at N=4096, the v1 kernel was L2-bandwidth bound);
+//   * a workgroup stages the target cloud into LDS once as three coordinate planes (48 KB per 4096
+//     points, chunked for larger clouds) -- without that every wave streamed the whole cloud from
+//     L2 (128 MB per launch at N=4096: the v1 kernel was L2-bandwidth bound);
 //   * a wave owns QW consecutive queries (wave-uniform -> SGPRs); its lanes stride over the staged
-//     targets (conflict-free ds_read_b128), each lane keeping the FIRST minimum over its own
-//     ascending targets; a (distance, index) lexicographic butterfly yields the global first min;
+//     targets in groups of 4 (ds_read2st64_b32 returns two targets' coordinate in one register
+//     pair, which is what v_pk_add_f32 wants);
+//   * per (group, query): 6 packed subs + 8 adds with |.| modifiers give the four distances
+//     d = (|dx|+|dy|)+|dz| (pytorch3d knn_cpu order, bit-exact); v_min3 + v_min reduce them and only
+//     the GROUP of the running first minimum is tracked (cmp + cndmask + min): 4.75 VALU ops per
+//     pair instead of 8 for per-pair index tracking (VALU issue is the bound of this kernel);
+//   * after the sweep each lane re-evaluates the 4 targets of its best group to recover the exact
+//     first index, then a DPP (distance, index) lexicographic reduction yields the global first min;
 //   * no atomics, no cross-workgroup reduction: results are final inside the launch, so the
 //     epilogue can consume them (the train plan's loss partials and sign scatter).
-// Pair cost: 3 sub + 2 add(|.|) + cmp + 2 cndmask = 8 VALU lane-ops; d = (|dx|+|dy|)+|dz| in fp32,
-// the pytorch3d knn_cpu accumulation order (bit-exact against the oracle).
 #pragma once
 #include <type_traits>
 #include "creg_dev.h"
 
 namespace creg {
 
-constexpr int NN_TCH = 4096;          // targets staged per LDS chunk (64 KB)
+constexpr int NN_TCH = 4096;          // targets staged per LDS chunk (3 planes x 16 KB)
 constexpr int NN_BLOCK = 512;         // 8 waves
+typedef float nn_f2 __attribute__((ext_vector_type(2)));
 
 struct NnEpilogueNone {
     __device__ __forceinline__ void operator()(int, int, int, float, int, float&) const {}
@@ -28,15 +33,15 @@ struct NnEpilogueNone {
 
 // A/B: point arrays with sa/sb floats per point (3 = packed xyz, 4 = float4 padded).
 // Blocks [0, blocksA) search B for A's queries (direction 0), the rest search A for B's (direction 1).
-// Epi::operator()(dir, q, lane, dist, idx, acc) runs on lane u for the wave's u-th query; Epi::finish(dir, blk, sum, scratch)
-// once per block with the block's fixed-order sum of `acc`.
+// Epi::operator()(dir, q, lane, dist, idx, acc) runs on lane u for the wave's u-th query;
+// Epi::finish(dir, blk, sum, scratch) once per block with the block's fixed-order sum of `acc`.
 template <int QW, typename IdxT, typename Epi>
 __global__ __launch_bounds__(NN_BLOCK) void k_nn_l1(
     const float* __restrict__ A, int na, int sa, const float* __restrict__ B, int nb, int sb,
     float* __restrict__ dA, IdxT* __restrict__ iA, float* __restrict__ dB, IdxT* __restrict__ iB,
     int blocksA, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float4* sT = (float4*)smem_raw;
+    float* sX = (float*)smem_raw;                 // planes of `padded` floats each
     __shared__ float s_part[NN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -48,19 +53,19 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_l1(
     const int q0 = (blk * (NN_BLOCK / 64) + wave) * QW;
 
     float qx[QW], qy[QW], qz[QW], best[QW];
-    int bidx[QW];
+    int bgrp[QW];                                  // first target index of the group holding the lane's first min
 #pragma unroll
     for (int u = 0; u < QW; ++u) {
         const int qi = min(q0 + u, nq - 1);                  // wave-uniform: scalar loads
         qx[u] = Q[(size_t)qi * sq]; qy[u] = Q[(size_t)qi * sq + 1]; qz[u] = Q[(size_t)qi * sq + 2];
-        best[u] = INFINITY; bidx[u] = 0x7fffffff;
+        best[u] = INFINITY; bgrp[u] = -1;
     }
     for (int t0 = 0; t0 < nt; t0 += NN_TCH) {
         const int cnt = min(NN_TCH, nt - t0);
         const int padded = (cnt + 255) & ~255;               // pad with +inf points: never selected
+        float* sY = sX + padded; float* sZ = sY + padded;
         if (t0) __syncthreads();
-        // all of a thread's (<= 8) target loads are issued before the first LDS write
-        {
+        {   // all of a thread's (<= 8) target loads are issued before the first LDS write
             float4 v[NN_TCH / NN_BLOCK];
 #pragma unroll
             for (int q = 0; q < NN_TCH / NN_BLOCK; ++q) {
@@ -71,32 +76,54 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_l1(
 #pragma unroll
             for (int q = 0; q < NN_TCH / NN_BLOCK; ++q) {
                 const int j = q * NN_BLOCK + tid;
-                if (j < padded) sT[j] = (j < cnt) ? v[q] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+                const bool real = j < cnt;
+                if (j < padded) { sX[j] = real ? v[q].x : INFINITY; sY[j] = real ? v[q].y : INFINITY; sZ[j] = real ? v[q].z : INFINITY; }
             }
         }
         __syncthreads();
         for (int jj = lane; jj < padded; jj += 256) {
+            const nn_f2 x01 = {sX[jj], sX[jj + 64]}, x23 = {sX[jj + 128], sX[jj + 192]};
+            const nn_f2 y01 = {sY[jj], sY[jj + 64]}, y23 = {sY[jj + 128], sY[jj + 192]};
+            const nn_f2 z01 = {sZ[jj], sZ[jj + 64]}, z23 = {sZ[jj + 128], sZ[jj + 192]};
+            const int grp = t0 + jj;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float4 t = sT[jj + 64 * e];
-                const int j = t0 + jj + 64 * e;
-#pragma unroll
-                for (int u = 0; u < QW; ++u) {
-                    const float d = l1_dist(qx[u], qy[u], qz[u], t.x, t.y, t.z);
-                    const bool lt = d < best[u];
-                    best[u] = lt ? d : best[u];
-                    bidx[u] = lt ? j : bidx[u];
-                }
+            for (int u = 0; u < QW; ++u) {
+                const nn_f2 qxx = {qx[u], qx[u]}, qyy = {qy[u], qy[u]}, qzz = {qz[u], qz[u]};
+                const nn_f2 ax = qxx - x01, bx = qxx - x23, ay = qyy - y01, by = qyy - y23, az = qzz - z01, bz = qzz - z23;
+                const float d0 = (fabsf(ax.x) + fabsf(ay.x)) + fabsf(az.x);
+                const float d1 = (fabsf(ax.y) + fabsf(ay.y)) + fabsf(az.y);
+                const float d2 = (fabsf(bx.x) + fabsf(by.x)) + fabsf(bz.x);
+                const float d3 = (fabsf(bx.y) + fabsf(by.y)) + fabsf(bz.y);
+                const float g = fminf(__builtin_fminf(__builtin_fminf(d0, d1), d2), d3);
+                const bool lt = g < best[u];
+                bgrp[u] = lt ? grp : bgrp[u];
+                best[u] = lt ? g : best[u];
             }
         }
     }
-    // results: lane u keeps query u's (distance, index) so the QW stores / epilogues run side by side
+    // exact first index inside the best group: re-evaluate its 4 targets (one batch of loads)
     float acc = 0.f, mv = 0.f;
     int mi = 0;
+    float rx[QW][4], ry[QW][4], rz[QW][4];
+#pragma unroll
+    for (int u = 0; u < QW; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = min(max(bgrp[u], 0) + 64 * e, nt - 1);
+            const float* p = T + (size_t)j * st;
+            rx[u][e] = p[0]; ry[u][e] = p[1]; rz[u][e] = p[2];
+        }
 #pragma unroll
     for (int u = 0; u < QW; ++u) {
-        float v = best[u]; int i = bidx[u];
-        wave_argmin(v, i);
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int e = 3; e >= 0; --e) {
+            const int j = bgrp[u] + 64 * e;
+            const float d = l1_dist(qx[u], qy[u], qz[u], rx[u][e], ry[u][e], rz[u][e]);
+            if (bgrp[u] >= 0 && j < nt && d == best[u]) bi = j;      // descending e: the smallest j survives
+        }
+        float v = best[u]; int i = bi;
+        wave_argmin_fast(v, i);
         if (lane == u) { mv = v; mi = i; }
     }
     if (lane < QW && q0 + lane < nq) {
@@ -127,7 +154,7 @@ inline NnGrid nn_grid(int na, int nb, bool doA, bool doB) {
     g.blocksB = doB ? (nb + per - 1) / per : 0;
     const int mx = na > nb ? na : nb;
     const int cnt = mx < NN_TCH ? mx : NN_TCH;
-    g.smem = ((cnt + 255) & ~255) * (int)sizeof(float4);
+    g.smem = ((cnt + 255) & ~255) * 3 * (int)sizeof(float);
     return g;
 }
 
