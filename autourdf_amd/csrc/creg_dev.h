@@ -28,20 +28,29 @@ __device__ __forceinline__ float wave_sum_fast(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// Cooperative global -> LDS copy of n float4 by NT threads with B loads in flight per thread.
-// (A plain `for (i = tid; i < n; i += NT) dst[i] = src[i]` costs one full memory round trip per
-// iteration: hipcc does not software-pipeline it, and on MI355X a dependent round trip is ~1 us.)
-template <int NT, int B>
-__device__ __forceinline__ void stage_f4(float4* __restrict__ dst, const float4* __restrict__ src, int n) {
-    for (int base = 0; base < n; base += NT * B) {
-        float4 v[B];
-        // index clamped on BOTH sides: an `if (i < n)` around the store makes hipcc sink the load into
-        // the branch and wait on each one; the tail threads just rewrite element n-1 with itself.
-#pragma unroll
-        for (int q = 0; q < B; ++q) v[q] = src[min(base + q * NT + (int)threadIdx.x, n - 1)];
-#pragma unroll
-        for (int q = 0; q < B; ++q) dst[min(base + q * NT + (int)threadIdx.x, n - 1)] = v[q];
+// Cooperative global -> LDS copy of n float4 by NT threads through the LDS-DMA path
+// (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR round trip).  Every request is in
+// flight before the single wait, so the copy costs ONE memory round trip.  The register-staged
+// alternative (`v[q] = src[..]; ...; dst[..] = v[q]`) does not survive hipcc: it sinks each load to
+// its LDS write and serialises the pairs (one ~1-2 us cold round trip each), and fences either get
+// bypassed (__restrict__) or push the array to scratch.
+// dst must be 16-byte aligned and have room for n rounded up to a multiple of 64 float4.
+// B is kept as a template argument for call-site documentation only.
+template <int NT>
+__device__ __forceinline__ void stage_issue(float4* dst, const float4* src, int n) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int c = wave; c * 64 < n; c += NT / 64) {
+        const int i = min(c * 64 + lane, n - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
+                                         (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
     }
+}
+// wait for this wave's outstanding DMA (and loads); follow with __syncthreads() before other waves read
+__device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int NT, int B>
+__device__ __forceinline__ void stage_f4(float4* dst, const float4* src, int n) {
+    stage_issue<NT>(dst, src, n);
+    stage_wait();
 }
 
 // (value, index) lexicographic minimum over the wave with DPP moves instead of LDS-crossbar

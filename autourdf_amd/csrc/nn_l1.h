@@ -27,13 +27,12 @@ constexpr int NN_BLOCK = 512;         // 8 waves
 typedef float nn_f2 __attribute__((ext_vector_type(2)));
 
 struct NnEpilogueNone {
-    __device__ __forceinline__ void operator()(int, int, int, float, int, float&) const {}
     __device__ __forceinline__ void finish(int, int, float, float*) const {}
 };
 
 // A/B: point arrays with sa/sb floats per point (3 = packed xyz, 4 = float4 padded).
 // Blocks [0, blocksA) search B for A's queries (direction 0), the rest search A for B's (direction 1).
-// Epi::operator()(dir, q, lane, dist, idx, acc) runs on lane u for the wave's u-th query;
+// Epi::operator()(dir, q, idx, dist, query xyz, matched-target xyz, acc) runs on lane u for the wave's u-th query;
 // Epi::finish(dir, blk, sum, scratch) once per block with the block's fixed-order sum of `acc`.
 template <int QW, typename IdxT, typename Epi>
 __global__ __launch_bounds__(NN_BLOCK) void k_nn_l1(
@@ -101,7 +100,10 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_l1(
             }
         }
     }
-    // exact first index inside the best group: re-evaluate its 4 targets (one batch of loads)
+    // exact first index inside the best group: re-evaluate its 4 targets.  With a single staged chunk
+    // (nt <= NN_TCH, the N=4096 case) they are still in LDS; otherwise one batch of global loads.
+    const bool in_lds = nt <= NN_TCH;
+    const int padded0 = (min(NN_TCH, nt) + 255) & ~255;
     float acc = 0.f, mv = 0.f;
     int mi = 0;
     float rx[QW][4], ry[QW][4], rz[QW][4];
@@ -110,9 +112,10 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_l1(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int j = min(max(bgrp[u], 0) + 64 * e, nt - 1);
-            const float* p = T + (size_t)j * st;
-            rx[u][e] = p[0]; ry[u][e] = p[1]; rz[u][e] = p[2];
+            if (in_lds) { rx[u][e] = sX[j]; ry[u][e] = sX[padded0 + j]; rz[u][e] = sX[2 * padded0 + j]; }
+            else { const float* p = T + (size_t)j * st; rx[u][e] = p[0]; ry[u][e] = p[1]; rz[u][e] = p[2]; }
         }
+    float mqx = 0.f, mqy = 0.f, mqz = 0.f;
 #pragma unroll
     for (int u = 0; u < QW; ++u) {
         int bi = 0x7fffffff;
@@ -124,11 +127,17 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_l1(
         }
         float v = best[u]; int i = bi;
         wave_argmin_fast(v, i);
-        if (lane == u) { mv = v; mi = i; }
+        if (lane == u) { mv = v; mi = i; mqx = qx[u]; mqy = qy[u]; mqz = qz[u]; }
     }
     if (lane < QW && q0 + lane < nq) {
         if (dO) { dO[q0 + lane] = mv; iO[q0 + lane] = (IdxT)mi; }
-        epi(dir, q0 + lane, lane, mv, mi, acc);
+        if constexpr (!std::is_same<Epi, NnEpilogueNone>::value) {
+            // coordinates of the matched target: LDS when staged, else global
+            float tx, ty, tz;
+            if (in_lds) { tx = sX[mi]; ty = sX[padded0 + mi]; tz = sX[2 * padded0 + mi]; }
+            else { const float* p = T + (size_t)mi * st; tx = p[0]; ty = p[1]; tz = p[2]; }
+            epi(dir, q0 + lane, mi, mv, mqx, mqy, mqz, tx, ty, tz, acc);
+        }
     }
     if constexpr (!std::is_same<Epi, NnEpilogueNone>::value) {
         acc = wave_sum_fast(acc);

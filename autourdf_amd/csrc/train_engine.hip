@@ -154,22 +154,27 @@ __host__ __device__ inline int rows_per_chunk(int K, int width) {
 // (all threads loading) instead of K dependent global reads per wave.  NC = H / 64 is a template
 // parameter so the per-row dot is straight-line code (runtime bounds made hipcc emit a branch and an
 // lgkmcnt(0) per element).
+constexpr int MLP_BLOCK = 1024;      // 16 waves = 16 parameter rows share one LDS copy of the activations
 template <int NC>
-__global__ __launch_bounds__(256) void k_l2(Dims D, Ws W, int par) {
+__global__ __launch_bounds__(MLP_BLOCK) void k_l2(Dims D, Ws W, int par) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = (float*)smem;                      // [rc][H]
     constexpr int H = NC * 64;
     const int lane = threadIdx.x & 63;
-    const int o = min((int)(blockIdx.x * 4 + (threadIdx.x >> 6)), D.H2 - 1);     // grid covers H2 exactly (H2 % 4 == 0)
+    const int o = min((int)(blockIdx.x * 16 + (threadIdx.x >> 6)), D.H2 - 1);    // grid covers H2 exactly (H2 % 16 == 0)
+    const int rc = rows_per_chunk(D.K, H);
+    stage_issue<MLP_BLOCK>((float4*)xs, (const float4*)W.x1[par], min(rc, D.K) * H / 4);
     float wr[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) wr[c] = W.P[D.oW2 + (size_t)o * H + c * 64 + lane];
     const float b = W.P[D.ob2 + o];
-    const int rc = rows_per_chunk(D.K, H);
     for (int r0 = 0; r0 < D.K; r0 += rc) {
         const int nr = min(rc, D.K - r0);
-        if (r0) __syncthreads();
-        stage_f4<256, (NC * 5 + 3) / 4>((float4*)xs, (const float4*)(W.x1[par] + (size_t)r0 * H), nr * H / 4);
+        if (r0) {
+            __syncthreads();
+            stage_issue<MLP_BLOCK>((float4*)xs, (const float4*)(W.x1[par] + (size_t)r0 * H), nr * H / 4);
+        }
+        stage_wait();
         __syncthreads();
 #pragma unroll 4
         for (int r = 0; r < nr; ++r) {
@@ -193,6 +198,12 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W) {
     __shared__ float m2s[12];
     const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NO = D.OA + D.OB;
+    // loads that do not depend on the dot products go first so they share its round trip
+    float pin[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pin[i] = W.pose_in[8 * r + i];
+    const int b = W.off[r], e = W.off[r + 1];
+    const float4 p_first = W.pts4[min(b + (int)threadIdx.x, D.NP - 1)];
     if (wave < NO) {
         const int o = wave;
         const float *w, *a; int n; float bias;
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float* in = W.pose_in + 8 * r;
+        const float* in = pin;
         float R[9], t[3], save[16];
         for (int i = 0; i < 16; ++i) save[i] = 0.f;
         if (D.rot == 0) {
@@ -235,9 +246,8 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W) {
         for (int i = 0; i < 16; ++i) W.head_save[16 * r + i] = save[i];
     }
     __syncthreads();
-    const int b = W.off[r], e = W.off[r + 1];
     for (int n = b + threadIdx.x; n < e; n += 512) {
-        const float4 p = W.pts4[n];
+        const float4 p = (n == b + (int)threadIdx.x) ? p_first : W.pts4[n];
         float o[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) o[a] = fmaf(p.z, m2s[4 * a + 2], fmaf(p.y, m2s[4 * a + 1], p.x * m2s[4 * a])) + m2s[4 * a + 3];
@@ -250,16 +260,15 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W) {
 // Runs inside the nearest-neighbour launch (results are final there): sign bits of the x->y term,
 // integer sign scatter of the y->x term (exact, order independent), per-block loss partials.
 struct EngineEpi {
-    const float4* pred4; const float4* y4; int* sgn_x; int4* cnt4; float* lossp_x; float* lossp_y;
-    __device__ __forceinline__ void operator()(int dir, int q, int, float d, int idx, float& acc) const {
+    int* sgn_x; int4* cnt4; float* lossp_x; float* lossp_y;
+    __device__ __forceinline__ void operator()(int dir, int q, int idx, float d, float qx, float qy, float qz,
+                                               float tx, float ty, float tz, float& acc) const {
         if (dir == 0) {          // query pred[q], nearest y[idx]: knn(p1=x,p2=y) grad_p1 sign = (p1 > p2 ? +1 : -1)
-            const float4 xv = pred4[q], yv = y4[idx];
-            sgn_x[q] = (xv.x > yv.x ? 1 : 0) | (xv.y > yv.y ? 2 : 0) | (xv.z > yv.z ? 4 : 0);
+            sgn_x[q] = (qx > tx ? 1 : 0) | (qy > ty ? 2 : 0) | (qz > tz ? 4 : 0);
         } else {                 // query y[q], nearest pred[idx]: knn(p1=y,p2=x) grad_p2 -= sign
-            const float4 yv = y4[q], xv = pred4[idx];
-            atomicAdd(&cnt4[idx].x, (yv.x > xv.x) ? -1 : 1);
-            atomicAdd(&cnt4[idx].y, (yv.y > xv.y) ? -1 : 1);
-            atomicAdd(&cnt4[idx].z, (yv.z > xv.z) ? -1 : 1);
+            atomicAdd(&cnt4[idx].x, (qx > tx) ? -1 : 1);
+            atomicAdd(&cnt4[idx].y, (qy > ty) ? -1 : 1);
+            atomicAdd(&cnt4[idx].z, (qz > tz) ? -1 : 1);
         }
         acc += d;
     }
@@ -313,6 +322,11 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W, int epoch, int nbx,
     const float4 p_first = W.pts4[n_first];
     const int4 c_first = W.cnt4[n_first];
     const int s_first = W.sgn_x[n_first];
+    const float4 pr_first = W.pred4[n_first];
+    const float m2v = W.m2[16 * k + (tid & 15)];
+    float sv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sv[i] = W.head_save[16 * k + i];
     // ---- loss = sum_x / NP + sum_y / NT from the NN launch's per-block partials (fixed order)
     float a = 0.f, b = 0.f;
     for (int i = tid; i < nbx; i += 256) a += W.lossp_x[i];
@@ -331,10 +345,10 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W, int epoch, int nbx,
     const bool improved = loss < S.min_loss;
     if (improved) {                                     // best_pcd / best_m  (mlp_reg.py:102-106)
         for (int n = b0 + tid; n < e0; n += 256) {
-            const float4 p = W.pred4[n];
+            const float4 p = (n == b0 + tid) ? pr_first : W.pred4[n];
             W.best_pred[3 * (size_t)n] = p.x; W.best_pred[3 * (size_t)n + 1] = p.y; W.best_pred[3 * (size_t)n + 2] = p.z;
         }
-        if (tid < 16) W.best_m[16 * k + tid] = W.m2[16 * k + tid];
+        if (tid < 16) W.best_m[16 * k + tid] = m2v;
     }
     if (k == 0 && tid == 0) {
         W.state[(epoch + 1) & 1] = N;
@@ -372,7 +386,6 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W, int epoch, int nbx,
     const float G[9] = {G12[0], G12[1], G12[2], G12[4], G12[5], G12[6], G12[8], G12[9], G12[10]};
     const float gt[3] = {G12[3], G12[7], G12[11]};
     float* go = W.g_out + 16 * k;          // [0..2] branch A, [4..11] branch B
-    const float* sv = W.head_save + 16 * k;
     if (D.rot == 0) {
         go[0] = gt[0]; go[1] = gt[1]; go[2] = gt[2];
         float gu[4];
@@ -392,7 +405,8 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W, int epoch, int nbx,
 }
 
 // ------------------------------------------------------------------------------------------ backward to x1
-// grid (H/256, OC): thread = one column of W2, block = one chunk of <= BW2_ROWS hidden rows.
+// grid (H/64, OC): lane = one column of W2, block = one chunk of <= BW2_ROWS hidden rows, its 4 waves
+// split the pose-row tiles.
 // Phase 1 builds the chunk's g_h2 = act'(h2) * (g_out . W3) in LDS from LDS-staged operands;
 // phase 2 keeps the column's weights of the chunk in registers (all loads in flight at once) and
 // walks the pose rows four at a time (one broadcast ds_read_b128 per weight).
@@ -404,8 +418,19 @@ __global__ __launch_bounds__(256) void k_bwd2(Dims D, Ws W, int epoch) {
     float* gs = (float*)smem;                  // [BW2_ROWS][KP]   g_h2 of the chunk (zero padded)
     float* gos = gs + BW2_ROWS * KP;           // [K][16]          g_out
     float* w3s = gos + 16 * D.K;               // [8][BW2_ROWS]    output-layer weights of the chunk's units
-    if (W.state[(epoch + 1) & 1].stopped) return;
+    // (no early exit on `stopped`: its outputs are only read by k_dw, which gates its stores; an
+    //  exit branch here would let hipcc sink the loads below it and serialise them)
     const int rows = D.H2 / BW2_OC, o0 = blockIdx.y * rows, tid = threadIdx.x;
+    const int col = blockIdx.x * 64 + (tid & 63);             // H % 64 == 0: always valid
+    float w[BW2_ROWS];                            // this column's weights of the chunk: issued first
+#pragma unroll
+    for (int ol = 0; ol < BW2_ROWS; ++ol) w[ol] = W.P[D.oW2 + (size_t)(o0 + min(ol, rows - 1)) * D.H + col];
+    float hv0[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int id = min(q * 256 + tid, rows * D.K - 1);
+        hv0[q] = W.h2[(size_t)(id / rows) * D.H2 + o0 + id % rows];
+    }
     stage_f4<256, 4>((float4*)gos, (const float4*)W.g_out, 4 * D.K);
     {
         float v[2] = {0.f, 0.f};
@@ -427,7 +452,7 @@ __global__ __launch_bounds__(256) void k_bwd2(Dims D, Ws W, int epoch) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int id = min(base + q * 256 + tid, rows * D.K - 1);
-            hv[q] = W.h2[(size_t)(id / rows) * D.H2 + o0 + id % rows];
+            hv[q] = base == 0 ? hv0[q] : W.h2[(size_t)(id / rows) * D.H2 + o0 + id % rows];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -445,15 +470,9 @@ __global__ __launch_bounds__(256) void k_bwd2(Dims D, Ws W, int epoch) {
         }
     }
     __syncthreads();
-    const int col = blockIdx.x * 256 + tid;
-    if (col >= D.H) return;
-    float w[BW2_ROWS];
 #pragma unroll
-    for (int ol = 0; ol < BW2_ROWS; ++ol) {
-        const float v = W.P[D.oW2 + (size_t)(o0 + min(ol, rows - 1)) * D.H + col];
-        w[ol] = ol < rows ? v : 0.f;
-    }
-    for (int r0 = 0; r0 < D.K; r0 += 4) {
+    for (int ol = 0; ol < BW2_ROWS; ++ol) w[ol] = ol < rows ? w[ol] : 0.f;
+    for (int r0 = 4 * (tid >> 6); r0 < D.K; r0 += 16) {       // wave w takes pose-row tiles w, w+4, ...
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int ol = 0; ol < BW2_ROWS; ++ol) {
@@ -483,11 +502,12 @@ __device__ __forceinline__ float adam_value(float p, float& mm, float& vv, float
 // ([K][H] encoder activation for hidden rows, [K][H2] hidden activation for output rows, [K][IN]
 // features for encoder rows) in LDS with batched loads; a row's parameter / Adam-state loads are all
 // issued together.  No loop over K contains a global load.
+constexpr int DW_BLOCK = 256;         // 4 parameter rows per block
 template <int NC>
-__global__ __launch_bounds__(256) void k_dw(Dims D, Ws W, int epoch) {
+__global__ __launch_bounds__(DW_BLOCK, 1) void k_dw(Dims D, Ws W, int epoch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const TrainState S = W.state[(epoch + 1) & 1];
-    if (S.stopped) return;                          // block-uniform
+    const bool live = !S.stopped;                   // gates every store (no early exit: see k_bwd2)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     float* g = (float*)smem + wib * D.K;            // per-wave gradient column g[r]
     float* as = (float*)smem + ((4 * D.K + 3) & ~3);   // staged activations [rc][width]
@@ -508,7 +528,9 @@ __global__ __launch_bounds__(256) void k_dw(Dims D, Ws W, int epoch) {
     else { active = false; oW = D.oW3B; ob = D.ob3B; n_in = D.HB; aoff = D.HA; }      // idle wave mirrors a valid row, stores nothing
     const float* amat = bkind == 0 ? W.x1[par] : (bkind == 1 ? W.h2 : W.enc);
     const int awidth = bkind == 0 ? D.H : (bkind == 1 ? D.H2 : D.IN);
-    // parameter, Adam state: all loads of the row in flight at once (indices clamped, not predicated)
+    const int rc = rows_per_chunk(D.K, awidth);
+    // Everything this wave needs from memory is requested before the first wait, in one round trip:
+    // parameter + Adam state of the row, the row's gradient column, then the activation matrix.
     float pw[NC], pm[NC], pv[NC], acc[NC];
     int idx[NC];
 #pragma unroll
@@ -517,30 +539,27 @@ __global__ __launch_bounds__(256) void k_dw(Dims D, Ws W, int epoch) {
         pw[c] = W.P[oW + idx[c]]; pm[c] = W.AM[oW + idx[c]]; pv[c] = W.AV[oW + idx[c]]; acc[c] = 0.f;
     }
     float pb = W.P[ob], mb = W.AM[ob], vb = W.AV[ob];
-    // gradient of this output unit for every pose row (lane r <-> pose row r, K > 64 loops)
-    for (int r = lane; r < D.K; r += 64) {
-        float v;
-        if (kind == 0) v = W.g_h2[(size_t)r * D.H2 + o];
-        else if (kind == 1) v = W.g_out[16 * r + o];
-        else if (kind == 2) v = W.g_out[16 * r + 4 + o];
-        else {
-            float part[BW2_OC];
+    auto grad_col = [&](int r) -> float {       // dL/d(pre-activation of unit o) for pose row r
+        if (kind == 0) return W.g_h2[(size_t)r * D.H2 + o];
+        if (kind == 1) return W.g_out[16 * r + o];
+        if (kind == 2) return W.g_out[16 * r + 4 + o];
+        float part[BW2_OC];
 #pragma unroll
-            for (int c = 0; c < BW2_OC; ++c) part[c] = W.gx1_part[((size_t)c * D.K + r) * D.H + o];
-            const float post = W.x1[par][(size_t)r * D.H + o];
-            float sum = 0.f;
+        for (int c = 0; c < BW2_OC; ++c) part[c] = W.gx1_part[((size_t)c * D.K + r) * D.H + o];
+        const float post = W.x1[par][(size_t)r * D.H + o];
+        float sum = 0.f;
 #pragma unroll
-            for (int c = 0; c < BW2_OC; ++c) sum += part[c];
-            v = sum * act_grad(post, D.slope);
-        }
-        g[r] = v;
-    }
+        for (int c = 0; c < BW2_OC; ++c) sum += part[c];
+        return sum * act_grad(post, D.slope);
+    };
     // accumulate g[r] * act[r][i] over the pose rows from the LDS-staged activation matrix
-    const int rc = rows_per_chunk(D.K, awidth);
     for (int r0 = 0; r0 < D.K; r0 += rc) {
         const int nr = min(rc, D.K - r0);
-        __syncthreads();
-        stage_f4<256, 10>((float4*)as, (const float4*)(amat + (size_t)r0 * awidth), nr * awidth / 4);
+        if (r0) __syncthreads();
+        stage_issue<DW_BLOCK>((float4*)as, (const float4*)(amat + (size_t)r0 * awidth), nr * awidth / 4);
+        if (r0 == 0)                                // gradient column: its loads ride the same round trip
+            for (int r = lane; r < D.K; r += 64) g[r] = grad_col(r);
+        stage_wait();
         __syncthreads();
 #pragma unroll 4
         for (int r = 0; r < nr; ++r) {
@@ -550,7 +569,7 @@ __global__ __launch_bounds__(256) void k_dw(Dims D, Ws W, int epoch) {
             for (int c = 0; c < NC; ++c) acc[c] = fmaf(gr, a[idx[c]], acc[c]);
         }
     }
-    if (active) {
+    if (active && live) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float nw = adam_value(pw[c], pm[c], pv[c], acc[c], S.step_size, S.bc2_sqrt);
@@ -562,7 +581,7 @@ __global__ __launch_bounds__(256) void k_dw(Dims D, Ws W, int epoch) {
         pb = adam_value(pb, mb, vb, sum, S.step_size, S.bc2_sqrt);
         if (lane == 0) { W.P[ob] = pb; W.AM[ob] = mb; W.AV[ob] = vb; }
     }
-    if (bkind == 3 && active) {
+    if (bkind == 3 && active && live) {
         // next epoch's encoder activation from the updated row held in registers (IN <= 64: one
         // weight per lane) and the LDS-staged features (K * IN floats always fit one chunk).  The MLP
         // input is the same every epoch: m.clone() of the same m (mlp_reg.py:62); only weights moved.
@@ -645,7 +664,7 @@ static void by_nc(int H, F f) {            // H in {64, 128, 256, 512}
 static void launch_l2(Plan* P, int par, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
     by_nc(D.H, [&](auto nc) {
-        hipLaunchKernelGGL((k_l2<decltype(nc)::value>), dim3(D.H2 / 4), dim3(256), P->smem_l2, s, D, W, par); });
+        hipLaunchKernelGGL((k_l2<decltype(nc)::value>), dim3(D.H2 / 16), dim3(MLP_BLOCK), P->smem_l2, s, D, W, par); });
 }
 static void launch_head(Plan* P, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
@@ -654,7 +673,7 @@ static void launch_head(Plan* P, hipStream_t s) {
 static void launch_dw(Plan* P, int epoch, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
     by_nc(D.H, [&](auto nc) {
-        hipLaunchKernelGGL((k_dw<decltype(nc)::value>), dim3(D.H2 / 4 + (D.OA + D.OB + 3) / 4 + cdiv(D.H, 4)), dim3(256),
+        hipLaunchKernelGGL((k_dw<decltype(nc)::value>), dim3(D.H2 / 4 + (D.OA + D.OB + 3) / 4 + cdiv(D.H, 4)), dim3(DW_BLOCK),
                            P->smem_dw, s, D, W, epoch); });
 }
 constexpr int NKERN = 6;
@@ -667,9 +686,9 @@ static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nu
     launch_l2(P, par, s); mark(1);
     launch_head(P, s); mark(2);
     launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
-                      true, true, EngineEpi{W.pred4, W.y4, W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y}, s); mark(3);
+                      true, true, EngineEpi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y}, s); mark(3);
     hipLaunchKernelGGL(k_gradc, dim3(D.K), dim3(256), 0, s, D, W, epoch, D.nbx, D.nby); mark(4);
-    hipLaunchKernelGGL(k_bwd2, dim3(cdiv(D.H, 256), D.OC), dim3(256), P->smem_bwd2, s, D, W, epoch); mark(5);
+    hipLaunchKernelGGL(k_bwd2, dim3(D.H / 64, D.OC), dim3(256), P->smem_bwd2, s, D, W, epoch); mark(5);
     launch_dw(P, epoch, s); mark(6);
 }
 
@@ -798,7 +817,7 @@ extern "C" int creg_train_plan_probe(creg_train_plan* plan, const creg_train_arg
     launch_l2(P, 0, s);
     launch_head(P, s);
     launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
-                      true, true, EngineEpi{W.pred4, W.y4, W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y}, s);
+                      true, true, EngineEpi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y}, s);
     hipLaunchKernelGGL(k_gradc, dim3(D.K), dim3(256), 0, s, D, W, 0, D.nbx, D.nby);
     CREG_LAUNCH_CHECK();
     if (m2) CREG_HIP(hipMemcpyAsync(m2, W.m2, sizeof(float) * 16 * D.K, hipMemcpyDeviceToDevice, s));
