@@ -848,6 +848,21 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
             acc[k] += ms;
         }
     for (int k = 0; k < NKERN; ++k) us_out[k] = (float)(acc[k] * 1000.0 / n_epochs);
+    // us_out[6]: the nearest-neighbour kernel alone, REP back-to-back launches between two events
+    // (per-kernel event brackets carry ~7 us of event overhead; this one carries only the
+    // launch-to-launch gap, so it upper-bounds the rocprofv3 kernel duration by ~1 us).
+    const int REP = 200;
+    const Dims& D = P->D; const Ws& W = P->W;
+    CREG_HIP(hipEventRecord(ev[0], s));
+    for (int i = 0; i < REP; ++i)
+        launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
+                          true, true, EngineEpi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y}, s);
+    CREG_HIP(hipEventRecord(ev[1], s));
+    CREG_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    CREG_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    us_out[6] = ms * 1000.f / REP;
+    us_out[7] = 0.f;
     for (auto& e : ev) (void)hipEventDestroy(e);
     return CREG_OK;
 }

@@ -270,4 +270,6 @@ class TrainPlan:
         a = self._args(m, y, pts, offsets, params, 2e-4, 0.7, 5, 200, (None, None, None, None, None))
         _lib.check(self.L.creg_train_plan_profile(self.plan, ctypes.byref(a), n_epochs, out, _stream()),
                    "creg_train_plan_profile")
-        return dict(zip(self.KERNELS, [float(v) for v in out]))
+        d = dict(zip(self.KERNELS, [float(v) for v in out]))
+        d["nn_l1_back_to_back"] = float(out[6])
+        return d

@@ -79,6 +79,7 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    from autourdf_amd.distributed import gather_poses
     from autourdf_amd.engine import SequenceRegistrar
     from autourdf_amd.synthetic import initial_segmentation, make_sequence
 
@@ -113,34 +114,35 @@ def main():
     fence()
     t0 = time.perf_counter()
     run_steps(args.warmup, total)
-    if dist is not None:                               # the one exchange of the job: final pose gather
-        gathered = torch.empty(world * args.steps, K_CLUSTERS, 4, 4, dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(gathered, poses[args.warmup:].contiguous())
+    gathered = gather_poses(poses[args.warmup:])       # the one exchange of the job (RCCL all_gather; no-op at N=1)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.isfinite(poses).all() and torch.isfinite(losses).all()
+    assert torch.isfinite(poses).all() and torch.isfinite(losses).all() and gathered.shape[0] == world * args.steps
 
     if rank == 0:
         # ---- roofline of the dominant kernel (L1 nearest neighbour), measured live with HIP events
         r = regs[0]
         prof = r.plan.profile(r.m, frames32[0][0], r.pts_init, r.off_init, r.p_anchor, n_epochs=100)
-        nn_us = prof["nn_l1"]
+        nn_us = prof.pop("nn_l1_back_to_back")     # 200 back-to-back launches between two HIP events
         alg_ops = 9.0 * N_POINTS * N_POINTS          # 9 VALU ops x N^2 per epoch (shared pair evaluation)
         achieved = alg_ops / (nn_us * 1e-6) / 1e12
         traffic = None
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_nn_l1_pmc.json")
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        roof = {"bound": "valu", "kernel": "k_nn_l1_bidir<4,int>", "achieved": round(achieved, 3),
+        roof = {"bound": "valu", "kernel": "k_nn_l1<4,int,EngineEpi>", "achieved": round(achieved, 3),
                 "peak": round(VALU_PEAK_TOPS, 1), "unit": "TFLOP/s", "frac": round(achieved / VALU_PEAK_TOPS, 4),
                 "traffic": traffic, "avg_launch_us": round(nn_us, 3),
-                "epoch_kernels_us": {k: round(v, 2) for k, v in prof.items()},
-                "note": "L1 min-search is sub/add/compare work: not a contraction (no MFMA) and 200 KB of traffic "
-                        "(not HBM); bound = fp32 VALU issue, peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz non-FMA ops"}
+                "epoch_kernels_event_bracketed_us": {k: round(v, 2) for k, v in prof.items()},
+                "note": "L1 min-search is sub/add/min work: not a contraction (no MFMA) and ~200 KB of algorithmic "
+                        "traffic (not HBM); bound = fp32 VALU issue. achieved = 9*N^2 algorithmic lane-ops (SURVEY 8d) / "
+                        "avg launch; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (= 157.3 TFLOP/s FMA peak / 2). "
+                        "avg_launch_us = 200 back-to-back launches between two HIP events (includes the launch gap); "
+                        "per-kernel event brackets carry ~7 us of event overhead each, see profiles/ for rocprofv3"}
         out = {"metric": "registered frames/sec (N=4096 pts, K=20 clusters)", "value": round(world * args.steps / elapsed, 4),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",

@@ -1,0 +1,108 @@
+"""GPU: the drop-in module surface end to end (scripts/registration.sh path) and the larger configs."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_ply(path, pts):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty double x\nproperty double y\n"
+                b"property double z\nend_header\n" % len(pts))
+        f.write(np.ascontiguousarray(pts, "<f8").tobytes())
+
+
+@pytest.fixture()
+def workdir(tmp_path, monkeypatch):
+    from autourdf_amd.synthetic import make_sequence
+    for v in range(2):
+        for t, fr in enumerate(make_sequence("wx200_5", v, 3, 1024)):
+            _write_ply(str(tmp_path / f"data/raw/wx200_5/4_deg_20_cams/V{v:04}/{t:04}/robot.ply"), fr)
+    json.dump({"wx200_5": {"num_seg": 8, "dof": 5}}, open(tmp_path / "parameters.json", "w"))
+    monkeypatch.chdir(tmp_path)
+    return tmp_path
+
+
+@pytest.mark.parametrize("flags", [["--loss"], ["--mlp_icp"], ["--r", "dq"]])
+def test_match_writes_the_reference_file_layout(workdir, flags, monkeypatch):
+    from autourdf_amd import mlp_reg
+    monkeypatch.setattr(mlp_reg, "EPOCHS", 12)
+    mlp_reg._PLANS.clear()
+    mlp_reg.main(["--robot", "wx200_5", "--num_video", "2"] + flags)
+    base = workdir / "data/part/wx200_5_8_seg/4_deg_20_cams"
+    for v in range(2):
+        d = base / f"V{v:04}"
+        for t in range(3):
+            m = np.load(d / "matrix" / f"{t:04}.npy")
+            assert m.shape == (8, 4, 4) and np.isfinite(m).all()
+            np.testing.assert_allclose(m[:, 3], np.tile([0, 0, 0, 1.0], (8, 1)), atol=1e-6)
+            R = m[:, :3, :3]
+            np.testing.assert_allclose(R @ R.transpose(0, 2, 1), np.tile(np.eye(3), (8, 1, 1)), atol=5e-3 if "dq" in flags else 1e-5)
+            with np.load(d / "cluster" / f"{t:04}.npz") as z:
+                keys = list(z.keys())
+                assert keys == [str(i) for i in range(8)]
+                assert sum(len(z[k]) for k in keys) == 1024 and z["0"].dtype == np.float64
+    # frame-0 state of the second sequence is the first one's (mlp_reg.py:242-253)
+    np.testing.assert_array_equal(np.load(base / "V0000/matrix/0000.npy"), np.load(base / "V0001/matrix/0000.npy"))
+    if "--loss" in flags:
+        assert np.loadtxt(base / "V0000/loss.txt").shape == (2,)
+    # local clusters really are inv(M) . world points of that frame
+    from autourdf_amd.cluster_icp import read_point_cloud
+    frame = read_point_cloud(str(workdir / "data/raw/wx200_5/4_deg_20_cams/V0000/0002/robot.ply")).points
+    m = np.load(base / "V0000/matrix/0002.npy").astype(np.float64)
+    with np.load(base / "V0000/cluster/0002.npz") as z:
+        world = np.concatenate([z[str(i)] @ m[i, :3, :3].T + m[i, :3, 3] for i in range(8)])
+    assert np.abs(np.sort(world, 0) - np.sort(frame, 0)).max() < 1e-6
+
+
+def test_train_signature_drop_in_returns(workdir):
+    """train(m, y, model, clusters, ...) -> (list of np (M_k,3) f32, list of .points objects, (K,4,4) tensor, float)."""
+    from autourdf_amd import mlp_reg
+    from autourdf_amd.model_utils import QRegMLP
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    dev = torch.device("cuda")
+    seq = make_sequence("wx200_5", 0, 2, 1024)
+    mats, clusters, _ = initial_segmentation(seq[0], 8, seed=0)
+    mlp_reg.ROT, mlp_reg.DEVICE = "q", dev
+    mlp_reg._PLANS.clear()
+    old, mlp_reg.EPOCHS = mlp_reg.EPOCHS, 10
+    try:
+        model = QRegMLP(True, hidden_dim=512).to(dev)
+        before = model.encoder[0].weight.detach().clone()
+        out = mlp_reg.train(torch.tensor(mats, dtype=torch.float32, device=dev), torch.tensor(seq[1], dtype=torch.float32, device=dev),
+                            model, [torch.tensor(c, dtype=torch.float32, device=dev) for c in clusters])
+    finally:
+        mlp_reg.EPOCHS = old
+    pred_np, pred_pcd, best_m, min_loss = out
+    assert len(pred_np) == 8 and all(p.dtype == np.float32 and p.shape[1] == 3 for p in pred_np)
+    assert all(hasattr(p, "points") for p in pred_pcd) and best_m.shape == (8, 4, 4) and isinstance(min_loss, float)
+    assert not torch.equal(before, model.encoder[0].weight)          # Adam updated the caller's module in place
+    pcs = mlp_reg.calculate_pc([torch.tensor(c, dtype=torch.float32, device=dev) for c in clusters], best_m)
+    np.testing.assert_allclose(torch.cat(pcs).cpu().numpy(), np.concatenate(pred_np), atol=1e-6)
+
+
+@pytest.mark.parametrize("robot,n,k", [("franka", 16384, 40), ("allegro", 4096, 30), ("chain32", 32768, 128)])
+def test_larger_configs_two_epochs_vs_oracle(robot, n, k):
+    """BASELINE configs 3-5 shapes (hidden 512): 2 epochs against the oracle, K up to 128, multi-chunk NN."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    from oracle import models, registration
+    dev = torch.device("cuda")
+    seq = make_sequence(robot, 1, 2, n)
+    mats, clusters, _ = initial_segmentation(seq[0], k, seed=1, iters=5)
+    torch.manual_seed(1)
+    model = models.QRegMLP(True, 512)
+    m, y = torch.tensor(mats, dtype=torch.float32), torch.tensor(seq[1], dtype=torch.float32)
+    cl = [torch.tensor(c, dtype=torch.float32) for c in clusters]
+    params = [model.state_dict()[key].clone().to(dev) for key in ops.Q_PARAM_ORDER]
+    pts, off = ops.pack_clusters(cl, dev)
+    plan = ops.TrainPlan("q", k, 512, n, n, epochs=2, use_graph=True, device=dev)
+    best_m, _, res, lh, _ = plan.run(m.to(dev), y.to(dev), pts, off, params)
+    _, o_best, o_min, hist = registration.train(m, y, model, cl, rot="q", epochs=2)
+    np.testing.assert_allclose(lh.cpu().numpy(), np.array(hist["loss"], np.float32), rtol=2e-5)
+    np.testing.assert_allclose(best_m.cpu().numpy(), o_best.detach().numpy(), atol=1e-5)      # poses within 1e-5
