@@ -1,6 +1,21 @@
-"""Farthest-point down-sampling (open3d PointCloud.farthest_point_down_sample, reference
-cluster_icp.py:43).  SURVEY.md 8(f) row N1 -- scheduled after the hot path; not built this round."""
+"""Farthest-point down-sampling on the GPU (open3d PointCloud.farthest_point_down_sample, reference
+cluster_icp.py:43)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, ops
 
 
-def farthest_point_sample(points, num_samples):
-    raise NotImplementedError("Segments(sample_size=...) needs the FPS kernel (SURVEY.md 8f N1): not built yet")
+def farthest_point_sample(points, num_samples: int) -> np.ndarray:
+    """points (N,3) array-like (fp64) -> int64 indices of the selected points, in selection order."""
+    L = _lib.load()
+    X = torch.as_tensor(np.asarray(points, np.float64), device="cuda").contiguous()
+    n = X.shape[0]
+    if not (1 <= num_samples <= n):
+        raise ValueError("need 1 <= num_samples <= number of points")
+    sel = torch.empty(num_samples, dtype=torch.int64, device=X.device)
+    scratch = torch.empty(L.creg_fps_scratch_bytes(n), dtype=torch.uint8, device=X.device)
+    _lib.check(L.creg_fps_f64(ops._p(X), n, num_samples, ops._p(sel), ops._p(scratch), ops._stream()), "creg_fps_f64")
+    return sel.cpu().numpy()

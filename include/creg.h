@@ -106,6 +106,14 @@ int creg_group_to_local_f64(const double* X, int64_t n, const int32_t* labels, i
                             creg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * N1  farthest-point down-sampling, fp64.  Replaces open3d farthest_point_down_sample as used by
+ * Segments._load_pc (cluster_icp.py:43): start at point 0, repeatedly select the point farthest
+ * (squared L2) from the selected set, first maximum wins.  sel (m) int64 indices in selection order.
+ * scratch: creg_fps_scratch_bytes(n) bytes. */
+size_t creg_fps_scratch_bytes(int64_t n);
+int creg_fps_f64(const double* X, int64_t n, int64_t m, int64_t* sel, void* scratch, creg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * K5  SE(3) <-> dual quaternion.  Replace transform_to_dualquat (dq_func.py:100-124) and
  * dualquat_to_transform (dq_func.py:170-186) incl. the pytorch3d matrix_to_quaternion /
  * quaternion_to_matrix they call.  M (k,4,4), dq (k,8) fp32.  The *_bwd forms give the vector-

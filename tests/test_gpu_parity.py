@@ -346,3 +346,22 @@ def test_train_300_epochs_golden_reference(dev, golden):
     assert abs(res[0].item() - o_min) < 0.02 * o_min
     assert lh[0].item() == pytest.approx(hist["loss"][0], rel=1e-5)
     assert np.abs(best_m.cpu().numpy() - o_best_m.detach().numpy()).max() < 2e-3
+
+
+# ------------------------------------------------------------------------------------------ N1
+@pytest.mark.parametrize("n,m", [(500, 64), (5000, 4096), (20000, 512)])
+def test_fps_indices_bit_exact_vs_oracle(dev, n, m):
+    from autourdf_amd.fps import farthest_point_sample
+    from oracle import kmeans
+    X = np.random.default_rng(n).normal(size=(n, 3))
+    if n == 500:
+        X[100:120] = X[0:20]                              # duplicates: ties must resolve to the first index
+    np.testing.assert_array_equal(farthest_point_sample(X, m), kmeans.farthest_point_sample(X, m))
+
+
+def test_segments_sample_size_uses_fps(dev, tmp_path):
+    from autourdf_amd.cluster_icp import PointCloud
+    from oracle import kmeans
+    X = np.random.default_rng(0).normal(size=(3000, 3))
+    out = PointCloud(X).farthest_point_down_sample(256)
+    np.testing.assert_array_equal(out.points, X[kmeans.farthest_point_sample(X, 256)])
