@@ -15,7 +15,7 @@ vp, i64, i32, f32, f64, sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, c
 
 class TrainShape(ctypes.Structure):
     _fields_ = [("rot", i32), ("k", i32), ("hidden", i32), ("epochs", i32), ("n_pred", i64),
-                ("n_tgt", i64), ("use_graph", i32), ("reserved", i32)]
+                ("n_tgt", i64), ("use_graph", i32), ("batch", i32)]
 
 
 class TrainArgs(ctypes.Structure):
@@ -56,6 +56,7 @@ SIGNATURES = {
     "creg_train_workspace_bytes": (sz, [ctypes.POINTER(TrainShape)]),
     "creg_train_plan_create": (ctypes.c_int, [ctypes.POINTER(TrainShape), vp, sz, ctypes.POINTER(vp)]),
     "creg_train_plan_run": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), vp]),
+    "creg_train_plan_run_batch": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), i32, vp]),
     "creg_train_plan_probe": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), vp, vp, vp, vp, vp]),
     "creg_train_plan_profile": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), i32, ctypes.POINTER(f32), vp]),
     "creg_train_plan_destroy": (ctypes.c_int, [vp]),

@@ -28,6 +28,7 @@ typedef float nn_f2 __attribute__((ext_vector_type(2)));
 
 struct NnEpilogueNone {
     __device__ __forceinline__ void finish(int, int, float, float*) const {}
+    __device__ __forceinline__ void shift(int) {}
 };
 
 // A/B: point arrays with sa/sb floats per point (3 = packed xyz, 4 = float4 padded).
@@ -36,9 +37,14 @@ struct NnEpilogueNone {
 // Epi::finish(dir, blk, sum, scratch) once per block with the block's fixed-order sum of `acc`.
 template <int QW, typename IdxT, typename Epi>
 __global__ __launch_bounds__(NN_BLOCK) void k_nn_l1(
-    const float* __restrict__ A, int na, int sa, const float* __restrict__ B, int nb, int sb,
+    const float* A, int na, int sa, const float* B, int nb, int sb,
     float* __restrict__ dA, IdxT* __restrict__ iA, float* __restrict__ dB, IdxT* __restrict__ iB,
-    int blocksA, Epi epi) {
+    int blocksA, Epi epi, size_t zstride) {
+    // grid.z = independent problems of a batch: point arrays and epilogue outputs of problem z live
+    // zstride bytes further on (0 for the standalone entry points)
+    A = (const float*)((const char*)A + blockIdx.z * zstride);
+    B = (const float*)((const char*)B + blockIdx.z * zstride);
+    epi.shift(blockIdx.z);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sX = (float*)smem_raw;                 // planes of `padded` floats each
     __shared__ float s_part[NN_BLOCK / 64];
@@ -169,15 +175,16 @@ inline NnGrid nn_grid(int na, int nb, bool doA, bool doB) {
 
 template <typename IdxT, typename Epi>
 inline void launch_nn_l1(const float* A, int na, int sa, const float* B, int nb, int sb, float* dA, IdxT* iA,
-                         float* dB, IdxT* iB, bool doA, bool doB, Epi epi, hipStream_t s) {
+                         float* dB, IdxT* iB, bool doA, bool doB, Epi epi, hipStream_t s, int nz = 1,
+                         size_t zstride = 0) {
     const NnGrid g = nn_grid(na, nb, doA, doB);
     if (g.blocksA + g.blocksB == 0) return;
     if (g.qw == 8)
-        hipLaunchKernelGGL((k_nn_l1<8, IdxT, Epi>), dim3(g.blocksA + g.blocksB), dim3(NN_BLOCK), g.smem, s, A, na, sa, B,
-                           nb, sb, dA, iA, dB, iB, g.blocksA, epi);
+        hipLaunchKernelGGL((k_nn_l1<8, IdxT, Epi>), dim3(g.blocksA + g.blocksB, 1, nz), dim3(NN_BLOCK), g.smem, s, A, na, sa,
+                           B, nb, sb, dA, iA, dB, iB, g.blocksA, epi, zstride);
     else
-        hipLaunchKernelGGL((k_nn_l1<4, IdxT, Epi>), dim3(g.blocksA + g.blocksB), dim3(NN_BLOCK), g.smem, s, A, na, sa, B,
-                           nb, sb, dA, iA, dB, iB, g.blocksA, epi);
+        hipLaunchKernelGGL((k_nn_l1<4, IdxT, Epi>), dim3(g.blocksA + g.blocksB, 1, nz), dim3(NN_BLOCK), g.smem, s, A, na, sa,
+                           B, nb, sb, dA, iA, dB, iB, g.blocksA, epi, zstride);
 }
 
 }  // namespace creg

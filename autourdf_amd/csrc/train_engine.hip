@@ -62,6 +62,16 @@ struct Ws {         // device pointers into the caller's workspace
     Hyper* hyper;
 };
 
+// Problem b of a batch lives in its own copy of the workspace layout, `bytes` = b * stride further on:
+// every member of Ws is a pointer, so shifting the struct is shifting each of them.
+static_assert(sizeof(Ws) % sizeof(char*) == 0, "Ws must hold pointers only");
+__host__ __device__ __forceinline__ Ws ws_shift(Ws W, size_t bytes) {
+    char** p = reinterpret_cast<char**>(&W);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(Ws) / sizeof(char*); ++i) p[i] += bytes;
+    return W;
+}
+
 __device__ __forceinline__ float act_f(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float act_grad(float post, float slope) { return post > 0.f ? 1.f : slope; }
 
@@ -156,14 +166,16 @@ __host__ __device__ inline int rows_per_chunk(int K, int width) {
 // lgkmcnt(0) per element).
 constexpr int MLP_BLOCK = 1024;      // 16 waves = 16 parameter rows share one LDS copy of the activations
 template <int NC>
-__global__ __launch_bounds__(MLP_BLOCK) void k_l2(Dims D, Ws W, int par) {
+__global__ __launch_bounds__(MLP_BLOCK) void k_l2(Dims D, Ws W0, int par, size_t bstride) {
+    const Ws W = ws_shift(W0, blockIdx.z * bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = (float*)smem;                      // [rc][H]
     constexpr int H = NC * 64;
     const int lane = threadIdx.x & 63;
     const int o = min((int)(blockIdx.x * 16 + (threadIdx.x >> 6)), D.H2 - 1);    // grid covers H2 exactly (H2 % 16 == 0)
     const int rc = rows_per_chunk(D.K, H);
-    stage_issue<MLP_BLOCK>((float4*)xs, (const float4*)W.x1[par], min(rc, D.K) * H / 4);
+    const float* x1cur = par ? W.x1[1] : W.x1[0];     // (a runtime index into the shifted struct would go to scratch)
+    stage_issue<MLP_BLOCK>((float4*)xs, (const float4*)x1cur, min(rc, D.K) * H / 4);
     float wr[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) wr[c] = W.P[D.oW2 + (size_t)o * H + c * 64 + lane];
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_l2(Dims D, Ws W, int par) {
         const int nr = min(rc, D.K - r0);
         if (r0) {
             __syncthreads();
-            stage_issue<MLP_BLOCK>((float4*)xs, (const float4*)(W.x1[par] + (size_t)r0 * H), nr * H / 4);
+            stage_issue<MLP_BLOCK>((float4*)xs, (const float4*)(x1cur + (size_t)r0 * H), nr * H / 4);
         }
         stage_wait();
         __syncthreads();
@@ -193,7 +205,8 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_l2(Dims D, Ws W, int par) {
 // transform of cluster r's points (clusters are stored back to back) -- calculate_pc needs no
 // launch of its own and nothing is recomputed.
 template <int NC>
-__global__ __launch_bounds__(512) void k_head(Dims D, Ws W) {
+__global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, size_t bstride) {
+    const Ws W = ws_shift(W0, blockIdx.z * bstride);
     __shared__ float outs[8];
     __shared__ float m2s[12];
     const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -261,6 +274,12 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W) {
 // integer sign scatter of the y->x term (exact, order independent), per-block loss partials.
 struct EngineEpi {
     int* sgn_x; int4* cnt4; float* lossp_x; float* lossp_y;
+    size_t bstride;
+    __device__ __forceinline__ void shift(int z) {
+        const size_t b = (size_t)z * bstride;
+        sgn_x = (int*)((char*)sgn_x + b); cnt4 = (int4*)((char*)cnt4 + b);
+        lossp_x = (float*)((char*)lossp_x + b); lossp_y = (float*)((char*)lossp_y + b);
+    }
     __device__ __forceinline__ void operator()(int dir, int q, int idx, float d, float qx, float qy, float qz,
                                                float tx, float ty, float tz, float& acc) const {
         if (dir == 0) {          // query pred[q], nearest y[idx]: knn(p1=x,p2=y) grad_p1 sign = (p1 > p2 ? +1 : -1)
@@ -305,7 +324,8 @@ __device__ __forceinline__ TrainState advance_state(const TrainState& S, float l
     return N;
 }
 
-__global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W, int epoch, int nbx, int nby) {
+__global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx, int nby, size_t bstride) {
+    const Ws W = ws_shift(W0, blockIdx.z * bstride);
     __shared__ float red[4][14];
     __shared__ float s_loss;
     const TrainState S = W.state[epoch & 1];
@@ -412,7 +432,8 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W, int epoch, int nbx,
 // walks the pose rows four at a time (one broadcast ds_read_b128 per weight).
 constexpr int BW2_ROWS = 48;
 constexpr int BW2_OC = 16;
-__global__ __launch_bounds__(256) void k_bwd2(Dims D, Ws W, int epoch) {
+__global__ __launch_bounds__(256) void k_bwd2(Dims D, Ws W0, int epoch, size_t bstride) {
+    const Ws W = ws_shift(W0, blockIdx.z * bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KP = (D.K + 3) & ~3;
     float* gs = (float*)smem;                  // [BW2_ROWS][KP]   g_h2 of the chunk (zero padded)
@@ -504,7 +525,8 @@ __device__ __forceinline__ float adam_value(float p, float& mm, float& vv, float
 // issued together.  No loop over K contains a global load.
 constexpr int DW_BLOCK = 256;         // 4 parameter rows per block
 template <int NC>
-__global__ __launch_bounds__(DW_BLOCK, 1) void k_dw(Dims D, Ws W, int epoch) {
+__global__ __launch_bounds__(DW_BLOCK, 1) void k_dw(Dims D, Ws W0, int epoch, size_t bstride) {
+    const Ws W = ws_shift(W0, blockIdx.z * bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const TrainState S = W.state[(epoch + 1) & 1];
     const bool live = !S.stopped;                   // gates every store (no early exit: see k_bwd2)
@@ -526,7 +548,9 @@ __global__ __launch_bounds__(DW_BLOCK, 1) void k_dw(Dims D, Ws W, int epoch) {
     else if (row < D.OA) { o = row; oW = D.oW3A + o * D.HA; ob = D.ob3A + o; n_in = D.HA; }
     else if (row < D.OA + D.OB) { o = row - D.OA; oW = D.oW3B + o * D.HB; ob = D.ob3B + o; n_in = D.HB; aoff = D.HA; }
     else { active = false; oW = D.oW3B; ob = D.ob3B; n_in = D.HB; aoff = D.HA; }      // idle wave mirrors a valid row, stores nothing
-    const float* amat = bkind == 0 ? W.x1[par] : (bkind == 1 ? W.h2 : W.enc);
+    const float* x1cur = par ? W.x1[1] : W.x1[0];     // (a runtime index into the shifted struct would go to scratch)
+    float* x1next = par ? W.x1[0] : W.x1[1];
+    const float* amat = bkind == 0 ? x1cur : (bkind == 1 ? W.h2 : W.enc);
     const int awidth = bkind == 0 ? D.H : (bkind == 1 ? D.H2 : D.IN);
     const int rc = rows_per_chunk(D.K, awidth);
     // Everything this wave needs from memory is requested before the first wait, in one round trip:
@@ -546,7 +570,7 @@ __global__ __launch_bounds__(DW_BLOCK, 1) void k_dw(Dims D, Ws W, int epoch) {
         float part[BW2_OC];
 #pragma unroll
         for (int c = 0; c < BW2_OC; ++c) part[c] = W.gx1_part[((size_t)c * D.K + r) * D.H + o];
-        const float post = W.x1[par][(size_t)r * D.H + o];
+        const float post = x1cur[(size_t)r * D.H + o];
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < BW2_OC; ++c) sum += part[c];
@@ -588,7 +612,7 @@ __global__ __launch_bounds__(DW_BLOCK, 1) void k_dw(Dims D, Ws W, int epoch) {
 #pragma unroll 4
         for (int r = 0; r < D.K; ++r) {
             const float v = wave_sum_fast(lane < D.IN ? pw[0] * as[r * D.IN + lane] : 0.f) + pb;
-            if (lane == 0) W.x1[par ^ 1][(size_t)r * D.H + o] = act_f(v, D.slope);
+            if (lane == 0) x1next[(size_t)r * D.H + o] = act_f(v, D.slope);
         }
     }
 }
@@ -602,6 +626,10 @@ struct Plan {
     size_t bytes;
     hipGraphExec_t gexec;     // two epochs (parity 0 then 1)
     bool graph_ready;
+    int graph_epochs;
+    int B;                    // problems the workspace holds
+    int nz;                   // problems per launch right now (grid.z): B for run, 1 for probe / profile
+    size_t bstride;           // bytes between consecutive problems' workspaces
     int smem_l2, smem_bwd2, smem_dw;
 };
 
@@ -664,17 +692,17 @@ static void by_nc(int H, F f) {            // H in {64, 128, 256, 512}
 static void launch_l2(Plan* P, int par, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
     by_nc(D.H, [&](auto nc) {
-        hipLaunchKernelGGL((k_l2<decltype(nc)::value>), dim3(D.H2 / 16), dim3(MLP_BLOCK), P->smem_l2, s, D, W, par); });
+        hipLaunchKernelGGL((k_l2<decltype(nc)::value>), dim3(D.H2 / 16, 1, P->nz), dim3(MLP_BLOCK), P->smem_l2, s, D, W, par, P->bstride); });
 }
 static void launch_head(Plan* P, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
-    by_nc(D.H, [&](auto nc) { hipLaunchKernelGGL((k_head<decltype(nc)::value>), dim3(D.K), dim3(512), 0, s, D, W); });
+    by_nc(D.H, [&](auto nc) { hipLaunchKernelGGL((k_head<decltype(nc)::value>), dim3(D.K, 1, P->nz), dim3(512), 0, s, D, W, P->bstride); });
 }
 static void launch_dw(Plan* P, int epoch, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
     by_nc(D.H, [&](auto nc) {
-        hipLaunchKernelGGL((k_dw<decltype(nc)::value>), dim3(D.H2 / 4 + (D.OA + D.OB + 3) / 4 + cdiv(D.H, 4)), dim3(DW_BLOCK),
-                           P->smem_dw, s, D, W, epoch); });
+        hipLaunchKernelGGL((k_dw<decltype(nc)::value>), dim3(D.H2 / 4 + (D.OA + D.OB + 3) / 4 + cdiv(D.H, 4), 1, P->nz),
+                           dim3(DW_BLOCK), P->smem_dw, s, D, W, epoch, P->bstride); });
 }
 constexpr int NKERN = 6;
 // `ev` (optional): NKERN + 1 events recorded before kernel 0 and after each kernel.
@@ -686,9 +714,9 @@ static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nu
     launch_l2(P, par, s); mark(1);
     launch_head(P, s); mark(2);
     launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
-                      true, true, EngineEpi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y}, s); mark(3);
-    hipLaunchKernelGGL(k_gradc, dim3(D.K), dim3(256), 0, s, D, W, epoch, D.nbx, D.nby); mark(4);
-    hipLaunchKernelGGL(k_bwd2, dim3(D.H / 64, D.OC), dim3(256), P->smem_bwd2, s, D, W, epoch); mark(5);
+                      true, true, EngineEpi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, P->bstride}, s, P->nz, P->bstride); mark(3);
+    hipLaunchKernelGGL(k_gradc, dim3(D.K, 1, P->nz), dim3(256), 0, s, D, W, epoch, D.nbx, D.nby, P->bstride); mark(4);
+    hipLaunchKernelGGL(k_bwd2, dim3(D.H / 64, D.OC, P->nz), dim3(256), P->smem_bwd2, s, D, W, epoch, P->bstride); mark(5);
     launch_dw(P, epoch, s); mark(6);
 }
 
@@ -706,8 +734,8 @@ static int param_map(const Dims& D, ParamMap* pm) {
     return 6;
 }
 
-static int stage_inputs(Plan* P, const creg_train_args* a, hipStream_t s) {
-    const Dims& D = P->D; const Ws& W = P->W;
+static int stage_inputs(Plan* P, const creg_train_args* a, hipStream_t s, int b = 0) {
+    const Dims& D = P->D; const Ws W = ws_shift(P->W, (size_t)b * P->bstride);
     ParamMap pm[10];
     const int np = param_map(D, pm);
     for (int i = 0; i < np; ++i) {
@@ -728,10 +756,12 @@ static int stage_inputs(Plan* P, const creg_train_args* a, hipStream_t s) {
 }  // namespace creg
 using namespace creg;
 
+static int batch_of(const creg_train_shape* s) { return s->batch >= 1 ? s->batch : 1; }
+
 extern "C" size_t creg_train_workspace_bytes(const creg_train_shape* shape) {
     Dims D;
-    if (!make_dims(shape, &D)) return 0;
-    return carve(D, nullptr, nullptr);
+    if (!make_dims(shape, &D) || shape->batch < 0 || shape->batch > 64) return 0;
+    return align_up(carve(D, nullptr, nullptr), 256) * batch_of(shape);
 }
 
 extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* workspace, size_t workspace_bytes,
@@ -740,11 +770,13 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     CREG_REQUIRE(plan && workspace, "creg_train_plan_create: null pointer");
     CREG_REQUIRE(make_dims(shape, &D), "creg_train_plan_create: unsupported shape (rot in {0,1}, 64 <= hidden <= 1024 multiple of 64, sizes >= 1)");
     CREG_REQUIRE(((uintptr_t)workspace & 255) == 0, "creg_train_plan_create: workspace must be 256-byte aligned");
-    const size_t need = carve(D, nullptr, nullptr);
+    CREG_REQUIRE(shape->batch >= 0 && shape->batch <= 64, "creg_train_plan_create: batch must be in [0, 64]");
+    const size_t one = align_up(carve(D, nullptr, nullptr), 256), need = one * batch_of(shape);
     CREG_REQUIRE(workspace_bytes >= need, "creg_train_plan_create: workspace too small (%zu < %zu)", workspace_bytes, need);
     Plan* P = new Plan();
     P->shape = *shape; P->D = D; P->base = (char*)workspace; P->bytes = workspace_bytes;
     carve(D, P->base, &P->W);
+    P->B = batch_of(shape); P->nz = P->B; P->bstride = one;
     P->gexec = nullptr; P->graph_ready = false;
     P->smem_l2 = (int)(sizeof(float) * rows_per_chunk(D.K, D.H) * D.H);
     P->smem_bwd2 = (int)(sizeof(float) * (BW2_ROWS * ((D.K + 3) & ~3) + 16 * D.K + 8 * BW2_ROWS));
@@ -762,48 +794,67 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     return CREG_OK;
 }
 
-extern "C" int creg_train_plan_run(creg_train_plan* plan, const creg_train_args* a, creg_stream_t stream) {
+extern "C" int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train_args* args, int32_t n,
+                                         creg_stream_t stream) {
     Plan* P = (Plan*)plan;
-    CREG_REQUIRE(P && a && a->m && a->y && a->local_pts && a->seg_offsets && a->params && a->best_m && a->best_pred &&
-                     a->result, "creg_train_plan_run: null pointer");
+    CREG_REQUIRE(P && args, "creg_train_plan_run_batch: null pointer");
+    CREG_REQUIRE(n == P->B, "creg_train_plan_run_batch: the plan was created for a batch of %d problems, got %d", P->B, n);
     hipStream_t s = (hipStream_t)stream;
-    const Dims& D = P->D; const Ws& W = P->W;
-    int rc = stage_inputs(P, a, s);
-    if (rc) return rc;
+    const Dims& D = P->D;
+    for (int b = 0; b < n; ++b) {
+        const creg_train_args* a = args + b;
+        CREG_REQUIRE(a->m && a->y && a->local_pts && a->seg_offsets && a->params && a->best_m && a->best_pred && a->result,
+                     "creg_train_plan_run_batch: null pointer in problem %d", b);
+        int rc = stage_inputs(P, a, s, b);
+        if (rc) return rc;
+    }
+    P->nz = P->B;
     int e = 0;
     if (P->shape.use_graph && D.epochs >= 2) {
+        // One graph holds EPG consecutive epochs (even count: the epoch number enters the kernels only
+        // through its parity, the history index comes from the device-side counter state.epochs_run),
+        // so a 300-epoch train is 6 graph launches instead of 1800 kernel launches.
+        int epg = P->shape.use_graph > 1 ? P->shape.use_graph : 50;
+        if (epg > D.epochs) epg = D.epochs;
+        epg &= ~1;
         if (!P->graph_ready) {
-            // capture one even + one odd epoch: the epoch number enters the kernels only through its
-            // parity (the history index comes from the device-side counter state.epochs_run).
             // captured on a private stream (torch's current stream is usually the null stream, which
             // cannot be captured); the instantiated graph is then launched on the caller's stream.
             hipGraph_t g;
             hipStream_t cs;
             CREG_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             CREG_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-            enqueue_epoch(P, 0, cs);
-            enqueue_epoch(P, 1, cs);
+            for (int i = 0; i < epg; ++i) enqueue_epoch(P, i, cs);
             CREG_HIP(hipStreamEndCapture(cs, &g));
             CREG_HIP(hipGraphInstantiate(&P->gexec, g, nullptr, nullptr, 0));
             CREG_HIP(hipGraphDestroy(g));
             CREG_HIP(hipStreamDestroy(cs));
             P->graph_ready = true;
+            P->graph_epochs = epg;
         }
-        for (; e + 2 <= D.epochs; e += 2) CREG_HIP(hipGraphLaunch(P->gexec, s));
+        for (; e + P->graph_epochs <= D.epochs; e += P->graph_epochs) CREG_HIP(hipGraphLaunch(P->gexec, s));
     }
     for (; e < D.epochs; ++e) enqueue_epoch(P, e, s);
     CREG_LAUNCH_CHECK();
-    // results out, parameters back into the caller's tensors
+    // results out, parameters back into the callers' tensors
     ParamMap pm[10];
     const int np = param_map(D, pm);
-    for (int i = 0; i < np; ++i)
-        CREG_HIP(hipMemcpyAsync(a->params[i], W.P + pm[i].off, sizeof(float) * pm[i].count, hipMemcpyDeviceToDevice, s));
-    CREG_HIP(hipMemcpyAsync(a->best_m, W.best_m, sizeof(float) * 16 * D.K, hipMemcpyDeviceToDevice, s));
-    CREG_HIP(hipMemcpyAsync(a->best_pred, W.best_pred, sizeof(float) * 3 * D.NP, hipMemcpyDeviceToDevice, s));
-    CREG_HIP(hipMemcpyAsync(a->result, W.result, sizeof(float) * 4, hipMemcpyDeviceToDevice, s));
-    if (a->loss_hist) CREG_HIP(hipMemcpyAsync(a->loss_hist, W.loss_hist, sizeof(float) * D.epochs, hipMemcpyDeviceToDevice, s));
-    if (a->lr_hist) CREG_HIP(hipMemcpyAsync(a->lr_hist, W.lr_hist, sizeof(float) * D.epochs, hipMemcpyDeviceToDevice, s));
+    for (int b = 0; b < n; ++b) {
+        const creg_train_args* a = args + b;
+        const Ws W = ws_shift(P->W, (size_t)b * P->bstride);
+        for (int i = 0; i < np; ++i)
+            CREG_HIP(hipMemcpyAsync(a->params[i], W.P + pm[i].off, sizeof(float) * pm[i].count, hipMemcpyDeviceToDevice, s));
+        CREG_HIP(hipMemcpyAsync(a->best_m, W.best_m, sizeof(float) * 16 * D.K, hipMemcpyDeviceToDevice, s));
+        CREG_HIP(hipMemcpyAsync(a->best_pred, W.best_pred, sizeof(float) * 3 * D.NP, hipMemcpyDeviceToDevice, s));
+        CREG_HIP(hipMemcpyAsync(a->result, W.result, sizeof(float) * 4, hipMemcpyDeviceToDevice, s));
+        if (a->loss_hist) CREG_HIP(hipMemcpyAsync(a->loss_hist, W.loss_hist, sizeof(float) * D.epochs, hipMemcpyDeviceToDevice, s));
+        if (a->lr_hist) CREG_HIP(hipMemcpyAsync(a->lr_hist, W.lr_hist, sizeof(float) * D.epochs, hipMemcpyDeviceToDevice, s));
+    }
     return CREG_OK;
+}
+
+extern "C" int creg_train_plan_run(creg_train_plan* plan, const creg_train_args* a, creg_stream_t stream) {
+    return creg_train_plan_run_batch(plan, a, 1, stream);
 }
 
 extern "C" int creg_train_plan_probe(creg_train_plan* plan, const creg_train_args* a, float* m2, float* pred,
@@ -814,11 +865,12 @@ extern "C" int creg_train_plan_probe(creg_train_plan* plan, const creg_train_arg
     const Dims& D = P->D; const Ws& W = P->W;
     int rc = stage_inputs(P, a, s);
     if (rc) return rc;
+    P->nz = 1;
     launch_l2(P, 0, s);
     launch_head(P, s);
     launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
-                      true, true, EngineEpi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y}, s);
-    hipLaunchKernelGGL(k_gradc, dim3(D.K), dim3(256), 0, s, D, W, 0, D.nbx, D.nby);
+                      true, true, EngineEpi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, 0}, s, 1, 0);
+    hipLaunchKernelGGL(k_gradc, dim3(D.K, 1, 1), dim3(256), 0, s, D, W, 0, D.nbx, D.nby, (size_t)0);
     CREG_LAUNCH_CHECK();
     if (m2) CREG_HIP(hipMemcpyAsync(m2, W.m2, sizeof(float) * 16 * D.K, hipMemcpyDeviceToDevice, s));
     if (pred) CREG_HIP(hipMemcpyAsync(pred, W.best_pred, sizeof(float) * 3 * D.NP, hipMemcpyDeviceToDevice, s));
@@ -835,6 +887,7 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
     hipStream_t s = (hipStream_t)stream;
     int rc = stage_inputs(P, a, s);
     if (rc) return rc;
+    P->nz = 1;
     std::vector<hipEvent_t> ev((size_t)(NKERN + 1) * n_epochs);
     for (auto& e : ev) CREG_HIP(hipEventCreate(&e));
     for (int e = 0; e < n_epochs; ++e) enqueue_epoch(P, e, s, ev.data() + (NKERN + 1) * e);
@@ -853,10 +906,11 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
     // launch-to-launch gap, so it upper-bounds the rocprofv3 kernel duration by ~1 us).
     const int REP = 200;
     const Dims& D = P->D; const Ws& W = P->W;
+    P->nz = P->B;          // the launch as the timed region issues it: all B problems of the batch in grid.z
     CREG_HIP(hipEventRecord(ev[0], s));
     for (int i = 0; i < REP; ++i)
         launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
-                          true, true, EngineEpi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y}, s);
+                          true, true, EngineEpi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, P->bstride}, s, P->nz, P->bstride);
     CREG_HIP(hipEventRecord(ev[1], s));
     CREG_HIP(hipStreamSynchronize(s));
     float ms = 0.f;

@@ -12,7 +12,12 @@ from .model_utils import DQRegMLP, QRegMLP
 class SequenceRegistrar:
     def __init__(self, mats0, clusters0, n_tgt, rot="q", hidden=512, epochs=300, use_graph=True, device="cuda",
                  seed=0):
-        self.device = torch.device(device)
+        self._init_state(mats0, clusters0, rot, hidden, torch.device(device), seed)
+        self.plan = ops.TrainPlan(rot, self.K, hidden, self.pts.shape[0], n_tgt, epochs=epochs, use_graph=use_graph,
+                                  device=self.device)
+
+    def _init_state(self, mats0, clusters0, rot, hidden, device, seed):
+        self.device = device
         self.rot, self.K = rot, len(clusters0)
         gen_state = torch.random.get_rng_state()
         torch.manual_seed(seed)                      # the reference leaves the MLP init unseeded
@@ -25,8 +30,6 @@ class SequenceRegistrar:
         self.m = torch.as_tensor(mats0, dtype=torch.float32).to(self.device).contiguous()
         self.pts, self.off = ops.pack_clusters(clusters0, self.device)
         self.pts_init, self.off_init = self.pts.clone(), self.off.clone()
-        self.plan = ops.TrainPlan(rot, self.K, hidden, self.pts.shape[0], n_tgt, epochs=epochs, use_graph=use_graph,
-                                  device=self.device)
 
     def step(self, frame64: torch.Tensor, frame32: torch.Tensor = None):
         """Register the next frame ((N,3) fp64 on the device).  Returns (poses (K,4,4) fp32, result (4))."""
@@ -39,3 +42,40 @@ class SequenceRegistrar:
         self.pts = local.to(torch.float32)
         self.m = m2
         return m2, res
+
+
+class BatchRegistrar:
+    """S independent sequences of identical shape registered in lock-step: frame t of every sequence
+    is one batched train plan run (Step), one more (Anchor), then the S re-segmentations.  Sequences
+    are independent in the reference (only frames inside a sequence depend on each other), so the
+    results are those of S separate SequenceRegistrars -- bit for bit -- while every launch carries S
+    problems and the latency-bound kernels of one sequence hide behind the others'."""
+
+    def __init__(self, mats0, clusters0, n_tgt, n_sequences, rot="q", hidden=512, epochs=300, use_graph=True,
+                 device="cuda", seeds=None):
+        self.device = torch.device(device)
+        self.S = n_sequences
+        seeds = list(seeds) if seeds is not None else list(range(n_sequences))
+        self.seqs = []
+        for s in range(n_sequences):
+            r = SequenceRegistrar.__new__(SequenceRegistrar)
+            SequenceRegistrar._init_state(r, mats0, clusters0, rot, hidden, self.device, seeds[s])
+            self.seqs.append(r)
+        self.plan = ops.TrainPlan(rot, len(clusters0), hidden, self.seqs[0].pts.shape[0], n_tgt, epochs=epochs,
+                                  use_graph=use_graph, device=self.device, batch=n_sequences)
+
+    def step(self, frames64, frames32=None):
+        """frames64: list of S (N,3) fp64 device tensors (the next frame of every sequence)."""
+        ys = frames32 if frames32 is not None else [f.to(torch.float32) for f in frames64]
+        step = self.plan.run_batch([(r.m, y, r.pts, r.off, r.p_step) for r, y in zip(self.seqs, ys)], lr=2e-4)
+        anchor = self.plan.run_batch([(o[0], y, r.pts_init, r.off_init, r.p_anchor)
+                                      for r, y, o in zip(self.seqs, ys, step)], lr=1e-4)
+        out = []
+        for r, f64, o in zip(self.seqs, frames64, anchor):
+            m2 = o[0]
+            M64 = m2.to(torch.float64)
+            _, labels, _, _ = ops.kmeans_lloyd(f64, M64[:, :3, 3].contiguous())
+            local, r.off = ops.group_to_local(f64, labels, M64)
+            r.pts, r.m = local.to(torch.float32), m2
+            out.append((m2, o[2]))
+        return out

@@ -199,11 +199,12 @@ class TrainPlan:
     """Device-resident `train` loop (mlp_reg.py:17-152) for one (rot, K, hidden, N) shape."""
 
     def __init__(self, rot: str, k: int, hidden: int, n_pred: int, n_tgt: int, epochs: int = 300,
-                 use_graph: bool = True, device=None):
+                 use_graph: bool = True, device=None, batch: int = 1):
         self.L = _lib.load()
         self.rot = {"q": 0, "dq": 1}[rot]
         self.device = torch.device(device if device is not None else "cuda")
-        self.shape = _lib.TrainShape(self.rot, k, hidden, epochs, n_pred, n_tgt, int(use_graph), 0)
+        self.batch = int(batch)
+        self.shape = _lib.TrainShape(self.rot, k, hidden, epochs, n_pred, n_tgt, int(use_graph), self.batch)
         need = self.L.creg_train_workspace_bytes(ctypes.byref(self.shape))
         if need == 0:
             raise ValueError("unsupported train shape")
@@ -223,32 +224,46 @@ class TrainPlan:
         n = 10 if self.rot == 0 else 6
         if len(params) != n:
             raise ValueError(f"expected {n} parameter tensors, got {len(params)}")
-        self._keep = [_need(m, torch.float32, "m"), _need(y, torch.float32, "y"), _need(pts, torch.float32, "pts"),
-                      _need(offsets, torch.int32, "offsets")]
+        keep = [_need(m, torch.float32, "m"), _need(y, torch.float32, "y"), _need(pts, torch.float32, "pts"),
+                _need(offsets, torch.int32, "offsets")]
         for p in params:
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                 raise TypeError("model parameters must be contiguous fp32 CUDA tensors")
         arr = (ctypes.c_void_p * n)(*[p.data_ptr() for p in params])
-        self._arr = arr
+        self._keep = getattr(self, "_keep", [])[-64:] + [keep, arr]      # alive until the enqueued work has read them
         a = _lib.TrainArgs()
-        a.m, a.y, a.local_pts, a.seg_offsets = [t.data_ptr() for t in self._keep]
+        a.m, a.y, a.local_pts, a.seg_offsets = [t.data_ptr() for t in keep]
         a.params = ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
         a.lr, a.sched_factor, a.sched_patience, a.stop = lr, factor, patience, stop
         a.best_m, a.best_pred, a.loss_hist, a.lr_hist, a.result = [o.data_ptr() if o is not None else None for o in outs]
         return a
 
+    def _outs(self):
+        dev = self.device
+        return (torch.empty(self.k, 4, 4, dtype=torch.float32, device=dev),
+                torch.empty(self.n_pred, 3, dtype=torch.float32, device=dev),
+                torch.empty(self.epochs, dtype=torch.float32, device=dev),
+                torch.empty(self.epochs, dtype=torch.float32, device=dev),
+                torch.empty(4, dtype=torch.float32, device=dev))
+
     def run(self, m, y, pts, offsets, params, lr=2e-4, factor=0.7, patience=5, stop=200):
         """Returns (best_m (k,4,4), best_pred (n_pred,3), result (4) = [min_loss, epochs_run, lr,
         best_epoch], loss_hist (epochs), lr_hist (epochs)); all device tensors, stream-ordered."""
-        dev = self.device
-        best_m = torch.empty(self.k, 4, 4, dtype=torch.float32, device=dev)
-        best_pred = torch.empty(self.n_pred, 3, dtype=torch.float32, device=dev)
-        result = torch.empty(4, dtype=torch.float32, device=dev)
-        lh = torch.empty(self.epochs, dtype=torch.float32, device=dev)
-        lrh = torch.empty(self.epochs, dtype=torch.float32, device=dev)
-        a = self._args(m, y, pts, offsets, params, lr, factor, patience, stop, (best_m, best_pred, lh, lrh, result))
-        _lib.check(self.L.creg_train_plan_run(self.plan, ctypes.byref(a), _stream()), "creg_train_plan_run")
-        return best_m, best_pred, result, lh, lrh
+        return self.run_batch([(m, y, pts, offsets, params)], lr, factor, patience, stop)[0]
+
+    def run_batch(self, problems, lr=2e-4, factor=0.7, patience=5, stop=200):
+        """problems: list of `batch` tuples (m, y, pts, offsets, params) of identical shape, advanced
+        together (one launch carries all of them).  Returns one result tuple per problem, as `run`."""
+        if len(problems) != self.batch:
+            raise ValueError(f"this plan advances {self.batch} problems per launch, got {len(problems)}")
+        arr = (_lib.TrainArgs * self.batch)()
+        outs = []
+        for b, (m, y, pts, offsets, params) in enumerate(problems):
+            best_m, best_pred, lh, lrh, result = o = self._outs()
+            arr[b] = self._args(m, y, pts, offsets, params, lr, factor, patience, stop, o)
+            outs.append((best_m, best_pred, result, lh, lrh))
+        _lib.check(self.L.creg_train_plan_run_batch(self.plan, arr, self.batch, _stream()), "creg_train_plan_run_batch")
+        return outs
 
     def probe(self, m, y, pts, offsets, params):
         """One forward + pose-gradient evaluation (test hook): (m2, pred, loss, grad_m2)."""

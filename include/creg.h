@@ -166,8 +166,8 @@ typedef struct creg_train_shape {
     int32_t epochs;       /* 300 in the reference (mlp_reg.py:60) */
     int64_t n_pred;       /* sum of cluster sizes */
     int64_t n_tgt;        /* points in the target frame */
-    int32_t use_graph;    /* replay the epoch as a captured hipGraph instead of eager launches */
-    int32_t reserved;
+    int32_t use_graph;    /* 0: eager launches; 1: hipGraph of 50 epochs per launch; n > 1: n epochs per graph */
+    int32_t batch;        /* independent problems (sequences) advanced per launch; 0 or 1 = one */
 } creg_train_shape;
 
 typedef struct creg_train_args {
@@ -189,12 +189,17 @@ typedef struct creg_train_args {
 
 typedef struct creg_train_plan creg_train_plan;
 
-size_t creg_train_workspace_bytes(const creg_train_shape* shape);
+size_t creg_train_workspace_bytes(const creg_train_shape* shape);   /* covers shape.batch problems */
 /* `workspace` (device, 256-byte aligned) must stay valid until creg_train_plan_destroy. */
 int creg_train_plan_create(const creg_train_shape* shape, void* workspace, size_t workspace_bytes,
                            creg_train_plan** plan);
 /* Enqueues the whole loop on `stream`; asynchronous (outputs are ready when the stream is). */
 int creg_train_plan_run(creg_train_plan* plan, const creg_train_args* args, creg_stream_t stream);
+/* Same for `n` == shape.batch independent problems of identical shape (K, N, hidden, epochs) advanced
+ * together: every launch carries all of them in grid.z, so the latency-bound kernels of one sequence
+ * overlap those of the others (sequences of a run are independent; frames of ONE sequence are not).
+ * args[b] describes problem b; results are bit-identical to n separate creg_train_plan_run calls. */
+int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train_args* args, int32_t n, creg_stream_t stream);
 int creg_train_plan_destroy(creg_train_plan* plan);
 
 /* Test / profiling hook: run exactly one epoch's forward and return intermediates.

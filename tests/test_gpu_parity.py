@@ -365,3 +365,36 @@ def test_segments_sample_size_uses_fps(dev, tmp_path):
     X = np.random.default_rng(0).normal(size=(3000, 3))
     out = PointCloud(X).farthest_point_down_sample(256)
     np.testing.assert_array_equal(out.points, X[kmeans.farthest_point_sample(X, 256)])
+
+
+def test_batched_plan_is_bit_identical_to_separate_runs(dev, golden):
+    """creg_train_plan_run_batch: 3 independent problems (different weights, targets and cluster sizes)
+    advanced per launch give exactly the results of 3 separate plans."""
+    from autourdf_amd import ops
+    from oracle import models
+    g, _, _ = _train_case(golden, "q")
+    base = [torch.from_numpy(c) for c in _split(g["q_local"], g["q_offsets"])]
+    y0, m0 = torch.from_numpy(g["q_y"]), torch.from_numpy(g["q_m"])
+    n = sum(len(c) for c in base)
+    problems, singles = [], []
+    for b in range(3):
+        torch.manual_seed(20 + b)
+        model = models.QRegMLP(True, 64)
+        flat = torch.cat(base)
+        cuts = sorted(torch.randperm(n - 1)[: len(base) - 1].add(1).tolist())          # different cluster sizes
+        cl = [flat[a:z] for a, z in zip([0] + cuts, cuts + [n])]
+        y = (y0 + 0.01 * b).to(dev)
+        pts, off = ops.pack_clusters(cl, dev)
+        mk = lambda: [model.state_dict()[k].clone().to(dev) for k in ops.Q_PARAM_ORDER]
+        problems.append((m0.to(dev), y, pts, off, mk()))
+        singles.append((m0.to(dev), y, pts, off, mk()))
+    plan_b = ops.TrainPlan("q", len(base), 64, n, y0.shape[0], epochs=30, use_graph=True, device=dev, batch=3)
+    outs_b = plan_b.run_batch(problems)
+    plan_1 = ops.TrainPlan("q", len(base), 64, n, y0.shape[0], epochs=30, use_graph=True, device=dev)
+    for b in range(3):
+        o1 = plan_1.run(*singles[b])
+        for tb, t1 in zip(outs_b[b], o1):
+            assert torch.equal(tb, t1) or (torch.isnan(tb) == torch.isnan(t1)).all() and torch.equal(tb.nan_to_num(), t1.nan_to_num())
+        for pb, p1 in zip(problems[b][4], singles[b][4]):
+            assert torch.equal(pb, p1)
+    assert not torch.equal(outs_b[0][0], outs_b[1][0])
