@@ -523,7 +523,26 @@ __device__ __forceinline__ float adam_value(float p, float& mm, float& vv, float
 // ([K][H] encoder activation for hidden rows, [K][H2] hidden activation for output rows, [K][IN]
 // features for encoder rows) in LDS with batched loads; a row's parameter / Adam-state loads are all
 // issued together.  No loop over K contains a global load.
-constexpr int DW_BLOCK = 256;         // 4 parameter rows per block
+constexpr int DW_BLOCK = 256;         // 4 waves
+constexpr int DW_RPW = 1;             // parameter rows per wave (1 measured best: 27 us vs 30 (2) vs 42 (4) at B=5;
+                                      // fewer, fatter waves cost more than the staging traffic they save)
+constexpr int DW_RPB = 4 * DW_RPW;    // rows per block sharing one LDS copy of the activations
+struct DwRow { int oW, ob, o, n_in, aoff, kind; bool active; };
+
+__device__ __forceinline__ DwRow dw_row(const Dims& D, int bkind, int row) {
+    DwRow R;
+    R.aoff = 0; R.active = true;
+    if (bkind == 0) { R.kind = 0; R.o = row; R.oW = D.oW2 + row * D.H; R.ob = D.ob2 + row; R.n_in = D.H; }
+    else if (bkind == 3) { R.kind = 3; R.o = min(row, D.H - 1); R.active = row < D.H; R.oW = D.oW1 + R.o * D.IN; R.ob = D.ob1 + R.o; R.n_in = D.IN; }
+    else if (row < D.OA) { R.kind = 1; R.o = row; R.oW = D.oW3A + row * D.HA; R.ob = D.ob3A + row; R.n_in = D.HA; }
+    else if (row < D.OA + D.OB) { R.kind = 2; R.o = row - D.OA; R.oW = D.oW3B + R.o * D.HB; R.ob = D.ob3B + R.o; R.n_in = D.HB; R.aoff = D.HA; }
+    else { R.kind = 2; R.o = 0; R.active = false; R.oW = D.oW3B; R.ob = D.ob3B; R.n_in = D.HB; R.aoff = D.HA; }   // idle: mirrors a valid row, stores nothing
+    return R;
+}
+
+// One wave owns DW_RPW parameter rows; the block's DW_RPB rows are of one kind (hidden / output / encoder)
+// and share ONE LDS copy of that kind's input activation matrix, fetched by LDS-DMA.  Parameter and
+// Adam-state loads of all rows, the gradient columns and the DMA are requested before the first wait.
 template <int NC>
 __global__ __launch_bounds__(DW_BLOCK, 1) void k_dw(Dims D, Ws W0, int epoch, size_t bstride) {
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
@@ -531,88 +550,101 @@ __global__ __launch_bounds__(DW_BLOCK, 1) void k_dw(Dims D, Ws W0, int epoch, si
     const TrainState S = W.state[(epoch + 1) & 1];
     const bool live = !S.stopped;                   // gates every store (no early exit: see k_bwd2)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    float* g = (float*)smem + wib * D.K;            // per-wave gradient column g[r]
-    float* as = (float*)smem + ((4 * D.K + 3) & ~3);   // staged activations [rc][width]
+    const int gsz = (4 * DW_RPW * D.K + 3) & ~3;
+    float* gall = (float*)smem;                     // [4 waves][DW_RPW][K] gradient columns
+    float* as = (float*)smem + gsz;                 // staged activations [rc][width]
     const int par = epoch & 1;
-    // block -> row kind.  Blocks: [hidden rows /4][output rows /4][encoder rows /4]
-    const int nb2 = D.H2 / 4, nb3 = (D.OA + D.OB + 3) / 4;
-    int kind, row;
-    if ((int)blockIdx.x < nb2) { kind = 0; row = blockIdx.x * 4 + wib; }
-    else if ((int)blockIdx.x < nb2 + nb3) { row = (blockIdx.x - nb2) * 4 + wib; kind = row < D.OA ? 1 : 2; }
-    else { kind = 3; row = (blockIdx.x - nb2 - nb3) * 4 + wib; }
+    // block -> row kind.  Blocks: [hidden rows / RPB][output rows / RPB][encoder rows / RPB]
+    const int nb2 = D.H2 / DW_RPB, nb3 = (D.OA + D.OB + DW_RPB - 1) / DW_RPB;
     const int bkind = (int)blockIdx.x < nb2 ? 0 : ((int)blockIdx.x < nb2 + nb3 ? 1 : 3);   // block-uniform
-    bool active = true;
-    int oW = 0, ob = 0, o = 0, n_in = 64, aoff = 0;
-    if (kind == 0) { o = row; oW = D.oW2 + o * D.H; ob = D.ob2 + o; n_in = D.H; }
-    else if (kind == 3) { o = min(row, D.H - 1); active = row < D.H; oW = D.oW1 + o * D.IN; ob = D.ob1 + o; n_in = D.IN; }
-    else if (row < D.OA) { o = row; oW = D.oW3A + o * D.HA; ob = D.ob3A + o; n_in = D.HA; }
-    else if (row < D.OA + D.OB) { o = row - D.OA; oW = D.oW3B + o * D.HB; ob = D.ob3B + o; n_in = D.HB; aoff = D.HA; }
-    else { active = false; oW = D.oW3B; ob = D.ob3B; n_in = D.HB; aoff = D.HA; }      // idle wave mirrors a valid row, stores nothing
+    const int row0 = (bkind == 0 ? blockIdx.x : (bkind == 1 ? blockIdx.x - nb2 : blockIdx.x - nb2 - nb3)) * DW_RPB + wib * DW_RPW;
     const float* x1cur = par ? W.x1[1] : W.x1[0];     // (a runtime index into the shifted struct would go to scratch)
     float* x1next = par ? W.x1[0] : W.x1[1];
     const float* amat = bkind == 0 ? x1cur : (bkind == 1 ? W.h2 : W.enc);
     const int awidth = bkind == 0 ? D.H : (bkind == 1 ? D.H2 : D.IN);
     const int rc = rows_per_chunk(D.K, awidth);
-    // Everything this wave needs from memory is requested before the first wait, in one round trip:
-    // parameter + Adam state of the row, the row's gradient column, then the activation matrix.
-    float pw[NC], pm[NC], pv[NC], acc[NC];
-    int idx[NC];
+    stage_issue<DW_BLOCK>((float4*)as, (const float4*)amat, min(rc, D.K) * awidth / 4);
+    DwRow R[DW_RPW];
+    float pw[DW_RPW][NC], pm[DW_RPW][NC], pv[DW_RPW][NC], acc[DW_RPW][NC], pb[DW_RPW], mb[DW_RPW], vb[DW_RPW];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        idx[c] = min(c * 64 + lane, n_in - 1);
-        pw[c] = W.P[oW + idx[c]]; pm[c] = W.AM[oW + idx[c]]; pv[c] = W.AV[oW + idx[c]]; acc[c] = 0.f;
+    for (int q = 0; q < DW_RPW; ++q) {
+        R[q] = dw_row(D, bkind, row0 + q);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int i = min(c * 64 + lane, R[q].n_in - 1);
+            pw[q][c] = W.P[R[q].oW + i]; pm[q][c] = W.AM[R[q].oW + i]; pv[q][c] = W.AV[R[q].oW + i]; acc[q][c] = 0.f;
+        }
+        pb[q] = W.P[R[q].ob]; mb[q] = W.AM[R[q].ob]; vb[q] = W.AV[R[q].ob];
     }
-    float pb = W.P[ob], mb = W.AM[ob], vb = W.AV[ob];
-    auto grad_col = [&](int r) -> float {       // dL/d(pre-activation of unit o) for pose row r
-        if (kind == 0) return W.g_h2[(size_t)r * D.H2 + o];
-        if (kind == 1) return W.g_out[16 * r + o];
-        if (kind == 2) return W.g_out[16 * r + 4 + o];
+    auto grad_col = [&](const DwRow& r_, int r) -> float {       // dL/d(pre-activation of unit o) for pose row r
+        if (r_.kind == 0) return W.g_h2[(size_t)r * D.H2 + r_.o];
+        if (r_.kind == 1) return W.g_out[16 * r + r_.o];
+        if (r_.kind == 2) return W.g_out[16 * r + 4 + r_.o];
         float part[BW2_OC];
 #pragma unroll
-        for (int c = 0; c < BW2_OC; ++c) part[c] = W.gx1_part[((size_t)c * D.K + r) * D.H + o];
-        const float post = x1cur[(size_t)r * D.H + o];
+        for (int c = 0; c < BW2_OC; ++c) part[c] = W.gx1_part[((size_t)c * D.K + r) * D.H + r_.o];
+        const float post = x1cur[(size_t)r * D.H + r_.o];
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < BW2_OC; ++c) sum += part[c];
         return sum * act_grad(post, D.slope);
     };
+#pragma unroll
+    for (int q = 0; q < DW_RPW; ++q)
+        for (int r = lane; r < D.K; r += 64) gall[(wib * DW_RPW + q) * D.K + r] = grad_col(R[q], r);
     // accumulate g[r] * act[r][i] over the pose rows from the LDS-staged activation matrix
     for (int r0 = 0; r0 < D.K; r0 += rc) {
         const int nr = min(rc, D.K - r0);
-        if (r0) __syncthreads();
-        stage_issue<DW_BLOCK>((float4*)as, (const float4*)(amat + (size_t)r0 * awidth), nr * awidth / 4);
-        if (r0 == 0)                                // gradient column: its loads ride the same round trip
-            for (int r = lane; r < D.K; r += 64) g[r] = grad_col(r);
+        if (r0) {
+            __syncthreads();
+            stage_issue<DW_BLOCK>((float4*)as, (const float4*)(amat + (size_t)r0 * awidth), nr * awidth / 4);
+        }
         stage_wait();
         __syncthreads();
-#pragma unroll 4
+#pragma unroll 2
         for (int r = 0; r < nr; ++r) {
-            const float gr = g[r0 + r];
-            const float* a = as + r * awidth + aoff;
+            float av[NC];                              // rows of one block read the same columns: load once
+            const float* a = as + r * awidth;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] = fmaf(gr, a[idx[c]], acc[c]);
+            for (int q = 0; q < DW_RPW; ++q) {
+                const float gr = gall[(wib * DW_RPW + q) * D.K + r0 + r];
+                if (q == 0 || bkind == 1) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) av[c] = a[R[q].aoff + min(c * 64 + lane, R[q].n_in - 1)];
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[q][c] = fmaf(gr, av[c], acc[q][c]);
+            }
         }
     }
-    if (active && live) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const float nw = adam_value(pw[c], pm[c], pv[c], acc[c], S.step_size, S.bc2_sqrt);
-            if (c * 64 + lane < n_in) { W.P[oW + idx[c]] = nw; W.AM[oW + idx[c]] = pm[c]; W.AV[oW + idx[c]] = pv[c]; }
-            pw[c] = nw;
+    for (int q = 0; q < DW_RPW; ++q) {
+        if (R[q].active && live) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int i = c * 64 + lane;
+                const float nw = adam_value(pw[q][c], pm[q][c], pv[q][c], acc[q][c], S.step_size, S.bc2_sqrt);
+                if (i < R[q].n_in) { W.P[R[q].oW + i] = nw; W.AM[R[q].oW + i] = pm[q][c]; W.AV[R[q].oW + i] = pv[q][c]; }
+                pw[q][c] = nw;
+            }
+            float sum = 0.f;
+            for (int r = 0; r < D.K; ++r) sum += gall[(wib * DW_RPW + q) * D.K + r];
+            pb[q] = adam_value(pb[q], mb[q], vb[q], sum, S.step_size, S.bc2_sqrt);
+            if (lane == 0) { W.P[R[q].ob] = pb[q]; W.AM[R[q].ob] = mb[q]; W.AV[R[q].ob] = vb[q]; }
         }
-        float sum = 0.f;
-        for (int r = 0; r < D.K; ++r) sum += g[r];
-        pb = adam_value(pb, mb, vb, sum, S.step_size, S.bc2_sqrt);
-        if (lane == 0) { W.P[ob] = pb; W.AM[ob] = mb; W.AV[ob] = vb; }
     }
-    if (bkind == 3 && active && live) {
-        // next epoch's encoder activation from the updated row held in registers (IN <= 64: one
+    if (bkind == 3 && live) {
+        // next epoch's encoder activation from the updated rows held in registers (IN <= 64: one
         // weight per lane) and the LDS-staged features (K * IN floats always fit one chunk).  The MLP
         // input is the same every epoch: m.clone() of the same m (mlp_reg.py:62); only weights moved.
+#pragma unroll
+        for (int q = 0; q < DW_RPW; ++q) {
+            if (!R[q].active) continue;
 #pragma unroll 4
-        for (int r = 0; r < D.K; ++r) {
-            const float v = wave_sum_fast(lane < D.IN ? pw[0] * as[r * D.IN + lane] : 0.f) + pb;
-            if (lane == 0) x1next[(size_t)r * D.H + o] = act_f(v, D.slope);
+            for (int r = 0; r < D.K; ++r) {
+                const float v = wave_sum_fast(lane < D.IN ? pw[q][0] * as[r * D.IN + lane] : 0.f) + pb[q];
+                if (lane == 0) x1next[(size_t)r * D.H + R[q].o] = act_f(v, D.slope);
+            }
         }
     }
 }
@@ -701,7 +733,7 @@ static void launch_head(Plan* P, hipStream_t s) {
 static void launch_dw(Plan* P, int epoch, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
     by_nc(D.H, [&](auto nc) {
-        hipLaunchKernelGGL((k_dw<decltype(nc)::value>), dim3(D.H2 / 4 + (D.OA + D.OB + 3) / 4 + cdiv(D.H, 4), 1, P->nz),
+        hipLaunchKernelGGL((k_dw<decltype(nc)::value>), dim3(D.H2 / DW_RPB + cdiv(D.OA + D.OB, DW_RPB) + cdiv(D.H, DW_RPB), 1, P->nz),
                            dim3(DW_BLOCK), P->smem_dw, s, D, W, epoch, P->bstride); });
 }
 constexpr int NKERN = 6;
@@ -780,7 +812,7 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     P->gexec = nullptr; P->graph_ready = false;
     P->smem_l2 = (int)(sizeof(float) * rows_per_chunk(D.K, D.H) * D.H);
     P->smem_bwd2 = (int)(sizeof(float) * (BW2_ROWS * ((D.K + 3) & ~3) + 16 * D.K + 8 * BW2_ROWS));
-    P->smem_dw = (int)(sizeof(float) * (((4 * D.K + 3) & ~3) + 16384 + 4));
+    P->smem_dw = (int)(sizeof(float) * (((4 * DW_RPW * D.K + 3) & ~3) + 16384 + 4));
     int rc_attr = 0;
     by_nc(D.H, [&](auto nc) {
         if (P->smem_dw > 65536 &&
