@@ -38,6 +38,8 @@ SIGNATURES = {
     "creg_cluster_transform_bwd_f32": (ctypes.c_int, [vp, vp, i32, vp, vp, vp]),
     "creg_kmeans_workspace_bytes": (sz, [i64, i32]),
     "creg_kmeans_lloyd_f64": (ctypes.c_int, [vp, i64, vp, i32, i32, f64, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "creg_kmeans_batch_workspace_bytes": (sz, [i64, i32, i32]),
+    "creg_kmeans_lloyd_batch_f64": (ctypes.c_int, [vp, i64, vp, i32, i32, i32, f64, vp, vp, vp, vp, vp, sz, vp]),
     "creg_kmeans_assign_f64": (ctypes.c_int, [vp, i64, vp, i32, i32, vp, vp]),
     "creg_group_to_local_f64": (ctypes.c_int, [vp, i64, vp, i32, vp, vp, vp, vp]),
     "creg_fps_scratch_bytes": (sz, [i64]),

@@ -305,6 +305,209 @@ __global__ __launch_bounds__(1024) void k_km_finish(const double* __restrict__ X
     for (int j = threadIdx.x; j < 3 * k; j += 1024) centers[j] = C[j] + f->mean[j % 3];
 }
 
+// ---- one-launch Lloyd for small clouds, one workgroup per problem ----------------------------------
+// For n * 24 B <= 128 KB (n <= 5461: the 4096 / 5000-point frames of the reference) the centred frame
+// fits one CU's LDS, so a whole k_means() -- mean/tol, centring, up to max_iter Lloyd iterations with
+// the strict-convergence / tol test, final E-step, inertia -- runs as ONE workgroup with no host
+// involvement, and B independent problems (the sequences of a batch) are B workgroups of one launch.
+// Every sum is formed in exactly the order of the multi-launch path above (k_km_stats: 1024 strided
+// partials + tree; k_km_accumulate: 256 strided partials per cluster + tree; k_km_finalize; k_km_finish),
+// so both paths give bit-identical labels, centres, inertia and iteration counts (tested).
+constexpr int KMS_MAXB = 16;
+struct KmBatch {
+    const double* X[KMS_MAXB]; const double* init[KMS_MAXB];
+    double* centers[KMS_MAXB]; int* labels[KMS_MAXB]; double* inertia[KMS_MAXB]; int* n_iter[KMS_MAXB];
+};
+
+__global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int max_iter, double tol_rel,
+                                                   char* __restrict__ ws, size_t ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* Xc = (double*)smem;                               // [n][3] centred points
+    __shared__ double sc[16];
+    __shared__ double s_mean[3], s_tol, s_shift;
+    __shared__ double gpart[4][4][4];                         // [group][wave in group][x,y,z,w]
+    __shared__ int s_changed, s_done, s_strict, s_it, s_nempty, s_argmax;
+    __shared__ double s_dmax, s_fv[16];
+    __shared__ int s_fi[16];
+    const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double* X = A.X[z];
+    char* w = ws + (size_t)z * ws_stride;                     // per-problem scratch: C2 (6k), B (4k), Cw (4k), far (n), lab2 (n ints)
+    double* C2 = (double*)w; double* Bm = C2 + 6 * k; double* Cw = Bm + 4 * k; double* far_d = Cw + 4 * k;
+    int* lab2 = (int*)(far_d + n);
+    int* lab[2] = {A.labels[z], lab2};
+    // ---- mean / tol (k_km_stats) ----
+    double var = 0;
+    for (int d = 0; d < 3; ++d) {
+        double s = 0;
+        for (int i = tid; i < n; i += 1024) s += X[3 * (size_t)i + d];
+        s = block_sum<double, 1024>(s, sc);
+        if (tid == 0) s_mean[d] = s / (double)n;
+    }
+    __syncthreads();
+    for (int d = 0; d < 3; ++d) {
+        double s = 0;
+        for (int i = tid; i < n; i += 1024) { const double t = X[3 * (size_t)i + d] - s_mean[d]; s = fma(t, t, s); }
+        s = block_sum<double, 1024>(s, sc);
+        if (tid == 0) var += s / (double)n;
+    }
+    if (tid == 0) { s_tol = (var / 3.0) * tol_rel; s_done = 0; s_strict = 0; s_it = 0; s_changed = 0; }
+    // ---- centre (k_km_center) ----
+    for (int i = tid; i < 3 * n; i += 1024) Xc[i] = X[i] - s_mean[i % 3];
+    for (int i = tid; i < n; i += 1024) lab2[i] = -1;         // iteration 0 compares against lab[1] = -1
+    if (tid < k) {
+        double c[3];
+        for (int d = 0; d < 3; ++d) { c[d] = A.init[z][3 * tid + d] - s_mean[d]; C2[3 * tid + d] = c[d]; }
+        make_b(c, Bm + 4 * tid);
+    }
+    __threadfence_block();
+    __syncthreads();
+    int cur = 0;                                             // centre buffer holding the current centres
+    for (int it = 0; it < max_iter; ++it) {
+        int* lcur = lab[it & 1];
+        const int* lprev = lab[(it + 1) & 1];
+        // ---- E-step (k_km_assign) ----
+        int diff = 0;
+        for (int i = tid; i < n; i += 1024) {
+            const double x0 = Xc[3 * i], x1 = Xc[3 * i + 1], x2 = Xc[3 * i + 2];
+            double best = fma(x2, Bm[2], fma(x1, Bm[1], fma(x0, Bm[0], Bm[3])));
+            int lb = 0;
+            for (int j = 1; j < k; ++j) {
+                const double d = fma(x2, Bm[4 * j + 2], fma(x1, Bm[4 * j + 1], fma(x0, Bm[4 * j], Bm[4 * j + 3])));
+                if (d < best) { best = d; lb = j; }
+            }
+            lcur[i] = lb;
+            diff += (lprev[i] != lb);
+        }
+        if (diff) atomicAdd(&s_changed, diff);
+        __threadfence_block();
+        __syncthreads();
+        // ---- per-cluster sums in k_km_accumulate's order: groups of 256 threads emulate its blocks ----
+        const int g = tid >> 8, tg = tid & 255, wg = (tid >> 6) & 3;
+        for (int j0 = 0; j0 < k; j0 += 4) {
+            const int j = j0 + g;
+            double a0 = 0, a1 = 0, a2 = 0, aw = 0;
+            if (j < k)
+                for (int i = tg; i < n; i += 256)
+                    if (lcur[i] == j) { a0 += Xc[3 * i]; a1 += Xc[3 * i + 1]; a2 += Xc[3 * i + 2]; aw += 1.0; }
+            a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); aw = wave_sum(aw);
+            if (lane == 0) { gpart[g][wg][0] = a0; gpart[g][wg][1] = a1; gpart[g][wg][2] = a2; gpart[g][wg][3] = aw; }
+            __syncthreads();
+            if (tg == 0 && j < k)
+                for (int d = 0; d < 4; ++d) {
+                    double r = 0;
+                    for (int q = 0; q < 4; ++q) r += gpart[g][q][d];
+                    Cw[4 * j + d] = r;                          // S = 1 segment: finalize's sum over segments is this value
+                }
+            __syncthreads();
+        }
+        // ---- k_km_finalize ----
+        const double* Cold = C2 + (size_t)cur * 3 * k;
+        double* Cnew = C2 + (size_t)(cur ^ 1) * 3 * k;
+        if (tid == 0) { int ne = 0; for (int j = 0; j < k; ++j) ne += (Cw[4 * j + 3] == 0.0); s_nempty = ne; }
+        __syncthreads();
+        if (s_nempty > 0) {
+            double dmax = 0;
+            for (int i = tid; i < n; i += 1024) {
+                const double* c = Cold + 3 * lcur[i];
+                const double a = Xc[3 * i] - c[0], b = Xc[3 * i + 1] - c[1], e = Xc[3 * i + 2] - c[2];
+                const double d = (a * a + b * b) + e * e;
+                far_d[i] = d;
+                dmax = fmax(dmax, d);
+            }
+            for (int off = 32; off >= 1; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+            __syncthreads();
+            if (lane == 0) sc[wv] = dmax;
+            __syncthreads();
+            if (tid == 0) { double m = 0; for (int i = 0; i < 16; ++i) m = fmax(m, sc[i]); s_dmax = m; }
+            __syncthreads();
+            if (s_dmax > 0) {
+                for (int j = 0; j < k; ++j) {
+                    if (Cw[4 * j + 3] != 0.0) continue;
+                    double bv = -1; int bi = 0x7fffffff;
+                    for (int i = tid; i < n; i += 1024) if (far_d[i] > bv) { bv = far_d[i]; bi = i; }
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        const double ov = __shfl_xor(bv, off, 64); const int oi = __shfl_xor(bi, off, 64);
+                        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                    }
+                    __syncthreads();
+                    if (lane == 0) { s_fv[wv] = bv; s_fi[wv] = bi; }
+                    __syncthreads();
+                    if (tid == 0) {
+                        for (int q = 0; q < 16; ++q) if (s_fv[q] > bv || (s_fv[q] == bv && s_fi[q] < bi)) { bv = s_fv[q]; bi = s_fi[q]; }
+                        far_d[bi] = -2;
+                        const int old = lcur[bi];
+                        for (int d = 0; d < 3; ++d) { Cw[4 * old + d] -= Xc[3 * bi + d]; Cw[4 * j + d] = Xc[3 * bi + d]; }
+                        Cw[4 * j + 3] = 1.0; Cw[4 * old + 3] -= 1.0;
+                    }
+                    __threadfence_block();
+                    __syncthreads();
+                }
+            }
+        }
+        if (tid == 0) { int am = 0; for (int j = 1; j < k; ++j) if (Cw[4 * j + 3] > Cw[4 * am + 3]) am = j; s_argmax = am; }
+        __syncthreads();
+        __shared__ double s_sh[1024];
+        double shift = 0;
+        if (tid < k) {
+            const int j = tid;
+            const double wj = Cw[4 * j + 3];
+            double c[3];
+            if (wj > 0) { const double alpha = 1.0 / wj; for (int d = 0; d < 3; ++d) c[d] = Cw[4 * j + d] * alpha; }
+            else { const double alpha = 1.0 / Cw[4 * s_argmax + 3]; for (int d = 0; d < 3; ++d) c[d] = Cw[4 * s_argmax + d] * alpha; }
+            double s = 0;
+            for (int d = 0; d < 3; ++d) { Cnew[3 * j + d] = c[d]; const double t = c[d] - Cold[3 * j + d]; s += t * t; }
+            const double sh = sqrt(s);
+            shift = sh * sh;
+            make_b(c, Bm + 4 * j);
+        }
+        s_sh[tid] = shift;
+        __threadfence_block();
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0;
+            for (int j = 0; j < k; ++j) tot += s_sh[j];
+            s_shift = tot;
+            s_it = it + 1;
+            if (s_changed == 0) { s_strict = 1; s_done = 1; }
+            else if (tot <= s_tol) s_done = 1;
+            s_changed = 0;
+        }
+        cur ^= 1;
+        __syncthreads();
+        if (s_done) break;
+    }
+    // ---- final E-step when not strictly converged, labels into the caller's buffer ----
+    int* last = lab[(s_it - 1) & 1];
+    if (!s_strict) {
+        for (int i = tid; i < n; i += 1024) {
+            const double x0 = Xc[3 * i], x1 = Xc[3 * i + 1], x2 = Xc[3 * i + 2];
+            double best = fma(x2, Bm[2], fma(x1, Bm[1], fma(x0, Bm[0], Bm[3])));
+            int lb = 0;
+            for (int j = 1; j < k; ++j) {
+                const double d = fma(x2, Bm[4 * j + 2], fma(x1, Bm[4 * j + 1], fma(x0, Bm[4 * j], Bm[4 * j + 3])));
+                if (d < best) { best = d; lb = j; }
+            }
+            last[i] = lb;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (last != A.labels[z]) for (int i = tid; i < n; i += 1024) A.labels[z][i] = last[i];
+    // ---- inertia, un-centred centres (k_km_finish) ----
+    const double* C = C2 + (size_t)cur * 3 * k;
+    double s = 0;
+    for (int i = tid; i < n; i += 1024) {
+        const double* c = C + 3 * last[i];
+        const double a = Xc[3 * i] - c[0], b = Xc[3 * i + 1] - c[1], e = Xc[3 * i + 2] - c[2];
+        s += (a * a + b * b) + e * e;
+    }
+    s = block_sum<double, 1024>(s, sc);
+    if (tid == 0) { A.inertia[z][0] = s; A.n_iter[z][0] = s_it; }
+    for (int j = tid; j < 3 * k; j += 1024) A.centers[z][j] = C[j] + s_mean[j % 3];
+}
+
+static size_t kms_stride(int64_t n, int k) { return align_up(sizeof(double) * (14 * (size_t)k + n) + sizeof(int) * n, 256); }
+
 __global__ __launch_bounds__(256) void k_make_b(const double* __restrict__ C, int k, double* __restrict__ B) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j < k) make_b(C + 3 * j, B + 4 * j);
@@ -474,6 +677,37 @@ extern "C" int creg_group_to_local_f64(const double* X, int64_t n, const int32_t
     hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(1024), sizeof(int) * (k + 1), s, labels, (int)n, k, seg_offsets, M, Minv);
     hipLaunchKernelGGL(k_group_scatter, dim3(k), dim3(64), 0, s, X, (int)n, labels, seg_offsets, Minv, out_local);
     CREG_HIP(hipFreeAsync(Minv, s));
+    CREG_LAUNCH_CHECK();
+    return CREG_OK;
+}
+
+extern "C" size_t creg_kmeans_batch_workspace_bytes(int64_t n, int32_t k, int32_t batch) {
+    if (n < 1 || k < 1 || batch < 1) return 0;
+    return kms_stride(n, k) * (size_t)batch;
+}
+
+extern "C" int creg_kmeans_lloyd_batch_f64(const double* const* X, int64_t n, const double* const* init, int32_t k,
+                                           int32_t batch, int32_t max_iter, double tol_rel, double* const* centers,
+                                           int32_t* const* labels, double* const* inertia, int32_t* const* n_iter,
+                                           void* workspace, size_t workspace_bytes, creg_stream_t stream) {
+    CREG_REQUIRE(X && init && centers && labels && inertia && n_iter && workspace, "creg_kmeans_lloyd_batch_f64: null pointer");
+    CREG_REQUIRE(batch >= 1 && batch <= KMS_MAXB, "creg_kmeans_lloyd_batch_f64: batch must be in [1, %d]", KMS_MAXB);
+    CREG_REQUIRE(n >= 1 && (size_t)n * 24 <= 131072 && k >= 1 && k <= 1024 && max_iter >= 1,
+                 "creg_kmeans_lloyd_batch_f64: needs n <= 5461 (frame resident in LDS), 1 <= k <= 1024; use creg_kmeans_lloyd_f64 otherwise");
+    CREG_REQUIRE(workspace_bytes >= kms_stride(n, k) * (size_t)batch, "creg_kmeans_lloyd_batch_f64: workspace too small");
+    KmBatch A;
+    for (int b = 0; b < batch; ++b) {
+        CREG_REQUIRE(X[b] && init[b] && centers[b] && labels[b] && inertia[b] && n_iter[b], "creg_kmeans_lloyd_batch_f64: null pointer in problem %d", b);
+        A.X[b] = X[b]; A.init[b] = init[b]; A.centers[b] = centers[b]; A.labels[b] = labels[b]; A.inertia[b] = inertia[b]; A.n_iter[b] = n_iter[b];
+    }
+    const int smem = (int)(sizeof(double) * 3 * n);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CREG_HIP(hipFuncSetAttribute((const void*)k_km_small, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_km_small, dim3(batch), dim3(1024), smem, (hipStream_t)stream, A, (int)n, k, max_iter, tol_rel,
+                       (char*)workspace, kms_stride(n, k));
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }

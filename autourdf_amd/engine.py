@@ -71,10 +71,14 @@ class BatchRegistrar:
         anchor = self.plan.run_batch([(o[0], y, r.pts_init, r.off_init, r.p_anchor)
                                       for r, y, o in zip(self.seqs, ys, step)], lr=1e-4)
         out = []
-        for r, f64, o in zip(self.seqs, frames64, anchor):
-            m2 = o[0]
-            M64 = m2.to(torch.float64)
-            _, labels, _, _ = ops.kmeans_lloyd(f64, M64[:, :3, 3].contiguous())
+        M64s = [o[0].to(torch.float64) for o in anchor]
+        inits = [M[:, :3, 3].contiguous() for M in M64s]
+        if frames64[0].shape[0] <= ops.KMEANS_BATCH_MAX_N and self.S <= 16:      # all S re-segmentations in one launch
+            km = ops.kmeans_lloyd_batch(frames64, inits)
+        else:
+            km = [ops.kmeans_lloyd(f, c) for f, c in zip(frames64, inits)]
+        for r, f64, o, M64, res in zip(self.seqs, frames64, anchor, M64s, km):
+            m2, labels = o[0], res[1]
             local, r.off = ops.group_to_local(f64, labels, M64)
             r.pts, r.m = local.to(torch.float32), m2
             out.append((m2, o[2]))

@@ -136,6 +136,30 @@ def kmeans_lloyd(X: torch.Tensor, init: torch.Tensor, max_iter: int = 300, tol: 
     return centers, labels, inertia, n_iter
 
 
+KMEANS_BATCH_MAX_N = 5461          # frame must fit one CU's LDS (n * 24 B <= 128 KB)
+
+
+def kmeans_lloyd_batch(Xs, inits, max_iter: int = 300, tol: float = 1e-4):
+    """k_means() for a list of same-sized frames in ONE asynchronous launch (one workgroup per frame,
+    n <= 5461).  Returns a list of (centers, labels, inertia, n_iter) like `kmeans_lloyd`."""
+    L = _lib.load()
+    Xs = [_need(x, torch.float64, "X") for x in Xs]
+    inits = [_need(c, torch.float64, "init") for c in inits]
+    B, n, k = len(Xs), Xs[0].shape[0], inits[0].shape[0]
+    if any(x.shape[0] != n for x in Xs) or any(c.shape[0] != k for c in inits) or len(inits) != B:
+        raise ValueError("kmeans_lloyd_batch: all problems must have the same n and k")
+    dev = Xs[0].device
+    ws_bytes = L.creg_kmeans_batch_workspace_bytes(n, k, B)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    outs = [(torch.empty(k, 3, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.int32, device=dev),
+             torch.empty(1, dtype=torch.float64, device=dev), torch.empty(1, dtype=torch.int32, device=dev)) for _ in range(B)]
+    arr = lambda ts: (ctypes.c_void_p * B)(*[t.data_ptr() for t in ts])
+    _lib.check(L.creg_kmeans_lloyd_batch_f64(arr(Xs), n, arr(inits), k, B, max_iter, tol, arr([o[0] for o in outs]),
+                                             arr([o[1] for o in outs]), arr([o[2] for o in outs]), arr([o[3] for o in outs]),
+                                             _p(ws), ws_bytes, _stream()), "creg_kmeans_lloyd_batch_f64")
+    return outs
+
+
 def kmeans_assign(X: torch.Tensor, C: torch.Tensor, use_mfma: bool = False) -> torch.Tensor:
     L = _lib.load()
     X, C = _need(X, torch.float64, "X"), _need(C, torch.float64, "C")

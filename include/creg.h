@@ -93,6 +93,15 @@ int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* init, int32_
                           int32_t max_iter, double tol_rel, int32_t use_mfma,
                           double* centers, int32_t* labels, double* inertia, int32_t* n_iter,
                           void* workspace, size_t workspace_bytes, creg_stream_t stream);
+/* The same k_means() for `batch` (<= 16) independent frames of identical size in ONE launch, one
+ * workgroup per frame, the centred frame resident in LDS (n <= 5461), fully asynchronous (no host
+ * synchronisation at all).  Bit-identical to creg_kmeans_lloyd_f64.  X, init, centers, labels, inertia,
+ * n_iter are HOST arrays of `batch` device pointers. */
+size_t creg_kmeans_batch_workspace_bytes(int64_t n, int32_t k, int32_t batch);
+int creg_kmeans_lloyd_batch_f64(const double* const* X, int64_t n, const double* const* init, int32_t k,
+                                int32_t batch, int32_t max_iter, double tol_rel, double* const* centers,
+                                int32_t* const* labels, double* const* inertia, int32_t* const* n_iter,
+                                void* workspace, size_t workspace_bytes, creg_stream_t stream);
 /* E-step only: labels[i] = argmin_k d(X_i, C_k) (no centring).  Asynchronous. */
 int creg_kmeans_assign_f64(const double* X, int64_t n, const double* C, int32_t k,
                            int32_t use_mfma, int32_t* labels, creg_stream_t stream);

@@ -398,3 +398,25 @@ def test_batched_plan_is_bit_identical_to_separate_runs(dev, golden):
         for pb, p1 in zip(problems[b][4], singles[b][4]):
             assert torch.equal(pb, p1)
     assert not torch.equal(outs_b[0][0], outs_b[1][0])
+
+
+def test_kmeans_batch_single_launch_bit_identical_to_multi_launch(dev, golden):
+    """creg_kmeans_lloyd_batch_f64 (one workgroup per frame, LDS resident, no host sync) against
+    creg_kmeans_lloyd_f64 and the sklearn golden: labels, centres, inertia, n_iter all identical."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    g = golden("kmeans_sklearn.npz")
+    Xs, inits = [_cuda(g["c1_X"], dev)], [_cuda(g["c1_init"], dev)]
+    for s in range(3):
+        seq = make_sequence("wx200_5", 40 + s, 2, 4096)
+        mats, _, _ = initial_segmentation(seq[0], 20, seed=s, iters=3)
+        Xs.append(_cuda(seq[1], dev)); inits.append(_cuda(mats[:, :3, 3].copy(), dev))
+    inits[3] = inits[3].clone(); inits[3][7] = torch.tensor([9.0, 9.0, 9.0], device=dev)        # forces an empty cluster
+    outs = ops.kmeans_lloyd_batch(Xs, inits)
+    np.testing.assert_array_equal(outs[0][1].cpu().numpy(), g["c1_labels"])
+    for X, c0, o in zip(Xs, inits, outs):
+        c, lab, inertia, n_iter = ops.kmeans_lloyd(X, c0)
+        assert torch.equal(o[1], lab) and torch.equal(o[0], c) and torch.equal(o[2], inertia) and torch.equal(o[3], n_iter)
+    small = [_cuda(g["small_X"], dev)] * 2
+    o2 = ops.kmeans_lloyd_batch(small, [_cuda(g["small_init"], dev)] * 2)
+    np.testing.assert_array_equal(o2[1][1].cpu().numpy(), g["small_labels"])
