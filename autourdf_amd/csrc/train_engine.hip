@@ -154,8 +154,9 @@ __global__ __launch_bounds__(256) void k_l1(Dims D, Ws W, int par) {
 }
 
 // rows of the K-row activation matrix staged per LDS chunk (<= 64 KB)
+constexpr int STAGE_FLOATS = 10240;   // 40 KB: K=20 rows of H=512 in one chunk, and 3 workgroups per CU
 __host__ __device__ inline int rows_per_chunk(int K, int width) {
-    int rc = 16384 / width;
+    int rc = STAGE_FLOATS / width;
     return rc < K ? rc : K;
 }
 
@@ -544,7 +545,7 @@ __device__ __forceinline__ DwRow dw_row(const Dims& D, int bkind, int row) {
 // and share ONE LDS copy of that kind's input activation matrix, fetched by LDS-DMA.  Parameter and
 // Adam-state loads of all rows, the gradient columns and the DMA are requested before the first wait.
 template <int NC>
-__global__ __launch_bounds__(DW_BLOCK, 1) void k_dw(Dims D, Ws W0, int epoch, size_t bstride) {
+__global__ __launch_bounds__(DW_BLOCK, 3) void k_dw(Dims D, Ws W0, int epoch, size_t bstride) {
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const TrainState S = W.state[(epoch + 1) & 1];
@@ -666,7 +667,7 @@ struct Plan {
 };
 
 static bool make_dims(const creg_train_shape* s, Dims* D) {
-    if (!s || (s->rot != 0 && s->rot != 1) || s->k < 1 || s->k > 256 || (s->hidden != 64 && s->hidden != 128 && s->hidden != 256 && s->hidden != 512) || s->epochs < 1 || s->n_pred < 1 || s->n_tgt < 1 || s->n_pred >= (1ll << 31) ||
+    if (!s || (s->rot != 0 && s->rot != 1) || s->k < 1 || s->k > 160 || (s->hidden != 64 && s->hidden != 128 && s->hidden != 256 && s->hidden != 512) || s->epochs < 1 || s->n_pred < 1 || s->n_tgt < 1 || s->n_pred >= (1ll << 31) ||
         s->n_tgt >= (1ll << 31))
         return false;
     memset(D, 0, sizeof(*D));
@@ -812,7 +813,7 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     P->gexec = nullptr; P->graph_ready = false;
     P->smem_l2 = (int)(sizeof(float) * rows_per_chunk(D.K, D.H) * D.H);
     P->smem_bwd2 = (int)(sizeof(float) * (BW2_ROWS * ((D.K + 3) & ~3) + 16 * D.K + 8 * BW2_ROWS));
-    P->smem_dw = (int)(sizeof(float) * (((4 * DW_RPW * D.K + 3) & ~3) + 16384 + 4));
+    P->smem_dw = (int)(sizeof(float) * (((4 * DW_RPW * D.K + 3) & ~3) + STAGE_FLOATS + 64 * 4));
     int rc_attr = 0;
     by_nc(D.H, [&](auto nc) {
         if (P->smem_dw > 65536 &&

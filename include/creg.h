@@ -170,7 +170,7 @@ int creg_masked_icp_f64(const double* local, const float* world, const int32_t* 
  */
 typedef struct creg_train_shape {
     int32_t rot;          /* 0 'q', 1 'dq' */
-    int32_t k;            /* clusters (poses), <= 256 */
+    int32_t k;            /* clusters (poses), <= 160 */
     int32_t hidden;       /* hidden_dim in {64, 128, 256, 512} (512 in the reference) */
     int32_t epochs;       /* 300 in the reference (mlp_reg.py:60) */
     int64_t n_pred;       /* sum of cluster sizes */
