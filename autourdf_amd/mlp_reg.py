@@ -45,6 +45,45 @@ def _plan(rot, k, hidden, n_pred, n_tgt, device):
     return _PLANS[key]
 
 
+def _train_compat(m, y, model, clusters, stop, learning_rate, scheduler_patience, scheduler_factor):
+    """--r rpy / --r 6d (mlp_reg.py:72-76, 86-90): the reference's loop with its MLP, representation maps
+    and Adam in PyTorch-ROCm, and the two point-cloud ops -- calculate_pc and the L1 Chamfer distance
+    with its backward -- on the HIP kernels (K3, K1).  These optional modes have no fused plan."""
+    from . import rot_repr as RR
+    pts, off = ops.pack_clusters(clusters, m.device)
+    sizes = [int(c.shape[0]) for c in clusters]
+    opt = torch.optim.Adam(model.parameters(), lr=learning_rate)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=scheduler_factor, patience=scheduler_patience)
+    min_loss, best_pred, best_m, count = 1000, None, None, 0
+    for epoch in range(EPOCHS):
+        m2 = m.clone()
+        if ROT == "rpy":
+            t, r = model(torch.cat([m2[:, :3, 3], RR.matrix_to_euler_angles(m2[:, :3, :3], "XYZ")], dim=1))
+            rot = RR.euler_angles_to_matrix(r, "XYZ")
+        else:
+            t, r = model(torch.cat([m2[:, :3, 3], RR.matrix_to_rotation_6d(m2[:, :3, :3])], dim=1))
+            rot = RR.rotation_6d_to_matrix(r)
+        m2[:, :3, :3] = rot
+        m2[:, :3, 3] = t
+        pred = ops.cluster_transform(pts, off, m2.contiguous())
+        loss, _ = ops.chamfer_distance(pred.unsqueeze(0), y.unsqueeze(0), norm=1)
+        lv = loss.item()
+        if lv < min_loss:
+            min_loss, best_pred, best_m, count = lv, pred.detach(), m2, 0
+        else:
+            count += 1
+            if count > stop:
+                print(f"Early stopping triggered after {epoch} epochs")
+                break
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sched.step(loss.detach())
+    pred_np = [p.cpu().numpy() for p in torch.split(best_pred, sizes, dim=0)]
+    print("Best Loss:", min_loss)
+    return pred_np, [PointCloud(p) for p in pred_np], best_m, min_loss
+
+
 def _model_params(model):
     if isinstance(model, QRegMLP):
         rot, order = "q", ops.Q_PARAM_ORDER
@@ -64,6 +103,8 @@ def train(m, y, model, clusters, stop=200, learning_rate=0.0002, scheduler_patie
     DQRegMLP, updated in place), clusters (list of K (M_k,3) fp32 local clouds).
     Returns (pred_pcd_np, pred_pcd, best_m, min_loss) like the reference.
     """
+    if ROT in ("rpy", "6d"):
+        return _train_compat(m, y, model, clusters, stop, learning_rate, scheduler_patience, scheduler_factor)
     rot, params, hidden = _model_params(model)
     if rot != ROT:
         raise ValueError(f"model {type(model).__name__} does not match ROT={ROT!r}")
@@ -122,8 +163,10 @@ def _make_models():
         print("Using QRegMLP")
         return QRegMLP(True, hidden_dim=512).to(DEVICE), QRegMLP(True, hidden_dim=512).to(DEVICE)
     if ROT == "rpy":
-        return RegMLP(6, 3), RegMLP(6, 3)              # raises: out of scope
-    return RRegMLP(hidden_dim=512), RRegMLP(hidden_dim=512)
+        print("Using RegMLP")
+        return RegMLP(6, 3).to(DEVICE), RegMLP(6, 3).to(DEVICE)          # the reference's call, mlp_reg.py:285
+    print("Using RRegMLP")
+    return RRegMLP(hidden_dim=512).to(DEVICE), RRegMLP(hidden_dim=512).to(DEVICE)
 
 
 def register_sequence(seg, step_matrices, step_cluster_np, save_dir=None, mlp_icp=False, models=None, loss_log=None):

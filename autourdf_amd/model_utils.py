@@ -51,16 +51,42 @@ class DQRegMLP(nn.Module):
         return self.decoder(self.encoder(_sincos(x))) + x
 
 
-class _OutOfScope(nn.Module):
-    def __init__(self, *a, **k):
+class RRegMLP(nn.Module):
+    """[t | 6-D rotation] (K,9) -> (t + dt, r6d + dr); model_utils.py:170-214 (--r 6d).  Trained by the
+    compatibility loop of mlp_reg (PyTorch MLP/Adam + HIP Chamfer and calculate_pc kernels)."""
+
+    def __init__(self, hidden_dim=512):
         super().__init__()
-        raise NotImplementedError(f"{type(self).__name__} (--r rpy / --r 6d) is outside this round's scope; "
-                                  "use --r q (default) or --r dq")
+        self.add, self.input_dim, self.output_dim_1, self.output_dim_2, self.hidden_dim = True, 9, 3, 6, hidden_dim
+        h = hidden_dim
+        self.decoder_1 = nn.Sequential(nn.Linear(h, h // 2), nn.LeakyReLU(), nn.Linear(h // 2, 3))
+        self.decoder_2 = nn.Sequential(nn.Linear(h, h), nn.LeakyReLU(), nn.Linear(h, 6))
+        self.encoder = nn.Sequential(nn.Linear(self.input_dim * 8, h), nn.LeakyReLU())
+
+    sin_encoding = staticmethod(_sincos)
+
+    def forward(self, x):
+        z = self.encoder(_sincos(x))
+        return self.decoder_1(z) + x[:, :3], self.decoder_2(z) + x[:, 3:]
 
 
-class RRegMLP(_OutOfScope):
-    """model_utils.py:170-214 (--r 6d): not implemented (parity-optional)."""
+class RegMLP(nn.Module):
+    """[t | rpy] (K,6) -> (t + dt, rpy + tanh(.)); model_utils.py:216-281 (--r rpy).  NB the reference
+    builds it as RegMLP(6, 3) (mlp_reg.py:285): multi_decoder=6 is merely truthy and hidden_dim is 3.
+    That call is reproduced as is (a latent bug that must not be fixed silently)."""
 
+    def __init__(self, multi_decoder=True, hidden_dim=512):
+        super().__init__()
+        if not multi_decoder:
+            raise NotImplementedError("single-decoder RegMLP is never constructed on the reference path")
+        self.multi_decoder, self.input_dim, self.hidden_dim, self.freq = multi_decoder, 6, hidden_dim, 4
+        h = hidden_dim
+        self.decoder_1 = nn.Sequential(nn.Linear(h, h // 2), nn.LeakyReLU(), nn.Linear(h // 2, 3))
+        self.decoder_2 = nn.Sequential(nn.Linear(h, h), nn.LeakyReLU(), nn.Linear(h, 3), nn.Tanh())
+        self.encoder = nn.Sequential(nn.Linear(self.input_dim * 8, h), nn.LeakyReLU())
 
-class RegMLP(_OutOfScope):
-    """model_utils.py:216-281 (--r rpy): not implemented (parity-optional)."""
+    sin_encoding = staticmethod(_sincos)
+
+    def forward(self, x):
+        z = self.encoder(_sincos(x))
+        return self.decoder_1(z) + x[:, :3], self.decoder_2(z) + x[:, 3:]

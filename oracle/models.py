@@ -40,3 +40,36 @@ class DQRegMLP(nn.Module):
 
     def forward(self, x):
         return self.decoder(self.encoder(sincos_features(x))) + x
+
+
+class RRegMLP(nn.Module):
+    """(K,9)=[t, 6d rotation] -> (t + dt, r6d + dr6d); model_utils.py:170-214 (--r 6d)."""
+
+    def __init__(self, hidden_dim: int = 512):
+        super().__init__()
+        h = hidden_dim
+        self.decoder_1 = nn.Sequential(nn.Linear(h, h // 2), nn.LeakyReLU(), nn.Linear(h // 2, 3))
+        self.decoder_2 = nn.Sequential(nn.Linear(h, h), nn.LeakyReLU(), nn.Linear(h, 6))
+        self.encoder = nn.Sequential(nn.Linear(72, h), nn.LeakyReLU())
+
+    def forward(self, x):
+        z = self.encoder(sincos_features(x))
+        return self.decoder_1(z) + x[:, :3], self.decoder_2(z) + x[:, 3:]
+
+
+class RegMLP(nn.Module):
+    """(K,6)=[t, rpy] -> (t + dt, rpy + tanh(.)); model_utils.py:216-281 (--r rpy).  The reference
+    constructs it as RegMLP(6, 3) (mlp_reg.py:285), i.e. multi_decoder=6 (truthy) and hidden_dim=3."""
+
+    def __init__(self, multi_decoder=True, hidden_dim: int = 512):
+        super().__init__()
+        if not multi_decoder:
+            raise NotImplementedError("single-decoder RegMLP is never constructed on the reference path")
+        h = hidden_dim
+        self.decoder_1 = nn.Sequential(nn.Linear(h, h // 2), nn.LeakyReLU(), nn.Linear(h // 2, 3))
+        self.decoder_2 = nn.Sequential(nn.Linear(h, h), nn.LeakyReLU(), nn.Linear(h, 3), nn.Tanh())
+        self.encoder = nn.Sequential(nn.Linear(48, h), nn.LeakyReLU())
+
+    def forward(self, x):
+        z = self.encoder(sincos_features(x))
+        return self.decoder_1(z) + x[:, :3], self.decoder_2(z) + x[:, 3:]

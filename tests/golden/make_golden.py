@@ -96,6 +96,16 @@ def g_models():
     d = ref_models.DQRegMLP(hidden_dim=32)
     out.update({"dq." + k: v for k, v in _small_state(d, 12).items()})
     out.update({"dq_in": x8.numpy(), "dq_out": d(x8).detach().numpy()})
+    x9 = torch.cat([M[:, :3, 3], T.matrix_to_rotation_6d(M[:, :3, :3])], 1)
+    r = ref_models.RRegMLP(hidden_dim=32)
+    out.update({"r6d." + k: v for k, v in _small_state(r, 13).items()})
+    t9, r9 = r(x9)
+    out.update({"r6d_in": x9.numpy(), "r6d_out_t": t9.detach().numpy(), "r6d_out_r": r9.detach().numpy()})
+    x6 = torch.cat([M[:, :3, 3], T.matrix_to_euler_angles(M[:, :3, :3], "XYZ")], 1)
+    e = ref_models.RegMLP(6, 3)                       # the reference's own call (mlp_reg.py:285)
+    out.update({"rpy." + k: v for k, v in _small_state(e, 14).items()})
+    t6, r6 = e(x6)
+    out.update({"rpy_in": x6.numpy(), "rpy_out_t": t6.detach().numpy(), "rpy_out_r": r6.detach().numpy()})
     save("models_reference.npz", **out)
 
 

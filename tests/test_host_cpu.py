@@ -80,6 +80,31 @@ def test_models_forward_match_reference_golden(golden):
     d = model_utils.DQRegMLP(hidden_dim=32)
     d.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("dq.")})
     np.testing.assert_allclose(d(torch.from_numpy(g["dq_in"])).detach().numpy(), g["dq_out"], atol=1e-7)
+    from oracle import models as omodels
+    for mod in (model_utils, omodels):                      # product modules and oracle restatements alike
+        r = mod.RRegMLP(hidden_dim=32)
+        r.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("r6d.")})
+        t, rr = r(torch.from_numpy(g["r6d_in"]))
+        np.testing.assert_allclose(t.detach().numpy(), g["r6d_out_t"], atol=1e-7)
+        np.testing.assert_allclose(rr.detach().numpy(), g["r6d_out_r"], atol=1e-7)
+        e = mod.RegMLP(6, 3)
+        e.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("rpy.")})
+        t, rr = e(torch.from_numpy(g["rpy_in"]))
+        np.testing.assert_allclose(t.detach().numpy(), g["rpy_out_t"], atol=1e-7)
+        np.testing.assert_allclose(rr.detach().numpy(), g["rpy_out_r"], atol=1e-7)
+
+
+def test_rotation_maps_match_oracle_conventions():
+    import torch
+    from scipy.spatial.transform import Rotation
+    from autourdf_amd import rot_repr as RR
+    from oracle import transforms as T
+    R = torch.from_numpy(Rotation.random(50, random_state=2).as_matrix())
+    for a, b in ((RR.matrix_to_euler_angles(R, "XYZ"), T.matrix_to_euler_angles(R, "XYZ")),
+                 (RR.matrix_to_rotation_6d(R), T.matrix_to_rotation_6d(R))):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), atol=1e-14)
+    np.testing.assert_allclose(RR.euler_angles_to_matrix(RR.matrix_to_euler_angles(R)).numpy(), R.numpy(), atol=1e-12)
+    np.testing.assert_allclose(RR.rotation_6d_to_matrix(RR.matrix_to_rotation_6d(R)).numpy(), R.numpy(), atol=1e-12)
 
 
 def test_npz_roundtrip_keeps_order_and_dtype(tmp_path):
