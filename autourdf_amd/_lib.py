@@ -54,7 +54,7 @@ SIGNATURES = {
     "creg_matrix_to_quat_f32": (ctypes.c_int, [vp, i32, vp, vp]),
     "creg_quat_to_matrix_f32": (ctypes.c_int, [vp, i32, vp, vp]),
     "creg_icp_workspace_bytes": (sz, [i64, i64, i32]),
-    "creg_masked_icp_f64": (ctypes.c_int, [vp, vp, vp, i32, vp, i64, vp, f64, f64, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "creg_masked_icp_f64": (ctypes.c_int, [vp, vp, i64, vp, i32, vp, i64, vp, f64, f64, i32, i32, vp, vp, vp, vp, sz, vp]),
     "creg_train_workspace_bytes": (sz, [ctypes.POINTER(TrainShape)]),
     "creg_train_plan_create": (ctypes.c_int, [ctypes.POINTER(TrainShape), vp, sz, ctypes.POINTER(vp)]),
     "creg_train_plan_run": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), vp]),

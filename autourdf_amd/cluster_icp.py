@@ -181,7 +181,7 @@ def masked_icp(clusters_local, clusters_world, step_pc_np, matrices, visual=Fals
     w_out = torch.empty(n, 3, dtype=torch.float64, device=dev)
     n_it = torch.empty(k, dtype=torch.int32, device=dev)
     p = ops._p
-    _lib.check(L.creg_masked_icp_f64(p(local), p(world), p(off), k, p(frame), nf, p(M), float(scale), float(th),
+    _lib.check(L.creg_masked_icp_f64(p(local), p(world), n, p(off), k, p(frame), nf, p(M), float(scale), float(th),
                                      int(max_iteration), int(bool(ori)), p(M_out), p(w_out), p(n_it), p(ws), ws_bytes,
                                      ops._stream()), "creg_masked_icp_f64")
     off_h = off.cpu().numpy()

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void k_masked_icp(
     const double* __restrict__ local, const float* __restrict__ world, const int* __restrict__ off,
     const double* __restrict__ frame, int nf, const double* __restrict__ Min, float half_scale, double th,
     int max_iter, int keep_t, double* __restrict__ Mout, double* __restrict__ world_out,
-    int* __restrict__ n_iter_out, double* __restrict__ srcw, int* __restrict__ tidx_all, int* __restrict__ nn) {
+    int* __restrict__ n_iter_out, double* __restrict__ srcw, int* __restrict__ tidx_all, int* __restrict__ nn,
+    int lds_cap) {
     __shared__ double sc[4];
     __shared__ float s_lo[3], s_hi[3];
     __shared__ int s_cnt, s_wofs[4];
@@ -114,6 +115,19 @@ __global__ __launch_bounds__(256) void k_masked_icp(
         __syncthreads();
     }
     const int nt = s_cnt;
+    // masked target coordinates into LDS (all threads sweep the same target at the same time, so the
+    // nearest-neighbour loop below becomes broadcast LDS reads instead of dependent global gathers)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sT = (double*)smem;                       // [lds_cap][3]
+    int* sI = (int*)(sT + 3 * (size_t)lds_cap);       // [lds_cap]
+    const bool in_lds = nt <= lds_cap;
+    if (in_lds)
+        for (int t = tid; t < nt; t += 256) {
+            const int j = tidx[t];
+            sT[3 * t] = frame[3 * (size_t)j]; sT[3 * t + 1] = frame[3 * (size_t)j + 1]; sT[3 * t + 2] = frame[3 * (size_t)j + 2];
+            sI[t] = j;
+        }
+    __syncthreads();
 
     // ---- 2. ICP ----
     if (tid < 16) T[tid] = Min[16 * k + tid];
@@ -131,12 +145,23 @@ __global__ __launch_bounds__(256) void k_masked_icp(
         double cnt = 0, err = 0;
         for (int i = tid; i < ns; i += 256) {
             const double* s = srcw + 3 * (size_t)(b + i);
+            const double s0 = s[0], s1 = s[1], s2 = s[2];
             double best = INFINITY; int bj = -1;
-            for (int t = 0; t < nt; ++t) {
-                const int j = tidx[t];
-                const double dx = s[0] - frame[3 * (size_t)j], dy = s[1] - frame[3 * (size_t)j + 1], dz = s[2] - frame[3 * (size_t)j + 2];
-                const double d2 = (dx * dx + dy * dy) + dz * dz;
-                if (d2 < best) { best = d2; bj = j; }
+            if (in_lds) {
+                int bt = -1;
+                for (int t = 0; t < nt; ++t) {
+                    const double dx = s0 - sT[3 * t], dy = s1 - sT[3 * t + 1], dz = s2 - sT[3 * t + 2];
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (d2 < best) { best = d2; bt = t; }
+                }
+                if (bt >= 0) bj = sI[bt];
+            } else {
+                for (int t = 0; t < nt; ++t) {
+                    const int j = tidx[t];
+                    const double dx = s0 - frame[3 * (size_t)j], dy = s1 - frame[3 * (size_t)j + 1], dz = s2 - frame[3 * (size_t)j + 2];
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (d2 < best) { best = d2; bj = j; }
+                }
             }
             if (bj >= 0 && best <= th2) { nn[b + i] = bj; cnt += 1.0; err += best; } else nn[b + i] = -1;
         }
@@ -222,26 +247,28 @@ extern "C" size_t creg_icp_workspace_bytes(int64_t n, int64_t nf, int32_t k) {
     return icp_layout(n, nf, k).total;
 }
 
-extern "C" int creg_masked_icp_f64(const double* local, const float* world, const int32_t* seg_offsets, int32_t k,
+extern "C" int creg_masked_icp_f64(const double* local, const float* world, int64_t n, const int32_t* seg_offsets, int32_t k,
                                    const double* frame, int64_t nf, const double* M, double scale, double th,
                                    int32_t max_iteration, int32_t keep_translation, double* M_out, double* world_out,
                                    int32_t* n_iter_out, void* workspace, size_t workspace_bytes, creg_stream_t stream) {
     CREG_REQUIRE(local && world && seg_offsets && frame && M && M_out && world_out && n_iter_out && workspace,
                  "creg_masked_icp_f64: null pointer");
     CREG_REQUIRE(k >= 1 && nf >= 1 && nf < (1ll << 31) && max_iteration >= 1, "creg_masked_icp_f64: bad size");
-    // n is only known on the device (seg_offsets[k]); the workspace bound uses the caller's n via
-    // creg_icp_workspace_bytes, so trust workspace_bytes >= layout(n_min = 1).
-    int n = 0;
+    CREG_REQUIRE(n >= 1 && n < (1ll << 31), "creg_masked_icp_f64: no source points");
     hipStream_t s = (hipStream_t)stream;
-    CREG_HIP(hipMemcpyAsync(&n, seg_offsets + k, sizeof(int), hipMemcpyDeviceToHost, s));
-    CREG_HIP(hipStreamSynchronize(s));
-    CREG_REQUIRE(n >= 1, "creg_masked_icp_f64: no source points");
     const IcpLayout L = icp_layout(n, nf, k);
     CREG_REQUIRE(workspace_bytes >= L.total, "creg_masked_icp_f64: workspace too small (%zu < %zu)", workspace_bytes, L.total);
     char* w = (char*)workspace;
-    hipLaunchKernelGGL(k_masked_icp, dim3(k), dim3(256), 0, s, local, world, seg_offsets, frame, (int)nf, M,
+    const int lds_cap = (int)(nf < 4096 ? nf : 4096);             // masked targets kept in LDS (28 B each, <= 112 KB)
+    const int smem = lds_cap * 28;
+    static bool attr_set = false;
+    if (!attr_set) {
+        CREG_HIP(hipFuncSetAttribute((const void*)k_masked_icp, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 28));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_masked_icp, dim3(k), dim3(256), smem, s, local, world, seg_offsets, frame, (int)nf, M,
                        (float)(0.5 * scale), th, max_iteration, keep_translation, M_out, world_out, n_iter_out,
-                       (double*)(w + L.srcw), (int*)(w + L.tidx), (int*)(w + L.nn));
+                       (double*)(w + L.srcw), (int*)(w + L.tidx), (int*)(w + L.nn), lds_cap);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }

@@ -50,7 +50,7 @@ struct TrainState {
 
 struct Ws {         // device pointers into the caller's workspace
     float *P, *AM, *AV;
-    float *pose_in, *enc, *x1[2], *h2, *head_save, *m_in, *m2, *gm2;
+    float *pose_in, *enc, *x1[2], *h2, *head_save, *m2, *gm2;
     float4 *pts4, *y4, *pred4;
     int* sgn_x;
     int4* cnt4;
@@ -81,13 +81,6 @@ __device__ __forceinline__ int seg_of(const int* __restrict__ off, int k, int n)
     return lo;
 }
 
-// sum_i w[i] * a[i], i < n, lanes strided, fixed order (per-lane ascending chunks, then butterfly)
-__device__ __forceinline__ float wave_dot(const float* __restrict__ w, const float* __restrict__ a, int n, int lane) {
-    float s = 0.f;
-    for (int i = lane; i < n; i += 64) s = fmaf(w[i], a[i], s);
-    return wave_sum(s);
-}
-
 // ------------------------------------------------------------------------------------------ prep
 __global__ __launch_bounds__(256) void k_prep(Dims D, Ws W, Hyper hy, const float* __restrict__ m,
                                               const float* __restrict__ y, const float* __restrict__ pts) {
@@ -104,7 +97,6 @@ __global__ __launch_bounds__(256) void k_prep(Dims D, Ws W, Hyper hy, const floa
     if (blockIdx.x == 0) {
         for (int r = threadIdx.x; r < D.K; r += 256) {
             const float* M = m + 16 * r;
-            for (int i = 0; i < 16; ++i) W.m_in[16 * r + i] = M[i];
             const float R[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
             const float tr[3] = {M[3], M[7], M[11]};
             float in[8];
@@ -697,7 +689,7 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     w.pose_in = (float*)take(f * 8 * D.K); w.enc = (float*)take(f * D.K * D.IN);
     w.x1[0] = (float*)take(f * D.K * D.H); w.x1[1] = (float*)take(f * D.K * D.H);
     w.h2 = (float*)take(f * D.K * D.H2); w.head_save = (float*)take(f * 16 * D.K);
-    w.m_in = (float*)take(f * 16 * D.K); w.m2 = (float*)take(f * 16 * D.K); w.gm2 = (float*)take(f * 16 * D.K);
+    w.m2 = (float*)take(f * 16 * D.K); w.gm2 = (float*)take(f * 16 * D.K);
     w.pts4 = (float4*)take(sizeof(float4) * D.NP); w.y4 = (float4*)take(sizeof(float4) * D.NT);
     w.pred4 = (float4*)take(sizeof(float4) * D.NP);
     w.sgn_x = (int*)take(sizeof(int) * D.NP);

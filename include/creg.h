@@ -145,11 +145,11 @@ int creg_quat_to_matrix_f32(const float* q, int32_t k, float* R, creg_stream_t s
  * including open3d registration_icp (TransformationEstimationPointToPoint, max_iteration,
  * relative_fitness = relative_rmse = 1e-6).
  * local (n,3) fp64 clusters back to back, world (n,3) fp32 predicted clusters (AABB source),
- * frame (nf,3) fp64 target, M (k,4,4) fp64 initial poses.  M_out (k,4,4) fp64,
+ * frame (nf,3) fp64 target, M (k,4,4) fp64 initial poses, n = seg_offsets[k] points in total.  M_out (k,4,4) fp64,
  * world_out (n,3) fp64 = M_out applied to local.  keep_translation mirrors `ori`.
  * workspace: creg_icp_workspace_bytes(n, nf, k). */
 size_t creg_icp_workspace_bytes(int64_t n, int64_t nf, int32_t k);
-int creg_masked_icp_f64(const double* local, const float* world, const int32_t* seg_offsets,
+int creg_masked_icp_f64(const double* local, const float* world, int64_t n, const int32_t* seg_offsets,
                         int32_t k, const double* frame, int64_t nf, const double* M,
                         double scale, double th, int32_t max_iteration, int32_t keep_translation,
                         double* M_out, double* world_out, int32_t* n_iter_out,
