@@ -85,34 +85,37 @@ def main():
     from autourdf_amd.synthetic import initial_segmentation, make_sequence
 
     # ---- synthetic inputs, resident in HBM before the clock starts -------------------------------
-    # configs[1]: 5 independent sequences x 10 frames per GPU.  Frames of ONE sequence are sequentially
-    # dependent (mlp_reg.py:293-378) but sequences are independent, so each sequence gets its own
-    # host thread + HIP stream + train plan and their latency-bound kernels overlap on the GPU.
-    total = args.warmup + args.steps
-    per_seq = FRAMES_PER_SEQ - 1
-    n_seq = max(1, args.sequences)
-    if args.warmup % n_seq or args.steps % n_seq or total > n_seq * per_seq:
-        raise SystemExit(f"--steps and --warmup must be multiples of --sequences ({n_seq}) and "
-                         f"steps + warmup <= {n_seq * per_seq} (each sequence has {per_seq} frames to register)")
-    seq0 = make_sequence(ROBOT, 0, FRAMES_PER_SEQ, N_POINTS)
+    # configs[1]: 5 independent sequences per GPU (10 frames each in the reference's data set).  Frames of
+    # ONE sequence are sequentially dependent (mlp_reg.py:293-378) but sequences are independent, so the S
+    # sequences advance in lock-step through ONE batched plan: every launch carries S problems.
+    # Step i of a rank is frame (i // S) + 1 of its sequence i % S.  Any --steps K / --warmup W works:
+    # S is 5 when it divides K, else K itself (K <= 16), else the largest divisor of K in [2, 8], else 5 with the last round
+    # padded (the padding is timed but not counted, so the reported value can only be understated);
+    # sequences are generated as long as W and K require.
+    S = max(1, args.sequences)
+    if args.steps % S:
+        divs = [d for d in range(8, 1, -1) if args.steps % d == 0]
+        S = args.steps if args.steps <= 16 else (divs[0] if divs else S)
+    n_seq = S
+    warm_rounds = (args.warmup + S - 1) // S
+    timed_rounds = (args.steps + S - 1) // S
+    n_frames = warm_rounds + timed_rounds + 1
+    seq0 = make_sequence(ROBOT, 0, max(n_frames, FRAMES_PER_SEQ), N_POINTS)
     mats0, clusters0, _ = initial_segmentation(seq0[0], K_CLUSTERS, seed=0)      # shared frame-0 state (mlp_reg.py:242-253)
-    seqs = [make_sequence(ROBOT, rank * 1000 + s, FRAMES_PER_SEQ, N_POINTS) for s in range(n_seq)]
-    frames64 = [[torch.as_tensor(f, dtype=torch.float64, device=dev) for f in s[1:]] for s in seqs]
+    seqs = [make_sequence(ROBOT, rank * 1000 + s, max(n_frames, FRAMES_PER_SEQ), N_POINTS) for s in range(S)]
+    frames64 = [[torch.as_tensor(f, dtype=torch.float64, device=dev) for f in s[1:n_frames]] for s in seqs]
     frames32 = [[f.to(torch.float32) for f in s] for s in frames64]
-    # the S sequences advance in lock-step through ONE batched plan: every launch carries S problems
-    reg = BatchRegistrar(mats0, clusters0, N_POINTS, n_seq, "q", HIDDEN, EPOCHS, not args.eager, dev,
-                         seeds=[rank * 1000 + s for s in range(n_seq)])
-    poses = torch.zeros(total, K_CLUSTERS, 4, 4, dtype=torch.float32, device=dev)
-    losses = torch.zeros(total, dtype=torch.float32, device=dev)
+    reg = BatchRegistrar(mats0, clusters0, N_POINTS, S, "q", HIDDEN, EPOCHS, not args.eager, dev,
+                         seeds=[rank * 1000 + s for s in range(S)])
+    poses = torch.zeros((warm_rounds + timed_rounds) * S, K_CLUSTERS, 4, 4, dtype=torch.float32, device=dev)
+    losses = torch.zeros((warm_rounds + timed_rounds) * S, dtype=torch.float32, device=dev)
 
-    # global step i -> sequence i % n_seq, frame i // n_seq of that sequence (in order inside a sequence)
-    def run_steps(lo, hi):
-        assert lo % n_seq == 0 and hi % n_seq == 0, "steps and warmup must be multiples of --sequences"
-        for f in range(lo // n_seq, hi // n_seq):
-            out = reg.step([frames64[s][f] for s in range(n_seq)], [frames32[s][f] for s in range(n_seq)])
+    def run_rounds(lo, hi):
+        for f in range(lo, hi):
+            out = reg.step([frames64[s][f] for s in range(S)], [frames32[s][f] for s in range(S)])
             for s, (m, res) in enumerate(out):
-                poses[f * n_seq + s].copy_(m)
-                losses[f * n_seq + s].copy_(res[0])
+                poses[f * S + s].copy_(m)
+                losses[f * S + s].copy_(res[0])
 
     def fence():
         torch.cuda.synchronize()
@@ -121,11 +124,12 @@ def main():
             torch.cuda.synchronize()
 
     torch.cuda.synchronize()
-    run_steps(0, args.warmup)
+    run_rounds(0, warm_rounds)
     fence()
     t0 = time.perf_counter()
-    run_steps(args.warmup, total)
-    gathered = gather_poses(poses[args.warmup:])       # the one exchange of the job (RCCL all_gather; no-op at N=1)
+    run_rounds(warm_rounds, warm_rounds + timed_rounds)
+    timed = poses[warm_rounds * S: warm_rounds * S + args.steps]
+    gathered = gather_poses(timed)                     # the one exchange of the job (RCCL all_gather; no-op at N=1)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -164,7 +168,7 @@ def main():
                                       "1 step = 1 registered frame = 2 x 300 Adam epochs (QRegMLP hidden 512, L1 Chamfer) "
                                       "+ Lloyd k-means resample", "n_points": N_POINTS, "k_clusters": K_CLUSTERS,
                           "epochs_per_frame": 2 * EPOCHS, "launch": "eager" if args.eager else "hipGraph",
-                          "sequences_in_flight_per_gpu": n_seq,
+                          "sequences_in_flight_per_gpu": n_seq, "padded_steps_timed_not_counted": timed_rounds * S - args.steps,
                           "sharding": "sequences per rank, final all_gather of poses" if world > 1 else "single GPU"},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
