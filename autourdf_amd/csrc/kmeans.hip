@@ -129,6 +129,8 @@ __global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict
     int lab[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { best[r] = INFINITY; lab[r] = 0x7fffffff; }
+    // each lane keeps the running first minimum of ITS centre column (j = col, col+16, ...) for its 4
+    // points; one 16-lane lexicographic (value, index) reduction at the end finishes the argmin
     for (int j0 = 0; j0 < k; j0 += 16) {
         const int j = j0 + col;
         const bool ok = j < k;
@@ -138,17 +140,23 @@ __global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict
         c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            double v = c[r];
-            int idx = ok ? j : 0x7fffffff;
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) {      // first-min across the 16 centres of the tile
-                const double ov = __shfl_xor(v, off, 64);
-                const int oi = __shfl_xor(idx, off, 64);
-                const bool take = (ov < v) || (ov == v && oi < idx);
-                v = take ? ov : v; idx = take ? oi : idx;
-            }
-            if (v < best[r]) { best[r] = v; lab[r] = idx; }     // tiles ascend: strict < keeps the first
+            const bool lt = c[r] < best[r];                     // tiles ascend: strict < keeps the first
+            best[r] = lt ? c[r] : best[r];
+            lab[r] = lt ? j : lab[r];
         }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double v = best[r];
+        int idx = lab[r];
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(v, off, 64);
+            const int oi = __shfl_xor(idx, off, 64);
+            const bool take = (ov < v) || (ov == v && oi < idx);
+            v = take ? ov : v; idx = take ? oi : idx;
+        }
+        lab[r] = idx;
     }
     int diff = 0;
     if (col == 0) {
