@@ -314,8 +314,8 @@ __global__ __launch_bounds__(1024) void k_km_finish(const double* __restrict__ X
 }
 
 // ---- one-launch Lloyd for small clouds, one workgroup per problem ----------------------------------
-// For n * 24 B <= 128 KB (n <= 5461: the 4096 / 5000-point frames of the reference) the centred frame
-// fits one CU's LDS, so a whole k_means() -- mean/tol, centring, up to max_iter Lloyd iterations with
+// For n <= 5120 (the 4096 / 5000-point frames of the reference) the centred frame (24 B/pt) and two
+// 16-bit label arrays fit one CU's LDS, so a whole k_means() -- mean/tol, centring, up to max_iter Lloyd iterations with
 // the strict-convergence / tol test, final E-step, inertia -- runs as ONE workgroup with no host
 // involvement, and B independent problems (the sequences of a batch) are B workgroups of one launch.
 // Every sum is formed in exactly the order of the multi-launch path above (k_km_stats: 1024 strided
@@ -339,10 +339,13 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
     __shared__ int s_fi[16];
     const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double* X = A.X[z];
-    char* w = ws + (size_t)z * ws_stride;                     // per-problem scratch: C2 (6k), B (4k), Cw (4k), far (n), lab2 (n ints)
-    double* C2 = (double*)w; double* Bm = C2 + 6 * k; double* Cw = Bm + 4 * k; double* far_d = Cw + 4 * k;
-    int* lab2 = (int*)(far_d + n);
-    int* lab[2] = {A.labels[z], lab2};
+    char* w = ws + (size_t)z * ws_stride;                     // per-problem global scratch: C2 (6k), Cw (4k), far (n)
+    double* C2 = (double*)w; double* Cw = C2 + 10 * k; double* far_d = Cw + 4 * k;
+    // LDS: Xc [3n] | (-2c, |c|^2) rows [4k] | labels ping-pong as 16-bit values [2n] (k <= 128 here).  The
+    // E-step reads every centre row and the accumulation sweeps read every label ceil(k/4) times per
+    // iteration; from global memory each of those reads was a dependent round trip.
+    double* Bm = Xc + 3 * (size_t)n;
+    unsigned short* lab[2] = {(unsigned short*)(Bm + 4 * k), (unsigned short*)(Bm + 4 * k) + n};
     // ---- mean / tol (k_km_stats) ----
     double var = 0;
     for (int d = 0; d < 3; ++d) {
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
     if (tid == 0) { s_tol = (var / 3.0) * tol_rel; s_done = 0; s_strict = 0; s_it = 0; s_changed = 0; }
     // ---- centre (k_km_center) ----
     for (int i = tid; i < 3 * n; i += 1024) Xc[i] = X[i] - s_mean[i % 3];
-    for (int i = tid; i < n; i += 1024) lab2[i] = -1;         // iteration 0 compares against lab[1] = -1
+    for (int i = tid; i < n; i += 1024) lab[1][i] = 0xFFFF;    // iteration 0 compares against lab[1] = "no label"
     if (tid < k) {
         double c[3];
         for (int d = 0; d < 3; ++d) { c[d] = A.init[z][3 * tid + d] - s_mean[d]; C2[3 * tid + d] = c[d]; }
@@ -371,8 +374,8 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
     __syncthreads();
     int cur = 0;                                             // centre buffer holding the current centres
     for (int it = 0; it < max_iter; ++it) {
-        int* lcur = lab[it & 1];
-        const int* lprev = lab[(it + 1) & 1];
+        unsigned short* lcur = lab[it & 1];
+        const unsigned short* lprev = lab[(it + 1) & 1];
         // ---- E-step (k_km_assign) ----
         int diff = 0;
         for (int i = tid; i < n; i += 1024) {
@@ -383,8 +386,8 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
                 const double d = fma(x2, Bm[4 * j + 2], fma(x1, Bm[4 * j + 1], fma(x0, Bm[4 * j], Bm[4 * j + 3])));
                 if (d < best) { best = d; lb = j; }
             }
-            lcur[i] = lb;
-            diff += (lprev[i] != lb);
+            lcur[i] = (unsigned short)lb;
+            diff += ((int)lprev[i] != lb);
         }
         if (diff) atomicAdd(&s_changed, diff);
         __threadfence_block();
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
             double a0 = 0, a1 = 0, a2 = 0, aw = 0;
             if (j < k)
                 for (int i = tg; i < n; i += 256)
-                    if (lcur[i] == j) { a0 += Xc[3 * i]; a1 += Xc[3 * i + 1]; a2 += Xc[3 * i + 2]; aw += 1.0; }
+                    if ((int)lcur[i] == j) { a0 += Xc[3 * i]; a1 += Xc[3 * i + 1]; a2 += Xc[3 * i + 2]; aw += 1.0; }
             a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); aw = wave_sum(aw);
             if (lane == 0) { gpart[g][wg][0] = a0; gpart[g][wg][1] = a1; gpart[g][wg][2] = a2; gpart[g][wg][3] = aw; }
             __syncthreads();
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
         if (s_done) break;
     }
     // ---- final E-step when not strictly converged, labels into the caller's buffer ----
-    int* last = lab[(s_it - 1) & 1];
+    unsigned short* last = lab[(s_it - 1) & 1];
     if (!s_strict) {
         for (int i = tid; i < n; i += 1024) {
             const double x0 = Xc[3 * i], x1 = Xc[3 * i + 1], x2 = Xc[3 * i + 2];
@@ -495,12 +498,12 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
                 const double d = fma(x2, Bm[4 * j + 2], fma(x1, Bm[4 * j + 1], fma(x0, Bm[4 * j], Bm[4 * j + 3])));
                 if (d < best) { best = d; lb = j; }
             }
-            last[i] = lb;
+            last[i] = (unsigned short)lb;
         }
         __threadfence_block();
         __syncthreads();
     }
-    if (last != A.labels[z]) for (int i = tid; i < n; i += 1024) A.labels[z][i] = last[i];
+    for (int i = tid; i < n; i += 1024) A.labels[z][i] = (int)last[i];
     // ---- inertia, un-centred centres (k_km_finish) ----
     const double* C = C2 + (size_t)cur * 3 * k;
     double s = 0;
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
     for (int j = tid; j < 3 * k; j += 1024) A.centers[z][j] = C[j] + s_mean[j % 3];
 }
 
-static size_t kms_stride(int64_t n, int k) { return align_up(sizeof(double) * (14 * (size_t)k + n) + sizeof(int) * n, 256); }
+static size_t kms_stride(int64_t n, int k) { return align_up(sizeof(double) * (14 * (size_t)k + n), 256); }
 
 __global__ __launch_bounds__(256) void k_make_b(const double* __restrict__ C, int k, double* __restrict__ B) {
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -700,18 +703,18 @@ extern "C" int creg_kmeans_lloyd_batch_f64(const double* const* X, int64_t n, co
                                            void* workspace, size_t workspace_bytes, creg_stream_t stream) {
     CREG_REQUIRE(X && init && centers && labels && inertia && n_iter && workspace, "creg_kmeans_lloyd_batch_f64: null pointer");
     CREG_REQUIRE(batch >= 1 && batch <= KMS_MAXB, "creg_kmeans_lloyd_batch_f64: batch must be in [1, %d]", KMS_MAXB);
-    CREG_REQUIRE(n >= 1 && (size_t)n * 24 <= 131072 && k >= 1 && k <= 1024 && max_iter >= 1,
-                 "creg_kmeans_lloyd_batch_f64: needs n <= 5461 (frame resident in LDS), 1 <= k <= 1024; use creg_kmeans_lloyd_f64 otherwise");
+    CREG_REQUIRE(n >= 1 && n <= 5120 && k >= 1 && k <= 128 && max_iter >= 1,
+                 "creg_kmeans_lloyd_batch_f64: needs n <= 5120 and k <= 128 (frame, centres and labels resident in LDS); use creg_kmeans_lloyd_f64 otherwise");
     CREG_REQUIRE(workspace_bytes >= kms_stride(n, k) * (size_t)batch, "creg_kmeans_lloyd_batch_f64: workspace too small");
     KmBatch A;
     for (int b = 0; b < batch; ++b) {
         CREG_REQUIRE(X[b] && init[b] && centers[b] && labels[b] && inertia[b] && n_iter[b], "creg_kmeans_lloyd_batch_f64: null pointer in problem %d", b);
         A.X[b] = X[b]; A.init[b] = init[b]; A.centers[b] = centers[b]; A.labels[b] = labels[b]; A.inertia[b] = inertia[b]; A.n_iter[b] = n_iter[b];
     }
-    const int smem = (int)(sizeof(double) * 3 * n);
+    const int smem = (int)(sizeof(double) * (3 * n + 4 * k) + 2 * sizeof(unsigned short) * n);
     static bool attr_set = false;
     if (!attr_set) {
-        CREG_HIP(hipFuncSetAttribute((const void*)k_km_small, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        CREG_HIP(hipFuncSetAttribute((const void*)k_km_small, hipFuncAttributeMaxDynamicSharedMemorySize, 5120 * 28 + 128 * 32));
         attr_set = true;
     }
     hipLaunchKernelGGL(k_km_small, dim3(batch), dim3(1024), smem, (hipStream_t)stream, A, (int)n, k, max_iter, tol_rel,

@@ -73,7 +73,7 @@ class BatchRegistrar:
         out = []
         M64s = [o[0].to(torch.float64) for o in anchor]
         inits = [M[:, :3, 3].contiguous() for M in M64s]
-        if frames64[0].shape[0] <= ops.KMEANS_BATCH_MAX_N and self.S <= 16:      # all S re-segmentations in one launch
+        if frames64[0].shape[0] <= ops.KMEANS_BATCH_MAX_N and self.S <= 16 and len(self.seqs[0].off) - 1 <= 128:      # all S re-segmentations in one launch
             km = ops.kmeans_lloyd_batch(frames64, inits)
         else:
             km = [ops.kmeans_lloyd(f, c) for f, c in zip(frames64, inits)]
