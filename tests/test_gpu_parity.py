@@ -420,3 +420,42 @@ def test_kmeans_batch_single_launch_bit_identical_to_multi_launch(dev, golden):
     small = [_cuda(g["small_X"], dev)] * 2
     o2 = ops.kmeans_lloyd_batch(small, [_cuda(g["small_init"], dev)] * 2)
     np.testing.assert_array_equal(o2[1][1].cpu().numpy(), g["small_labels"])
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_c5_nn_and_kmeans_properties(dev):
+    """BASELINE configs[4] sizes (N=262144, K=128): too big for the CPU oracle end to end, so
+    size-independent properties + an exact spot check of 512 queries against the oracle."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import make_sequence
+    from oracle import chamfer, kmeans
+    n, k = 262144, 128
+    fr = make_sequence("chain32", 0, 2, n)
+    x, y = fr[0].astype(np.float32), fr[1].astype(np.float32)
+    xd, yd = _cuda(x, dev), _cuda(y, dev)
+    dx, ix, dy, iy = ops.nn_l1_bidir(xd, yd)
+    # (1) role swap gives the same answer, (2) every reported distance is the distance to the reported index
+    dy2, iy2, dx2, ix2 = ops.nn_l1_bidir(yd, xd)
+    assert torch.equal(ix, ix2) and torch.equal(dx, dx2) and torch.equal(iy, iy2) and torch.equal(dy, dy2)
+    d_chk = (xd - yd[ix]).abs()
+    assert torch.equal((d_chk[:, 0] + d_chk[:, 1]) + d_chk[:, 2], dx)
+    # (3) exact spot check: 512 random queries brute-forced by the oracle over all 262144 targets
+    sel = np.random.default_rng(0).choice(n, 512, replace=False)
+    od, oi = chamfer.nn_l1(x[sel], y)
+    np.testing.assert_array_equal(ix.cpu().numpy()[sel], oi)
+    np.testing.assert_array_equal(dx.cpu().numpy()[sel], od)
+    # k-means: returned labels are the E-step of the returned centres (sklearn's final E-step), the MFMA
+    # E-step agrees with the VALU one, and restarting from the solution stops at once (tol) without
+    # increasing the inertia
+    X = _cuda(fr[1], dev)
+    init = X[torch.as_tensor(np.random.default_rng(1).choice(n, k, replace=False), device=dev)].clone()
+    c, lab, inertia, n_iter = ops.kmeans_lloyd(X, init, max_iter=300)
+    assert torch.equal(ops.kmeans_assign(X, c), lab) and torch.equal(ops.kmeans_assign(X, c, use_mfma=True), lab)
+    assert len(torch.unique(lab)) == k
+    sel = np.random.default_rng(2).choice(n, 4096, replace=False)
+    np.testing.assert_array_equal(kmeans.assign(fr[1][sel], c.cpu().numpy()), lab.cpu().numpy()[sel])
+    c2, lab2, inertia2, n_iter2 = ops.kmeans_lloyd(X, c, max_iter=300)
+    assert n_iter2.item() <= 2 and inertia2.item() <= inertia.item() * (1 + 1e-12)
+    assert torch.equal(ops.kmeans_assign(X, c2), lab2)
+    local, off = ops.group_to_local(X, lab, torch.eye(4, dtype=torch.float64, device=dev).repeat(k, 1, 1).contiguous())
+    assert off[-1].item() == n and torch.equal(torch.sort(local[:, 0])[0], torch.sort(X[:, 0])[0])     # a permutation
