@@ -169,9 +169,14 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_l2(Dims D, Ws W0, int par, size_t
     const int rc = rows_per_chunk(D.K, H);
     const float* x1cur = par ? W.x1[1] : W.x1[0];     // (a runtime index into the shifted struct would go to scratch)
     stage_issue<MLP_BLOCK>((float4*)xs, (const float4*)x1cur, min(rc, D.K) * H / 4);
-    float wr[NC];
+    // a lane owns 4 consecutive inputs per 256-wide slab: one global_load_dwordx4 / ds_read_b128 each
+    constexpr int NV = (NC + 3) / 4;
+    float4 wr[NV];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) wr[c] = W.P[D.oW2 + (size_t)o * H + c * 64 + lane];
+    for (int v = 0; v < NV; ++v) {
+        const int i = v * 256 + lane * 4;
+        wr[v] = i < H ? *(const float4*)(W.P + D.oW2 + (size_t)o * H + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const float b = W.P[D.ob2 + o];
     for (int r0 = 0; r0 < D.K; r0 += rc) {
         const int nr = min(rc, D.K - r0);
@@ -183,10 +188,13 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_l2(Dims D, Ws W0, int par, size_t
         __syncthreads();
 #pragma unroll 4
         for (int r = 0; r < nr; ++r) {
-            const float* a = xs + r * H + lane;
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) s = fmaf(wr[c], a[c * 64], s);
+            for (int v = 0; v < NV; ++v) {
+                const int i = min(v * 256 + lane * 4, H - 4);
+                const float4 a = *(const float4*)(xs + r * H + i);
+                s = fmaf(wr[v].x, a.x, s); s = fmaf(wr[v].y, a.y, s); s = fmaf(wr[v].z, a.z, s); s = fmaf(wr[v].w, a.w, s);
+            }
             s = wave_sum_fast(s) + b;
             if (lane == 0) W.h2[(size_t)(r0 + r) * D.H2 + o] = act_f(s, D.slope);
         }
@@ -557,15 +565,20 @@ __global__ __launch_bounds__(DW_BLOCK, 3) void k_dw(Dims D, Ws W0, int epoch, si
     const int awidth = bkind == 0 ? D.H : (bkind == 1 ? D.H2 : D.IN);
     const int rc = rows_per_chunk(D.K, awidth);
     stage_issue<DW_BLOCK>((float4*)as, (const float4*)amat, min(rc, D.K) * awidth / 4);
+    // a lane owns 4 consecutive inputs per 256-wide slab: parameters / Adam state move as dwordx4, the
+    // staged activations are read as ds_read_b128
+    constexpr int NV = (NC + 3) / 4;
     DwRow R[DW_RPW];
-    float pw[DW_RPW][NC], pm[DW_RPW][NC], pv[DW_RPW][NC], acc[DW_RPW][NC], pb[DW_RPW], mb[DW_RPW], vb[DW_RPW];
+    float4 pw[DW_RPW][NV], pm[DW_RPW][NV], pv[DW_RPW][NV], acc[DW_RPW][NV];
+    float pb[DW_RPW], mb[DW_RPW], vb[DW_RPW];
 #pragma unroll
     for (int q = 0; q < DW_RPW; ++q) {
         R[q] = dw_row(D, bkind, row0 + q);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int i = min(c * 64 + lane, R[q].n_in - 1);
-            pw[q][c] = W.P[R[q].oW + i]; pm[q][c] = W.AM[R[q].oW + i]; pv[q][c] = W.AV[R[q].oW + i]; acc[q][c] = 0.f;
+        for (int v = 0; v < NV; ++v) {
+            const int i = min(v * 256 + lane * 4, R[q].n_in - 4);
+            pw[q][v] = *(const float4*)(W.P + R[q].oW + i); pm[q][v] = *(const float4*)(W.AM + R[q].oW + i);
+            pv[q][v] = *(const float4*)(W.AV + R[q].oW + i); acc[q][v] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         pb[q] = W.P[R[q].ob]; mb[q] = W.AM[R[q].ob]; vb[q] = W.AV[R[q].ob];
     }
@@ -596,17 +609,16 @@ __global__ __launch_bounds__(DW_BLOCK, 3) void k_dw(Dims D, Ws W0, int epoch, si
         __syncthreads();
 #pragma unroll 2
         for (int r = 0; r < nr; ++r) {
-            float av[NC];                              // rows of one block read the same columns: load once
             const float* a = as + r * awidth;
 #pragma unroll
             for (int q = 0; q < DW_RPW; ++q) {
                 const float gr = gall[(wib * DW_RPW + q) * D.K + r0 + r];
-                if (q == 0 || bkind == 1) {
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) av[c] = a[R[q].aoff + min(c * 64 + lane, R[q].n_in - 1)];
+                for (int v = 0; v < NV; ++v) {
+                    const float4 av = *(const float4*)(a + R[q].aoff + min(v * 256 + lane * 4, R[q].n_in - 4));
+                    acc[q][v].x = fmaf(gr, av.x, acc[q][v].x); acc[q][v].y = fmaf(gr, av.y, acc[q][v].y);
+                    acc[q][v].z = fmaf(gr, av.z, acc[q][v].z); acc[q][v].w = fmaf(gr, av.w, acc[q][v].w);
                 }
-#pragma unroll
-                for (int c = 0; c < NC; ++c) acc[q][c] = fmaf(gr, av[c], acc[q][c]);
             }
         }
     }
@@ -614,11 +626,17 @@ __global__ __launch_bounds__(DW_BLOCK, 3) void k_dw(Dims D, Ws W0, int epoch, si
     for (int q = 0; q < DW_RPW; ++q) {
         if (R[q].active && live) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int i = c * 64 + lane;
-                const float nw = adam_value(pw[q][c], pm[q][c], pv[q][c], acc[q][c], S.step_size, S.bc2_sqrt);
-                if (i < R[q].n_in) { W.P[R[q].oW + i] = nw; W.AM[R[q].oW + i] = pm[q][c]; W.AV[R[q].oW + i] = pv[q][c]; }
-                pw[q][c] = nw;
+            for (int v = 0; v < NV; ++v) {
+                const int i = v * 256 + lane * 4;
+                float4 nw;
+                nw.x = adam_value(pw[q][v].x, pm[q][v].x, pv[q][v].x, acc[q][v].x, S.step_size, S.bc2_sqrt);
+                nw.y = adam_value(pw[q][v].y, pm[q][v].y, pv[q][v].y, acc[q][v].y, S.step_size, S.bc2_sqrt);
+                nw.z = adam_value(pw[q][v].z, pm[q][v].z, pv[q][v].z, acc[q][v].z, S.step_size, S.bc2_sqrt);
+                nw.w = adam_value(pw[q][v].w, pm[q][v].w, pv[q][v].w, acc[q][v].w, S.step_size, S.bc2_sqrt);
+                if (i < R[q].n_in) {
+                    *(float4*)(W.P + R[q].oW + i) = nw; *(float4*)(W.AM + R[q].oW + i) = pm[q][v]; *(float4*)(W.AV + R[q].oW + i) = pv[q][v];
+                }
+                pw[q][v] = nw;
             }
             float sum = 0.f;
             for (int r = 0; r < D.K; ++r) sum += gall[(wib * DW_RPW + q) * D.K + r];
@@ -627,15 +645,20 @@ __global__ __launch_bounds__(DW_BLOCK, 3) void k_dw(Dims D, Ws W0, int epoch, si
         }
     }
     if (bkind == 3 && live) {
-        // next epoch's encoder activation from the updated rows held in registers (IN <= 64: one
-        // weight per lane) and the LDS-staged features (K * IN floats always fit one chunk).  The MLP
-        // input is the same every epoch: m.clone() of the same m (mlp_reg.py:62); only weights moved.
+        // next epoch's encoder activation from the updated rows held in registers (IN <= 64: four
+        // weights per lane, lanes 0..IN/4-1) and the LDS-staged features (K * IN floats always fit one
+        // chunk).  The MLP input is the same every epoch: m.clone() of the same m (mlp_reg.py:62).
 #pragma unroll
         for (int q = 0; q < DW_RPW; ++q) {
             if (!R[q].active) continue;
 #pragma unroll 4
             for (int r = 0; r < D.K; ++r) {
-                const float v = wave_sum_fast(lane < D.IN ? pw[q][0] * as[r * D.IN + lane] : 0.f) + pb[q];
+                float v = 0.f;
+                if (lane * 4 < D.IN) {
+                    const float4 e = *(const float4*)(as + r * D.IN + lane * 4);
+                    v = fmaf(pw[q][0].w, e.w, fmaf(pw[q][0].z, e.z, fmaf(pw[q][0].y, e.y, pw[q][0].x * e.x)));
+                }
+                v = wave_sum_fast(v) + pb[q];
                 if (lane == 0) x1next[(size_t)r * D.H + R[q].o] = act_f(v, D.slope);
             }
         }

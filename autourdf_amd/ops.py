@@ -240,9 +240,10 @@ class TrainPlan:
         self.k, self.n_pred, self.n_tgt, self.epochs = k, n_pred, n_tgt, epochs
 
     def __del__(self):
-        if getattr(self, "plan", None) and self.plan.value:
-            self.L.creg_train_plan_destroy(self.plan)
-            self.plan = ctypes.c_void_p()
+        plan = getattr(self, "plan", None)
+        if plan is not None and plan.value and ctypes is not None:      # (module globals may be gone at interpreter exit)
+            self.L.creg_train_plan_destroy(plan)
+            self.plan = None
 
     def _args(self, m, y, pts, offsets, params, lr, factor, patience, stop, outs):
         n = 10 if self.rot == 0 else 6
