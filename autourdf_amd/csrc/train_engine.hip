@@ -431,22 +431,28 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
 // Phase 1 builds the chunk's g_h2 = act'(h2) * (g_out . W3) in LDS from LDS-staged operands;
 // phase 2 keeps the column's weights of the chunk in registers (all loads in flight at once) and
 // walks the pose rows four at a time (one broadcast ds_read_b128 per weight).
-constexpr int BW2_ROWS = 48;
+constexpr int BW2_ROWS = 48;          // largest chunk: H2 / 16 at hidden 512, 'q' model
 constexpr int BW2_OC = 16;
+// ROWS = H2 / BW2_OC and H = 64 NC are template parameters: the chunk's weight loads then use one base
+// address + constant strides (runtime strides cost two address VGPRs per load: 254 VGPRs, 2 waves/SIMD).
+template <int NC, int ROWS>
 __global__ __launch_bounds__(256) void k_bwd2(Dims D, Ws W0, int epoch, size_t bstride) {
+    constexpr int H = NC * 64;
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KP = (D.K + 3) & ~3;
-    float* gs = (float*)smem;                  // [BW2_ROWS][KP]   g_h2 of the chunk (zero padded)
-    float* gos = gs + BW2_ROWS * KP;           // [K][16]          g_out
-    float* w3s = gos + 16 * D.K;               // [8][BW2_ROWS]    output-layer weights of the chunk's units
+    float* gs = (float*)smem;                  // [ROWS][KP]   g_h2 of the chunk
+    float* gos = gs + ROWS * KP;               // [K][16]      g_out
+    float* w3s = gos + 16 * D.K;               // [8][ROWS]    output-layer weights of the chunk's units
     // (no early exit on `stopped`: its outputs are only read by k_dw, which gates its stores; an
     //  exit branch here would let hipcc sink the loads below it and serialise them)
-    const int rows = D.H2 / BW2_OC, o0 = blockIdx.y * rows, tid = threadIdx.x;
+    constexpr int rows = ROWS;
+    const int o0 = blockIdx.y * rows, tid = threadIdx.x;
     const int col = blockIdx.x * 64 + (tid & 63);             // H % 64 == 0: always valid
-    float w[BW2_ROWS];                            // this column's weights of the chunk: issued first
+    float w[ROWS];                                // this column's weights of the chunk: issued first
+    const float* wbase = W.P + D.oW2 + (size_t)o0 * H;       // wave-uniform row bases (SGPR) + one per-lane column offset
 #pragma unroll
-    for (int ol = 0; ol < BW2_ROWS; ++ol) w[ol] = W.P[D.oW2 + (size_t)(o0 + min(ol, rows - 1)) * D.H + col];
+    for (int ol = 0; ol < ROWS; ++ol) w[ol] = (wbase + ol * H)[col];
     float hv0[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -457,17 +463,17 @@ __global__ __launch_bounds__(256) void k_bwd2(Dims D, Ws W0, int epoch, size_t b
     {
         float v[2] = {0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {                 // 8 * BW2_ROWS = 384 <= 512: both loads in flight
-            const int id = q * 256 + tid, j = id / BW2_ROWS, ol = id % BW2_ROWS, o = o0 + ol;
-            if (id < 8 * BW2_ROWS && ol < rows) {
+        for (int q = 0; q < 2; ++q) {                 // 8 * ROWS = 384 <= 512: both loads in flight
+            const int id = q * 256 + tid, j = id / ROWS, ol = id % ROWS, o = o0 + ol;
+            if (id < 8 * ROWS && ol < rows) {
                 if (o < D.HA) { if (j < D.OA) v[q] = W.P[D.oW3A + (size_t)j * D.HA + o]; }
                 else if (j < D.OB) v[q] = W.P[D.oW3B + (size_t)j * D.HB + (o - D.HA)];
             }
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) if (q * 256 + tid < 8 * BW2_ROWS) w3s[q * 256 + tid] = v[q];
+        for (int q = 0; q < 2; ++q) if (q * 256 + tid < 8 * ROWS) w3s[q * 256 + tid] = v[q];
     }
-    for (int id = tid; id < BW2_ROWS * KP; id += 256) gs[id] = 0.f;
+    for (int id = tid; id < ROWS * KP; id += 256) gs[id] = 0.f;
     __syncthreads();
     for (int base = 0; base < rows * D.K; base += 256 * 4) {
         float hv[4];
@@ -483,8 +489,8 @@ __global__ __launch_bounds__(256) void k_bwd2(Dims D, Ws W0, int epoch, size_t b
                 const int r = id / rows, ol = id % rows, o = o0 + ol;
                 const float* go = gos + 16 * r;
                 float sum = 0.f;
-                if (o < D.HA) { for (int j = 0; j < D.OA; ++j) sum = fmaf(go[j], w3s[j * BW2_ROWS + ol], sum); }
-                else { for (int j = 0; j < D.OB; ++j) sum = fmaf(go[4 + j], w3s[j * BW2_ROWS + ol], sum); }
+                if (o < D.HA) { for (int j = 0; j < D.OA; ++j) sum = fmaf(go[j], w3s[j * ROWS + ol], sum); }
+                else { for (int j = 0; j < D.OB; ++j) sum = fmaf(go[4 + j], w3s[j * ROWS + ol], sum); }
                 sum *= act_grad(hv[q], D.slope);
                 gs[ol * KP + r] = sum;
                 if (blockIdx.x == 0) W.g_h2[(size_t)r * D.H2 + o] = sum;
@@ -492,20 +498,18 @@ __global__ __launch_bounds__(256) void k_bwd2(Dims D, Ws W0, int epoch, size_t b
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int ol = 0; ol < BW2_ROWS; ++ol) w[ol] = ol < rows ? w[ol] : 0.f;
     for (int r0 = 4 * (tid >> 6); r0 < D.K; r0 += 16) {       // wave w takes pose-row tiles w, w+4, ...
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-        for (int ol = 0; ol < BW2_ROWS; ++ol) {
+        for (int ol = 0; ol < ROWS; ++ol) {
             const float4 g = *(const float4*)(gs + ol * KP + r0);
             a0 = fmaf(g.x, w[ol], a0); a1 = fmaf(g.y, w[ol], a1); a2 = fmaf(g.z, w[ol], a2); a3 = fmaf(g.w, w[ol], a3);
         }
-        float* out = W.gx1_part + ((size_t)blockIdx.y * D.K + r0) * D.H + col;
+        float* out = W.gx1_part + ((size_t)blockIdx.y * D.K + r0) * H + col;
         out[0] = a0;
-        if (r0 + 1 < D.K) out[D.H] = a1;
-        if (r0 + 2 < D.K) out[2 * (size_t)D.H] = a2;
-        if (r0 + 3 < D.K) out[3 * (size_t)D.H] = a3;
+        if (r0 + 1 < D.K) out[H] = a1;
+        if (r0 + 2 < D.K) out[2 * (size_t)H] = a2;
+        if (r0 + 3 < D.K) out[3 * (size_t)H] = a3;
     }
 }
 
@@ -746,6 +750,15 @@ static void launch_head(Plan* P, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
     by_nc(D.H, [&](auto nc) { hipLaunchKernelGGL((k_head<decltype(nc)::value>), dim3(D.K, 1, P->nz), dim3(512), 0, s, D, W, P->bstride); });
 }
+static void launch_bwd2(Plan* P, int epoch, hipStream_t s) {
+    const Dims& D = P->D; const Ws& W = P->W;
+    by_nc(D.H, [&](auto nc) {
+        constexpr int NC = decltype(nc)::value;
+        const dim3 grid(NC, D.OC, P->nz);
+        if (D.rot == 0) hipLaunchKernelGGL((k_bwd2<NC, 6 * NC>), grid, dim3(256), P->smem_bwd2, s, D, W, epoch, P->bstride);
+        else hipLaunchKernelGGL((k_bwd2<NC, 4 * NC>), grid, dim3(256), P->smem_bwd2, s, D, W, epoch, P->bstride);
+    });
+}
 static void launch_dw(Plan* P, int epoch, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
     by_nc(D.H, [&](auto nc) {
@@ -764,7 +777,7 @@ static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nu
     launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
                       true, true, EngineEpi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, P->bstride}, s, P->nz, P->bstride); mark(3);
     hipLaunchKernelGGL(k_gradc, dim3(D.K, 1, P->nz), dim3(256), 0, s, D, W, epoch, D.nbx, D.nby, P->bstride); mark(4);
-    hipLaunchKernelGGL(k_bwd2, dim3(D.H / 64, D.OC, P->nz), dim3(256), P->smem_bwd2, s, D, W, epoch, P->bstride); mark(5);
+    launch_bwd2(P, epoch, s); mark(5);
     launch_dw(P, epoch, s); mark(6);
 }
 
@@ -836,8 +849,7 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
                                 P->smem_dw) != hipSuccess) rc_attr = 1;
     });
     CREG_REQUIRE(rc_attr == 0, "creg_train_plan_create: cannot raise the dynamic LDS limit of k_dw");
-    if (P->smem_bwd2 > 65536)
-        CREG_HIP(hipFuncSetAttribute((const void*)k_bwd2, hipFuncAttributeMaxDynamicSharedMemorySize, P->smem_bwd2));
+    CREG_REQUIRE(P->smem_bwd2 <= 65536, "creg_train_plan_create: k_bwd2 needs %d B of LDS (K too large)", P->smem_bwd2);
     *plan = (creg_train_plan*)P;
     return CREG_OK;
 }
