@@ -25,6 +25,11 @@ class TrainArgs(ctypes.Structure):
                 ("loss_hist", vp), ("lr_hist", vp), ("result", vp)]
 
 
+class IcpProblem(ctypes.Structure):
+    _fields_ = [("local", vp), ("world", vp), ("seg_offsets", vp), ("frame", vp), ("M", vp),
+                ("M_out", vp), ("world_out", vp), ("n_iter_out", vp)]
+
+
 # name -> (restype, argtypes); every symbol include/creg.h declares
 SIGNATURES = {
     "creg_version": (ctypes.c_int, []),
@@ -55,6 +60,8 @@ SIGNATURES = {
     "creg_quat_to_matrix_f32": (ctypes.c_int, [vp, i32, vp, vp]),
     "creg_icp_workspace_bytes": (sz, [i64, i64, i32]),
     "creg_masked_icp_f64": (ctypes.c_int, [vp, vp, i64, vp, i32, vp, i64, vp, f64, f64, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "creg_icp_batch_workspace_bytes": (sz, [i64, i64, i32, i32]),
+    "creg_masked_icp_batch_f64": (ctypes.c_int, [ctypes.POINTER(IcpProblem), i32, i64, i32, i64, f64, f64, i32, i32, vp, sz, vp]),
     "creg_train_workspace_bytes": (sz, [ctypes.POINTER(TrainShape)]),
     "creg_train_plan_create": (ctypes.c_int, [ctypes.POINTER(TrainShape), vp, sz, ctypes.POINTER(vp)]),
     "creg_train_plan_run": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), vp]),

@@ -165,7 +165,6 @@ def masked_icp(clusters_local, clusters_world, step_pc_np, matrices, visual=Fals
     Returns (list of world-frame clusters (M_k,3) f64, new matrices (K,4,4) f64) like the reference."""
     if visual:
         raise NotImplementedError("visual=True needs Open3D's GUI (out of scope)")
-    L = _lib.load()
     dev = torch.device("cuda")
     k = len(clusters_local)
     local, off = ops.pack_clusters(clusters_local, dev, torch.float64)
@@ -174,16 +173,7 @@ def masked_icp(clusters_local, clusters_world, step_pc_np, matrices, visual=Fals
         raise ValueError("clusters_local and clusters_world must have matching sizes")
     frame = torch.as_tensor(np.asarray(step_pc_np), dtype=torch.float64, device=dev).contiguous()
     M = torch.as_tensor(np.asarray(matrices), dtype=torch.float64, device=dev).contiguous()
-    n, nf = local.shape[0], frame.shape[0]
-    ws_bytes = L.creg_icp_workspace_bytes(n, nf, k)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    M_out = torch.empty(k, 4, 4, dtype=torch.float64, device=dev)
-    w_out = torch.empty(n, 3, dtype=torch.float64, device=dev)
-    n_it = torch.empty(k, dtype=torch.int32, device=dev)
-    p = ops._p
-    _lib.check(L.creg_masked_icp_f64(p(local), p(world), n, p(off), k, p(frame), nf, p(M), float(scale), float(th),
-                                     int(max_iteration), int(bool(ori)), p(M_out), p(w_out), p(n_it), p(ws), ws_bytes,
-                                     ops._stream()), "creg_masked_icp_f64")
+    M_out, w_out, _ = ops.masked_icp(local, world, off, frame, M, scale, th, max_iteration, ori)
     off_h = off.cpu().numpy()
     w_h = w_out.cpu().numpy()
     return [w_h[off_h[i]:off_h[i + 1]] for i in range(k)], M_out.cpu().numpy()

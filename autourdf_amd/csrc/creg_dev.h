@@ -28,6 +28,23 @@ __device__ __forceinline__ float wave_sum_fast(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// fp64 flavour: the two halves travel through the same DPP moves (old = 0 in both halves is +0.0)
+#define CREG_DPP_STEP_F64(v, ctrl, mask)                                                                   \
+    {                                                                                                      \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, mask, 0xF, false);         \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, mask, 0xF, false);         \
+        v += __hiloint2double(hi_, lo_);                                                                   \
+    }
+__device__ __forceinline__ double wave_sum_fast(double v) {
+    CREG_DPP_STEP_F64(v, 0xB1, 0xF)
+    CREG_DPP_STEP_F64(v, 0x4E, 0xF)
+    CREG_DPP_STEP_F64(v, 0x141, 0xF)
+    CREG_DPP_STEP_F64(v, 0x140, 0xF)
+    CREG_DPP_STEP_F64(v, 0x142, 0xA)
+    CREG_DPP_STEP_F64(v, 0x143, 0xC)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 // Cooperative global -> LDS copy of n float4 by NT threads through the LDS-DMA path
 // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR round trip).  Every request is in
 // flight before the single wait, so the copy costs ONE memory round trip.  The register-staged

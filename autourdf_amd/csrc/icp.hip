@@ -13,32 +13,85 @@
 
 namespace creg {
 
-// dominant eigenvector of a symmetric 4x4 (cyclic Jacobi), returned as a unit quaternion
-__device__ void sym4_max_eigvec(double A[4][4], double q[4]) {
-    double V[4][4];
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+// 1/x and 1/sqrt(x) from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-23) + two Newton steps (~2^-90
+// before rounding): a few ulp, ~6 instructions instead of the ~30 of the IEEE division / sqrt expansions.
+// Used only inside the Jacobi rotations (x finite, away from 0 and inf), where a few-ulp angle is as good
+// as a correctly rounded one: every rotation is re-orthogonalising by construction.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+    return fma(0.5 * r, fma(-x * r, r, 1.0), r);
+}
+
+// dominant eigenvector of a symmetric 4x4 (cyclic Jacobi with the usual small-element skip, warm started),
+// returned as a unit quaternion.  Runs on one lane: the rotation chain is serial, so it is written for few
+// instructions (fast_rcp / fast_rsqrt, skipped negligible rotations, eps-level stopping rule).
+// Vp (LDS, in/out): the eigenvector basis of the previous call.  Successive ICP iterations have nearly
+// the same profile matrix, so Vp^T N Vp is almost diagonal and one or two sweeps finish the job instead
+// of five or six; the first call passes the identity.
+__device__ void sym4_max_eigvec(const double N[4][4], double q[4], double* Vp) {
+    double V[4][4], A[4][4];
+    {
+        double M[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) V[i][j] = Vp[4 * i + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) M[i][j] = fma(N[i][3], V[3][j], fma(N[i][2], V[2][j], fma(N[i][1], V[1][j], N[i][0] * V[0][j])));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i; j < 4; ++j) {
+                A[i][j] = fma(V[3][i], M[3][j], fma(V[2][i], M[2][j], fma(V[1][i], M[1][j], V[0][i] * M[0][j])));
+                A[j][i] = A[i][j];
+            }
+    }
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0, diag = 0;
         for (int i = 0; i < 4; ++i) { diag += A[i][i] * A[i][i]; for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j]; }
-        if (off <= 1e-60 + 1e-34 * diag) break;
+        if (off <= 1e-60 + 1e-31 * diag) break;            // |off-diagonal| <= 3e-16 |diagonal|
+#pragma unroll
         for (int p = 0; p < 3; ++p)
+#pragma unroll
             for (int r = p + 1; r < 4; ++r) {
-                if (A[p][r] == 0.0) continue;
-                const double theta = (A[r][r] - A[p][p]) / (2.0 * A[p][r]);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                const double apr = A[p][r];
+                if (fabs(apr) <= 1e-22 * (fabs(A[p][p]) + fabs(A[r][r]))) { A[p][r] = 0.0; A[r][p] = 0.0; continue; }
+                const double theta = 0.5 * (A[r][r] - A[p][p]) * fast_rcp(apr);
+                const double th2p1 = fma(theta, theta, 1.0);
+                const double t = (theta >= 0 ? 1.0 : -1.0) * fast_rcp(fabs(theta) + th2p1 * fast_rsqrt(th2p1));
+                const double c = fast_rsqrt(fma(t, t, 1.0)), s = t * c;
+#pragma unroll
                 for (int k = 0; k < 4; ++k) { const double akp = A[k][p], akr = A[k][r]; A[k][p] = c * akp - s * akr; A[k][r] = s * akp + c * akr; }
+#pragma unroll
                 for (int k = 0; k < 4; ++k) { const double apk = A[p][k], ark = A[r][k]; A[p][k] = c * apk - s * ark; A[r][k] = s * apk + c * ark; }
+#pragma unroll
                 for (int k = 0; k < 4; ++k) { const double vkp = V[k][p], vkr = V[k][r]; V[k][p] = c * vkp - s * vkr; V[k][r] = s * vkp + c * vkr; }
             }
     }
-    int m = 0;
-    for (int i = 1; i < 4; ++i) if (A[i][i] > A[m][m]) m = i;
-    double n = 0;
-    for (int i = 0; i < 4; ++i) n += V[i][m] * V[i][m];
-    n = sqrt(n);
-    const double sg = V[0][m] < 0 ? -1.0 : 1.0;
-    for (int i = 0; i < 4; ++i) q[i] = sg * V[i][m] / n;
+    // column of the largest eigenvalue, selected with static indices only (a runtime column index would
+    // push A and V to scratch)
+    double lam = A[0][0], v0 = V[0][0], v1 = V[1][0], v2 = V[2][0], v3 = V[3][0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) {
+        const bool gt = A[c][c] > lam;
+        lam = gt ? A[c][c] : lam;
+        v0 = gt ? V[0][c] : v0; v1 = gt ? V[1][c] : v1; v2 = gt ? V[2][c] : v2; v3 = gt ? V[3][c] : v3;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Vp[4 * i + j] = V[i][j];
+    const double n = sqrt(((v0 * v0 + v1 * v1) + v2 * v2) + v3 * v3);
+    const double sg = v0 < 0 ? -1.0 : 1.0;
+    q[0] = sg * v0 / n; q[1] = sg * v1 / n; q[2] = sg * v2 / n; q[3] = sg * v3 / n;
 }
 
 struct IcpLayout { size_t srcw, tidx, nn, total; };
@@ -52,154 +105,205 @@ static IcpLayout icp_layout(int64_t n, int64_t nf, int k) {
     return L;
 }
 
-template <int NT>
-__device__ __forceinline__ double bsum(double v, double* sc) {
-    const double r = block_sum<double, NT>(v, sc);
-    __shared__ double bc;
-    if (threadIdx.x == 0) bc = r;
+constexpr int ICP_NT = 512;                           // threads per workgroup (16 waves)
+constexpr int ICP_ROWS = 256;                          // threads that own source points ("row" threads)
+constexpr int ICP_PARTS = ICP_NT / ICP_ROWS;           // the target list is split this many ways per source point
+constexpr int ICP_BATCH_MAX = 16;
+constexpr int ICP_SRC_LDS = 1024;                      // source points of a cluster kept in LDS (28 B each)
+
+// Sum N values held by the row threads (waves 0..3) over the block, result in every thread.
+// Fixed association: DPP wave sum per wave, then 0 + w0 + w1 + w2 + w3.
+template <int N>
+__device__ __forceinline__ void bsum_n(double (&v)[N], double* sc /* [4][N] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (wv < ICP_ROWS / 64) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = wave_sum_fast(v[i]);
+    }
+    __syncthreads();                                   // previous readers of sc are done
+    if (lane == 0 && wv < ICP_ROWS / 64) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) sc[wv * N + i] = v[i];
+    }
     __syncthreads();
-    const double out = bc;
-    __syncthreads();
-    return out;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { double r = 0.0; for (int w = 0; w < ICP_ROWS / 64; ++w) r += sc[w * N + i]; v[i] = r; }
 }
 
-__global__ __launch_bounds__(256) void k_masked_icp(
-    const double* __restrict__ local, const float* __restrict__ world, const int* __restrict__ off,
-    const double* __restrict__ frame, int nf, const double* __restrict__ Min, float half_scale, double th,
-    int max_iter, int keep_t, double* __restrict__ Mout, double* __restrict__ world_out,
-    int* __restrict__ n_iter_out, double* __restrict__ srcw, int* __restrict__ tidx_all, int* __restrict__ nn,
-    int lds_cap) {
-    __shared__ double sc[4];
+struct IcpBatch {
+    const double* local[ICP_BATCH_MAX]; const float* world[ICP_BATCH_MAX]; const int* off[ICP_BATCH_MAX];
+    const double* frame[ICP_BATCH_MAX]; const double* Min[ICP_BATCH_MAX];
+    double* Mout[ICP_BATCH_MAX]; double* world_out[ICP_BATCH_MAX]; int* n_iter_out[ICP_BATCH_MAX];
+};
+
+// grid (k, batch): one 1024-thread workgroup per cluster per problem.  Masked targets (<= lds_cap) and the
+// cluster's moving source points (<= ICP_SRC_LDS) live in LDS for the whole loop; larger ones fall back to
+// the workspace in global memory through the same (flat) pointers.  Threads 0..255 own the source points
+// (sums, moves); the nearest-target search of a point is split over 4 threads (quarters of the target list,
+// ascending, combined with strict '<' so the first minimum wins exactly as a sequential scan).
+__global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float half_scale, double th, int max_iter,
+                                                       int keep_t, char* __restrict__ ws, size_t ws_stride, size_t o_srcw,
+                                                       size_t o_tidx, size_t o_nn, int lds_cap) {
+    __shared__ double sc[4 * 9];
     __shared__ float s_lo[3], s_hi[3];
-    __shared__ int s_cnt, s_wofs[4];
-    __shared__ double T[16], U[16];
+    __shared__ int s_wofs[ICP_NT / 64];
+    __shared__ double T[16], U[16], Vp[16];
+    __shared__ double sB[ICP_PARTS][ICP_ROWS];         // per part: best squared distance of the round's points
+    __shared__ int sM[ICP_PARTS][ICP_ROWS];            //           and its target
+    const int z = blockIdx.y;
+    const double* __restrict__ local = P.local[z]; const float* __restrict__ world = P.world[z];
+    const int* __restrict__ off = P.off[z]; const double* __restrict__ frame = P.frame[z];
+    const double* __restrict__ Min = P.Min[z];
+    char* wz = ws + (size_t)z * ws_stride;
     const int k = blockIdx.x, b = off[k], e = off[k + 1], ns = e - b;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int* tidx = tidx_all + (size_t)k * nf;
+    const bool row = tid < ICP_ROWS;
+    int* tidx = (int*)(wz + o_tidx) + (size_t)k * nf;
 
-    // ---- 1. box in float32, exactly as numpy evaluates it on the float32 cluster ----
+    // ---- 1. box in float32, exactly as numpy evaluates it on the float32 cluster (min / max: any order) ----
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = b + tid; i < e; i += 256)
+    for (int i = b + tid; i < e; i += ICP_NT)
         for (int d = 0; d < 3; ++d) { const float v = world[3 * (size_t)i + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
-    for (int d = 0; d < 3; ++d) {
-        for (int o = 32; o >= 1; o >>= 1) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64)); }
-        __shared__ float wl[4], wh[4];
-        if (lane == 0) { wl[wv] = lo[d]; wh[wv] = hi[d]; }
+    {
+        __shared__ float wl[ICP_NT / 64][3], wh[ICP_NT / 64][3];
+        for (int d = 0; d < 3; ++d) {
+            for (int o = 32; o >= 1; o >>= 1) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64)); }
+            if (lane == 0) { wl[wv][d] = lo[d]; wh[wv][d] = hi[d]; }
+        }
         __syncthreads();
-        if (tid == 0) {
-            const float l = fminf(fminf(wl[0], wl[1]), fminf(wl[2], wl[3])), h = fmaxf(fmaxf(wh[0], wh[1]), fmaxf(wh[2], wh[3]));
+        if (tid < 3) {
+            const int d = tid;
+            float l = wl[0][d], h = wh[0][d];
+            for (int w = 1; w < ICP_NT / 64; ++w) { l = fminf(l, wl[w][d]); h = fmaxf(h, wh[w][d]); }
             const float c = (l + h) / 2.0f, sz = h - l;
             s_lo[d] = c - half_scale * sz; s_hi[d] = c + half_scale * sz;
         }
         __syncthreads();
     }
     // ---- ordered compaction of the frame points strictly inside the box ----
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    for (int base = 0; base < nf; base += 256) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sT = (double*)smem;                       // [lds_cap][3] masked target coordinates
+    int* sI = (int*)(sT + 3 * (size_t)lds_cap);       // [lds_cap]    their frame indices
+    double* sS = (double*)(sI + lds_cap);             // [ICP_SRC_LDS][3] moving source points
+    int* sN = (int*)(sS + 3 * ICP_SRC_LDS);           // [ICP_SRC_LDS] matched target slot / frame index, -1 = none
+    const double blo0 = (double)s_lo[0], blo1 = (double)s_lo[1], blo2 = (double)s_lo[2];
+    const double bhi0 = (double)s_hi[0], bhi1 = (double)s_hi[1], bhi2 = (double)s_hi[2];
+    int run = 0;                                      // points kept so far (block-uniform)
+    for (int base = 0; base < nf; base += ICP_NT) {
         const int j = base + tid;
         bool in = false;
+        double x = 0, y = 0, zc = 0;
         if (j < nf && ns > 0) {
-            const double x = frame[3 * (size_t)j], y = frame[3 * (size_t)j + 1], z = frame[3 * (size_t)j + 2];
-            in = x > (double)s_lo[0] && x < (double)s_hi[0] && y > (double)s_lo[1] && y < (double)s_hi[1] &&
-                 z > (double)s_lo[2] && z < (double)s_hi[2];
+            x = frame[3 * (size_t)j]; y = frame[3 * (size_t)j + 1]; zc = frame[3 * (size_t)j + 2];
+            in = x > blo0 && x < bhi0 && y > blo1 && y < bhi1 && zc > blo2 && zc < bhi2;
         }
         const unsigned long long m = __ballot(in);
+        __syncthreads();                              // s_wofs of the previous round has been read
         if (lane == 0) s_wofs[wv] = __popcll(m);
         __syncthreads();
-        int before = s_cnt;
-        for (int w = 0; w < wv; ++w) before += s_wofs[w];
-        if (in) tidx[before + __popcll(m & ((1ull << lane) - 1ull))] = j;
-        __syncthreads();
-        if (tid == 0) s_cnt += s_wofs[0] + s_wofs[1] + s_wofs[2] + s_wofs[3];
-        __syncthreads();
-    }
-    const int nt = s_cnt;
-    // masked target coordinates into LDS (all threads sweep the same target at the same time, so the
-    // nearest-neighbour loop below becomes broadcast LDS reads instead of dependent global gathers)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* sT = (double*)smem;                       // [lds_cap][3]
-    int* sI = (int*)(sT + 3 * (size_t)lds_cap);       // [lds_cap]
-    const bool in_lds = nt <= lds_cap;
-    if (in_lds)
-        for (int t = tid; t < nt; t += 256) {
-            const int j = tidx[t];
-            sT[3 * t] = frame[3 * (size_t)j]; sT[3 * t + 1] = frame[3 * (size_t)j + 1]; sT[3 * t + 2] = frame[3 * (size_t)j + 2];
-            sI[t] = j;
+        int before = run, total = 0;
+        for (int w = 0; w < ICP_NT / 64; ++w) { const int c = s_wofs[w]; before += w < wv ? c : 0; total += c; }
+        if (in) {
+            const int slot = before + __popcll(m & ((1ull << lane) - 1ull));
+            tidx[slot] = j;
+            if (slot < lds_cap) { sT[3 * slot] = x; sT[3 * slot + 1] = y; sT[3 * slot + 2] = zc; sI[slot] = j; }
         }
-    __syncthreads();
+        run += total;
+    }
+    const int nt = run;
+    const bool in_lds = nt <= lds_cap;
+    const bool src_lds = ns <= ICP_SRC_LDS;
+    double* S = src_lds ? sS : (double*)(wz + o_srcw) + 3 * (size_t)b;      // flat pointer: LDS or workspace
+    int* nn = src_lds ? sN : (int*)(wz + o_nn) + b;
 
     // ---- 2. ICP ----
-    if (tid < 16) T[tid] = Min[16 * k + tid];
-    __syncthreads();
-    for (int i = tid; i < ns; i += 256) {
-        const double* p = local + 3 * (size_t)(b + i);
-        for (int a = 0; a < 3; ++a)
-            srcw[3 * (size_t)(b + i) + a] = fma(T[4 * a + 2], p[2], fma(T[4 * a + 1], p[1], T[4 * a] * p[0])) + T[4 * a + 3];
-    }
-    __syncthreads();
+    if (tid < 16) { T[tid] = Min[16 * k + tid]; Vp[tid] = (tid % 5 == 0) ? 1.0 : 0.0; }
+    __syncthreads();                                  // T, sT/sI and (not in_lds) tidx visible to the block
+    if (row)
+        for (int i = tid; i < ns; i += ICP_ROWS) {
+            const double* p = local + 3 * (size_t)(b + i);
+            const double p0 = p[0], p1 = p[1], p2 = p[2];
+            for (int a = 0; a < 3; ++a) S[3 * i + a] = fma(T[4 * a + 2], p2, fma(T[4 * a + 1], p1, T[4 * a] * p0)) + T[4 * a + 3];
+        }
     const double th2 = th * th;
     double fit = 0, rmse = 0;
     int it = 0;
+    const int part = __builtin_amdgcn_readfirstlane(tid / ICP_ROWS), pi = tid % ICP_ROWS;
+    const int t0 = (int)((long long)nt * part / ICP_PARTS), t1 = (int)((long long)nt * (part + 1) / ICP_PARTS);
+    // matched target of a source point (slot in LDS, or frame index when the targets did not fit)
+    auto tgt = [&](int m, int a) -> double { return in_lds ? sT[3 * m + a] : frame[3 * (size_t)m + a]; };
     auto correspond = [&](double& fitness, double& rm) {
-        double cnt = 0, err = 0;
-        for (int i = tid; i < ns; i += 256) {
-            const double* s = srcw + 3 * (size_t)(b + i);
-            const double s0 = s[0], s1 = s[1], s2 = s[2];
-            double best = INFINITY; int bj = -1;
-            if (in_lds) {
-                int bt = -1;
-                for (int t = 0; t < nt; ++t) {
-                    const double dx = s0 - sT[3 * t], dy = s1 - sT[3 * t + 1], dz = s2 - sT[3 * t + 2];
-                    const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (d2 < best) { best = d2; bt = t; }
-                }
-                if (bt >= 0) bj = sI[bt];
-            } else {
-                for (int t = 0; t < nt; ++t) {
-                    const int j = tidx[t];
-                    const double dx = s0 - frame[3 * (size_t)j], dy = s1 - frame[3 * (size_t)j + 1], dz = s2 - frame[3 * (size_t)j + 2];
-                    const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (d2 < best) { best = d2; bj = j; }
+        double ce[2] = {0, 0};
+        __syncthreads();                              // the row threads' moves of S are visible
+        for (int r0 = 0; r0 < ns; r0 += ICP_ROWS) {
+            const int i = r0 + pi;
+            double best = INFINITY; int bm = -1;
+            if (i < ns) {
+                const double s0 = S[3 * i], s1 = S[3 * i + 1], s2 = S[3 * i + 2];
+                if (in_lds) {
+#pragma unroll 4
+                    for (int t = t0; t < t1; ++t) {
+                        const double dx = s0 - sT[3 * t], dy = s1 - sT[3 * t + 1], dz = s2 - sT[3 * t + 2];
+                        const double d2 = (dx * dx + dy * dy) + dz * dz;
+                        if (d2 < best) { best = d2; bm = t; }
+                    }
+                } else {
+                    for (int t = t0; t < t1; ++t) {
+                        const int j = tidx[t];
+                        const double dx = s0 - frame[3 * (size_t)j], dy = s1 - frame[3 * (size_t)j + 1], dz = s2 - frame[3 * (size_t)j + 2];
+                        const double d2 = (dx * dx + dy * dy) + dz * dz;
+                        if (d2 < best) { best = d2; bm = j; }
+                    }
                 }
             }
-            if (bj >= 0 && best <= th2) { nn[b + i] = bj; cnt += 1.0; err += best; } else nn[b + i] = -1;
+            sB[part][pi] = best; sM[part][pi] = bm;
+            __syncthreads();
+            if (row && i < ns) {                      // quarters in ascending target order, strict '<': first minimum
+                best = sB[0][pi]; bm = sM[0][pi];
+#pragma unroll
+                for (int q = 1; q < ICP_PARTS; ++q) { const double d = sB[q][pi]; if (d < best) { best = d; bm = sM[q][pi]; } }
+                if (bm >= 0 && best <= th2) { nn[i] = bm; ce[0] += 1.0; ce[1] += best; } else nn[i] = -1;
+            }
+            if (r0 + ICP_ROWS < ns) __syncthreads();  // sB / sM are rewritten by the next round
         }
-        cnt = bsum<256>(cnt, sc); err = bsum<256>(err, sc);
-        fitness = ns > 0 ? cnt / (double)ns : 0.0;
-        rm = cnt > 0 ? sqrt(err / cnt) : 0.0;
-        return cnt;
+        bsum_n<2>(ce, sc);
+        fitness = ns > 0 ? ce[0] / (double)ns : 0.0;
+        rm = ce[0] > 0 ? sqrt(ce[1] / ce[0]) : 0.0;
+        return ce[0];
     };
     double ncorr = correspond(fit, rmse);
     for (it = 1; it <= max_iter; ++it) {
         // best rigid update from the current correspondences
-        double ms[3] = {0, 0, 0}, md[3] = {0, 0, 0};
-        for (int i = tid; i < ns; i += 256) {
-            const int j = nn[b + i];
-            if (j < 0) continue;
-            for (int a = 0; a < 3; ++a) { ms[a] += srcw[3 * (size_t)(b + i) + a]; md[a] += frame[3 * (size_t)j + a]; }
-        }
-        for (int a = 0; a < 3; ++a) { ms[a] = bsum<256>(ms[a], sc); md[a] = bsum<256>(md[a], sc); }
-        if (ncorr > 0) for (int a = 0; a < 3; ++a) { ms[a] /= ncorr; md[a] /= ncorr; }
-        double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};            // S[a][c] = sum (src-ms)_a (dst-md)_c
-        for (int i = tid; i < ns; i += 256) {
-            const int j = nn[b + i];
-            if (j < 0) continue;
-            double sv[3], dv[3];
-            for (int a = 0; a < 3; ++a) { sv[a] = srcw[3 * (size_t)(b + i) + a] - ms[a]; dv[a] = frame[3 * (size_t)j + a] - md[a]; }
-            for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) S[3 * a + c] = fma(sv[a], dv[c], S[3 * a + c]);
-        }
-        for (int i = 0; i < 9; ++i) S[i] = bsum<256>(S[i], sc);
+        double mm[6] = {0, 0, 0, 0, 0, 0};            // sums of matched source / target coordinates
+        if (row)
+            for (int i = tid; i < ns; i += ICP_ROWS) {
+                const int m = nn[i];
+                if (m < 0) continue;
+                for (int a = 0; a < 3; ++a) { mm[a] += S[3 * i + a]; mm[3 + a] += tgt(m, a); }
+            }
+        bsum_n<6>(mm, sc);
+        if (ncorr > 0) for (int a = 0; a < 6; ++a) mm[a] /= ncorr;
+        const double* ms = mm; const double* md = mm + 3;
+        double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};            // C[a][c] = sum (src-ms)_a (dst-md)_c
+        if (row)
+            for (int i = tid; i < ns; i += ICP_ROWS) {
+                const int m = nn[i];
+                if (m < 0) continue;
+                double sv[3], dv[3];
+                for (int a = 0; a < 3; ++a) { sv[a] = S[3 * i + a] - ms[a]; dv[a] = tgt(m, a) - md[a]; }
+                for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) C[3 * a + c] = fma(sv[a], dv[c], C[3 * a + c]);
+            }
+        bsum_n<9>(C, sc);
         if (tid == 0) {
             for (int i = 0; i < 16; ++i) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
             if (ncorr > 0) {
-                const double Sxx = S[0], Sxy = S[1], Sxz = S[2], Syx = S[3], Syy = S[4], Syz = S[5], Szx = S[6], Szy = S[7], Szz = S[8];
+                const double Sxx = C[0], Sxy = C[1], Sxz = C[2], Syx = C[3], Syy = C[4], Syz = C[5], Szx = C[6], Szy = C[7], Szz = C[8];
                 double N[4][4] = {{Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx},
                                   {Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz},
                                   {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
                                   {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
                 double q[4], R[9];
-                sym4_max_eigvec(N, q);
+                sym4_max_eigvec(N, q, Vp);
                 quat_to_matrix(q, R);
                 for (int a = 0; a < 3; ++a) {
                     U[4 * a] = R[3 * a]; U[4 * a + 1] = R[3 * a + 1]; U[4 * a + 2] = R[3 * a + 2];
@@ -215,24 +319,25 @@ __global__ __launch_bounds__(256) void k_masked_icp(
             for (int i = 0; i < 16; ++i) T[i] = Tn[i];
         }
         __syncthreads();
-        for (int i = tid; i < ns; i += 256) {
-            double* s = srcw + 3 * (size_t)(b + i);
-            const double p0 = s[0], p1 = s[1], p2 = s[2];
-            for (int a = 0; a < 3; ++a) s[a] = fma(U[4 * a + 2], p2, fma(U[4 * a + 1], p1, U[4 * a] * p0)) + U[4 * a + 3];
-        }
-        __syncthreads();
+        if (row)
+            for (int i = tid; i < ns; i += ICP_ROWS) {
+                const double p0 = S[3 * i], p1 = S[3 * i + 1], p2 = S[3 * i + 2];
+                for (int a = 0; a < 3; ++a) S[3 * i + a] = fma(U[4 * a + 2], p2, fma(U[4 * a + 1], p1, U[4 * a] * p0)) + U[4 * a + 3];
+            }
         const double pf = fit, pr = rmse;
         ncorr = correspond(fit, rmse);
         if (fabs(pf - fit) < 1e-6 && fabs(pr - rmse) < 1e-6) break;
     }
     // ---- 3. outputs: icp matrix (optionally with the old translation), cluster moved by it ----
+    __syncthreads();
     if (tid == 0) {
         if (keep_t) { T[3] = Min[16 * k + 3]; T[7] = Min[16 * k + 7]; T[11] = Min[16 * k + 11]; }
-        for (int i = 0; i < 16; ++i) Mout[16 * k + i] = T[i];
-        n_iter_out[k] = it > max_iter ? max_iter : it;
+        for (int i = 0; i < 16; ++i) P.Mout[z][16 * k + i] = T[i];
+        P.n_iter_out[z][k] = it > max_iter ? max_iter : it;
     }
     __syncthreads();
-    for (int i = tid; i < ns; i += 256) {
+    double* world_out = P.world_out[z];
+    for (int i = tid; i < ns; i += ICP_NT) {
         const double* p = local + 3 * (size_t)(b + i);
         for (int a = 0; a < 3; ++a)
             world_out[3 * (size_t)(b + i) + a] = fma(T[4 * a + 2], p[2], fma(T[4 * a + 1], p[1], T[4 * a] * p[0])) + T[4 * a + 3];
@@ -247,28 +352,55 @@ extern "C" size_t creg_icp_workspace_bytes(int64_t n, int64_t nf, int32_t k) {
     return icp_layout(n, nf, k).total;
 }
 
+extern "C" size_t creg_icp_batch_workspace_bytes(int64_t n, int64_t nf, int32_t k, int32_t batch) {
+    if (n < 1 || nf < 1 || k < 1 || batch < 1) return 0;
+    return icp_layout(n, nf, k).total * (size_t)batch;
+}
+
+static int icp_launch(const creg_icp_problem* pr, int batch, int64_t n, int32_t k, int64_t nf, double scale, double th,
+                      int32_t max_iteration, int32_t keep_translation, void* workspace, size_t workspace_bytes,
+                      hipStream_t s, const char* who) {
+    CREG_REQUIRE(pr && workspace, "%s: null pointer", who);
+    CREG_REQUIRE(batch >= 1 && batch <= ICP_BATCH_MAX, "%s: batch must be in 1..%d", who, ICP_BATCH_MAX);
+    CREG_REQUIRE(k >= 1 && nf >= 1 && nf < (1ll << 31) && max_iteration >= 1, "%s: bad size", who);
+    CREG_REQUIRE(n >= 1 && n < (1ll << 31), "%s: no source points", who);
+    const IcpLayout L = icp_layout(n, nf, k);
+    CREG_REQUIRE(workspace_bytes >= L.total * (size_t)batch, "%s: workspace too small (%zu < %zu)", who, workspace_bytes,
+                 L.total * (size_t)batch);
+    IcpBatch B;
+    for (int i = 0; i < batch; ++i) {
+        const creg_icp_problem& q = pr[i];
+        CREG_REQUIRE(q.local && q.world && q.seg_offsets && q.frame && q.M && q.M_out && q.world_out && q.n_iter_out,
+                     "%s: null pointer in problem %d", who, i);
+        B.local[i] = q.local; B.world[i] = q.world; B.off[i] = q.seg_offsets; B.frame[i] = q.frame; B.Min[i] = q.M;
+        B.Mout[i] = q.M_out; B.world_out[i] = q.world_out; B.n_iter_out[i] = q.n_iter_out;
+    }
+    const int lds_cap = (int)(nf < 4096 ? nf : 4096);             // masked targets kept in LDS (28 B each, <= 112 KB)
+    const int smem = lds_cap * 28 + ICP_SRC_LDS * 28;
+    static bool attr_set = false;
+    if (!attr_set) {
+        CREG_HIP(hipFuncSetAttribute((const void*)k_masked_icp, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     4096 * 28 + ICP_SRC_LDS * 28));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_masked_icp, dim3(k, batch), dim3(ICP_NT), smem, s, B, (int)nf, (float)(0.5 * scale), th,
+                       max_iteration, keep_translation, (char*)workspace, L.total, L.srcw, L.tidx, L.nn, lds_cap);
+    CREG_LAUNCH_CHECK();
+    return CREG_OK;
+}
+
 extern "C" int creg_masked_icp_f64(const double* local, const float* world, int64_t n, const int32_t* seg_offsets, int32_t k,
                                    const double* frame, int64_t nf, const double* M, double scale, double th,
                                    int32_t max_iteration, int32_t keep_translation, double* M_out, double* world_out,
                                    int32_t* n_iter_out, void* workspace, size_t workspace_bytes, creg_stream_t stream) {
-    CREG_REQUIRE(local && world && seg_offsets && frame && M && M_out && world_out && n_iter_out && workspace,
-                 "creg_masked_icp_f64: null pointer");
-    CREG_REQUIRE(k >= 1 && nf >= 1 && nf < (1ll << 31) && max_iteration >= 1, "creg_masked_icp_f64: bad size");
-    CREG_REQUIRE(n >= 1 && n < (1ll << 31), "creg_masked_icp_f64: no source points");
-    hipStream_t s = (hipStream_t)stream;
-    const IcpLayout L = icp_layout(n, nf, k);
-    CREG_REQUIRE(workspace_bytes >= L.total, "creg_masked_icp_f64: workspace too small (%zu < %zu)", workspace_bytes, L.total);
-    char* w = (char*)workspace;
-    const int lds_cap = (int)(nf < 4096 ? nf : 4096);             // masked targets kept in LDS (28 B each, <= 112 KB)
-    const int smem = lds_cap * 28;
-    static bool attr_set = false;
-    if (!attr_set) {
-        CREG_HIP(hipFuncSetAttribute((const void*)k_masked_icp, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 28));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_masked_icp, dim3(k), dim3(256), smem, s, local, world, seg_offsets, frame, (int)nf, M,
-                       (float)(0.5 * scale), th, max_iteration, keep_translation, M_out, world_out, n_iter_out,
-                       (double*)(w + L.srcw), (int*)(w + L.tidx), (int*)(w + L.nn), lds_cap);
-    CREG_LAUNCH_CHECK();
-    return CREG_OK;
+    const creg_icp_problem p{local, world, seg_offsets, frame, M, M_out, world_out, n_iter_out};
+    return icp_launch(&p, 1, n, k, nf, scale, th, max_iteration, keep_translation, workspace, workspace_bytes,
+                      (hipStream_t)stream, "creg_masked_icp_f64");
+}
+
+extern "C" int creg_masked_icp_batch_f64(const creg_icp_problem* problems, int32_t batch, int64_t n, int32_t k, int64_t nf,
+                                         double scale, double th, int32_t max_iteration, int32_t keep_translation,
+                                         void* workspace, size_t workspace_bytes, creg_stream_t stream) {
+    return icp_launch(problems, batch, n, k, nf, scale, th, max_iteration, keep_translation,
+                      workspace, workspace_bytes, (hipStream_t)stream, "creg_masked_icp_batch_f64");
 }

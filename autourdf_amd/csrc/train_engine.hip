@@ -528,10 +528,11 @@ __device__ __forceinline__ float adam_value(float p, float& mm, float& vv, float
 // ([K][H] encoder activation for hidden rows, [K][H2] hidden activation for output rows, [K][IN]
 // features for encoder rows) in LDS with batched loads; a row's parameter / Adam-state loads are all
 // issued together.  No loop over K contains a global load.
-constexpr int DW_BLOCK = 256;         // 4 waves
+constexpr int DW_BLOCK = 512;         // 8 waves
+constexpr int DW_WAVES = DW_BLOCK / 64;
 constexpr int DW_RPW = 1;             // parameter rows per wave (1 measured best: 27 us vs 30 (2) vs 42 (4) at B=5;
                                       // fewer, fatter waves cost more than the staging traffic they save)
-constexpr int DW_RPB = 4 * DW_RPW;    // rows per block sharing one LDS copy of the activations
+constexpr int DW_RPB = DW_WAVES * DW_RPW;    // rows per block sharing one LDS copy of the activations
 struct DwRow { int oW, ob, o, n_in, aoff, kind; bool active; };
 
 __device__ __forceinline__ DwRow dw_row(const Dims& D, int bkind, int row) {
@@ -549,13 +550,13 @@ __device__ __forceinline__ DwRow dw_row(const Dims& D, int bkind, int row) {
 // and share ONE LDS copy of that kind's input activation matrix, fetched by LDS-DMA.  Parameter and
 // Adam-state loads of all rows, the gradient columns and the DMA are requested before the first wait.
 template <int NC>
-__global__ __launch_bounds__(DW_BLOCK, 3) void k_dw(Dims D, Ws W0, int epoch, size_t bstride) {
+__global__ __launch_bounds__(DW_BLOCK, 2) void k_dw(Dims D, Ws W0, int epoch, size_t bstride) {
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const TrainState S = W.state[(epoch + 1) & 1];
     const bool live = !S.stopped;                   // gates every store (no early exit: see k_bwd2)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int gsz = (4 * DW_RPW * D.K + 3) & ~3;
+    const int gsz = (DW_WAVES * DW_RPW * D.K + 3) & ~3;
     float* gall = (float*)smem;                     // [4 waves][DW_RPW][K] gradient columns
     float* as = (float*)smem + gsz;                 // staged activations [rc][width]
     const int par = epoch & 1;
@@ -841,7 +842,7 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     P->gexec = nullptr; P->graph_ready = false;
     P->smem_l2 = (int)(sizeof(float) * rows_per_chunk(D.K, D.H) * D.H);
     P->smem_bwd2 = (int)(sizeof(float) * (BW2_ROWS * ((D.K + 3) & ~3) + 16 * D.K + 8 * BW2_ROWS));
-    P->smem_dw = (int)(sizeof(float) * (((4 * DW_RPW * D.K + 3) & ~3) + STAGE_FLOATS + 64 * 4));
+    P->smem_dw = (int)(sizeof(float) * (((DW_WAVES * DW_RPW * D.K + 3) & ~3) + STAGE_FLOATS + 64 * 4));
     int rc_attr = 0;
     by_nc(D.H, [&](auto nc) {
         if (P->smem_dw > 65536 &&

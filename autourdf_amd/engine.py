@@ -83,3 +83,56 @@ class BatchRegistrar:
             r.pts, r.m = local.to(torch.float32), m2
             out.append((m2, o[2]))
         return out
+
+
+class IcpRegistrar:
+    """The ICP-style frame of the north star (SURVEY 8(d) second line), device resident, no MLP:
+    K3 cluster_transform (current world clusters = mask boxes) -> K4 masked point-to-point ICP of every
+    cluster against the new frame (cluster_icp.py:118-191) -> K5 poses as dual quaternions
+    (dq_func.py:100-124) -> K2 Lloyd k-means seeded at the new translations + change of frame
+    (resample_cluster, mlp_reg.py:172-237).  The same kernels the `--mlp_icp` branch of match() runs
+    (mlp_reg.py:325-326), minus train."""
+
+    def __init__(self, mats0, clusters0, device="cuda"):
+        self.device = torch.device(device)
+        self.M = torch.as_tensor(mats0, dtype=torch.float64).to(self.device).contiguous()
+        self.local, self.off = ops.pack_clusters(clusters0, self.device, torch.float64)
+
+    def step(self, frame64: torch.Tensor):
+        """Returns (poses (K,4,4) fp64, dual quaternions (K,8) fp32, ICP iterations (K) int32)."""
+        world32 = ops.cluster_transform(self.local.to(torch.float32), self.off, self.M.to(torch.float32))
+        M_new, _, n_it = ops.masked_icp(self.local, world32, self.off, frame64, self.M)
+        dq = ops.se3_to_dq(M_new.to(torch.float32))
+        _, labels, _, _ = ops.kmeans_lloyd(frame64, M_new[:, :3, 3].contiguous())
+        self.local, self.off = ops.group_to_local(frame64, labels, M_new)
+        self.M = M_new
+        return M_new, dq, n_it
+
+
+class BatchIcpRegistrar:
+    """S sequences of identical frame size through IcpRegistrar's steps in lock-step: the S ICP launches
+    share one launch (grid clusters x sequences) and the S re-segmentations one k-means launch (no host sync in a
+    round).  Results equal S separate IcpRegistrars (the batched k-means is bit-identical to the
+    multi-launch one)."""
+
+    def __init__(self, mats0, clusters0, n_sequences, device="cuda"):
+        self.regs = [IcpRegistrar(mats0, clusters0, device) for _ in range(n_sequences)]
+
+    def step(self, frames64):
+        worlds = [ops.cluster_transform(r.local.to(torch.float32), r.off, r.M.to(torch.float32)) for r in self.regs]
+        probs = [(r.local, w, r.off, f, r.M) for r, w, f in zip(self.regs, worlds, frames64)]
+        if len(probs) <= ops.ICP_BATCH_MAX and len({(p[0].shape[0], p[3].shape[0]) for p in probs}) == 1:
+            icp = ops.masked_icp_batch(probs)                  # all sequences' clusters in one launch
+        else:
+            icp = [ops.masked_icp(*p) for p in probs]
+        res = [(M_new, ops.se3_to_dq(M_new.to(torch.float32)), n_it) for M_new, _, n_it in icp]
+        inits = [o[0][:, :3, 3].contiguous() for o in res]
+        k = inits[0].shape[0]
+        if frames64[0].shape[0] <= ops.KMEANS_BATCH_MAX_N and len(self.regs) <= 16 and k <= 128:
+            km = ops.kmeans_lloyd_batch(frames64, inits)
+        else:
+            km = [ops.kmeans_lloyd(f, c) for f, c in zip(frames64, inits)]
+        for r, f, o, kr in zip(self.regs, frames64, res, km):
+            r.local, r.off = ops.group_to_local(f, kr[1], o[0])
+            r.M = o[0]
+        return res

@@ -182,6 +182,68 @@ def group_to_local(X: torch.Tensor, labels: torch.Tensor, M: torch.Tensor):
 
 
 # ------------------------------------------------------------------------------ K5 row conversions
+def masked_icp(local: torch.Tensor, world: torch.Tensor, offsets: torch.Tensor, frame: torch.Tensor, M: torch.Tensor,
+               scale: float = 1.2, th: float = 1.0, max_iteration: int = 10000, ori: bool = False):
+    """K4, device resident: AABB-masked point-to-point ICP of every cluster against `frame`, one launch
+    (reference cluster_icp.py:118-191 + open3d registration_icp).  local (n,3) f64 cluster-frame
+    points, world (n,3) f32 their current world positions (the mask boxes), offsets (k+1) int32,
+    frame (nf,3) f64, M (k,4,4) f64 initial poses.  Returns (M_out (k,4,4) f64, world_out (n,3) f64,
+    iterations (k) int32); stream-ordered, no host sync."""
+    L = _lib.load()
+    local, world = _need(local, torch.float64, "local"), _need(world, torch.float32, "world")
+    frame, M = _need(frame, torch.float64, "frame"), _need(M, torch.float64, "M")
+    offsets = _need(offsets, torch.int32, "offsets")
+    n, nf, k = local.shape[0], frame.shape[0], offsets.shape[0] - 1
+    if world.shape[0] != n or M.shape[0] != k:
+        raise ValueError("local/world/offsets/M disagree on sizes")
+    ws_bytes = L.creg_icp_workspace_bytes(n, nf, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=local.device)
+    M_out = torch.empty(k, 4, 4, dtype=torch.float64, device=local.device)
+    w_out = torch.empty(n, 3, dtype=torch.float64, device=local.device)
+    n_it = torch.empty(k, dtype=torch.int32, device=local.device)
+    _lib.check(L.creg_masked_icp_f64(_p(local), _p(world), n, _p(offsets), k, _p(frame), nf, _p(M), float(scale),
+                                     float(th), int(max_iteration), int(bool(ori)), _p(M_out), _p(w_out), _p(n_it),
+                                     _p(ws), ws_bytes, _stream()), "creg_masked_icp_f64")
+    return M_out, w_out, n_it
+
+
+ICP_BATCH_MAX = 16
+
+
+def masked_icp_batch(problems, scale: float = 1.2, th: float = 1.0, max_iteration: int = 10000, ori: bool = False):
+    """`masked_icp` for a list of (local, world, offsets, frame, M) of identical sizes in ONE launch
+    (grid clusters x problems); returns a list of (M_out, world_out, iterations), bit-identical to
+    separate calls."""
+    L = _lib.load()
+    B = len(problems)
+    if not 1 <= B <= ICP_BATCH_MAX:
+        raise ValueError(f"masked_icp_batch: 1..{ICP_BATCH_MAX} problems per launch, got {B}")
+    arr = (_lib.IcpProblem * B)()
+    keep, outs = [], []
+    n = nf = k = None
+    for b, (local, world, offsets, frame, M) in enumerate(problems):
+        local, world = _need(local, torch.float64, "local"), _need(world, torch.float32, "world")
+        frame, M = _need(frame, torch.float64, "frame"), _need(M, torch.float64, "M")
+        offsets = _need(offsets, torch.int32, "offsets")
+        shape = (local.shape[0], frame.shape[0], offsets.shape[0] - 1)
+        if b == 0:
+            n, nf, k = shape
+        if shape != (n, nf, k) or world.shape[0] != n or M.shape[0] != k:
+            raise ValueError("masked_icp_batch: all problems must share n, nf and k")
+        dev = local.device
+        M_out = torch.empty(k, 4, 4, dtype=torch.float64, device=dev)
+        w_out = torch.empty(n, 3, dtype=torch.float64, device=dev)
+        n_it = torch.empty(k, dtype=torch.int32, device=dev)
+        arr[b] = _lib.IcpProblem(_p(local), _p(world), _p(offsets), _p(frame), _p(M), _p(M_out), _p(w_out), _p(n_it))
+        keep.append((local, world, offsets, frame, M))
+        outs.append((M_out, w_out, n_it))
+    ws_bytes = L.creg_icp_batch_workspace_bytes(n, nf, k, B)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(L.creg_masked_icp_batch_f64(arr, B, n, k, nf, float(scale), float(th), int(max_iteration),
+                                           int(bool(ori)), _p(ws), ws_bytes, _stream()), "creg_masked_icp_batch_f64")
+    return outs
+
+
 def _rows(fn_name, a, out_shape, b=None, out2_shape=None):
     L = _lib.load()
     a = _need(a, torch.float32, "input")

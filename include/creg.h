@@ -155,6 +155,18 @@ int creg_masked_icp_f64(const double* local, const float* world, int64_t n, cons
                         double* M_out, double* world_out, int32_t* n_iter_out,
                         void* workspace, size_t workspace_bytes, creg_stream_t stream);
 
+/* The same for `batch` (<= 16) independent problems of identical n, nf and k (the frames of several
+ * sequences) in ONE launch: grid (k, batch).  Results are those of `batch` separate calls, bit for bit.
+ * workspace: creg_icp_batch_workspace_bytes(n, nf, k, batch). */
+typedef struct creg_icp_problem {
+    const double* local; const float* world; const int32_t* seg_offsets; const double* frame; const double* M;
+    double* M_out; double* world_out; int32_t* n_iter_out;
+} creg_icp_problem;
+size_t creg_icp_batch_workspace_bytes(int64_t n, int64_t nf, int32_t k, int32_t batch);
+int creg_masked_icp_batch_f64(const creg_icp_problem* problems, int32_t batch, int64_t n, int32_t k, int64_t nf,
+                              double scale, double th, int32_t max_iteration, int32_t keep_translation,
+                              void* workspace, size_t workspace_bytes, creg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * A1  the whole `train` loop (mlp_reg.py:17-152) as one device-resident plan: per epoch
  * pose -> sin/cos features -> MLP -> pose -> calculate_pc -> L1 Chamfer -> backward -> Adam ->

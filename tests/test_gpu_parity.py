@@ -207,6 +207,52 @@ def test_masked_icp_vs_reference_golden(dev, golden):
     np.testing.assert_allclose(np.concatenate(w), g["new_world"], atol=1e-8)
 
 
+def test_icp_registrar_two_frames_vs_oracle(dev):
+    """The ICP-style frame (K3 -> K4 -> K5 -> K2) device resident, against the oracle's composition
+    of the same reference steps; labels bit-exact, poses far inside 1e-5."""
+    from autourdf_amd.engine import IcpRegistrar
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    from oracle import dq as odq, icp as oicp, registration as oreg
+    seq = make_sequence("wx200_5", 7, 3, 2048)
+    mats, clusters, _ = initial_segmentation(seq[0], 12, seed=3)
+    reg = IcpRegistrar(mats, clusters, dev)
+    M = np.asarray(mats, np.float64)
+    local = [np.asarray(c, np.float64) for c in clusters]
+    for f in (1, 2):
+        frame = np.asarray(seq[f], np.float64)
+        M_gpu, dq_gpu, n_it = reg.step(torch.as_tensor(frame, device=dev))
+        M32 = M.astype(np.float32)
+        world32 = [c.astype(np.float32) @ m[:3, :3].T + m[:3, 3] for c, m in zip(local, M32)]
+        _, M_new = oicp.masked_icp(local, world32, frame, M)
+        np.testing.assert_allclose(M_gpu.cpu().numpy(), M_new, atol=1e-7)
+        dq_ref = odq.transform_to_dualquat(torch.from_numpy(M_new.astype(np.float32))).numpy()
+        np.testing.assert_allclose(dq_gpu.cpu().numpy(), dq_ref, atol=1e-5)
+        # continue both sides from the SAME poses so the label comparison is exact by construction
+        M = M_gpu.cpu().numpy()
+        local, labels = oreg.resample_cluster(frame, len(clusters), M)
+        off = reg.off.cpu().numpy()
+        assert [len(c) for c in local] == list(np.diff(off))
+        np.testing.assert_allclose(reg.local.cpu().numpy(), np.concatenate(local), atol=1e-9)
+        assert (n_it.cpu().numpy() >= 1).all()
+
+
+def test_batch_icp_registrar_equals_separate_registrars(dev):
+    from autourdf_amd.engine import BatchIcpRegistrar, IcpRegistrar
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    seqs = [make_sequence("wx200_5", 40 + s, 3, 2048) for s in range(3)]
+    mats, clusters, _ = initial_segmentation(seqs[0][0], 12, seed=3)
+    breg = BatchIcpRegistrar(mats, clusters, 3, dev)
+    singles = [IcpRegistrar(mats, clusters, dev) for _ in range(3)]
+    for f in (1, 2):
+        frames = [torch.as_tensor(s[f], dtype=torch.float64, device=dev) for s in seqs]
+        outs = breg.step(frames)
+        for r, fr, o in zip(singles, frames, outs):
+            M, dq, it = r.step(fr)
+            assert torch.equal(M, o[0]) and torch.equal(dq, o[1]) and torch.equal(it, o[2])
+    for r, b in zip(singles, breg.regs):
+        assert torch.equal(r.local, b.local) and torch.equal(r.off, b.off)
+
+
 # ------------------------------------------------------------------------------------------ A1
 def _train_case(golden, rot):
     g = golden("train_reference.npz")
