@@ -181,6 +181,35 @@ def group_to_local(X: torch.Tensor, labels: torch.Tensor, M: torch.Tensor):
     return out, off
 
 
+# ------------------------------------------------------------------------------ N2 pose distance maps
+def coord_dist_map(M: torch.Tensor, bounding_box: float, diff: bool = True):
+    """CoordMap.coord_dist_map (coord_map.py:230-307) for poses M (T,K,4,4) f64 on the device:
+    returns (coord_dist_map (K,K,T') f64, sum_map (K,K) f64), T' = T-1 if diff else T."""
+    L = _lib.load()
+    M = _need(M, torch.float64, "M")
+    if M.dim() != 4 or M.shape[2:] != (4, 4):
+        raise ValueError("coord_dist_map: M must be (T,K,4,4)")
+    T, K = M.shape[:2]
+    Tn = T - 1 if diff else T
+    d_map = torch.empty(K, K, Tn, dtype=torch.float64, device=M.device)
+    s_map = torch.empty(K, K, dtype=torch.float64, device=M.device)
+    ws_bytes = L.creg_coord_dist_map_workspace_bytes(T, K)
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=M.device)
+    _lib.check(L.creg_coord_dist_map_f64(_p(M), T, K, float(bounding_box), int(bool(diff)), _p(d_map), _p(s_map), _p(ws),
+                                         ws.numel(), _stream()), "creg_coord_dist_map_f64")
+    return d_map, s_map
+
+
+def pose_coords(M: torch.Tensor) -> torch.Tensor:
+    """(...,4,4) f64 poses -> (...,7) [xyz, pytorch3d quaternion wxyz] (load_matrix, coord_map.py:204-219)."""
+    L = _lib.load()
+    M = _need(M, torch.float64, "M")
+    n = M.numel() // 16
+    out = torch.empty(M.shape[:-2] + (7,), dtype=torch.float64, device=M.device)
+    _lib.check(L.creg_pose_coords_f64(_p(M), n, _p(out), _stream()), "creg_pose_coords_f64")
+    return out
+
+
 # ------------------------------------------------------------------------------ K5 row conversions
 def masked_icp(local: torch.Tensor, world: torch.Tensor, offsets: torch.Tensor, frame: torch.Tensor, M: torch.Tensor,
                scale: float = 1.2, th: float = 1.0, max_iteration: int = 10000, ori: bool = False):

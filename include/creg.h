@@ -168,6 +168,22 @@ int creg_masked_icp_batch_f64(const creg_icp_problem* problems, int32_t batch, i
                               void* workspace, size_t workspace_bytes, creg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * N2  pose-sequence distance maps, fp64: the consumer of match()'s matrix/*.npy files.  Replaces the
+ * Python loops of CoordMap.coord_dist_map (coord_map.py:230-307; roma rotmat_to_rotvec,
+ * utils.rotvec_geodesic_distance and rotmat_geodesic_distance inside) and load_matrix's
+ * pose -> xyz + quaternion step (coord_map.py:204-219).
+ * M (T,K,4,4) fp64 poses.  diff != 0: T-1 maps built from step-to-step motion differences and the
+ * row-distance step (:250-281); diff == 0: T maps of pose distances (:283-301).
+ * d_map (K,K,T') fp64 laid out like np.stack(..., axis=2); sum_map (K,K) = sum_t |d_map| (:304-305).
+ * bounding_box = CoordMap.bounding_box (diagonal of the raw clouds' AABB, :153-173).
+ * coords (n,7) = [x, y, z, qw, qx, qy, qz] with pytorch3d's matrix_to_quaternion in fp64. */
+size_t creg_coord_dist_map_workspace_bytes(int32_t T, int32_t K);
+int creg_coord_dist_map_f64(const double* M, int32_t T, int32_t K, double bounding_box, int32_t diff,
+                            double* d_map, double* sum_map, void* workspace, size_t workspace_bytes,
+                            creg_stream_t stream);
+int creg_pose_coords_f64(const double* M, int64_t n, double* coords, creg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * A1  the whole `train` loop (mlp_reg.py:17-152) as one device-resident plan: per epoch
  * pose -> sin/cos features -> MLP -> pose -> calculate_pc -> L1 Chamfer -> backward -> Adam ->
  * ReduceLROnPlateau, best-loss tracking and early stop, with no host round trip per epoch

@@ -21,6 +21,12 @@ What it restates (file:line into /root/reference, or the third-party wheel named
 * ``oracle.icp``          open3d==0.18.0 ``registration_icp`` point-to-point (cluster_icp.py:157)
                           + reference cluster_icp.py:118-191 masking         -- parity UNPINNED
 
+* ``oracle.coord_map``    reference PointCloud/coord_map.py:175-332 (CoordMap.load_matrix pose->quaternion,
+                          get_scale, coord_dist_map both branches, coord_dist_map_legacy) -- PINNED
+                          (reference loops run under shims -> tests/golden/coord_map_reference.npz);
+                          the roma functions inside (rotmat_to_rotvec, rotvec_geodesic_distance,
+                          rotmat_geodesic_distance; wheel absent)            -- parity UNPINNED
+
 "UNPINNED" = the reference repository holds no test, golden vector or vendored source for that
 third-party arithmetic; the restatement follows the published algorithm and
 is cross-checked against independent implementations (scipy Rotation, torch.cdist, numpy SVD).

@@ -209,3 +209,40 @@ def test_fps_is_a_permutation_prefix_and_spreads():
     d_sel = np.sqrt(((X[sel][:, None] - X[sel][None]) ** 2).sum(-1) + np.eye(64) * 1e9).min()
     d_rnd = np.sqrt(((X[:64][:, None] - X[:64][None]) ** 2).sum(-1) + np.eye(64) * 1e9).min()
     assert d_sel > d_rnd
+
+
+# ------------------------------------------------------------------------------------------ N2: pose distance maps
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_coord_map_oracle_vs_reference_golden(golden, tag):
+    """oracle.coord_map vs the reference CoordMap's own loops (coord_map.py:185-332 under shims)."""
+    from oracle import coord_map as ocm
+    g = golden("coord_map_reference.npz")
+    M, bbox = g[f"{tag}.matrices"], float(g[f"{tag}.bounding_box"])
+    coords = ocm.coords_from_matrices(M)
+    np.testing.assert_allclose(coords, g[f"{tag}.coords"], atol=1e-12)
+    assert abs(ocm.get_scale(coords) - float(g[f"{tag}.scale"])) < 1e-12
+    for diff in (True, False):
+        cmap, smap = ocm.coord_dist_map(M, bbox, diff)
+        np.testing.assert_allclose(cmap, g[f"{tag}.diff{int(diff)}.map"], atol=1e-12)
+        np.testing.assert_allclose(smap, g[f"{tag}.diff{int(diff)}.sum"], atol=1e-12)
+    cmap, smap = ocm.coord_dist_map_legacy(coords)
+    np.testing.assert_allclose(cmap, g[f"{tag}.legacy.map"], atol=1e-12)
+    np.testing.assert_allclose(smap, g[f"{tag}.legacy.sum"], atol=1e-12)
+
+
+def test_roma_restatement_vs_scipy_rotation():
+    """The unpinned roma arithmetic against an independent implementation."""
+    from scipy.spatial.transform import Rotation
+    from oracle import coord_map as ocm
+    rot = Rotation.random(200, random_state=3)
+    R = rot.as_matrix()
+    np.testing.assert_allclose(ocm.rotmat_to_rotvec(R), rot.as_rotvec(), atol=1e-12)
+    q = ocm.rotmat_to_unitquat(R)
+    qs = rot.as_quat()
+    np.testing.assert_allclose(q * np.sign(q[:, 3:4]), qs * np.sign(qs[:, 3:4]), atol=1e-12)
+    a, b = rot[:100], rot[100:]
+    want = (a.inv() * b).magnitude()
+    np.testing.assert_allclose(ocm.rotvec_geodesic_distance(a.as_rotvec(), b.as_rotvec()), want, atol=1e-9)
+    np.testing.assert_allclose(ocm.rotmat_geodesic_distance(a.as_matrix(), b.as_matrix()), want, atol=1e-7)
+    tiny = Rotation.from_rotvec(np.array([[1e-5, -2e-5, 3e-6], [0, 0, 0]]))
+    np.testing.assert_allclose(ocm.rotmat_to_rotvec(tiny.as_matrix()), tiny.as_rotvec(), atol=1e-15)
