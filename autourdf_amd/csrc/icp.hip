@@ -133,6 +133,7 @@ __device__ __forceinline__ void bsum_n(double (&v)[N], double* sc /* [4][N] */) 
 struct IcpBatch {
     const double* local[ICP_BATCH_MAX]; const float* world[ICP_BATCH_MAX]; const int* off[ICP_BATCH_MAX];
     const double* frame[ICP_BATCH_MAX]; const double* Min[ICP_BATCH_MAX];
+    const int* toff[ICP_BATCH_MAX];                    // point-to-point mode: target segment offsets into `frame`; null = masked mode
     double* Mout[ICP_BATCH_MAX]; double* world_out[ICP_BATCH_MAX]; int* n_iter_out[ICP_BATCH_MAX];
 };
 
@@ -160,7 +161,9 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
     const bool row = tid < ICP_ROWS;
     int* tidx = (int*)(wz + o_tidx) + (size_t)k * nf;
 
+    const int* __restrict__ toff = P.toff[z];         // block-uniform
     // ---- 1. box in float32, exactly as numpy evaluates it on the float32 cluster (min / max: any order) ----
+    if (!toff) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = b + tid; i < e; i += ICP_NT)
         for (int d = 0; d < 3; ++d) { const float v = world[3 * (size_t)i + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
@@ -180,16 +183,26 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
         }
         __syncthreads();
     }
+    }
     // ---- ordered compaction of the frame points strictly inside the box ----
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sT = (double*)smem;                       // [lds_cap][3] masked target coordinates
     int* sI = (int*)(sT + 3 * (size_t)lds_cap);       // [lds_cap]    their frame indices
     double* sS = (double*)(sI + lds_cap);             // [ICP_SRC_LDS][3] moving source points
     int* sN = (int*)(sS + 3 * ICP_SRC_LDS);           // [ICP_SRC_LDS] matched target slot / frame index, -1 = none
+    int run = 0;                                      // points kept so far (block-uniform)
+    if (toff) {                                       // point-to-point mode: the cluster's own target segment, unmasked
+        const int tb = toff[k];
+        run = toff[k + 1] - tb;
+        for (int t = tid; t < run; t += ICP_NT) {
+            const int j = tb + t;
+            tidx[t] = j;
+            if (t < lds_cap) { sT[3 * t] = frame[3 * (size_t)j]; sT[3 * t + 1] = frame[3 * (size_t)j + 1]; sT[3 * t + 2] = frame[3 * (size_t)j + 2]; sI[t] = j; }
+        }
+    }
     const double blo0 = (double)s_lo[0], blo1 = (double)s_lo[1], blo2 = (double)s_lo[2];
     const double bhi0 = (double)s_hi[0], bhi1 = (double)s_hi[1], bhi2 = (double)s_hi[2];
-    int run = 0;                                      // points kept so far (block-uniform)
-    for (int base = 0; base < nf; base += ICP_NT) {
+    for (int base = 0; base < (toff ? 0 : nf); base += ICP_NT) {
         const int j = base + tid;
         bool in = false;
         double x = 0, y = 0, zc = 0;
@@ -370,9 +383,10 @@ static int icp_launch(const creg_icp_problem* pr, int batch, int64_t n, int32_t 
     IcpBatch B;
     for (int i = 0; i < batch; ++i) {
         const creg_icp_problem& q = pr[i];
-        CREG_REQUIRE(q.local && q.world && q.seg_offsets && q.frame && q.M && q.M_out && q.world_out && q.n_iter_out,
+        CREG_REQUIRE(q.local && (q.world || q.tgt_offsets) && q.seg_offsets && q.frame && q.M && q.M_out && q.world_out && q.n_iter_out,
                      "%s: null pointer in problem %d", who, i);
         B.local[i] = q.local; B.world[i] = q.world; B.off[i] = q.seg_offsets; B.frame[i] = q.frame; B.Min[i] = q.M;
+        B.toff[i] = q.tgt_offsets;
         B.Mout[i] = q.M_out; B.world_out[i] = q.world_out; B.n_iter_out[i] = q.n_iter_out;
     }
     const int lds_cap = (int)(nf < 4096 ? nf : 4096);             // masked targets kept in LDS (28 B each, <= 112 KB)
@@ -393,7 +407,7 @@ extern "C" int creg_masked_icp_f64(const double* local, const float* world, int6
                                    const double* frame, int64_t nf, const double* M, double scale, double th,
                                    int32_t max_iteration, int32_t keep_translation, double* M_out, double* world_out,
                                    int32_t* n_iter_out, void* workspace, size_t workspace_bytes, creg_stream_t stream) {
-    const creg_icp_problem p{local, world, seg_offsets, frame, M, M_out, world_out, n_iter_out};
+    const creg_icp_problem p{local, world, seg_offsets, frame, M, M_out, world_out, n_iter_out, nullptr};
     return icp_launch(&p, 1, n, k, nf, scale, th, max_iteration, keep_translation, workspace, workspace_bytes,
                       (hipStream_t)stream, "creg_masked_icp_f64");
 }
@@ -403,4 +417,14 @@ extern "C" int creg_masked_icp_batch_f64(const creg_icp_problem* problems, int32
                                          void* workspace, size_t workspace_bytes, creg_stream_t stream) {
     return icp_launch(problems, batch, n, k, nf, scale, th, max_iteration, keep_translation,
                       workspace, workspace_bytes, (hipStream_t)stream, "creg_masked_icp_batch_f64");
+}
+
+extern "C" int creg_icp_p2p_f64(const double* src, int64_t n_src, const int32_t* src_offsets, const double* tgt,
+                                int64_t n_tgt, const int32_t* tgt_offsets, int32_t k, const double* init, double th,
+                                int32_t max_iteration, double* T_out, double* src_out, int32_t* n_iter_out,
+                                void* workspace, size_t workspace_bytes, creg_stream_t stream) {
+    CREG_REQUIRE(tgt_offsets, "creg_icp_p2p_f64: null pointer");
+    const creg_icp_problem p{src, nullptr, src_offsets, tgt, init, T_out, src_out, n_iter_out, tgt_offsets};
+    return icp_launch(&p, 1, n_src, k, n_tgt, 1.0, th, max_iteration, 0, workspace, workspace_bytes, (hipStream_t)stream,
+                      "creg_icp_p2p_f64");
 }

@@ -181,6 +181,58 @@ def group_to_local(X: torch.Tensor, labels: torch.Tensor, M: torch.Tensor):
     return out, off
 
 
+def icp_p2p_batch(problems, th: float = 1.0, max_iteration: int = 100000):
+    """N3: plain point-to-point ICP (open3d registration_icp semantics) of packed cloud pairs.
+    problems: list (<= 16) of (src (n,3) f64, src_offsets (k+1) i32, tgt (m,3) f64, tgt_offsets (k+1) i32,
+    init (k,4,4) f64) with identical n, m, k -- e.g. the time steps of link.refine_links_clusters
+    (link.py:85-127), each holding k links.  One launch (grid links x problems).
+    Returns a list of (T (k,4,4) f64, moved source (n,3) f64, iterations (k) i32)."""
+    L = _lib.load()
+    B = len(problems)
+    if not 1 <= B <= ICP_BATCH_MAX:
+        raise ValueError(f"icp_p2p_batch: 1..{ICP_BATCH_MAX} problems per launch, got {B}")
+    arr = (_lib.IcpProblem * B)()
+    keep, outs = [], []
+    for b, (src, soff, tgt, toff, init) in enumerate(problems):
+        src, tgt, init = _need(src, torch.float64, "src"), _need(tgt, torch.float64, "tgt"), _need(init, torch.float64, "init")
+        soff, toff = _need(soff, torch.int32, "src_offsets"), _need(toff, torch.int32, "tgt_offsets")
+        shape = (src.shape[0], tgt.shape[0], soff.shape[0] - 1)
+        if b == 0:
+            n, m, k = shape
+        if shape != (n, m, k) or toff.shape[0] != k + 1 or init.shape[0] != k:
+            raise ValueError("icp_p2p_batch: all problems must share n_src, n_tgt and k")
+        dev = src.device
+        T = torch.empty(k, 4, 4, dtype=torch.float64, device=dev)
+        moved = torch.empty(n, 3, dtype=torch.float64, device=dev)
+        n_it = torch.empty(k, dtype=torch.int32, device=dev)
+        arr[b] = _lib.IcpProblem(_p(src), None, _p(soff), _p(tgt), _p(init), _p(T), _p(moved), _p(n_it), _p(toff))
+        keep.append((src, soff, tgt, toff, init))
+        outs.append((T, moved, n_it))
+    ws_bytes = L.creg_icp_batch_workspace_bytes(n, m, k, B)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(L.creg_masked_icp_batch_f64(arr, B, n, k, m, 1.0, float(th), int(max_iteration), 0, _p(ws), ws_bytes,
+                                           _stream()), "creg_masked_icp_batch_f64")
+    return outs
+
+
+def icp_p2p(src, src_offsets, tgt, tgt_offsets, init, th: float = 1.0, max_iteration: int = 100000):
+    """`icp_p2p_batch` for one problem, through creg_icp_p2p_f64."""
+    L = _lib.load()
+    src, tgt, init = _need(src, torch.float64, "src"), _need(tgt, torch.float64, "tgt"), _need(init, torch.float64, "init")
+    soff, toff = _need(src_offsets, torch.int32, "src_offsets"), _need(tgt_offsets, torch.int32, "tgt_offsets")
+    n, m, k = src.shape[0], tgt.shape[0], soff.shape[0] - 1
+    if toff.shape[0] != k + 1 or init.shape[0] != k:
+        raise ValueError("icp_p2p: offsets / init disagree on the number of pairs")
+    T = torch.empty(k, 4, 4, dtype=torch.float64, device=src.device)
+    moved = torch.empty(n, 3, dtype=torch.float64, device=src.device)
+    n_it = torch.empty(k, dtype=torch.int32, device=src.device)
+    ws_bytes = L.creg_icp_workspace_bytes(n, m, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=src.device)
+    _lib.check(L.creg_icp_p2p_f64(_p(src), n, _p(soff), _p(tgt), m, _p(toff), k, _p(init), float(th), int(max_iteration),
+                                  _p(T), _p(moved), _p(n_it), _p(ws), ws_bytes, _stream()), "creg_icp_p2p_f64")
+    return T, moved, n_it
+
+
 # ------------------------------------------------------------------------------ N2 pose distance maps
 def coord_dist_map(M: torch.Tensor, bounding_box: float, diff: bool = True):
     """CoordMap.coord_dist_map (coord_map.py:230-307) for poses M (T,K,4,4) f64 on the device:
@@ -263,7 +315,7 @@ def masked_icp_batch(problems, scale: float = 1.2, th: float = 1.0, max_iteratio
         M_out = torch.empty(k, 4, 4, dtype=torch.float64, device=dev)
         w_out = torch.empty(n, 3, dtype=torch.float64, device=dev)
         n_it = torch.empty(k, dtype=torch.int32, device=dev)
-        arr[b] = _lib.IcpProblem(_p(local), _p(world), _p(offsets), _p(frame), _p(M), _p(M_out), _p(w_out), _p(n_it))
+        arr[b] = _lib.IcpProblem(_p(local), _p(world), _p(offsets), _p(frame), _p(M), _p(M_out), _p(w_out), _p(n_it), None)
         keep.append((local, world, offsets, frame, M))
         outs.append((M_out, w_out, n_it))
     ws_bytes = L.creg_icp_batch_workspace_bytes(n, nf, k, B)

@@ -161,11 +161,26 @@ int creg_masked_icp_f64(const double* local, const float* world, int64_t n, cons
 typedef struct creg_icp_problem {
     const double* local; const float* world; const int32_t* seg_offsets; const double* frame; const double* M;
     double* M_out; double* world_out; int32_t* n_iter_out;
+    const int32_t* tgt_offsets;   /* NULL: masked mode above.  Non-NULL (k+1 offsets into `frame`): point-to-point
+                                     mode, cluster i registers to frame[tgt_offsets[i] .. tgt_offsets[i+1]) unmasked,
+                                     `world` is ignored and nf is the total number of target points */
 } creg_icp_problem;
 size_t creg_icp_batch_workspace_bytes(int64_t n, int64_t nf, int32_t k, int32_t batch);
 int creg_masked_icp_batch_f64(const creg_icp_problem* problems, int32_t batch, int64_t n, int32_t k, int64_t nf,
                               double scale, double th, int32_t max_iteration, int32_t keep_translation,
                               void* workspace, size_t workspace_bytes, creg_stream_t stream);
+
+/* N3  plain point-to-point ICP of k independent (source, target) cloud pairs in one launch: the
+ * registration_icp(source, target, threshold, init, TransformationEstimationPointToPoint,
+ * ICPConvergenceCriteria(max_iteration)) calls of link.refine_links_clusters (link.py:85-127, th = 1,
+ * init = I, per link and time step) and Sim/evaluation.py:358-362 (th = 0.01).  Same kernel, iteration and
+ * stopping rule as K4 without the box mask.  src (n_src,3) / tgt (n_tgt,3) fp64 segments back to back,
+ * init and T_out (k,4,4) fp64, src_out = T_out applied to src.  Several time steps per launch:
+ * creg_masked_icp_batch_f64 with tgt_offsets set.  workspace: creg_icp_workspace_bytes(n_src, n_tgt, k). */
+int creg_icp_p2p_f64(const double* src, int64_t n_src, const int32_t* src_offsets, const double* tgt, int64_t n_tgt,
+                     const int32_t* tgt_offsets, int32_t k, const double* init, double th, int32_t max_iteration,
+                     double* T_out, double* src_out, int32_t* n_iter_out,
+                     void* workspace, size_t workspace_bytes, creg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * N2  pose-sequence distance maps, fp64: the consumer of match()'s matrix/*.npy files.  Replaces the

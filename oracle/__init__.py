@@ -27,6 +27,10 @@ What it restates (file:line into /root/reference, or the third-party wheel named
                           the roma functions inside (rotmat_to_rotvec, rotvec_geodesic_distance,
                           rotmat_geodesic_distance; wheel absent)            -- parity UNPINNED
 
+* ``oracle.link``         reference PointCloud/link.py:85-127 (refine_links_clusters) and the ICP filter of
+                          Sim/evaluation.py:358-362                          -- PINNED (composition; reference
+                          function run on disk under shims -> tests/golden/link_refine_reference.npz)
+
 "UNPINNED" = the reference repository holds no test, golden vector or vendored source for that
 third-party arithmetic; the restatement follows the published algorithm and
 is cross-checked against independent implementations (scipy Rotation, torch.cdist, numpy SVD).

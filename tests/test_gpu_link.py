@@ -1,0 +1,77 @@
+"""N3: link refinement and the evaluation ICP filter on the K4 kernel's point-to-point mode."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_links(g, d, T):
+    os.makedirs(d + "cluster")
+    for t in range(T):
+        np.savez(d + f"cluster/{t:04}.npz", **{str(i): g[f"in.{t}.{i}"] for i in range(4)})
+
+
+def test_refine_links_clusters_vs_reference_golden(golden, tmp_path):
+    from autourdf_amd.helper_functions import load_pc_npz
+    from autourdf_amd.link import refine_links_clusters
+    g = golden("link_refine_reference.npz")
+    T, dof = int(g["T"]), int(g["dof"])
+    d = str(tmp_path) + "/"
+    _write_links(g, d, T)
+    refine_links_clusters([d], 0, T, dof)
+    for t in range(T):
+        got = load_pc_npz(d + f"cluster_rf/{t:04}.npz")
+        assert len(got) == dof + 1
+        for i in range(dof + 1):
+            assert got[i].dtype == np.float64
+            np.testing.assert_allclose(got[i], g[f"out.{t}.{i}"], atol=1e-8)       # poses: 1e-5 demanded
+
+
+def test_icp_p2p_single_equals_batch_and_oracle(golden):
+    """creg_icp_p2p_f64 == the batched entry point bit for bit; both within 1e-8 of the oracle ICP;
+    sources larger than the LDS budget (workspace path) and an empty pair."""
+    from autourdf_amd import ops
+    from oracle.icp import registration_icp
+    from scipy.spatial.transform import Rotation
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(2)
+    tgt = [rng.uniform(-0.2, 0.2, size=(n, 3)) for n in (1500, 300, 64)]
+    src = []
+    for c in tgt:
+        R = Rotation.from_rotvec(rng.normal(scale=0.02, size=3)).as_matrix()
+        src.append(c[rng.permutation(len(c))[: len(c) - 7]] @ R.T + rng.normal(scale=0.003, size=3))
+    src.append(np.zeros((0, 3))); tgt.append(rng.uniform(size=(10, 3)))                 # empty source: T stays I
+    cat = lambda cs: torch.as_tensor(np.concatenate(cs), device=dev)
+    off = lambda cs: torch.tensor(np.concatenate([[0], np.cumsum([len(c) for c in cs])]), dtype=torch.int32, device=dev)
+    init = torch.eye(4, dtype=torch.float64, device=dev).repeat(len(src), 1, 1)
+    T1, m1, it1 = ops.icp_p2p(cat(src), off(src), cat(tgt), off(tgt), init, th=1.0, max_iteration=1000)
+    (T2, m2, it2), (T3, _, _) = ops.icp_p2p_batch([(cat(src), off(src), cat(tgt), off(tgt), init)] * 2, th=1.0, max_iteration=1000)
+    assert torch.equal(T1, T2) and torch.equal(m1, m2) and torch.equal(it1, it2) and torch.equal(T2, T3)
+    o = off(src).cpu().numpy()
+    for i, (s, t) in enumerate(zip(src, tgt)):
+        if len(s) == 0:
+            np.testing.assert_array_equal(T1[i].cpu().numpy(), np.eye(4))
+            continue
+        T_ref, _, _, _ = registration_icp(s, t, 1.0, np.eye(4), 1000)
+        np.testing.assert_allclose(T1[i].cpu().numpy(), T_ref, atol=1e-8)
+        np.testing.assert_allclose(m1[o[i]:o[i + 1]].cpu().numpy(), s @ T_ref[:3, :3].T + T_ref[:3, 3], atol=1e-8)
+
+
+def test_evaluation_icp_filter_and_chamfer_vs_oracle():
+    """Sim/evaluation.py:69-81,358-362: ICP filter (th 0.01) then L1 Chamfer in float32."""
+    from autourdf_amd.cluster_icp import PointCloud
+    from autourdf_amd.evaluation import icp_filter, torch_chamfer_distance
+    from oracle import chamfer as ochamfer, link as olink
+    rng = np.random.default_rng(8)
+    gt = rng.uniform(-0.1, 0.1, size=(900, 3))
+    pred = gt[:850] + np.array([0.002, -0.001, 0.0015]) + rng.normal(scale=2e-4, size=(850, 3))
+    T, moved = icp_filter(PointCloud(pred), PointCloud(gt))
+    T_ref, moved_ref = olink.icp_filter(pred, gt)
+    np.testing.assert_allclose(T, T_ref, atol=1e-8)
+    np.testing.assert_allclose(moved.points, moved_ref, atol=1e-8)
+    loss = torch_chamfer_distance(moved, PointCloud(gt))
+    want = ochamfer.chamfer_distance(torch.tensor(moved_ref, dtype=torch.float32)[None], torch.tensor(gt, dtype=torch.float32)[None], norm=1)[0].item()
+    assert abs(loss - want) <= 1e-6 * max(1.0, abs(want))

@@ -246,3 +246,17 @@ def test_roma_restatement_vs_scipy_rotation():
     np.testing.assert_allclose(ocm.rotmat_geodesic_distance(a.as_matrix(), b.as_matrix()), want, atol=1e-7)
     tiny = Rotation.from_rotvec(np.array([[1e-5, -2e-5, 3e-6], [0, 0, 0]]))
     np.testing.assert_allclose(ocm.rotmat_to_rotvec(tiny.as_matrix()), tiny.as_rotvec(), atol=1e-15)
+
+
+# ------------------------------------------------------------------------------------------ N3: link refinement
+def test_link_refine_oracle_vs_reference_golden(golden):
+    """oracle.link.refine_links vs the reference refine_links_clusters run on disk (link.py:85-127)."""
+    from oracle import link as olink
+    g = golden("link_refine_reference.npz")
+    T, dof = int(g["T"]), int(g["dof"])
+    clusters = [[g[f"in.{t}.{i}"] for i in range(4)] for t in range(T)]
+    moved = olink.refine_links(clusters, clusters[0], dof)
+    for t in range(T):
+        assert len(moved[t]) == dof + 1
+        for i in range(dof + 1):
+            np.testing.assert_allclose(moved[t][i], g[f"out.{t}.{i}"], atol=1e-12)
