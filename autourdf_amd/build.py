@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcreg.so")
-SOURCES = ["core.hip", "nn_l1.hip", "transform.hip", "se3.hip", "kmeans.hip", "icp.hip", "fps.hip", "coord_map.hip", "train_engine.hip"]
+SOURCES = ["core.hip", "nn_l1.hip", "transform.hip", "se3.hip", "kmeans.hip", "icp.hip", "fps.hip", "coord_map.hip", "sample.hip", "train_engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function"]
 

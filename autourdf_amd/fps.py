@@ -9,9 +9,12 @@ from . import _lib, ops
 
 
 def farthest_point_sample(points, num_samples: int) -> np.ndarray:
-    """points (N,3) array-like (fp64) -> int64 indices of the selected points, in selection order."""
+    """points (N,3) array-like or CUDA tensor (fp64) -> int64 indices of the selected points, in selection order."""
     L = _lib.load()
-    X = torch.as_tensor(np.asarray(points, np.float64), device="cuda").contiguous()
+    if isinstance(points, torch.Tensor) and points.is_cuda:
+        X = points.to(torch.float64).contiguous()
+    else:
+        X = torch.as_tensor(np.asarray(points, np.float64), device="cuda").contiguous()
     n = X.shape[0]
     if not (1 <= num_samples <= n):
         raise ValueError("need 1 <= num_samples <= number of points")

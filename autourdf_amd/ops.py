@@ -233,6 +233,24 @@ def icp_p2p(src, src_offsets, tgt, tgt_offsets, init, th: float = 1.0, max_itera
     return T, moved, n_it
 
 
+# ------------------------------------------------------------------------------ N4 mesh surface sampling
+def sample_mesh(tri, cum_area, tri_link, link_T, u, with_links: bool = False):
+    """Area-weighted points on an articulated triangle mesh (creg_sample_mesh_f64): tri (F,3,3) f64 in link
+    frames, cum_area (F) f64, tri_link (F) i32, link_T (L,4,4) f64, u (n,3) f64 uniforms -> (n,3) f64 world points
+    (and the link index of every point when with_links)."""
+    L = _lib.load()
+    tri, cum_area, link_T, u = (_need(t, torch.float64, nm) for t, nm in ((tri, "tri"), (cum_area, "cum_area"), (link_T, "link_T"), (u, "u")))
+    tri_link = _need(tri_link, torch.int32, "tri_link")
+    n, F = u.shape[0], tri.shape[0]
+    if cum_area.shape[0] != F or tri_link.shape[0] != F:
+        raise ValueError("sample_mesh: tri / cum_area / tri_link disagree on the number of triangles")
+    out = torch.empty(n, 3, dtype=torch.float64, device=u.device)
+    links = torch.empty(n, dtype=torch.int32, device=u.device) if with_links else None
+    _lib.check(L.creg_sample_mesh_f64(_p(tri), _p(cum_area), _p(tri_link), F, _p(link_T), link_T.shape[0], _p(u), n, _p(out),
+                                      _p(links) if with_links else None, _stream()), "creg_sample_mesh_f64")
+    return (out, links) if with_links else out
+
+
 # ------------------------------------------------------------------------------ N2 pose distance maps
 def coord_dist_map(M: torch.Tensor, bounding_box: float, diff: bool = True):
     """CoordMap.coord_dist_map (coord_map.py:230-307) for poses M (T,K,4,4) f64 on the device:

@@ -199,6 +199,16 @@ int creg_coord_dist_map_f64(const double* M, int32_t T, int32_t K, double boundi
 int creg_pose_coords_f64(const double* M, int64_t n, double* coords, creg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * N4  synthetic frames from a URDF + triangle meshes (the data side: Sim/sim_data.py:246-370 renders and
+ * fuses depth images of the PyBullet model; here the mesh surfaces are sampled directly).
+ * tri (n_tri,3,3) fp64 triangles in their link's frame, cum_area (n_tri) inclusive prefix sum of their
+ * areas, tri_link (n_tri) link index, link_T (n_links,4,4) link poses of the current joint state,
+ * u (n,3) uniforms in [0,1).  out (n,3) world points, link_out (n) optional link index per point. */
+int creg_sample_mesh_f64(const double* tri, const double* cum_area, const int32_t* tri_link, int32_t n_tri,
+                         const double* link_T, int32_t n_links, const double* u, int64_t n, double* out,
+                         int32_t* link_out, creg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * A1  the whole `train` loop (mlp_reg.py:17-152) as one device-resident plan: per epoch
  * pose -> sin/cos features -> MLP -> pose -> calculate_pc -> L1 Chamfer -> backward -> Adam ->
  * ReduceLROnPlateau, best-loss tracking and early stop, with no host round trip per epoch

@@ -31,6 +31,11 @@ What it restates (file:line into /root/reference, or the third-party wheel named
                           Sim/evaluation.py:358-362                          -- PINNED (composition; reference
                           function run on disk under shims -> tests/golden/link_refine_reference.npz)
 
+* ``oracle.sim_data``     numpy restatement of creg_sample_mesh_f64 (bit-exact check) and an independent
+                          URDF forward kinematics (scipy Rotation); ``angle_list`` is pinned by the reference's
+                          own function (Sim/sim_data.py:372-430 -> tests/golden/sim_angle_list.npz); the
+                          PyBullet/OpenGL rendering it replaces is not restatable     -- parity UNPINNED
+
 "UNPINNED" = the reference repository holds no test, golden vector or vendored source for that
 third-party arithmetic; the restatement follows the published algorithm and
 is cross-checked against independent implementations (scipy Rotation, torch.cdist, numpy SVD).
