@@ -199,7 +199,7 @@ __global__ __launch_bounds__(1024) void k_km_finalize(const double* __restrict__
                                                       double* __restrict__ B, double* __restrict__ Cw,
                                                       double* __restrict__ far_d, KmFlags* __restrict__ f) {
     __shared__ double sc[16];
-    __shared__ int s_nempty, s_argmax, s_far;
+    __shared__ int s_nempty, s_argmax;
     __shared__ double s_dmax;
     if (f->done) return;
     const int cur = f->cur;
@@ -250,7 +250,6 @@ __global__ __launch_bounds__(1024) void k_km_finalize(const double* __restrict__
                 __syncthreads();
                 if (threadIdx.x == 0) {
                     for (int w = 0; w < 16; ++w) if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) { bv = s_v[w]; bi = s_i[w]; }
-                    s_far = bi;
                     far_d[bi] = -2;
                     const int old = labels[bi];
                     for (int d = 0; d < 3; ++d) { Cw[4 * old + d] -= X[3 * (size_t)bi + d]; Cw[4 * j + d] = X[3 * (size_t)bi + d]; }
@@ -332,7 +331,7 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* Xc = (double*)smem;                               // [n][3] centred points
     __shared__ double sc[16];
-    __shared__ double s_mean[3], s_tol, s_shift;
+    __shared__ double s_mean[3], s_tol;
     __shared__ double gpart[4][4][4];                         // [group][wave in group][x,y,z,w]
     __shared__ int s_changed, s_done, s_strict, s_it, s_nempty, s_argmax;
     __shared__ double s_dmax, s_fv[16];
@@ -477,7 +476,6 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
         if (tid == 0) {
             double tot = 0;
             for (int j = 0; j < k; ++j) tot += s_sh[j];
-            s_shift = tot;
             s_it = it + 1;
             if (s_changed == 0) { s_strict = 1; s_done = 1; }
             else if (tot <= s_tol) s_done = 1;

@@ -186,7 +186,6 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_l2(Dims D, Ws W0, int par, size_t
         }
         stage_wait();
         __syncthreads();
-#pragma unroll 4
         for (int r = 0; r < nr; ++r) {
             float s = 0.f;
 #pragma unroll
@@ -656,7 +655,6 @@ __global__ __launch_bounds__(DW_BLOCK, 2) void k_dw(Dims D, Ws W0, int epoch, si
 #pragma unroll
         for (int q = 0; q < DW_RPW; ++q) {
             if (!R[q].active) continue;
-#pragma unroll 4
             for (int r = 0; r < D.K; ++r) {
                 float v = 0.f;
                 if (lane * 4 < D.IN) {

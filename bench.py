@@ -216,7 +216,8 @@ def main():
         traffic = None
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_nn_l1_pmc.json")
         if os.path.exists(pmc) and args.workload == "wx200_5":
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            per_problem = json.load(open(pmc)).get("hbm_bytes_per_problem")      # PMC passes, tools/collect_profiles.sh
+            traffic = per_problem * nn_problems if per_problem else None
         roof = {"bound": "valu", "kernel": "k_nn_l1<4,int,EngineEpi>", "achieved": round(achieved, 3),
                 "peak": round(VALU_PEAK_TOPS, 1), "unit": "TFLOP/s", "frac": round(achieved / VALU_PEAK_TOPS, 4),
                 "traffic": traffic, "avg_launch_us": round(nn_us, 3), "problems_per_launch": nn_problems,

@@ -183,7 +183,7 @@ int creg_icp_p2p_f64(const double* src, int64_t n_src, const int32_t* src_offset
                      void* workspace, size_t workspace_bytes, creg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * N2  pose-sequence distance maps, fp64: the consumer of match()'s matrix/*.npy files.  Replaces the
+ * N2  pose-sequence distance maps, fp64: the consumer of match()'s matrix/NNNN.npy files.  Replaces the
  * Python loops of CoordMap.coord_dist_map (coord_map.py:230-307; roma rotmat_to_rotvec,
  * utils.rotvec_geodesic_distance and rotmat_geodesic_distance inside) and load_matrix's
  * pose -> xyz + quaternion step (coord_map.py:204-219).
