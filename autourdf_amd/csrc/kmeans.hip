@@ -327,7 +327,7 @@ struct KmBatch {
 };
 
 __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int max_iter, double tol_rel,
-                                                   char* __restrict__ ws, size_t ws_stride) {
+                                                   char* __restrict__ ws, size_t ws_stride, int c_in_lds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* Xc = (double*)smem;                               // [n][3] centred points
     __shared__ double sc[16];
@@ -339,12 +339,17 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
     const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double* X = A.X[z];
     char* w = ws + (size_t)z * ws_stride;                     // per-problem global scratch: C2 (6k), Cw (4k), far (n)
-    double* C2 = (double*)w; double* Cw = C2 + 10 * k; double* far_d = Cw + 4 * k;
+    double* far_d = (double*)w + 14 * k;
     // LDS: Xc [3n] | (-2c, |c|^2) rows [4k] | labels ping-pong as 16-bit values [2n] (k <= 128 here).  The
     // E-step reads every centre row and the accumulation sweeps read every label ceil(k/4) times per
     // iteration; from global memory each of those reads was a dependent round trip.
     double* Bm = Xc + 3 * (size_t)n;
     unsigned short* lab[2] = {(unsigned short*)(Bm + 4 * k), (unsigned short*)(Bm + 4 * k) + n};
+    // centre ping-pong C2 [2][k][3] (+ spare) and per-cluster sums Cw [k][4]: in LDS when they fit next to the
+    // frame (every Lloyd iteration reads and writes them several times between barriers -- from global memory
+    // each of those was a dependent ~1 us round trip inside the workgroup), else in the global scratch
+    double* C2 = c_in_lds ? (double*)(smem + (((size_t)(3 * n + 4 * k) * 8 + 4 * (size_t)n + 7) & ~(size_t)7)) : (double*)w;
+    double* Cw = C2 + 10 * k;
     // ---- mean / tol (k_km_stats) ----
     double var = 0;
     for (int d = 0; d < 3; ++d) {
@@ -709,14 +714,17 @@ extern "C" int creg_kmeans_lloyd_batch_f64(const double* const* X, int64_t n, co
         CREG_REQUIRE(X[b] && init[b] && centers[b] && labels[b] && inertia[b] && n_iter[b], "creg_kmeans_lloyd_batch_f64: null pointer in problem %d", b);
         A.X[b] = X[b]; A.init[b] = init[b]; A.centers[b] = centers[b]; A.labels[b] = labels[b]; A.inertia[b] = inertia[b]; A.n_iter[b] = n_iter[b];
     }
-    const int smem = (int)(sizeof(double) * (3 * n + 4 * k) + 2 * sizeof(unsigned short) * n);
+    int smem = (int)(sizeof(double) * (3 * n + 4 * k) + 2 * sizeof(unsigned short) * n);
+    const int with_c = ((smem + 7) & ~7) + (int)sizeof(double) * 14 * k;
+    const int c_in_lds = with_c <= 5120 * 28 + 128 * 32;           // the limit requested from the runtime below
+    if (c_in_lds) smem = with_c;
     static bool attr_set = false;
     if (!attr_set) {
         CREG_HIP(hipFuncSetAttribute((const void*)k_km_small, hipFuncAttributeMaxDynamicSharedMemorySize, 5120 * 28 + 128 * 32));
         attr_set = true;
     }
     hipLaunchKernelGGL(k_km_small, dim3(batch), dim3(1024), smem, (hipStream_t)stream, A, (int)n, k, max_iter, tol_rel,
-                       (char*)workspace, kms_stride(n, k));
+                       (char*)workspace, kms_stride(n, k), c_in_lds);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }

@@ -152,14 +152,14 @@ def main():
     # configs[1]: 5 independent sequences per GPU (10 frames each in the reference's data set).  Frames of
     # ONE sequence are sequentially dependent (mlp_reg.py:293-378) but sequences are independent, so the S
     # sequences advance in lock-step through ONE batched plan: every launch carries S problems.
-    # Step i of a rank is frame (i // S) + 1 of its sequence i % S.  Any --steps K / --warmup W works:
-    # S is 5 when it divides K, else K itself (K <= 16), else the largest divisor of K in [2, 8], else 5 with the last round
-    # padded (the padding is timed but not counted, so the reported value can only be understated);
-    # sequences are generated as long as W and K require.
-    S = max(1, args.sequences)
+    # Step i of a rank is frame (i // S) + 1 of its sequence i % S.  Any --steps K / --warmup W works without ever
+    # putting MORE sequences in flight than the configuration has (5): S = --sequences when it divides K, else the
+    # largest divisor of K in [2, S), else S with the last round padded (the padding is timed but not counted, so
+    # the reported value can only be understated); sequences are generated as long as W and K require.
+    S = min(max(1, args.sequences), args.steps)
     if args.steps % S:
-        divs = [d for d in range(8, 1, -1) if args.steps % d == 0]
-        S = args.steps if args.steps <= 16 else (divs[0] if divs else S)
+        divs = [d for d in range(S - 1, 1, -1) if args.steps % d == 0]
+        S = divs[0] if divs else S
     n_seq = S
     warm_rounds = (args.warmup + S - 1) // S
     timed_rounds = (args.steps + S - 1) // S
