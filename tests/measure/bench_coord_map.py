@@ -1,7 +1,7 @@
 """N2 measurement: creg_coord_dist_map_f64 on the GPU vs the oracle (vectorised numpy restatement of
 CoordMap.coord_dist_map) on the host, same inputs.  Writes one line per size.
 
-    python tools/bench_coord_map.py > gpurun_out/coord_map.log
+    python tests/measure/bench_coord_map.py > gpurun_out/coord_map.log
 """
 import os
 import sys
@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from autourdf_amd import ops          # noqa: E402
 from oracle import coord_map as ocm   # noqa: E402  (checker / CPU baseline only)
 from scipy.spatial.transform import Rotation  # noqa: E402

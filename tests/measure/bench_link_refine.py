@@ -1,7 +1,7 @@
 """N3 measurement: link refinement (point-to-point ICP of every link of every time step to the first
 step) on the GPU vs the oracle's ICP on the host.  wx200_5-shaped: 10 steps x 6 links, N=4096.
 
-    python tools/bench_link_refine.py > gpurun_out/link_refine.log
+    python tests/measure/bench_link_refine.py > gpurun_out/link_refine.log
 """
 import os
 import sys
@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from autourdf_amd import ops                      # noqa: E402
 from autourdf_amd.synthetic import make_sequence  # noqa: E402
 from oracle import link as olink                  # noqa: E402  (checker / CPU baseline only)

@@ -1,7 +1,7 @@
 """N4 measurement: creg_sample_mesh_f64 (area-weighted surface sampling of a posed mesh) on the GPU vs the numpy
 oracle, same inputs; algorithmic bytes = 24 (uniforms) + 72 (triangle) + 24 (point) per sample.
 
-    python tools/bench_sample_mesh.py > gpurun_out/sample_mesh.log
+    python tests/measure/bench_sample_mesh.py > gpurun_out/sample_mesh.log
 """
 import os
 import sys
@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from autourdf_amd import ops            # noqa: E402
 from oracle import sim_data as osim     # noqa: E402  (checker / CPU baseline only)
 
