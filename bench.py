@@ -213,6 +213,7 @@ def main():
         # back-to-back timing launches exactly that grid
         alg_ops = 9.0 * N_POINTS * N_POINTS * nn_problems
         achieved = alg_ops / (nn_us * 1e-6) / 1e12
+        alg_bytes = nn_problems * (2 * 12 * N_POINTS + 2 * (4 + 8) * N_POINTS)
         traffic = None
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_nn_l1_pmc.json")
         if os.path.exists(pmc) and args.workload == "wx200_5":
@@ -221,6 +222,10 @@ def main():
         roof = {"bound": "valu", "kernel": "k_nn_l1<4,int,EngineEpi>", "achieved": round(achieved, 3),
                 "peak": round(VALU_PEAK_TOPS, 1), "unit": "TFLOP/s", "frac": round(achieved / VALU_PEAK_TOPS, 4),
                 "traffic": traffic, "avg_launch_us": round(nn_us, 3), "problems_per_launch": nn_problems,
+                # the same launch against the HBM roofline, to show it is not the bound: algorithmic bytes (both clouds
+                # in, distances + indices' worth of results out) / launch time vs 8 TB/s
+                "hbm_view": {"algorithmic_bytes": alg_bytes, "achieved_GBps": round(alg_bytes / (nn_us * 1e-6) / 1e9, 2),
+                             "peak_GBps": 8000.0, "frac": round(alg_bytes / (nn_us * 1e-6) / 8e12, 5)},
                 "epoch_kernels_event_bracketed_us": {k: round(v, 2) for k, v in prof.items()},
                 "note": "L1 min-search is sub/add/min work: not a contraction (no MFMA) and ~200 KB of algorithmic "
                         "traffic (not HBM); bound = fp32 VALU issue. achieved = 9*N^2 algorithmic lane-ops (SURVEY 8d) / "
