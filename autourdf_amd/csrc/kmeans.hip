@@ -398,12 +398,25 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
         __syncthreads();
         // ---- per-cluster sums in k_km_accumulate's order: groups of 256 threads emulate its blocks ----
         const int g = tid >> 8, tg = tid & 255, wg = (tid >> 6) & 3;
+        // this thread's points (tg, tg + 256, ...) keep their labels in registers for all ceil(k/4) sweeps, and
+        // a sweep is branch-free: adding +0.0 for foreign points leaves every partial sum bit-identical to the
+        // conditional accumulation (the sums start at +0.0 and can never become -0.0)
+        constexpr int KMS_PTS = 20;                            // ceil(5120 / 256)
+        int lbl[KMS_PTS];
+#pragma unroll
+        for (int m = 0; m < KMS_PTS; ++m) { const int i = tg + 256 * m; lbl[m] = i < n ? (int)lcur[i] : -1; }
         for (int j0 = 0; j0 < k; j0 += 4) {
             const int j = j0 + g;
             double a0 = 0, a1 = 0, a2 = 0, aw = 0;
-            if (j < k)
-                for (int i = tg; i < n; i += 256)
-                    if ((int)lcur[i] == j) { a0 += Xc[3 * i]; a1 += Xc[3 * i + 1]; a2 += Xc[3 * i + 2]; aw += 1.0; }
+            if (j < k) {
+#pragma unroll
+                for (int m = 0; m < KMS_PTS; ++m) {
+                    const int i = min(tg + 256 * m, n - 1);
+                    const bool mine = lbl[m] == j;
+                    const double x0 = Xc[3 * i], x1 = Xc[3 * i + 1], x2 = Xc[3 * i + 2];
+                    a0 += mine ? x0 : 0.0; a1 += mine ? x1 : 0.0; a2 += mine ? x2 : 0.0; aw += mine ? 1.0 : 0.0;
+                }
+            }
             a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); aw = wave_sum(aw);
             if (lane == 0) { gpart[g][wg][0] = a0; gpart[g][wg][1] = a1; gpart[g][wg][2] = a2; gpart[g][wg][3] = aw; }
             __syncthreads();
