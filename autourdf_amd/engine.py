@@ -16,14 +16,17 @@ class SequenceRegistrar:
         self.plan = ops.TrainPlan(rot, self.K, hidden, self.pts.shape[0], n_tgt, epochs=epochs, use_graph=use_graph,
                                   device=self.device)
 
-    def _init_state(self, mats0, clusters0, rot, hidden, device, seed):
+    def _init_state(self, mats0, clusters0, rot, hidden, device, seed, models=None):
         self.device = device
         self.rot, self.K = rot, len(clusters0)
-        gen_state = torch.random.get_rng_state()
-        torch.manual_seed(seed)                      # the reference leaves the MLP init unseeded
-        ctor = (lambda: QRegMLP(True, hidden_dim=hidden)) if rot == "q" else (lambda: DQRegMLP(hidden_dim=hidden))
-        self.model, self.model_rf = ctor().to(self.device), ctor().to(self.device)
-        torch.random.set_rng_state(gen_state)
+        if models is not None:                       # caller-made (model, model_rf), e.g. the drop-in's _make_models()
+            self.model, self.model_rf = models[0].to(self.device), models[1].to(self.device)
+        else:
+            gen_state = torch.random.get_rng_state()
+            torch.manual_seed(seed)                  # the reference leaves the MLP init unseeded
+            ctor = (lambda: QRegMLP(True, hidden_dim=hidden)) if rot == "q" else (lambda: DQRegMLP(hidden_dim=hidden))
+            self.model, self.model_rf = ctor().to(self.device), ctor().to(self.device)
+            torch.random.set_rng_state(gen_state)
         order = ops.Q_PARAM_ORDER if rot == "q" else ops.DQ_PARAM_ORDER
         self.p_step = [dict(self.model.named_parameters())[n].data for n in order]
         self.p_anchor = [dict(self.model_rf.named_parameters())[n].data for n in order]
@@ -52,14 +55,15 @@ class BatchRegistrar:
     problems and the latency-bound kernels of one sequence hide behind the others'."""
 
     def __init__(self, mats0, clusters0, n_tgt, n_sequences, rot="q", hidden=512, epochs=300, use_graph=True,
-                 device="cuda", seeds=None):
+                 device="cuda", seeds=None, models=None):
         self.device = torch.device(device)
         self.S = n_sequences
         seeds = list(seeds) if seeds is not None else list(range(n_sequences))
         self.seqs = []
         for s in range(n_sequences):
             r = SequenceRegistrar.__new__(SequenceRegistrar)
-            SequenceRegistrar._init_state(r, mats0, clusters0, rot, hidden, self.device, seeds[s])
+            SequenceRegistrar._init_state(r, mats0, clusters0, rot, hidden, self.device, seeds[s],
+                                          None if models is None else models[s])
             self.seqs.append(r)
         self.plan = ops.TrainPlan(rot, len(clusters0), hidden, self.seqs[0].pts.shape[0], n_tgt, epochs=epochs,
                                   use_graph=use_graph, device=self.device, batch=n_sequences)
@@ -80,6 +84,7 @@ class BatchRegistrar:
         for r, f64, o, M64, res in zip(self.seqs, frames64, anchor, M64s, km):
             m2, labels = o[0], res[1]
             local, r.off = ops.group_to_local(f64, labels, M64)
+            r.local64 = local                        # what resample_cluster returns (the cluster/NNNN.npz contents)
             r.pts, r.m = local.to(torch.float32), m2
             out.append((m2, o[2]))
         return out

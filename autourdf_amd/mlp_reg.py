@@ -232,6 +232,51 @@ def match(data_dir, idx):
         np.savetxt(save_dir + "loss.txt", best_losses)
 
 
+def match_all(data_dirs):
+    """Every sequence of a run in lock-step (not in the reference, which calls match() per sequence):
+    sequences are independent once sequence 0 has produced the shared frame-0 state (mlp_reg.py:242-253), so the
+    S default-path (MLP + MLP) registrations advance as ONE batched train plan per step -- the same kernels and
+    arithmetic as S match() calls, the same files, ~3x the throughput.  Falls back to match() per sequence when
+    the sequences differ in length or size, or for --mlp_icp / --r rpy|6d."""
+    from .engine import BatchRegistrar
+    segs = [Segments(d) for d in data_dirs]
+    same = len({(sg.data_size, len(sg.pc_list[0].points)) for sg in segs}) == 1 and \
+        all(len(p.points) == len(segs[0].pc_list[0].points) for sg in segs for p in sg.pc_list)
+    if MLP_ICP or ROT not in ("q", "dq") or not same or len(segs) < 2:
+        for i, d in enumerate(data_dirs):
+            match(d, i)
+        return
+    base = f"data/part/{ROBOT}_{NUM_SEG}_seg/{STEP_SZIE}_deg_{NUM_CAMERAS}_cams/"
+    done = sorted(glob.glob(base + "*/"))
+    if len(done) == 0:                                   # frame-0 state from the first raw sequence (mlp_reg.py:244-249)
+        seg0 = Segments(RAW_PATH_LIST[0])
+        seg0.k_means_cluster(0, NUM_SEG, NORMAL)
+        step_matrices, step_cluster_np = np.array(seg0.init_matrix_list), seg0.init_segment_list
+    else:
+        step_matrices, step_cluster_np = np.load(done[0] + "matrix/0000.npy"), load_pc_npz(done[0] + "cluster/0000.npz")
+    save_dirs = [base + d.split("/")[-2] + "/" for d in data_dirs]
+    for sd in save_dirs:
+        os.makedirs(sd + "cluster", exist_ok=True)
+        os.makedirs(sd + "matrix", exist_ok=True)
+        np.save(sd + "matrix/0000.npy", step_matrices)
+        save_pc_npz(step_cluster_np, sd + "cluster/0000.npz")
+    n = len(segs[0].pc_list[0].points)
+    reg = BatchRegistrar(np.asarray(step_matrices, np.float32), [np.asarray(c, np.float32) for c in step_cluster_np], n,
+                         len(segs), ROT, 512, EPOCHS, USE_GRAPH, DEVICE, models=[_make_models() for _ in segs])
+    losses = [[] for _ in segs]
+    for i in range(segs[0].data_size - 1):
+        frames = [torch.as_tensor(np.asarray(sg.pc_list[i + 1].points), dtype=torch.float64, device=DEVICE) for sg in segs]
+        out = reg.step(frames)
+        for s, (r, (m2, res)) in enumerate(zip(reg.seqs, out)):
+            off, local = r.off.cpu().numpy(), r.local64.cpu().numpy()
+            np.save(save_dirs[s] + f"matrix/{(i + 1):04}.npy", m2.cpu().numpy())
+            save_pc_npz([local[off[j]:off[j + 1]] for j in range(len(off) - 1)], save_dirs[s] + f"cluster/{(i + 1):04}.npz")
+            losses[s].append(float(res[0]))
+    if LOSS:
+        for sd, l in zip(save_dirs, losses):
+            np.savetxt(sd + "loss.txt", l)
+
+
 def main(argv=None):
     global DEVICE, ROBOT, NUM_SEG, DOF, STEP_SZIE, NUM_CAMERAS, MLP_ICP, VIS, ROT, LOSS, NORMAL, RAW_PATH_LIST
     if not torch.cuda.is_available():
@@ -248,6 +293,8 @@ def main(argv=None):
     parser.add_argument("--step_size", type=int, default=4)
     parser.add_argument("--num_video", type=int, default=5)
     parser.add_argument("--r", type=str, default="q", choices=["q", "rpy", "dq", "6d"])
+    parser.add_argument("--sequential", action="store_true",
+                        help="one match() per sequence like the reference's main loop (default: all sequences in lock-step)")
     args = parser.parse_args(argv)
     with open("parameters.json") as f:
         robot_params = json.load(f)[args.robot]
@@ -260,8 +307,11 @@ def main(argv=None):
     if len(RAW_PATH_LIST) == 0:
         RAW_PATH_LIST = sorted(glob.glob(f"data/raw/{ROBOT}/*/"))
     print(f"Found {len(RAW_PATH_LIST)} raw data directories")
-    for i, data_dir in enumerate(RAW_PATH_LIST[: args.num_video]):
-        match(data_dir, i)
+    if args.sequential:
+        for i, data_dir in enumerate(RAW_PATH_LIST[: args.num_video]):
+            match(data_dir, i)
+    else:
+        match_all(RAW_PATH_LIST[: args.num_video])
 
 
 if __name__ == "__main__":
