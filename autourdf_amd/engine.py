@@ -33,6 +33,7 @@ class SequenceRegistrar:
         self.m = torch.as_tensor(mats0, dtype=torch.float32).to(self.device).contiguous()
         self.pts, self.off = ops.pack_clusters(clusters0, self.device)
         self.pts_init, self.off_init = self.pts.clone(), self.off.clone()
+        self.local64, _ = ops.pack_clusters(clusters0, self.device, torch.float64)   # step_cluster_np of the reference
 
     def step(self, frame64: torch.Tensor, frame32: torch.Tensor = None):
         """Register the next frame ((N,3) fp64 on the device).  Returns (poses (K,4,4) fp32, result (4))."""
@@ -88,6 +89,33 @@ class BatchRegistrar:
             r.pts, r.m = local.to(torch.float32), m2
             out.append((m2, o[2]))
         return out
+
+
+def _step_mlp_icp(self, frames64, frames32=None):
+    """The `--mlp_icp` frame of match() (mlp_reg.py:296-332) for all S sequences: ONE batched "Step" train, ONE
+    masked-ICP launch (clusters x sequences) started from the trained poses with the trained clouds as mask
+    boxes, ONE k-means launch.  Returns [(poses (K,4,4) fp64, train result (4))] per sequence."""
+    ys = frames32 if frames32 is not None else [f.to(torch.float32) for f in frames64]
+    step = self.plan.run_batch([(r.m, y, r.pts, r.off, r.p_step) for r, y in zip(self.seqs, ys)], lr=2e-4)
+    probs = [(r.local64, o[1], r.off, f, o[0].to(torch.float64)) for r, f, o in zip(self.seqs, frames64, step)]
+    if len(probs) <= ops.ICP_BATCH_MAX:
+        icp = ops.masked_icp_batch(probs)
+    else:
+        icp = [ops.masked_icp(*p) for p in probs]
+    inits = [M[:, :3, 3].contiguous() for M, _, _ in icp]
+    if frames64[0].shape[0] <= ops.KMEANS_BATCH_MAX_N and self.S <= 16 and inits[0].shape[0] <= 128:
+        km = ops.kmeans_lloyd_batch(frames64, inits)
+    else:
+        km = [ops.kmeans_lloyd(f, c) for f, c in zip(frames64, inits)]
+    out = []
+    for r, f64, (M, _, _), o, res in zip(self.seqs, frames64, icp, step, km):
+        r.local64, r.off = ops.group_to_local(f64, res[1], M)
+        r.pts, r.m = r.local64.to(torch.float32), M.to(torch.float32)
+        out.append((M, o[2]))
+    return out
+
+
+BatchRegistrar.step_mlp_icp = _step_mlp_icp
 
 
 class IcpRegistrar:

@@ -237,12 +237,13 @@ def match_all(data_dirs):
     sequences are independent once sequence 0 has produced the shared frame-0 state (mlp_reg.py:242-253), so the
     S default-path (MLP + MLP) registrations advance as ONE batched train plan per step -- the same kernels and
     arithmetic as S match() calls, the same files, ~3x the throughput.  Falls back to match() per sequence when
-    the sequences differ in length or size, or for --mlp_icp / --r rpy|6d."""
+    the sequences differ in length or size, or for --r rpy|6d.  --mlp_icp takes the same route with one batched
+    masked-ICP launch per step (mlp_reg.py:296-332)."""
     from .engine import BatchRegistrar
     segs = [Segments(d) for d in data_dirs]
     same = len({(sg.data_size, len(sg.pc_list[0].points)) for sg in segs}) == 1 and \
         all(len(p.points) == len(segs[0].pc_list[0].points) for sg in segs for p in sg.pc_list)
-    if MLP_ICP or ROT not in ("q", "dq") or not same or len(segs) < 2:
+    if ROT not in ("q", "dq") or not same or len(segs) < 2:
         for i, d in enumerate(data_dirs):
             match(d, i)
         return
@@ -261,12 +262,12 @@ def match_all(data_dirs):
         np.save(sd + "matrix/0000.npy", step_matrices)
         save_pc_npz(step_cluster_np, sd + "cluster/0000.npz")
     n = len(segs[0].pc_list[0].points)
-    reg = BatchRegistrar(np.asarray(step_matrices, np.float32), [np.asarray(c, np.float32) for c in step_cluster_np], n,
+    reg = BatchRegistrar(np.asarray(step_matrices, np.float32), [np.asarray(c, np.float64) for c in step_cluster_np], n,
                          len(segs), ROT, 512, EPOCHS, USE_GRAPH, DEVICE, models=[_make_models() for _ in segs])
     losses = [[] for _ in segs]
     for i in range(segs[0].data_size - 1):
         frames = [torch.as_tensor(np.asarray(sg.pc_list[i + 1].points), dtype=torch.float64, device=DEVICE) for sg in segs]
-        out = reg.step(frames)
+        out = reg.step_mlp_icp(frames) if MLP_ICP else reg.step(frames)
         for s, (r, (m2, res)) in enumerate(zip(reg.seqs, out)):
             off, local = r.off.cpu().numpy(), r.local64.cpu().numpy()
             np.save(save_dirs[s] + f"matrix/{(i + 1):04}.npy", m2.cpu().numpy())

@@ -60,8 +60,8 @@ def test_match_writes_the_reference_file_layout(workdir, flags, monkeypatch):
     assert np.abs(np.sort(world, 0) - np.sort(frame, 0)).max() < 1e-6
 
 
-@pytest.mark.parametrize("rot", ["q", "dq"])
-def test_lock_step_run_equals_one_match_per_sequence(workdir, rot, monkeypatch):
+@pytest.mark.parametrize("rot,extra", [("q", []), ("dq", []), ("q", ["--mlp_icp"])])
+def test_lock_step_run_equals_one_match_per_sequence(workdir, rot, extra, monkeypatch):
     """main() registers all sequences in lock-step (match_all); --sequential is the reference's loop of match()
     calls.  Same frame-0 state + same model initialisation => identical files, bit for bit."""
     import shutil
@@ -70,13 +70,13 @@ def test_lock_step_run_equals_one_match_per_sequence(workdir, rot, monkeypatch):
     base = workdir / "data/part/wx200_5_8_seg/4_deg_20_cams"
     mlp_reg._PLANS.clear()
     torch.manual_seed(0)
-    mlp_reg.main(["--robot", "wx200_5", "--num_video", "2", "--loss", "--sequential", "--r", rot])
+    mlp_reg.main(["--robot", "wx200_5", "--num_video", "2", "--loss", "--sequential", "--r", rot] + extra)
     shutil.copytree(base, workdir / "sequential")
     for v in range(2):                                   # keep only the shared frame-0 state, as a finished first run leaves it
         for t in (1, 2):
             os.remove(base / f"V{v:04}/matrix/{t:04}.npy"); os.remove(base / f"V{v:04}/cluster/{t:04}.npz")
     torch.manual_seed(0)
-    mlp_reg.main(["--robot", "wx200_5", "--num_video", "2", "--loss", "--r", rot])
+    mlp_reg.main(["--robot", "wx200_5", "--num_video", "2", "--loss", "--r", rot] + extra)
     for v in range(2):
         for t in range(3):
             np.testing.assert_array_equal(np.load(base / f"V{v:04}/matrix/{t:04}.npy"),
