@@ -232,6 +232,21 @@ def match(data_dir, idx):
         np.savetxt(save_dir + "loss.txt", best_losses)
 
 
+def _ensure_frame0(first_dir):
+    """The frame-0 state every sequence starts from (mlp_reg.py:242-253), written once into the first sequence's
+    output directory if no output exists yet."""
+    base = f"data/part/{ROBOT}_{NUM_SEG}_seg/{STEP_SZIE}_deg_{NUM_CAMERAS}_cams/"
+    if sorted(glob.glob(base + "*/")):
+        return
+    seg0 = Segments(RAW_PATH_LIST[0])
+    seg0.k_means_cluster(0, NUM_SEG, NORMAL)
+    sd = base + first_dir.split("/")[-2] + "/"
+    os.makedirs(sd + "cluster", exist_ok=True)
+    os.makedirs(sd + "matrix", exist_ok=True)
+    np.save(sd + "matrix/0000.npy", np.array(seg0.init_matrix_list))
+    save_pc_npz(seg0.init_segment_list, sd + "cluster/0000.npz")
+
+
 def match_all(data_dirs):
     """Every sequence of a run in lock-step (not in the reference, which calls match() per sequence):
     sequences are independent once sequence 0 has produced the shared frame-0 state (mlp_reg.py:242-253), so the
@@ -308,11 +323,30 @@ def main(argv=None):
     if len(RAW_PATH_LIST) == 0:
         RAW_PATH_LIST = sorted(glob.glob(f"data/raw/{ROBOT}/*/"))
     print(f"Found {len(RAW_PATH_LIST)} raw data directories")
+    dirs = RAW_PATH_LIST[: args.num_video]
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    distributed = "RANK" in os.environ and bool(dirs)          # launched by torch.distributed.run (any world size)
+    if distributed:
+        # one process per GPU (python -m torch.distributed.run ... -m autourdf_amd.mlp_reg): sequences are sharded
+        # round-robin, nothing is exchanged but the shared frame-0 state, which rank 0 writes first
+        import torch.distributed as dist
+        from .distributed import shard_sequences
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        DEVICE = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=DEVICE)
+        if rank == 0:
+            _ensure_frame0(dirs[0])
+        dist.barrier()
+        dirs = [dirs[i] for i in shard_sequences(len(dirs), rank, world)]
     if args.sequential:
-        for i, data_dir in enumerate(RAW_PATH_LIST[: args.num_video]):
+        for i, data_dir in enumerate(dirs):
             match(data_dir, i)
-    else:
-        match_all(RAW_PATH_LIST[: args.num_video])
+    elif dirs:
+        match_all(dirs)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
