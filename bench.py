@@ -209,7 +209,8 @@ def main():
         nn_us = prof.pop("nn_l1_back_to_back")     # 200 back-to-back launches between two HIP events
         nn_problems = prof.pop("nn_l1_problems_per_launch")
         # 9 VALU ops x N^2 per problem-epoch (shared pair evaluation); one launch carries the
-        # problems of all sequences in flight in grid.z and the back-to-back timing launches exactly that grid
+        # problems of one graph branch in grid.z (3 of the 5 sequences; the other branch carries 2) and the
+        # back-to-back timing launches exactly that grid
         alg_ops = 9.0 * N_POINTS * N_POINTS * nn_problems
         achieved = alg_ops / (nn_us * 1e-6) / 1e12
         alg_bytes = nn_problems * (2 * 12 * N_POINTS + 2 * (4 + 8) * N_POINTS)
@@ -229,7 +230,9 @@ def main():
                 "note": "L1 min-search is sub/add/min work: not a contraction (no MFMA) and ~200 KB of algorithmic "
                         "traffic (not HBM); bound = fp32 VALU issue. achieved = 9*N^2 algorithmic lane-ops (SURVEY 8d) / "
                         "avg launch; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (= 157.3 TFLOP/s FMA peak / 2). "
-                        "avg_launch_us = 200 back-to-back launches between two HIP events (includes the launch gap); "
+                        "avg_launch_us = 200 back-to-back launches between two HIP events (includes the launch gap), kernel alone; "
+                        "in the timed region the sequences run as two graph branches (3 + 2 problems) on two hardware queues, so "
+                        "rocprofv3's per-launch durations there are those of kernels sharing the chip with the other branch; "
                         "per-kernel event brackets carry ~7 us of event overhead each, see profiles/ for rocprofv3"}
         out = {"metric": f"registered frames/sec (N={N_POINTS} pts, K={K_CLUSTERS} clusters)", "value": round(world * args.steps / elapsed, 4),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

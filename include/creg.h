@@ -230,10 +230,10 @@ typedef struct creg_train_shape {
     int64_t n_tgt;        /* points in the target frame */
     int32_t use_graph;    /* 0: eager launches; 1: hipGraph of 50 epochs per launch; n > 1: n epochs per graph */
     int32_t batch;        /* independent problems (sequences) advanced per launch; 0 or 1 = one */
-    int32_t graph_branches; /* 0 or 1: one chain of launches per epoch (default).  > 1: EXPERIMENTAL -- the batch is
-                               captured as this many independent graph branches on different hardware queues (+8 % at
-                               batch 5).  NOT SAFE on ROCm 7.2 / MI355X: concurrently running chains were measured to
-                               corrupt each other's results intermittently; kept for investigation only. */
+    int32_t graph_branches; /* parallel chains in the captured graph: the batch is split into this many contiguous
+                               groups whose epochs are captured as independent branches (different hardware queues,
+                               so one group's small kernels overlap the other's NN launch).  0 = auto (2 when
+                               batch >= 2), 1 = single chain.  Results do not depend on it. */
 } creg_train_shape;
 
 typedef struct creg_train_args {

@@ -446,6 +446,35 @@ def test_batched_plan_is_bit_identical_to_separate_runs(dev, golden):
     assert not torch.equal(outs_b[0][0], outs_b[1][0])
 
 
+@pytest.mark.parametrize("rot", ["q", "dq"])
+def test_graph_branches_stress_bit_identical_to_single_runs(dev, rot):
+    """Two (and three) concurrently running chains of the train kernels against single runs, many repetitions at
+    the full hidden size: this is the test that caught the LDS-DMA tail overrun of k_bwd2 (the last DMA instruction
+    wrote a full 1 KiB over the next LDS array; which write landed last was decided by memory contention from the
+    other chain, so 1-10 % of runs differed).  Any timing-dependent hazard inside a kernel shows up here."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    from oracle import models
+    seq = make_sequence("wx200_5", 3, 3, 1024)
+    mats, cl, _ = initial_segmentation(seq[0], 8, seed=1)
+    m = torch.tensor(mats, dtype=torch.float32, device=dev)
+    ys = [torch.tensor(seq[1] + 0.001 * b, dtype=torch.float32, device=dev) for b in range(5)]
+    pts, off = ops.pack_clusters([torch.tensor(c, dtype=torch.float32) for c in cl], dev)
+    torch.manual_seed(3)
+    model, order = (models.QRegMLP(True, 512), ops.Q_PARAM_ORDER) if rot == "q" else (models.DQRegMLP(512), ops.DQ_PARAM_ORDER)
+    mk = lambda: [model.state_dict()[k].clone().to(dev) for k in order]
+    single = ops.TrainPlan(rot, 8, 512, pts.shape[0], ys[0].shape[0], epochs=40, use_graph=True, device=dev)
+    ref = [[t.cpu() for t in single.run(m, ys[b], pts, off, mk())] for b in range(5)]
+    for batch, branches, reps in ((5, 2, 12), (4, 2, 6), (5, 3, 4)):
+        for _ in range(reps):
+            plan = ops.TrainPlan(rot, 8, 512, pts.shape[0], ys[0].shape[0], epochs=40, use_graph=True, device=dev,
+                                 batch=batch, graph_branches=branches)
+            outs = plan.run_batch([(m, ys[b], pts, off, mk()) for b in range(batch)])
+            for b in range(batch):
+                for got, want in zip(outs[b], ref[b]):
+                    assert torch.equal(got.cpu().nan_to_num(), want.nan_to_num())
+
+
 def test_kmeans_batch_single_launch_bit_identical_to_multi_launch(dev, golden):
     """creg_kmeans_lloyd_batch_f64 (one workgroup per frame, LDS resident, no host sync) against
     creg_kmeans_lloyd_f64 and the sklearn golden: labels, centres, inertia, n_iter all identical."""

@@ -36,14 +36,15 @@ def main(src, tag):
                      f"active_valu={4 * m['SQ_ACTIVE_INST_VALU'] / wv:6.0f} wait_inst={4 * m['SQ_WAIT_INST_ANY'] / wv:6.0f} "
                      f"wait_any={4 * m['SQ_WAIT_ANY'] / wv:6.0f} dur_us={m['dur'] / 1e3:6.2f}")
         out[k] = (fs, ws)
-    header = ("rocprofv3 PMC, `bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-icp-variant` (5 problems per launch, N=4096, K=20, H=512); one counter set "
+    header = ("rocprofv3 PMC, `bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-icp-variant` (5 sequences as two graph branches: launches carry "
+              "3 or 2 problems, the values below average over both; N=4096, K=20, H=512); one counter set "
               "per pass (FETCH_SIZE | WRITE_SIZE | SQ_*); per-wave values are cycles (quad-cycle counters x4); FETCH_SIZE / WRITE_SIZE are the "
               "raw rocprofv3 values in KB.  MI355X_MICROARCH.md: FETCH_SIZE counts 128-B requests of wide (16 B/lane) coalesced reads as 64 B -> "
               "double it for the dwordx4 / LDS-DMA streams (k_nn_l1 fill, k_dw, k_l2 staging); dword-wide reads are uncorrected.\n")
     open(f"profiles/{tag}_pmc_summary.txt", "w").write(header + "\n".join(lines) + "\n")
     fs, ws = out["k_nn_l1"]
-    json.dump({"kernel": "k_nn_l1<4,int,EngineEpi>", "problems_per_launch": 5, "FETCH_SIZE_KB": fs, "WRITE_SIZE_KB": ws,
-               "hbm_bytes_per_launch": (2 * fs + ws) * 1024, "hbm_bytes_per_problem": (2 * fs + ws) * 1024 / 5,
+    json.dump({"kernel": "k_nn_l1<4,int,EngineEpi>", "problems_per_launch_avg": 2.5, "FETCH_SIZE_KB": fs, "WRITE_SIZE_KB": ws,
+               "hbm_bytes_per_launch_avg": (2 * fs + ws) * 1024, "hbm_bytes_per_problem": (2 * fs + ws) * 1024 / 2.5,
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 5 --warmup 5 --no-cpu-baseline), "
                          "averaged over all launches of the kernel; FETCH_SIZE doubled per MI355X_MICROARCH.md (the fill is 16 B/lane coalesced), "
                          "WRITE_SIZE uncorrected",
