@@ -293,6 +293,30 @@ def test_train_probe_forward_and_pose_gradient_vs_oracle(dev, golden, rot):
     np.testing.assert_allclose(ggrad.cpu().numpy()[:, :3, :], m2.grad.numpy()[:, :3, :], rtol=1e-4, atol=2e-6)
 
 
+@pytest.mark.parametrize("rot,hidden,k", [("q", 64, 7), ("q", 128, 5), ("dq", 64, 3), ("dq", 128, 9), ("q", 256, 21), ("dq", 512, 33)])
+def test_train_three_steps_odd_shapes_vs_oracle(dev, rot, hidden, k):
+    """Hidden sizes and cluster counts whose staged activation blocks do NOT end on a 64 x 16-byte boundary (the
+    LDS-DMA tail case): three full Adam steps against the oracle, loss history and poses."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    from oracle import models, registration
+    seq = make_sequence("wx200_5", 17, 2, 1500)
+    mats, cl, _ = initial_segmentation(seq[0], k, seed=2)
+    m = torch.tensor(mats, dtype=torch.float32)
+    y = torch.tensor(seq[1], dtype=torch.float32)
+    clusters = [torch.tensor(c, dtype=torch.float32) for c in cl]
+    torch.manual_seed(9)
+    model = models.QRegMLP(True, hidden) if rot == "q" else models.DQRegMLP(hidden)
+    order = ops.Q_PARAM_ORDER if rot == "q" else ops.DQ_PARAM_ORDER
+    params = [model.state_dict()[n].clone().to(dev) for n in order]
+    pts, off = ops.pack_clusters(clusters, dev)
+    plan = ops.TrainPlan(rot, k, hidden, pts.shape[0], y.shape[0], epochs=3, use_graph=True, device=dev)
+    bm, bp, res, lh, _ = plan.run(m.to(dev), y.to(dev), pts, off, params, lr=1e-3)
+    _, best_m, min_loss, hist = registration.train(m, y, model, clusters, rot=rot, epochs=3, learning_rate=1e-3)
+    np.testing.assert_allclose(lh.cpu().numpy(), np.array(hist["loss"], np.float32), rtol=2e-5)
+    np.testing.assert_allclose(bm.cpu().numpy(), best_m.detach().numpy(), atol=1e-5)
+
+
 @pytest.mark.parametrize("rot", ["q", "dq"])
 @pytest.mark.parametrize("graph", [False, True])
 def test_train_short_trajectory_vs_oracle(dev, golden, rot, graph):
