@@ -499,6 +499,29 @@ def test_graph_branches_stress_bit_identical_to_single_runs(dev, rot):
                     assert torch.equal(got.cpu().nan_to_num(), want.nan_to_num())
 
 
+def test_graph_branches_bench_shape_bit_identical_to_single_runs(dev):
+    """The exact shape bench.py runs (N=4096, K=20, hidden 512, 5 problems as 3 + 2): two chains vs single runs."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    from oracle import models
+    seq = make_sequence("wx200_5", 5, 2, 4096)
+    mats, cl, _ = initial_segmentation(seq[0], 20, seed=0)
+    m = torch.tensor(mats, dtype=torch.float32, device=dev)
+    ys = [torch.tensor(seq[1] + 0.0005 * b, dtype=torch.float32, device=dev) for b in range(5)]
+    pts, off = ops.pack_clusters([torch.tensor(c, dtype=torch.float32) for c in cl], dev)
+    torch.manual_seed(1)
+    model = models.QRegMLP(True, 512)
+    mk = lambda: [model.state_dict()[k].clone().to(dev) for k in ops.Q_PARAM_ORDER]
+    single = ops.TrainPlan("q", 20, 512, 4096, 4096, epochs=60, use_graph=True, device=dev)
+    ref = [[t.cpu() for t in single.run(m, ys[b], pts, off, mk())] for b in range(5)]
+    for _ in range(5):
+        plan = ops.TrainPlan("q", 20, 512, 4096, 4096, epochs=60, use_graph=True, device=dev, batch=5)       # default: 2 branches
+        outs = plan.run_batch([(m, ys[b], pts, off, mk()) for b in range(5)])
+        for b in range(5):
+            for got, want in zip(outs[b], ref[b]):
+                assert torch.equal(got.cpu().nan_to_num(), want.nan_to_num())
+
+
 def test_kmeans_batch_single_launch_bit_identical_to_multi_launch(dev, golden):
     """creg_kmeans_lloyd_batch_f64 (one workgroup per frame, LDS resident, no host sync) against
     creg_kmeans_lloyd_f64 and the sklearn golden: labels, centres, inertia, n_iter all identical."""
