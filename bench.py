@@ -231,8 +231,9 @@ def main():
                         "traffic (not HBM); bound = fp32 VALU issue. achieved = 9*N^2 algorithmic lane-ops (SURVEY 8d) / "
                         "avg launch; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (= 157.3 TFLOP/s FMA peak / 2). "
                         "avg_launch_us = 200 back-to-back launches between two HIP events (includes the launch gap), kernel alone; "
-                        "in the timed region the sequences run as two graph branches (3 + 2 problems) on two hardware queues, so "
-                        "rocprofv3's per-launch durations there are those of kernels sharing the chip with the other branch; "
+                        "in the timed region the sequences run as two graph branches (3 + 2 problems) on two hardware queues; "
+                        "rocprofv3's kernel trace largely serialises them (2 % of the traced time has two kernels in flight), so "
+                        "its per-kernel averages are the mean of the standalone 3- and 2-problem launches; "
                         "per-kernel event brackets carry ~7 us of event overhead each, see profiles/ for rocprofv3"}
         out = {"metric": f"registered frames/sec (N={N_POINTS} pts, K={K_CLUSTERS} clusters)", "value": round(world * args.steps / elapsed, 4),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
