@@ -411,6 +411,7 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
             if (j < k) {
 #pragma unroll
                 for (int m = 0; m < KMS_PTS; ++m) {
+                    if (256 * m >= n) break;                       // block-uniform: no point of this slot exists
                     const int i = min(tg + 256 * m, n - 1);
                     const bool mine = lbl[m] == j;
                     const double x0 = Xc[3 * i], x1 = Xc[3 * i + 1], x2 = Xc[3 * i + 2];
