@@ -109,62 +109,88 @@ __global__ __launch_bounds__(256) void k_km_assign(const double* __restrict__ X,
     }
 }
 
-// E-step, matrix-core form: v_mfma_f64_16x16x4_f64 evaluates a 16-point x 16-centre tile of
-// |c|^2 - 2 x.c as D = C + A.B with A = [x0 x1 x2 0], B = [b0;b1;b2;0], C = |c|^2 per column; the
-// k-ordered fma chain of the instruction is the same chain the VALU form spells out.
-// Layout (gfx950 f64 MFMA): A[i=l&15][kk=l>>4], B[kk=l>>4][j=l&15], D[i=(l>>4)+4r][j=l&15].
+// E-step, matrix-core form: v_mfma_f64_16x16x4_f64 evaluates a 16-centre x 16-point tile of |c|^2 - 2 x.c as
+// D = C + A.B with A = the centres' (-2c0, -2c1, -2c2, 0) rows, B = the points' (x0; x1; x2; 0) columns and
+// C = |c|^2 per ROW; the k-ordered fma chain of the instruction is the chain the VALU form spells out, so both
+// forms give bit-identical distances and labels.
+// Layout (gfx950 f64 MFMA): A[i=l&15][kk=l>>4], B[kk=l>>4][j=l&15], D[i=(l>>4)+4r][j=l&15]: a lane owns ONE point
+// (column l&15) and sees 4 centres of every tile in ascending order, so its running first minimum needs no
+// cross-lane work inside the sweep; the four lane groups of a point are combined once per point tile (two steps).
+// A wave keeps up to 8 centre tiles (k <= 128) in registers and walks many point tiles (v1 reloaded the centres
+// for every 16 points and reduced 4 rows x 16 lanes per tile: 78 us at n = 2^20, k = 128; this form: 60 us, the VALU
+// form 50 us -- on CDNA4 one fp64 16x16x4 MFMA occupies the matrix pipe for 64 cycles, i.e. the fp64 matrix peak equals
+// the fp64 vector peak, a quarter of every K=4 slot is padding and the argmin stays on the VALU, so the contraction
+// cannot win here; kept selectable because the north star asks for it).
+template <int NT>   // centre tiles held in registers (k <= 16 NT); 0: any k, centre operands re-read from LDS per tile
 __global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict__ X, int n,
                                                         const double* __restrict__ B, int k,
                                                         int* __restrict__ labels, const int* __restrict__ prev,
                                                         KmFlags* __restrict__ f) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sB = (double*)smem;                                  // [kpad][4], rows past k: (0, 0, 0, +inf)
     if (f && f->done) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int i0 = wave * 16;
-    if (i0 >= n) return;
-    const int kk = lane >> 4, col = lane & 15;
-    const int pi = min(i0 + col, n - 1);
-    const double a = (kk < 3) ? X[3 * (size_t)pi + kk] : 0.0;
-    double best[4];
-    int lab[4];
+    const int kpad = (k + 15) & ~15, ktiles = kpad / 16;
+    for (int i = threadIdx.x; i < 4 * kpad; i += 256) sB[i] = (i >> 2) < k ? B[i] : ((i & 3) == 3 ? INFINITY : 0.0);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
+    constexpr int NR = NT > 0 ? NT : 1;
+    double at[NR], cs[NR][4];
+    if (NT > 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { best[r] = INFINITY; lab[r] = 0x7fffffff; }
-    // each lane keeps the running first minimum of ITS centre column (j = col, col+16, ...) for its 4
-    // points; one 16-lane lexicographic (value, index) reduction at the end finishes the argmin
-    for (int j0 = 0; j0 < k; j0 += 16) {
-        const int j = j0 + col;
-        const bool ok = j < k;
-        const double b = (ok && kk < 3) ? B[4 * j + kk] : 0.0;
-        const double csq = ok ? B[4 * j + 3] : INFINITY;
-        double4v c = {csq, csq, csq, csq};
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+        for (int t = 0; t < NR; ++t) {
+            const int tt = min(t, ktiles - 1);                   // tiles past k repeat the last one: never smaller
+            at[t] = g < 3 ? sB[4 * (16 * tt + col) + g] : 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool lt = c[r] < best[r];                     // tiles ascend: strict < keeps the first
-            best[r] = lt ? c[r] : best[r];
-            lab[r] = lt ? j : lab[r];
+            for (int r = 0; r < 4; ++r) cs[t][r] = t < ktiles ? sB[4 * (16 * tt + g + 4 * r) + 3] : INFINITY;
         }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        double v = best[r];
-        int idx = lab[r];
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(v, off, 64);
-            const int oi = __shfl_xor(idx, off, 64);
-            const bool take = (ov < v) || (ov == v && oi < idx);
-            v = take ? ov : v; idx = take ? oi : idx;
-        }
-        lab[r] = idx;
-    }
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4, ntile = (n + 15) >> 4;
     int diff = 0;
-    if (col == 0) {
+    double bnext = 0.0;
+    if (wid < ntile) bnext = g < 3 ? X[3 * (size_t)min(wid * 16 + col, n - 1) + g] : 0.0;
+    for (int tile = wid; tile < ntile; tile += nw) {
+        const double b = bnext;
+        if (tile + nw < ntile) bnext = g < 3 ? X[3 * (size_t)min((tile + nw) * 16 + col, n - 1) + g] : 0.0;
+        double best = INFINITY;
+        int lab = 0x7fffffff;
+        auto track = [&](const double4v& c, int j0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = i0 + kk + 4 * r;
-            if (i < n) { labels[i] = lab[r]; if (prev) diff += (prev[i] != lab[r]); }
+            for (int r = 0; r < 4; ++r) {                        // centres j0 + g + 4 r: ascending, strict < keeps the first
+                const bool lt = c[r] < best;
+                best = lt ? c[r] : best;
+                lab = lt ? j0 + g + 4 * r : lab;
+            }
+        };
+        if (NT > 0) {
+#pragma unroll
+            for (int t0 = 0; t0 < NR; t0 += 4) {                 // four independent MFMAs in flight, then their tracking
+                double4v c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (t0 + u < NR) {
+                        c[u] = double4v{cs[t0 + u][0], cs[t0 + u][1], cs[t0 + u][2], cs[t0 + u][3]};
+                        c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[t0 + u], b, c[u], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (t0 + u < NR) track(c[u], 16 * (t0 + u));
+            }
+        } else {
+            for (int t = 0; t < ktiles; ++t) {
+                const double a = g < 3 ? sB[4 * (16 * t + col) + g] : 0.0;
+                double4v c = {sB[4 * (16 * t + g) + 3], sB[4 * (16 * t + g + 4) + 3], sB[4 * (16 * t + g + 8) + 3], sB[4 * (16 * t + g + 12) + 3]};
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+                track(c, 16 * t);
+            }
         }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {               // the point's four lane groups: (value, index) lexicographic
+            const double ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(lab, off, 64);
+            const bool take = (ov < best) || (ov == best && oi < lab);
+            best = take ? ov : best; lab = take ? oi : lab;
+        }
+        const int i = tile * 16 + col;
+        if (g == 0 && i < n) { labels[i] = lab; if (prev) diff += (prev[i] != lab); }
     }
     if (prev && f) {
         diff = wave_sum(diff);
@@ -616,8 +642,17 @@ static KmLayout km_layout(int64_t n, int k) {
 
 static void launch_assign(const double* X, int n, const double* B, int k, int* labels, const int* prev,
                           KmFlags* f, int use_mfma, hipStream_t s) {
-    if (use_mfma)
-        hipLaunchKernelGGL(k_km_assign_mfma, dim3(cdiv(cdiv(n, 16), 4)), dim3(256), 0, s, X, n, B, k, labels, prev, f);
+    if (use_mfma) {
+        const int ntile = cdiv(n, 16);
+        int blocks = cdiv(ntile, 4);
+        if (blocks > 2048) blocks = 2048;                        // a wave then walks several point tiles with its centres in registers
+        const size_t smem = sizeof(double) * 4 * ((k + 15) & ~15);
+        if (k <= 16) hipLaunchKernelGGL(k_km_assign_mfma<1>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f);
+        else if (k <= 32) hipLaunchKernelGGL(k_km_assign_mfma<2>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f);
+        else if (k <= 64) hipLaunchKernelGGL(k_km_assign_mfma<4>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f);
+        else if (k <= 128) hipLaunchKernelGGL(k_km_assign_mfma<8>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f);
+        else hipLaunchKernelGGL(k_km_assign_mfma<0>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f);
+    }
     else
         hipLaunchKernelGGL(k_km_assign, dim3(cdiv(n, 256)), dim3(256), sizeof(double) * 4 * k, s, X, n, B, k, labels, prev, f);
 }

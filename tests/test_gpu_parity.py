@@ -121,7 +121,7 @@ def test_kmeans_labels_bit_exact_vs_sklearn_golden(dev, golden, tag, mfma):
     assert abs(inertia.item() - float(g[f"{tag}_inertia"])) < 1e-9 * max(1.0, float(g[f"{tag}_inertia"]))
 
 
-@pytest.mark.parametrize("n,k", [(64, 8), (4096, 20), (16384, 40), (262144, 128)])
+@pytest.mark.parametrize("n,k", [(64, 8), (17, 1), (4096, 20), (16384, 40), (5000, 200), (262144, 128)])
 def test_kmeans_assign_valu_mfma_oracle_identical(dev, n, k):
     from autourdf_amd import ops
     from oracle import kmeans
