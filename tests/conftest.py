@@ -24,8 +24,8 @@ def golden():
 
 @pytest.fixture(scope="session", autouse=True)
 def _memory_contention():
-    """CREG_TEST_CONTENTION=1: a background thread keeps a second stream busy with LDS-free streaming kernels
-    (64 MB read-modify-write passes) for the whole session, so every kernel under test runs with its memory
+    """CREG_TEST_CONTENTION=1: a background thread keeps a second stream busy (64 MB read-modify-write passes, the
+    LDS-heavy nearest-neighbour kernel on 16384-point clouds, an fp64 k-means E-step) for the whole session, so every kernel under test runs with its memory
     latencies perturbed.  Timing-dependent hazards inside a kernel (the k_bwd2 LDS-DMA overrun was one) then show
     up as flaky bit-exactness tests; a clean run under contention is evidence there are none left."""
     if os.environ.get("CREG_TEST_CONTENTION") != "1":
@@ -39,12 +39,20 @@ def _memory_contention():
     stop = threading.Event()
 
     def worker():
+        from autourdf_amd import ops
         st = torch.cuda.Stream()
         buf = torch.ones(16 << 20, dtype=torch.float32, device="cuda")
+        g = torch.Generator(device="cuda").manual_seed(0)
+        a = torch.rand(16384, 3, device="cuda", generator=g)
+        b = torch.rand(16384, 3, device="cuda", generator=g)
+        x64 = torch.rand(262144, 3, device="cuda", generator=g, dtype=torch.float64)
+        c64 = x64[:128].clone()
         with torch.cuda.stream(st):
             while not stop.is_set():
-                for _ in range(20):
+                for _ in range(8):                       # streaming traffic, an LDS-heavy VALU kernel, an fp64 kernel
                     buf.mul_(1.0000001)
+                    ops.nn_l1_bidir(a, b)
+                    ops.kmeans_assign(x64, c64)
                 st.synchronize()
 
     t = threading.Thread(target=worker, daemon=True)
