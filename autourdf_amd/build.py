@@ -13,7 +13,10 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcreg.so")
 SOURCES = ["core.hip", "nn_l1.hip", "transform.hip", "se3.hip", "kmeans.hip", "icp.hip", "fps.hip", "coord_map.hip", "sample.hip", "train_engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function",
+         # MFMA accumulators in VGPRs: the default AGPR form costs 8 v_accvgpr_read per fp64 16x16x4 MFMA whose
+         # result the VALU consumes (the K2 matrix-core E-step), which doubled that kernel's VALU work
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc():

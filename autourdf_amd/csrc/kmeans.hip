@@ -117,10 +117,10 @@ __global__ __launch_bounds__(256) void k_km_assign(const double* __restrict__ X,
 // (column l&15) and sees 4 centres of every tile in ascending order, so its running first minimum needs no
 // cross-lane work inside the sweep; the four lane groups of a point are combined once per point tile (two steps).
 // A wave keeps up to 8 centre tiles (k <= 128) in registers and walks many point tiles (v1 reloaded the centres
-// for every 16 points and reduced 4 rows x 16 lanes per tile: 78 us at n = 2^20, k = 128; this form: 60 us, the VALU
+// for every 16 points and reduced 4 rows x 16 lanes per tile: 78 us at n = 2^20, k = 128; this form: 53 us, the VALU
 // form 50 us -- on CDNA4 one fp64 16x16x4 MFMA occupies the matrix pipe for 64 cycles, i.e. the fp64 matrix peak equals
 // the fp64 vector peak, a quarter of every K=4 slot is padding and the argmin stays on the VALU, so the contraction
-// cannot win here; kept selectable because the north star asks for it).
+// only draws level here; kept selectable because the north star asks for it).
 template <int NT>   // centre tiles held in registers (k <= 16 NT); 0: any k, centre operands re-read from LDS per tile
 __global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict__ X, int n,
                                                         const double* __restrict__ B, int k,
@@ -130,19 +130,21 @@ __global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict
     double* sB = (double*)smem;                                  // [kpad][4], rows past k: (0, 0, 0, +inf)
     if (f && f->done) return;
     const int kpad = (k + 15) & ~15, ktiles = kpad / 16;
+    // C operands as the lanes read them: sC[tile][lane group g][r] = |c|^2 of centre 16 tile + g + 4 r, 32 contiguous
+    // bytes per (tile, group) -> two ds_read_b128 per MFMA instead of eight register copies of a resident table
+    double* sC = sB + 4 * (size_t)kpad;                          // [ktiles][4][4]
     for (int i = threadIdx.x; i < 4 * kpad; i += 256) sB[i] = (i >> 2) < k ? B[i] : ((i & 3) == 3 ? INFINITY : 0.0);
+    for (int i = threadIdx.x; i < 16 * ktiles; i += 256) {
+        const int t = i >> 4, gg = (i >> 2) & 3, r = i & 3, j = 16 * t + gg + 4 * r;
+        sC[i] = j < k ? B[4 * j + 3] : INFINITY;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
     constexpr int NR = NT > 0 ? NT : 1;
-    double at[NR], cs[NR][4];
+    double at[NR];
     if (NT > 0) {
 #pragma unroll
-        for (int t = 0; t < NR; ++t) {
-            const int tt = min(t, ktiles - 1);                   // tiles past k repeat the last one: never smaller
-            at[t] = g < 3 ? sB[4 * (16 * tt + col) + g] : 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cs[t][r] = t < ktiles ? sB[4 * (16 * tt + g + 4 * r) + 3] : INFINITY;
-        }
+        for (int t = 0; t < NR; ++t) at[t] = g < 3 ? sB[4 * (16 * min(t, ktiles - 1) + col) + g] : 0.0;
     }
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4, ntile = (n + 15) >> 4;
     int diff = 0;
@@ -153,35 +155,42 @@ __global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict
         if (tile + nw < ntile) bnext = g < 3 ? X[3 * (size_t)min((tile + nw) * 16 + col, n - 1) + g] : 0.0;
         double best = INFINITY;
         int lab = 0x7fffffff;
-        auto track = [&](const double4v& c, int j0) {
+        int opq = 4 * g;                                         // opaque per iteration: keeps the C-operand reads inside the
+        asm volatile("" : "+v"(opq));                            // loop (hoisted, they become 80 AGPRs + accvgpr moves)
+        // the lane's running first minimum; `lab` holds the CODE 4 tile + r of the winner (a compile-time constant per
+        // element in the register-resident form, so the select takes an inline constant) and becomes the centre index
+        // 16 tile + g + 4 r after the sweep
+        auto track = [&](const double4v& c, int t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {                        // centres j0 + g + 4 r: ascending, strict < keeps the first
+            for (int r = 0; r < 4; ++r) {                        // centres 16 t + g + 4 r: ascending, strict < keeps the first
                 const bool lt = c[r] < best;
                 best = lt ? c[r] : best;
-                lab = lt ? j0 + g + 4 * r : lab;
+                lab = lt ? 4 * t + r : lab;
             }
         };
         if (NT > 0) {
 #pragma unroll
-            for (int t0 = 0; t0 < NR; t0 += 4) {                 // four independent MFMAs in flight, then their tracking
-                double4v c[4];
+            for (int t0 = 0; t0 < NR; t0 += 2) {                 // two independent MFMAs in flight, then their tracking
+                double4v c[2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 2; ++u)
                     if (t0 + u < NR) {
-                        c[u] = double4v{cs[t0 + u][0], cs[t0 + u][1], cs[t0 + u][2], cs[t0 + u][3]};
+                        const int tt = min(t0 + u, ktiles - 1);  // tiles past k repeat the last one: never smaller, never first
+                        c[u] = *(const double4v*)(sC + 16 * tt + opq);
                         c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[t0 + u], b, c[u], 0, 0, 0);
                     }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) if (t0 + u < NR) track(c[u], 16 * (t0 + u));
+                for (int u = 0; u < 2; ++u) if (t0 + u < min(NR, ktiles)) track(c[u], t0 + u);
             }
         } else {
             for (int t = 0; t < ktiles; ++t) {
                 const double a = g < 3 ? sB[4 * (16 * t + col) + g] : 0.0;
-                double4v c = {sB[4 * (16 * t + g) + 3], sB[4 * (16 * t + g + 4) + 3], sB[4 * (16 * t + g + 8) + 3], sB[4 * (16 * t + g + 12) + 3]};
+                double4v c = *(const double4v*)(sC + 16 * t + opq);
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-                track(c, 16 * t);
+                track(c, t);
             }
         }
+        lab = lab == 0x7fffffff ? lab : 16 * (lab >> 2) + g + 4 * (lab & 3);
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {               // the point's four lane groups: (value, index) lexicographic
             const double ov = __shfl_xor(best, off, 64);
@@ -646,7 +655,7 @@ static void launch_assign(const double* X, int n, const double* B, int k, int* l
         const int ntile = cdiv(n, 16);
         int blocks = cdiv(ntile, 4);
         if (blocks > 2048) blocks = 2048;                        // a wave then walks several point tiles with its centres in registers
-        const size_t smem = sizeof(double) * 4 * ((k + 15) & ~15);
+        const size_t smem = sizeof(double) * 5 * ((k + 15) & ~15);          // centre rows + the C-operand table
         if (k <= 16) hipLaunchKernelGGL(k_km_assign_mfma<1>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f);
         else if (k <= 32) hipLaunchKernelGGL(k_km_assign_mfma<2>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f);
         else if (k <= 64) hipLaunchKernelGGL(k_km_assign_mfma<4>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f);

@@ -18,7 +18,10 @@ from autourdf_amd import ops  # noqa: E402
 def main():
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(0)
-    for n, k in ((4096, 20), (16384, 40), (262144, 128), (1048576, 128)):
+    shapes = ((4096, 20), (16384, 40), (262144, 128), (1048576, 128))
+    if os.environ.get("CREG_KM_SHAPE"):                      # e.g. CREG_KM_SHAPE=1048576,128 for counter passes
+        shapes = (tuple(int(v) for v in os.environ["CREG_KM_SHAPE"].split(",")),)
+    for n, k in shapes:
         X = torch.as_tensor(rng.normal(size=(n, 3)), device=dev)
         C = X[torch.as_tensor(rng.choice(n, k, replace=False), device=dev)].clone() + 1e-3
         ref = None
