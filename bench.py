@@ -54,7 +54,22 @@ def cpu_baseline(seq0, mats0, clusters0, budget_s=12.0):
         okm.k_means(seq0[1], mats0[:, :3, 3])
     t_km = (time.perf_counter() - t0) / 3
     frame_s = 2 * EPOCHS * per_epoch + t_km
+    # the same port on ONE host thread (SURVEY 8(d) asks for both), a few epochs only
+    os.environ["OMP_NUM_THREADS"] = "1"
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    registration.train(m, y, model, cl, rot="q", epochs=6)
+    per_epoch_1 = (time.perf_counter() - t0) / 6
+    torch.set_num_threads(threads)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    cpu_model = ""
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
     return {"value": 1.0 / frame_s, "unit": "frames/s", "cores": threads, "kind": "port",
+            "one_thread": {"value": 1.0 / (2 * EPOCHS * per_epoch_1 + t_km), "ms_per_epoch": round(per_epoch_1 * 1e3, 2)},
+            "host": {"cpu_model": cpu_model, "os_cpu_count": os.cpu_count()},
             "sample": f"{n_ep} of the 600 Adam epochs of one frame (N={N_POINTS}, K={K_CLUSTERS}, hidden {HIDDEN}) "
                       f"at {per_epoch * 1e3:.2f} ms/epoch + 1 Lloyd k-means at {t_km * 1e3:.2f} ms, extrapolated to "
                       "600 epochs + 1 k-means; oracle = torch-CPU MLP/Adam + OpenMP C L1-NN (oracle/creg_oracle.c)"}
