@@ -211,6 +211,9 @@ __global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict
 __global__ __launch_bounds__(256) void k_km_accumulate(const double* __restrict__ X, int n,
                                                        const int* __restrict__ labels, int k, int S,
                                                        double* __restrict__ part, const KmFlags* __restrict__ f) {
+    // one block per (cluster, segment): every label is read k times, but 2048 small blocks hide the latency;
+    // an 8-clusters-per-block variant that reads each label once (bit-identical sums) measured SLOWER at
+    // n = 262144, k = 128 (51 vs 45 us): one block per CU cannot hide its own round trips
     __shared__ double sc[4];
     if (f->done) return;
     const int j = blockIdx.x, s = blockIdx.y;
@@ -226,8 +229,6 @@ __global__ __launch_bounds__(256) void k_km_accumulate(const double* __restrict_
         p[0] = a0; p[1] = a1; p[2] = a2; p[3] = w;
     }
 }
-
-// single block.  Cw: (k,4) scratch for sums / weights.  C[2]: double-buffered centres.
 __global__ __launch_bounds__(1024) void k_km_finalize(const double* __restrict__ X, int n,
                                                       const int* __restrict__ labels, int k, int S,
                                                       const double* __restrict__ part, double* __restrict__ C2,
@@ -240,17 +241,26 @@ __global__ __launch_bounds__(1024) void k_km_finalize(const double* __restrict__
     const int cur = f->cur;
     const double* Cold = C2 + (size_t)cur * 3 * k;
     double* Cnew = C2 + (size_t)(cur ^ 1) * 3 * k;
+    // (v1 let thread 0 walk Cw in global memory for the empty count and the arg-max: 2 k dependent round trips,
+    //  40 of this kernel's 48 us at k = 128.  Same sums in the same order; only who scans changed.)
+    if (threadIdx.x == 0) s_nempty = 0;
+    __syncthreads();
     for (int j = threadIdx.x; j < k; j += 1024) {
         double a[4] = {0, 0, 0, 0};
-        for (int s = 0; s < S; ++s)
-            for (int d = 0; d < 4; ++d) a[d] += part[4 * ((size_t)s * k + j) + d];
+        for (int s0 = 0; s0 < S; s0 += 8) {                       // 8 segments' partials in flight, added in segment order
+            double v[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) v[u][d] = part[4 * ((size_t)min(s0 + u, S - 1) * k + j) + d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < S)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) a[d] += v[u][d];
+        }
         for (int d = 0; d < 4; ++d) Cw[4 * j + d] = a[d];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int ne = 0;
-        for (int j = 0; j < k; ++j) ne += (Cw[4 * j + 3] == 0.0);
-        s_nempty = ne;
+        if (a[3] == 0.0) atomicAdd(&s_nempty, 1);                 // integer count: order independent
     }
     __syncthreads();
     if (s_nempty > 0) {
@@ -294,10 +304,21 @@ __global__ __launch_bounds__(1024) void k_km_finalize(const double* __restrict__
             }
         }
     }
-    if (threadIdx.x == 0) {
-        int am = 0;
-        for (int j = 1; j < k; ++j) if (Cw[4 * j + 3] > Cw[4 * am + 3]) am = j;
-        s_argmax = am;
+    {   // first cluster of maximal weight (k <= 1024: one candidate per thread), block-wide (weight desc, index asc)
+        double bw = threadIdx.x < k ? Cw[4 * threadIdx.x + 3] : -1.0;
+        int bj = threadIdx.x < k ? (int)threadIdx.x : 0x7fffffff;
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ow = __shfl_xor(bw, off, 64); const int oj = __shfl_xor(bj, off, 64);
+            if (ow > bw || (ow == bw && oj < bj)) { bw = ow; bj = oj; }
+        }
+        __shared__ double s_w[16]; __shared__ int s_j[16];
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = bw; s_j[threadIdx.x >> 6] = bj; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 16; ++w) if (s_w[w] > bw || (s_w[w] == bw && s_j[w] < bj)) { bw = s_w[w]; bj = s_j[w]; }
+            s_argmax = bj;
+        }
     }
     __syncthreads();
     double shift = 0;
