@@ -55,6 +55,30 @@ def test_nn_l1_ties_and_duplicates_take_first_index(dev):
     np.testing.assert_array_equal(iy.cpu().numpy(), chamfer.nn_l1(y, x)[1])
 
 
+def test_nn_l1_randomised_sizes_and_ties_vs_oracle(dev):
+    """40 seeded random shapes (1..9000 points per side, crossing the 4096-target LDS chunk and the 256 / 512 padding
+    boundaries), half of them on a coarse lattice so that exact ties and duplicates are everywhere: indices and
+    distances bit-exact against the C oracle."""
+    from autourdf_amd import ops
+    from oracle import chamfer
+    rng = np.random.default_rng(2024)
+    edge = [1, 2, 63, 64, 65, 255, 256, 257, 511, 512, 513, 4095, 4096, 4097, 8191, 8192, 8193]
+    for trial in range(40):
+        nx = int(rng.choice(edge)) if rng.random() < 0.4 else int(rng.integers(1, 9000))
+        ny = int(rng.choice(edge)) if rng.random() < 0.4 else int(rng.integers(1, 9000))
+        if trial % 2:
+            x = rng.integers(-4, 5, size=(nx, 3)).astype(np.float32) / 4
+            y = rng.integers(-4, 5, size=(ny, 3)).astype(np.float32) / 4
+        else:
+            x = rng.normal(size=(nx, 3)).astype(np.float32)
+            y = (rng.normal(size=(ny, 3)) * 0.5 + 0.1).astype(np.float32)
+        dx, ix, dy, iy = ops.nn_l1_bidir(_cuda(x, dev), _cuda(y, dev))
+        odx, oix = chamfer.nn_l1(x, y)
+        ody, oiy = chamfer.nn_l1(y, x)
+        assert np.array_equal(ix.cpu().numpy(), oix) and np.array_equal(iy.cpu().numpy(), oiy), (trial, nx, ny)
+        assert np.array_equal(dx.cpu().numpy(), odx) and np.array_equal(dy.cpu().numpy(), ody), (trial, nx, ny)
+
+
 def test_chamfer_loss_and_grad_vs_golden(dev, golden):
     from autourdf_amd import ops
     g = golden("chamfer_l1.npz")
