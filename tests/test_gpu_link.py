@@ -75,3 +75,29 @@ def test_evaluation_icp_filter_and_chamfer_vs_oracle():
     loss = torch_chamfer_distance(moved, PointCloud(gt))
     want = ochamfer.chamfer_distance(torch.tensor(moved_ref, dtype=torch.float32)[None], torch.tensor(gt, dtype=torch.float32)[None], norm=1)[0].item()
     assert abs(loss - want) <= 1e-6 * max(1.0, abs(want))
+
+
+def test_icp_targets_beyond_the_lds_budget_use_the_workspace_path():
+    """> 4096 targets of one pair do not fit the kernel's LDS table: the same loop then reads them through the
+    workspace index list (both the point-to-point and the masked entry points), same poses as the oracle."""
+    from autourdf_amd import ops
+    from autourdf_amd.cluster_icp import masked_icp
+    from oracle import icp as oicp
+    from scipy.spatial.transform import Rotation
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(12)
+    tgt = rng.uniform(-0.3, 0.3, size=(6000, 3))
+    R = Rotation.from_rotvec([0.01, -0.02, 0.015]).as_matrix()
+    src = tgt[rng.permutation(6000)[:700]] @ R.T + np.array([0.002, -0.001, 0.003])
+    off = lambda n: torch.tensor([0, n], dtype=torch.int32, device=dev)
+    T, moved, it = ops.icp_p2p(torch.as_tensor(src, device=dev), off(700), torch.as_tensor(tgt, device=dev), off(6000),
+                               torch.eye(4, dtype=torch.float64, device=dev)[None], th=1.0, max_iteration=200)
+    T_ref, _, _, _ = oicp.registration_icp(src, tgt, 1.0, np.eye(4), 200)
+    np.testing.assert_allclose(T[0].cpu().numpy(), T_ref, atol=1e-8)
+    # masked entry point: one cluster whose box (x 1.2) keeps ~all 6000 frame points
+    world = (src + 0.0).astype(np.float32)
+    big = np.concatenate([world, np.array([[-0.35, -0.35, -0.35], [0.35, 0.35, 0.35]], np.float32)])   # stretch the box
+    local = np.concatenate([src, [[-0.35, -0.35, -0.35], [0.35, 0.35, 0.35]]])
+    w, M = masked_icp([local], [big], tgt, np.eye(4)[None])
+    _, M_ref = oicp.masked_icp([local], [big], tgt, np.eye(4)[None])
+    np.testing.assert_allclose(M, M_ref, atol=1e-8)
