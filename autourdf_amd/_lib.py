@@ -15,7 +15,7 @@ vp, i64, i32, f32, f64, sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, c
 
 class TrainShape(ctypes.Structure):
     _fields_ = [("rot", i32), ("k", i32), ("hidden", i32), ("epochs", i32), ("n_pred", i64),
-                ("n_tgt", i64), ("use_graph", i32), ("batch", i32), ("graph_branches", i32)]
+                ("n_tgt", i64), ("use_graph", i32), ("batch", i32), ("graph_branches", i32), ("nn_search", i32)]
 
 
 class TrainArgs(ctypes.Structure):

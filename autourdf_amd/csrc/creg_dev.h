@@ -96,6 +96,20 @@ __device__ __forceinline__ void wave_argmin_fast(float& v, int& i) {
     i = __builtin_amdgcn_readlane(i, 63);
 }
 
+// Wave-uniform minimum of a float / int over the 64 lanes (same DPP tree as wave_argmin_fast).
+#define CREG_DPP_FMIN_STEP(ctrl, mask) v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, mask, 0xF, false)));
+#define CREG_DPP_IMIN_STEP(ctrl, mask) v = min(v, __builtin_amdgcn_update_dpp(v, v, ctrl, mask, 0xF, false));
+__device__ __forceinline__ float wave_min_fast(float v) {
+    CREG_DPP_FMIN_STEP(0xB1, 0xF) CREG_DPP_FMIN_STEP(0x4E, 0xF) CREG_DPP_FMIN_STEP(0x141, 0xF)
+    CREG_DPP_FMIN_STEP(0x140, 0xF) CREG_DPP_FMIN_STEP(0x142, 0xA) CREG_DPP_FMIN_STEP(0x143, 0xC)
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_fast(int v) {
+    CREG_DPP_IMIN_STEP(0xB1, 0xF) CREG_DPP_IMIN_STEP(0x4E, 0xF) CREG_DPP_IMIN_STEP(0x141, 0xF)
+    CREG_DPP_IMIN_STEP(0x140, 0xF) CREG_DPP_IMIN_STEP(0x142, 0xA) CREG_DPP_IMIN_STEP(0x143, 0xC)
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // (value, index) lexicographic minimum across the wave: smallest value, then smallest index.
 __device__ __forceinline__ void wave_argmin(float& v, int& i) {
 #pragma unroll

@@ -36,21 +36,16 @@ struct NnEpilogueNone {
 // Epi::operator()(dir, q, idx, dist, query xyz, matched-target xyz, acc) runs on lane u for the wave's u-th query;
 // Epi::finish(dir, blk, sum, scratch) once per block with the block's fixed-order sum of `acc`.
 template <int QW, typename IdxT, typename Epi>
-__global__ __launch_bounds__(NN_BLOCK) void k_nn_l1(
+__device__ __forceinline__ void nn_l1_block(
     const float* A, int na, int sa, const float* B, int nb, int sb,
     float* __restrict__ dA, IdxT* __restrict__ iA, float* __restrict__ dB, IdxT* __restrict__ iB,
-    int blocksA, Epi epi, size_t zstride) {
-    // grid.z = independent problems of a batch: point arrays and epilogue outputs of problem z live
-    // zstride bytes further on (0 for the standalone entry points)
-    A = (const float*)((const char*)A + blockIdx.z * zstride);
-    B = (const float*)((const char*)B + blockIdx.z * zstride);
-    epi.shift(blockIdx.z);
+    int blocksA, Epi& epi, int bx) {      // bx: block index in [0, blocksA + blocksB)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sX = (float*)smem_raw;                 // planes of `padded` floats each
     __shared__ float s_part[NN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int blk = blockIdx.x, dir = 0;
+    int blk = bx, dir = 0;
     const float* Q = A; const float* T = B;
     int nq = na, nt = nb, sq = sa, st = sb;
     float* dO = dA; IdxT* iO = iA;
@@ -156,6 +151,135 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_l1(
             epi.finish(dir, blk, s, nullptr);
         }
     }
+}
+
+// ---- exact search over a block-sorted target cloud --------------------------------------------------
+// The targets are laid out in blocks of 64 consecutive slots that are spatially compact (leaves of a k-d tree)
+// with an axis-aligned box each: `ts4[slot] = (x, y, z, bits(original index))`, +inf padding slots carry index
+// INT_MAX, `tbox[b] = (lo xyz, hi xyz)`, at most 64 * NB blocks so a wave holds NB boxes per lane.
+// A wave owns 4 queries as in the exhaustive kernel.  Per query: every lane evaluates the L1 distance from the
+// query to its box(es) -- a lower bound of the distance to every target inside, and in float arithmetic too:
+// each |q - t| is a monotone function of t on either side of the box and rounding is monotone; the block with
+// the smallest bound is visited first (one target per lane, one coalesced 1 KB read), the wave minimum becomes
+// the pruning radius, and only blocks whose bound is <= the radius (ties included) are visited after it.
+// The result is the exhaustive kernel's: smallest distance, then smallest ORIGINAL index.  On the registration
+// clouds 2-3 of the 64-80 blocks are visited.
+struct NnBlocks { const float4* ts4; const float* tbox; int nblk; const int* nblk_dev; };
+
+template <int NB, typename Epi>
+__device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int sq, NnBlocks tb, int dir, Epi& epi, int blk) {
+    constexpr int QW = 4;
+    __shared__ float s_partp[NN_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q0 = (blk * (NN_BLOCK / 64) + wave) * QW;
+    const int nblk = tb.nblk_dev ? *tb.nblk_dev : tb.nblk;
+    unsigned long long valid[NB];
+    float lox[NB], loy[NB], loz[NB], hix[NB], hiy[NB], hiz[NB];
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        const int ng = min(max(nblk - 64 * g, 0), 64);
+        valid[g] = ng == 64 ? ~0ull : ((1ull << ng) - 1ull);
+        const float* bx = tb.tbox + 6 * min(64 * g + lane, nblk - 1);
+        lox[g] = bx[0]; loy[g] = bx[1]; loz[g] = bx[2]; hix[g] = bx[3]; hiy[g] = bx[4]; hiz[g] = bx[5];
+    }
+    float qx[QW], qy[QW], qz[QW], lb[QW][NB], bd[QW], tx[QW], ty[QW], tz[QW], wb[QW];
+    int bi[QW];
+    unsigned long long pend[QW][NB], vis[QW][NB];
+#pragma unroll
+    for (int u = 0; u < QW; ++u) {
+        const int qi = min(q0 + u, nq - 1);
+        qx[u] = Q[(size_t)qi * sq]; qy[u] = Q[(size_t)qi * sq + 1]; qz[u] = Q[(size_t)qi * sq + 2];
+        float lm = INFINITY;
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            const float ex = fmaxf(fmaxf(lox[g] - qx[u], qx[u] - hix[g]), 0.f);
+            const float ey = fmaxf(fmaxf(loy[g] - qy[u], qy[u] - hiy[g]), 0.f);
+            const float ez = fmaxf(fmaxf(loz[g] - qz[u], qz[u] - hiz[g]), 0.f);
+            lb[u][g] = (ex + ey) + ez;                          // same association as l1_dist
+            lm = __builtin_fminf(lm, 64 * g + lane < nblk ? lb[u][g] : INFINITY);
+        }
+        const float m = wave_min_fast(lm);                      // start from the block with the smallest bound
+        bool found = false;
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            const unsigned long long f = __ballot(lb[u][g] == m) & valid[g];
+            pend[u][g] = (!found && f) ? (f & (~f + 1ull)) : 0ull;       // lowest set bit
+            found = found || f != 0ull;
+            vis[u][g] = 0ull;
+        }
+        if (!found) pend[u][0] = 1ull;                          // NaN bound: any block, nothing will be taken
+        bd[u] = INFINITY; bi[u] = 0x7fffffff; tx[u] = ty[u] = tz[u] = 0.f; wb[u] = INFINITY;
+    }
+    bool more = true;
+    while (more) {
+        float4 v[QW];
+        int b[QW];
+        bool act[QW];
+#pragma unroll
+        for (int u = 0; u < QW; ++u) {                        // the loads of all four queries are in flight together
+            b[u] = 0; act[u] = false;
+#pragma unroll
+            for (int g = NB - 1; g >= 0; --g)
+                if (pend[u][g]) { b[u] = 64 * g + __builtin_ctzll(pend[u][g]); act[u] = true; }
+            v[u] = tb.ts4[(size_t)b[u] * 64 + lane];
+        }
+        more = false;
+#pragma unroll
+        for (int u = 0; u < QW; ++u) {
+            if (act[u]) {                                    // wave-uniform
+#pragma unroll
+                for (int g = 0; g < NB; ++g)
+                    if ((b[u] >> 6) == g) vis[u][g] |= 1ull << (b[u] & 63);
+                const float d = l1_dist(qx[u], qy[u], qz[u], v[u].x, v[u].y, v[u].z);
+                const int oi = __float_as_int(v[u].w);
+                const bool take = d < bd[u] || (d == bd[u] && oi < bi[u]);
+                bd[u] = take ? d : bd[u]; bi[u] = take ? oi : bi[u];
+                tx[u] = take ? v[u].x : tx[u]; ty[u] = take ? v[u].y : ty[u]; tz[u] = take ? v[u].z : tz[u];
+                wb[u] = wave_min_fast(bd[u]);
+#pragma unroll
+                for (int g = 0; g < NB; ++g) {
+                    pend[u][g] = __ballot(lb[u][g] <= wb[u]) & valid[g] & ~vis[u][g];
+                    more |= pend[u][g] != 0ull;
+                }
+            }
+        }
+    }
+    float acc = 0.f, mv = 0.f, mqx = 0.f, mqy = 0.f, mqz = 0.f, mtx = 0.f, mty = 0.f, mtz = 0.f;
+    int mi = 0;
+#pragma unroll
+    for (int u = 0; u < QW; ++u) {
+        const int i = wave_min_fast(bd[u] == wb[u] ? bi[u] : 0x7fffffff);
+        const unsigned long long win = __ballot(bd[u] == wb[u] && bi[u] == i);
+        const int src = win ? __builtin_ctzll(win) : 0;
+        const float fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tx[u]), src));
+        const float fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty[u]), src));
+        const float fz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tz[u]), src));
+        if (lane == u) { mv = wb[u]; mi = i; mqx = qx[u]; mqy = qy[u]; mqz = qz[u]; mtx = fx; mty = fy; mtz = fz; }
+    }
+    if (lane < QW && q0 + lane < nq) epi(dir, q0 + lane, mi, mv, mqx, mqy, mqz, mtx, mty, mtz, acc);
+    acc = wave_sum_fast(acc);
+    if (lane == 0) s_partp[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NN_BLOCK / 64; ++w) s += s_partp[w];
+        epi.finish(dir, blk, s, nullptr);
+    }
+}
+
+template <int QW, typename IdxT, typename Epi>
+__global__ __launch_bounds__(NN_BLOCK) void k_nn_l1(
+    const float* A, int na, int sa, const float* B, int nb, int sb,
+    float* __restrict__ dA, IdxT* __restrict__ iA, float* __restrict__ dB, IdxT* __restrict__ iB,
+    int blocksA, Epi epi, size_t zstride) {
+    // grid.z = independent problems of a batch: point arrays and epilogue outputs of problem z live
+    // zstride bytes further on (0 for the standalone entry points)
+    A = (const float*)((const char*)A + blockIdx.z * zstride);
+    B = (const float*)((const char*)B + blockIdx.z * zstride);
+    epi.shift(blockIdx.z);
+    nn_l1_block<QW, IdxT, Epi>(A, na, sa, B, nb, sb, dA, iA, dB, iB, blocksA, epi, (int)blockIdx.x);
 }
 
 struct NnGrid { int qw, blocksA, blocksB, smem; };

@@ -32,6 +32,8 @@ struct Dims {
     int oW1, ob1, oW2, ob2, oW3A, ob3A, oW3B, ob3B, NPAR;
     int OC;        // o-chunks of k_bwd2
     int nbx, nby;  // NN blocks per direction (= loss partial counts)
+    int nyb;       // 64-point blocks of the sorted target frame (0: exhaustive search only)
+    int npb;       // upper bound of the 64-point blocks of the predicted cloud, clusters padded (0: that direction exhaustive)
 };
 
 struct Hyper {      // uploaded per run
@@ -51,7 +53,9 @@ struct TrainState {
 struct Ws {         // device pointers into the caller's workspace
     float *P, *AM, *AV;
     float *pose_in, *enc, *x1[2], *h2, *head_save, *m2, *gm2;
-    float4 *pts4, *y4, *pred4;
+    float4 *pts4, *y4, *pred4, *ys4, *psl4, *ps4;
+    float *ybox, *pbox;
+    int* sb;
     int* sgn_x;
     int4* cnt4;
     float *lossp_x, *lossp_y;
@@ -216,7 +220,9 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, size_t bstride) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) pin[i] = W.pose_in[8 * r + i];
     const int b = W.off[r], e = W.off[r + 1];
-    const float4 p_first = W.pts4[min(b + (int)threadIdx.x, D.NP - 1)];
+    // block-sorted walk (D.npb): cluster r owns the slots of blocks [sb[r], sb[r + 1])
+    const int s0 = D.npb ? 64 * W.sb[r] : 0, s1 = D.npb ? 64 * W.sb[r + 1] : 0;
+    const float4 p_first = D.npb ? W.psl4[min(s0 + (int)threadIdx.x, 64 * D.npb - 1)] : W.pts4[min(b + (int)threadIdx.x, D.NP - 1)];
     if (wave < NO) {
         const int o = wave;
         const float *w, *a; int n; float bias;
@@ -259,6 +265,35 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, size_t bstride) {
         for (int i = 0; i < 16; ++i) W.head_save[16 * r + i] = save[i];
     }
     __syncthreads();
+    if (D.npb) {
+        // slot order: a wave covers one 64-slot block per trip, so the block's box is a wave reduction of the
+        // coordinates just computed (exact: the search compares against these very values)
+        for (int sl = s0 + threadIdx.x; sl < s1; sl += 512) {
+            const float4 p = (sl == s0 + (int)threadIdx.x) ? p_first : W.psl4[sl];
+            const int n = __float_as_int(p.w);
+            const bool real = n != 0x7fffffff;
+            float o[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) o[a] = fmaf(p.z, m2s[4 * a + 2], fmaf(p.y, m2s[4 * a + 1], p.x * m2s[4 * a])) + m2s[4 * a + 3];
+            if (real) {
+                W.pred4[n] = make_float4(o[0], o[1], o[2], 0.f);
+                W.cnt4[n] = make_int4(0, 0, 0, 0);
+            }
+            W.ps4[sl] = real ? make_float4(o[0], o[1], o[2], p.w) : make_float4(INFINITY, INFINITY, INFINITY, p.w);
+            float bx[6];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                bx[a] = wave_min_fast(real ? o[a] : INFINITY);
+                bx[3 + a] = -wave_min_fast(real ? -o[a] : INFINITY);
+            }
+            if (lane == 0) {
+                float* pb = W.pbox + 6 * (sl >> 6);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) pb[a] = bx[a];
+            }
+        }
+        return;
+    }
     for (int n = b + threadIdx.x; n < e; n += 512) {
         const float4 p = (n == b + (int)threadIdx.x) ? p_first : W.pts4[n];
         float o[3];
@@ -266,6 +301,170 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, size_t bstride) {
         for (int a = 0; a < 3; ++a) o[a] = fmaf(p.z, m2s[4 * a + 2], fmaf(p.y, m2s[4 * a + 1], p.x * m2s[4 * a])) + m2s[4 * a + 3];
         W.pred4[n] = make_float4(o[0], o[1], o[2], 0.f);
         W.cnt4[n] = make_int4(0, 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ target blocks
+// Once per train: the target frame (it does not move during the 300 epochs) cut into blocks of 64 points with an
+// axis-aligned box each, for nn_l1_block_pruned.  The blocks are the leaves of a balanced k-d tree -- sort all
+// slots on x and halve, sort each half on y and halve, ... six levels (x,y,z,x,y,z), i.e. a 4 x 4 x 4 grid in
+// rank space -- so the boxes of different blocks do not overlap and a query usually has to look into one to three
+// of them (Morton-curve blocks, tried first, overlapped enough to need eight).  One workgroup per problem; every
+// level is a bitonic sort of the 4096 slots restricted to segments of 4096 >> level, keys = (order-preserving bits
+// of the coordinate, original index): unique, so the layout is deterministic.  Slots past n_tgt hold +inf keys and
+// stay at the end through every level.  Any permutation gives the same search result -- ties are broken on the
+// original index stored with the point -- so none of this is visible in the plan's outputs.
+__global__ __launch_bounds__(1024) void k_sort_y(Dims D, Ws W0, size_t bstride) {
+    const Ws W = ws_shift(W0, blockIdx.z * bstride);
+    __shared__ unsigned long long key[4096];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int j = tid; j < 4096; j += 1024) key[j] = j < D.NT ? (unsigned long long)j : ~0ull;
+    __syncthreads();
+    for (int level = 0; level < 6; ++level) {
+        const int seg = 4096 >> level, axis = level % 3;
+        for (int j = tid; j < 4096; j += 1024) {
+            const unsigned long long k = key[j];
+            if (k != ~0ull) {
+                const int idx = (int)(k & 0xFFFFull);
+                const float4 p = W.y4[idx];
+                const float c = axis == 0 ? p.x : axis == 1 ? p.y : p.z;
+                unsigned u = (unsigned)__float_as_int(c);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);            // total order of the floats
+                if (u == 0xFFFFFFFFu) u = 0xFFFFFFFEu;                     // keep real keys below the padding key
+                key[j] = ((unsigned long long)u << 32) | (unsigned)idx;
+            }
+        }
+        __syncthreads();
+        for (int size = 2; size <= seg; size <<= 1)
+            for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+                for (int t = tid; t < 2048; t += 1024) {
+                    const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), j = i | stride;
+                    const unsigned long long a = key[i], b = key[j];
+                    const bool up = size == seg || (i & size) == 0;        // every segment ends ascending
+                    if ((a > b) == up) { key[i] = b; key[j] = a; }
+                }
+                __syncthreads();
+            }
+    }
+    // sorted slots + per-block boxes: wave w writes blocks w, w+16, ...
+    for (int b = wv; b < D.nyb; b += 16) {
+        const unsigned long long k = key[b * 64 + lane];
+        float4 p = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
+        float l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (k != ~0ull) {
+            const int j = (int)(k & 0xFFFFull);
+            const float4 y = W.y4[j];
+            p = make_float4(y.x, y.y, y.z, __int_as_float(j));
+            l[0] = h[0] = y.x; l[1] = h[1] = y.y; l[2] = h[2] = y.z;
+        }
+        W.ys4[b * 64 + lane] = p;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            for (int off = 32; off >= 1; off >>= 1) {
+                l[c] = fminf(l[c], __shfl_xor(l[c], off, 64));
+                h[c] = fmaxf(h[c], __shfl_xor(h[c], off, 64));
+            }
+        if (lane == 0) {
+            float* o = W.ybox + 6 * b;
+            o[0] = l[0]; o[1] = l[1]; o[2] = l[2]; o[3] = h[0]; o[4] = h[1]; o[5] = h[2];
+        }
+    }
+}
+
+// The same for the predicted cloud, whose points move rigidly with their cluster every epoch: each cluster's
+// LOCAL points are cut into k-d leaves of 64 once per train (a cluster of n points owns ceil(n / 64) blocks, the
+// last one padded), and k_head, which transforms cluster r's points anyway, walks them in slot order and reduces
+// each block's box from the transformed coordinates it has just computed.  All clusters are split at once: one
+// bitonic sort per level over every slot with key = (first block of the slot's segment, coordinate, index) --
+// segments hold exactly 64 * blocks slots, so after the sort each one sits in its own slot range again, ordered on
+// the level's axis, and is halved at a block boundary (padding sorts last inside its segment and so stays in the
+// cluster's last block).  psl4[slot] = (local xyz, bits(point index)), padding = index INT_MAX; sb[c] = first block
+// of cluster c, sb[K] = blocks in use.
+constexpr int PS_MAXB = 128;                   // blocks: two boxes per lane in the search
+__global__ __launch_bounds__(1024) void k_sort_p(Dims D, Ws W0, size_t bstride) {
+    const Ws W = ws_shift(W0, blockIdx.z * bstride);
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned long long* key = (unsigned long long*)smem_raw;            // PS_MAXB * 64 keys
+    __shared__ unsigned char sf[PS_MAXB], sm[PS_MAXB];                  // per block: its segment's first block, block count
+    __shared__ short blk_cluster[PS_MAXB];
+    __shared__ int s_nb, s_more;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int nb = 0;
+        for (int c = 0; c < D.K; ++c) {
+            const int n = W.off[c + 1] - W.off[c], m = (n + 63) >> 6;
+            W.sb[c] = nb;
+            for (int i = 0; i < m; ++i) { sf[nb + i] = (unsigned char)nb; sm[nb + i] = (unsigned char)(m > 255 ? 255 : m); blk_cluster[nb + i] = (short)c; }
+            nb += m;
+        }
+        W.sb[D.K] = nb;
+        s_nb = nb;
+    }
+    __syncthreads();
+    const int nb = s_nb, ns = nb * 64;
+    int npow = 64;
+    while (npow < ns) npow <<= 1;
+    // slot -> point index (0x1FFF = padding)
+    for (int sl = tid; sl < npow; sl += 1024) {
+        unsigned long long k = ~0ull;
+        if (sl < ns) {
+            const int b = sl >> 6, c = blk_cluster[b];
+            const int p = sl - 64 * W.sb[c], n = W.off[c + 1] - W.off[c];
+            k = p < n ? (unsigned long long)(W.off[c] + p) : 0x1FFFull;
+        }
+        key[sl] = k;
+    }
+    __syncthreads();
+    for (int level = 0; level < 8; ++level) {
+        if (tid == 0) s_more = 0;
+        __syncthreads();
+        for (int b = tid; b < nb; b += 1024) if (sm[b] > 1) s_more = 1;
+        __syncthreads();
+        if (!s_more) break;
+        const int axis = level % 3;
+        for (int sl = tid; sl < ns; sl += 1024) {
+            const unsigned idx = (unsigned)(key[sl] & 0x1FFFull);
+            unsigned u = 0xFFFFFFFFu;
+            if (idx != 0x1FFFu) {
+                const float4 p = W.pts4[idx];
+                const float c = axis == 0 ? p.x : axis == 1 ? p.y : p.z;
+                u = (unsigned)__float_as_int(c);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                if (u == 0xFFFFFFFFu) u = 0xFFFFFFFEu;
+            }
+            key[sl] = ((unsigned long long)sf[sl >> 6] << 45) | ((unsigned long long)u << 13) | idx;
+        }
+        __syncthreads();
+        for (int size = 2; size <= npow; size <<= 1)
+            for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+                for (int t = tid; t < (npow >> 1); t += 1024) {
+                    const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), j = i | stride;
+                    const unsigned long long a = key[i], b = key[j];
+                    const bool up = (i & size) == 0;
+                    if ((a > b) == up) { key[i] = b; key[j] = a; }
+                }
+                __syncthreads();
+            }
+        unsigned char nf = 0, nm = 0;
+        const bool mine = tid < nb;
+        if (mine) {
+            const int f = sf[tid], m = sm[tid];
+            nf = (unsigned char)f; nm = (unsigned char)m;
+            if (m >= 2) {
+                const int ml = m >> 1;
+                if (tid < f + ml) nm = (unsigned char)ml;
+                else { nf = (unsigned char)(f + ml); nm = (unsigned char)(m - ml); }
+            }
+        }
+        __syncthreads();
+        if (mine) { sf[tid] = nf; sm[tid] = nm; }
+        __syncthreads();
+    }
+    for (int sl = tid; sl < ns; sl += 1024) {
+        const unsigned idx = (unsigned)(key[sl] & 0x1FFFull);
+        float4 o = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
+        if (idx != 0x1FFFu) { const float4 p = W.pts4[idx]; o = make_float4(p.x, p.y, p.z, __int_as_float((int)idx)); }
+        W.psl4[sl] = o;
     }
 }
 
@@ -293,6 +492,35 @@ struct EngineEpi {
     }
     __device__ __forceinline__ void finish(int dir, int blk, float s, float*) const { (dir == 0 ? lossp_x : lossp_y)[blk] = s; }
 };
+
+// The plan's nearest-neighbour launch: blocks of direction 0 search the block-sorted target frame for the predicted
+// points (pruned, exact); direction 1 searches the predicted cloud for the target points -- over k_head's
+// block-sorted copy of it (P1) or exhaustively.  Same epilogue, same per-block loss partials as k_nn_l1: the
+// launches are interchangeable bit for bit.
+template <bool P1>
+__global__ __launch_bounds__(NN_BLOCK) void k_nn_plan(const float* A, int na, const float* B, int nb, int blocksA,
+                                                      int blocksB, EngineEpi epi, NnBlocks yb, NnBlocks pb, size_t zstride) {
+    // grid.x = (blocksA + blocksB) * problems, direction 1 (the long blocks when it is exhaustive) of ALL problems
+    // first: the dispatcher hands workgroups out in index order, so the long ones spread over the CUs before the
+    // short ones fill in
+    const int nz = gridDim.x / (blocksA + blocksB);
+    int i = blockIdx.x, z, bx;
+    if (i < blocksB * nz) { z = i / blocksB; bx = blocksA + (i - z * blocksB); }
+    else { i -= blocksB * nz; z = i / blocksA; bx = i - z * blocksA; }
+    const size_t zb = z * zstride;
+    A = (const float*)((const char*)A + zb);
+    B = (const float*)((const char*)B + zb);
+    yb.ts4 = (const float4*)((const char*)yb.ts4 + zb);
+    yb.tbox = (const float*)((const char*)yb.tbox + zb);
+    epi.shift(z);
+    if (bx < blocksA) nn_l1_block_pruned<1, EngineEpi>(A, na, 4, yb, 0, epi, bx);
+    else if constexpr (P1) {
+        pb.ts4 = (const float4*)((const char*)pb.ts4 + zb);
+        pb.tbox = (const float*)((const char*)pb.tbox + zb);
+        pb.nblk_dev = (const int*)((const char*)pb.nblk_dev + zb);
+        nn_l1_block_pruned<2, EngineEpi>(B, nb, 4, pb, 1, epi, bx - blocksA);
+    } else nn_l1_block<4, int, EngineEpi>(A, na, 4, B, nb, 4, nullptr, nullptr, nullptr, nullptr, blocksA, epi, bx);
+}
 
 // ------------------------------------------------------------------------------------------ control + cluster grads
 // K blocks.  Every block derives the same loss and the same decisions from the same inputs; block 0
@@ -704,6 +932,10 @@ static bool make_dims(const creg_train_shape* s, Dims* D) {
     if (D->H2 % BW2_OC || D->H2 / BW2_OC > BW2_ROWS) return false;
     const NnGrid g = nn_grid(D->NP, D->NT, true, true);
     D->nbx = g.blocksA; D->nby = g.blocksB;
+    // block-pruned search of the (static) target cloud: one box per lane, 4 queries per wave
+    D->nyb = (s->nn_search == 0 && D->NT <= 64 * 64 && g.qw == 4) ? (D->NT + 63) / 64 : 0;
+    // the other direction: clusters padded to whole blocks, two boxes per lane -> at most 128 blocks
+    D->npb = (s->nn_search == 0 && g.qw == 4 && (D->NP + 63) / 64 + D->K <= PS_MAXB) ? (D->NP + 63) / 64 + D->K : 0;
     return true;
 }
 
@@ -719,6 +951,9 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     w.m2 = (float*)take(f * 16 * D.K); w.gm2 = (float*)take(f * 16 * D.K);
     w.pts4 = (float4*)take(sizeof(float4) * D.NP); w.y4 = (float4*)take(sizeof(float4) * D.NT);
     w.pred4 = (float4*)take(sizeof(float4) * D.NP);
+    w.ys4 = (float4*)take(sizeof(float4) * 64 * (D.nyb ? D.nyb : 1)); w.ybox = (float*)take(f * 6 * 64);
+    w.psl4 = (float4*)take(sizeof(float4) * 64 * (D.npb ? D.npb : 1)); w.ps4 = (float4*)take(sizeof(float4) * 64 * (D.npb ? D.npb : 1));
+    w.pbox = (float*)take(f * 6 * 128); w.sb = (int*)take(sizeof(int) * (D.K + 1));
     w.sgn_x = (int*)take(sizeof(int) * D.NP);
     w.cnt4 = (int4*)take(sizeof(int4) * D.NP);
     w.lossp_x = (float*)take(f * D.nbx); w.lossp_y = (float*)take(f * D.nby);
@@ -765,6 +1000,22 @@ static void launch_dw(Plan* P, int epoch, hipStream_t s) {
         hipLaunchKernelGGL((k_dw<decltype(nc)::value>), dim3(D.H2 / DW_RPB + cdiv(D.OA + D.OB, DW_RPB) + cdiv(D.H, DW_RPB), 1, P->nz),
                            dim3(DW_BLOCK), P->smem_dw, s, D, W, epoch, P->bstride); });
 }
+static void launch_nn(const Dims& D, const Ws& W, size_t bstride, int nz, hipStream_t s) {
+    const EngineEpi epi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, bstride};
+    if (D.nyb) {
+        const NnGrid g = nn_grid(D.NP, D.NT, true, true);
+        const NnBlocks yb{W.ys4, W.ybox, D.nyb, nullptr}, pb{W.ps4, W.pbox, 0, W.sb + D.K};
+        if (D.npb)
+            hipLaunchKernelGGL(k_nn_plan<true>, dim3((g.blocksA + g.blocksB) * nz), dim3(NN_BLOCK), 0, s, (const float*)W.pred4,
+                               D.NP, (const float*)W.y4, D.NT, g.blocksA, g.blocksB, epi, yb, pb, bstride);
+        else
+            hipLaunchKernelGGL(k_nn_plan<false>, dim3((g.blocksA + g.blocksB) * nz), dim3(NN_BLOCK), g.smem, s, (const float*)W.pred4,
+                               D.NP, (const float*)W.y4, D.NT, g.blocksA, g.blocksB, epi, yb, pb, bstride);
+    } else {
+        launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
+                          true, true, epi, s, nz, bstride);
+    }
+}
 constexpr int NKERN = 6;
 // `ev` (optional): NKERN + 1 events recorded before kernel 0 and after each kernel.
 static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nullptr) {
@@ -774,8 +1025,7 @@ static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nu
     mark(0);
     launch_l2(P, par, s); mark(1);
     launch_head(P, s); mark(2);
-    launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
-                      true, true, EngineEpi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, P->bstride}, s, P->nz, P->bstride); mark(3);
+    launch_nn(D, W, P->bstride, P->nz, s); mark(3);
     hipLaunchKernelGGL(k_gradc, dim3(D.K, 1, P->nz), dim3(256), 0, s, D, W, epoch, D.nbx, D.nby, P->bstride); mark(4);
     launch_bwd2(P, epoch, s); mark(5);
     launch_dw(P, epoch, s); mark(6);
@@ -808,6 +1058,18 @@ static int param_map(const Dims& D, ParamMap* pm) {
     const ParamMap m[6] = {{D.oW1, D.H * D.IN}, {D.ob1, D.H}, {D.oW2, D.HB * D.H}, {D.ob2, D.HB}, {D.oW3B, D.OB * D.HB}, {D.ob3B, D.OB}};
     memcpy(pm, m, sizeof(m));
     return 6;
+}
+
+// After the problems' inputs are staged: the once-per-train block layouts of the two clouds, all problems in one launch each.
+static int ps_sort_smem(const Dims& D) {
+    int npow = 64;
+    while (npow < 64 * D.npb) npow <<= 1;
+    return npow * (int)sizeof(unsigned long long);
+}
+static void launch_sorts(Plan* P, hipStream_t s, int nz) {
+    const Dims& D = P->D;
+    if (D.nyb) hipLaunchKernelGGL(k_sort_y, dim3(1, 1, nz), dim3(1024), 0, s, D, P->W, P->bstride);
+    if (D.npb) hipLaunchKernelGGL(k_sort_p, dim3(1, 1, nz), dim3(1024), ps_sort_smem(D), s, D, P->W, P->bstride);
 }
 
 static int stage_inputs(Plan* P, const creg_train_args* a, hipStream_t s, int b = 0) {
@@ -869,6 +1131,8 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
                                 P->smem_dw) != hipSuccess) rc_attr = 1;
     });
     CREG_REQUIRE(rc_attr == 0, "creg_train_plan_create: cannot raise the dynamic LDS limit of k_dw");
+    if (D.npb && ps_sort_smem(D) >= 60 * 1024)
+        CREG_HIP(hipFuncSetAttribute((const void*)k_sort_p, hipFuncAttributeMaxDynamicSharedMemorySize, ps_sort_smem(D)));
     CREG_REQUIRE(P->smem_bwd2 <= 65536, "creg_train_plan_create: k_bwd2 needs %d B of LDS (K too large)", P->smem_bwd2);
     *plan = (creg_train_plan*)P;
     return CREG_OK;
@@ -888,6 +1152,7 @@ extern "C" int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train
         int rc = stage_inputs(P, a, s, b);
         if (rc) return rc;
     }
+    launch_sorts(P, s, P->B);
     P->nz = P->B;
     int e = 0;
     if (P->shape.use_graph && D.epochs >= 2) {
@@ -981,11 +1246,11 @@ extern "C" int creg_train_plan_probe(creg_train_plan* plan, const creg_train_arg
     const Dims& D = P->D; const Ws& W = P->W;
     int rc = stage_inputs(P, a, s);
     if (rc) return rc;
+    launch_sorts(P, s, 1);
     P->nz = 1;
     launch_l2(P, 0, s);
     launch_head(P, s);
-    launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
-                      true, true, EngineEpi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, 0}, s, 1, 0);
+    launch_nn(D, W, 0, 1, s);
     hipLaunchKernelGGL(k_gradc, dim3(D.K, 1, 1), dim3(256), 0, s, D, W, 0, D.nbx, D.nby, (size_t)0);
     CREG_LAUNCH_CHECK();
     if (m2) CREG_HIP(hipMemcpyAsync(m2, W.m2, sizeof(float) * 16 * D.K, hipMemcpyDeviceToDevice, s));
@@ -1003,6 +1268,7 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
     hipStream_t s = (hipStream_t)stream;
     int rc = stage_inputs(P, a, s);
     if (rc) return rc;
+    launch_sorts(P, s, 1);
     P->nz = 1;
     std::vector<hipEvent_t> ev((size_t)(NKERN + 1) * n_epochs);
     for (auto& e : ev) CREG_HIP(hipEventCreate(&e));
@@ -1027,8 +1293,7 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
     P->nz = P->B / br + (P->B % br ? 1 : 0);
     CREG_HIP(hipEventRecord(ev[0], s));
     for (int i = 0; i < REP; ++i)
-        launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
-                          true, true, EngineEpi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, P->bstride}, s, P->nz, P->bstride);
+        launch_nn(D, W, P->bstride, P->nz, s);
     CREG_HIP(hipEventRecord(ev[1], s));
     CREG_HIP(hipStreamSynchronize(s));
     float ms = 0.f;

@@ -56,7 +56,7 @@ class BatchRegistrar:
     problems and the latency-bound kernels of one sequence hide behind the others'."""
 
     def __init__(self, mats0, clusters0, n_tgt, n_sequences, rot="q", hidden=512, epochs=300, use_graph=True,
-                 device="cuda", seeds=None, models=None, graph_branches=0):
+                 device="cuda", seeds=None, models=None, graph_branches=0, nn_search=0):
         self.device = torch.device(device)
         self.S = n_sequences
         seeds = list(seeds) if seeds is not None else list(range(n_sequences))
@@ -67,7 +67,8 @@ class BatchRegistrar:
                                           None if models is None else models[s])
             self.seqs.append(r)
         self.plan = ops.TrainPlan(rot, len(clusters0), hidden, self.seqs[0].pts.shape[0], n_tgt, epochs=epochs,
-                                  use_graph=use_graph, device=self.device, batch=n_sequences, graph_branches=graph_branches)
+                                  use_graph=use_graph, device=self.device, batch=n_sequences, graph_branches=graph_branches,
+                                 nn_search=nn_search)
 
     def step(self, frames64, frames32=None):
         """frames64: list of S (N,3) fp64 device tensors (the next frame of every sequence)."""

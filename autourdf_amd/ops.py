@@ -384,13 +384,14 @@ class TrainPlan:
     """Device-resident `train` loop (mlp_reg.py:17-152) for one (rot, K, hidden, N) shape."""
 
     def __init__(self, rot: str, k: int, hidden: int, n_pred: int, n_tgt: int, epochs: int = 300,
-                 use_graph: bool = True, device=None, batch: int = 1, graph_branches: int = 0):
+                 use_graph: bool = True, device=None, batch: int = 1, graph_branches: int = 0,
+                 nn_search: int = 0):
         self.L = _lib.load()
         self.rot = {"q": 0, "dq": 1}[rot]
         self.device = torch.device(device if device is not None else "cuda")
         self.batch = int(batch)
         self.shape = _lib.TrainShape(self.rot, k, hidden, epochs, n_pred, n_tgt, int(use_graph), self.batch,
-                                     int(graph_branches))
+                                     int(graph_branches), int(nn_search))
         need = self.L.creg_train_workspace_bytes(ctypes.byref(self.shape))
         if need == 0:
             raise ValueError("unsupported train shape")

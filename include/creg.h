@@ -234,6 +234,9 @@ typedef struct creg_train_shape {
                                groups whose epochs are captured as independent branches (different hardware queues,
                                so one group's small kernels overlap the other's NN launch).  0 = auto (2 when
                                batch >= 2), 1 = single chain.  Results do not depend on it. */
+    int32_t nn_search;    /* 0 = auto: predicted -> target searches run over the Morton-sorted, boxed target frame
+                             (exact pruning) when n_tgt <= 4096; 1 = exhaustive in both directions.  Results do not
+                             depend on it. */
 } creg_train_shape;
 
 typedef struct creg_train_args {

@@ -546,6 +546,56 @@ def test_graph_branches_bench_shape_bit_identical_to_single_runs(dev):
                 assert torch.equal(got.cpu().nan_to_num(), want.nan_to_num())
 
 
+@pytest.mark.parametrize("rot,k,hidden,n_pred,n_tgt,lattice", [
+    ("q", 20, 512, 4096, 4096, False),      # the bench shape
+    ("dq", 8, 64, 1000, 777, False),        # ragged last block of targets
+    ("q", 5, 64, 300, 50, False),           # fewer targets than one block
+    ("q", 6, 64, 2048, 4096, True),         # lattice clouds: exact distance ties everywhere
+    ("dq", 3, 128, 513, 4033, False),
+    ("q", 4, 64, 700, 1, False),            # a single target
+    ("q", 70, 64, 4096, 4096, False),       # 64 + 70 blocks > 128: the target -> predicted direction stays exhaustive
+    ("dq", 1, 64, 4096, 3000, False),       # one cluster of 64 blocks: six k-d levels
+    ("q", 9, 64, 640, 900, False),          # cluster sizes forced to multiples of 64 below + an empty cluster
+])
+def test_train_pruned_search_bit_identical_to_exhaustive(dev, rot, k, hidden, n_pred, n_tgt, lattice):
+    """nn_search 0 (predicted -> target direction over the Morton-sorted, boxed target frame) against nn_search 1
+    (exhaustive both ways): every output of the plan -- poses, best prediction, loss and lr history, trained
+    parameters -- must be identical bit for bit; the pruning is exact, ties on the original index included."""
+    from autourdf_amd import ops
+    from oracle import models
+    g = torch.Generator().manual_seed(n_pred * 7 + n_tgt)
+    if lattice:
+        y = torch.randint(0, 12, (n_tgt, 3), generator=g).float() * 0.03125
+        flat = torch.randint(0, 12, (n_pred, 3), generator=g).float() * 0.03125
+    else:
+        y = torch.rand(n_tgt, 3, generator=g) * 0.4
+        flat = y[torch.randint(0, n_tgt, (n_pred,), generator=g)] + 0.004 * torch.randn(n_pred, 3, generator=g)
+    cuts = sorted(torch.randperm(n_pred - 1, generator=g)[: k - 1].add(1).tolist())
+    if n_pred == 640:
+        cuts = [64, 128, 128, 320, 384, 448, 512, 576]          # whole blocks only, cluster 2 empty
+    m = torch.eye(4).repeat(k, 1, 1)
+    cl = []
+    for a, z in zip([0] + cuts, cuts + [n_pred]):
+        c = flat[a:z]
+        ctr = c.mean(0) if z > a else torch.zeros(3)
+        m[len(cl), :3, 3] = ctr
+        cl.append(c if lattice else c - ctr)          # lattice: identity poses keep the coordinates exact
+    if lattice:
+        m[:, :3, 3] = 0
+    pts, off = ops.pack_clusters(cl, dev)
+    torch.manual_seed(5)
+    model, order = (models.QRegMLP(True, hidden), ops.Q_PARAM_ORDER) if rot == "q" else (models.DQRegMLP(hidden), ops.DQ_PARAM_ORDER)
+    outs = []
+    for mode in (0, 1):
+        params = [model.state_dict()[key].clone().to(dev) for key in order]
+        plan = ops.TrainPlan(rot, k, hidden, n_pred, n_tgt, epochs=25, use_graph=True, device=dev, nn_search=mode)
+        o = plan.run(m.to(dev), y.to(dev), pts, off, params)
+        outs.append([t.cpu() for t in o] + [t.cpu() for t in params])
+    for a, b in zip(*outs):
+        assert torch.equal(a.nan_to_num(), b.nan_to_num())
+    assert torch.isfinite(outs[0][0]).all()
+
+
 def test_kmeans_batch_single_launch_bit_identical_to_multi_launch(dev, golden):
     """creg_kmeans_lloyd_batch_f64 (one workgroup per frame, LDS resident, no host sync) against
     creg_kmeans_lloyd_f64 and the sklearn golden: labels, centres, inertia, n_iter all identical."""
