@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-icp-variant", action="store_true", help="skip the ICP-style second line (SURVEY 8(d))")
     ap.add_argument("--eager", action="store_true", help="eager launches instead of the captured epoch graph")
+    ap.add_argument("--graph-branches", type=int, default=0, help="parallel chains in the captured graph (0 = the library's default)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="wx200_5",
                     help="default = the configuration BASELINE.json's metric is quoted on")
     args = ap.parse_args()
@@ -185,7 +186,7 @@ def main():
     frames64 = [[torch.as_tensor(f, dtype=torch.float64, device=dev) for f in s[1:n_frames]] for s in seqs]
     frames32 = [[f.to(torch.float32) for f in s] for s in frames64]
     reg = BatchRegistrar(mats0, clusters0, N_POINTS, S, "q", HIDDEN, EPOCHS, not args.eager, dev,
-                         seeds=[rank * 1000 + s for s in range(S)])
+                         seeds=[rank * 1000 + s for s in range(S)], graph_branches=args.graph_branches)
     poses = torch.zeros((warm_rounds + timed_rounds) * S, K_CLUSTERS, 4, 4, dtype=torch.float32, device=dev)
     losses = torch.zeros((warm_rounds + timed_rounds) * S, dtype=torch.float32, device=dev)
 
@@ -234,7 +235,7 @@ def main():
         if os.path.exists(pmc) and args.workload == "wx200_5":
             per_problem = json.load(open(pmc)).get("hbm_bytes_per_problem")      # PMC passes, tools/collect_profiles.sh
             traffic = per_problem * nn_problems if per_problem else None
-        roof = {"bound": "valu", "kernel": "k_nn_l1<4,int,EngineEpi>", "achieved": round(achieved, 3),
+        roof = {"bound": "valu", "kernel": "k_nn_plan<true>", "achieved": round(achieved, 3),
                 "peak": round(VALU_PEAK_TOPS, 1), "unit": "TFLOP/s", "frac": round(achieved / VALU_PEAK_TOPS, 4),
                 "traffic": traffic, "avg_launch_us": round(nn_us, 3), "problems_per_launch": nn_problems,
                 # the same launch against the HBM roofline, to show it is not the bound: algorithmic bytes (both clouds
@@ -243,11 +244,15 @@ def main():
                              "peak_GBps": 8000.0, "frac": round(alg_bytes / (nn_us * 1e-6) / 8e12, 5)},
                 "epoch_kernels_event_bracketed_us": {k: round(v, 2) for k, v in prof.items()},
                 "note": "L1 min-search is sub/add/min work: not a contraction (no MFMA) and ~200 KB of algorithmic "
-                        "traffic (not HBM); bound = fp32 VALU issue. achieved = 9*N^2 algorithmic lane-ops (SURVEY 8d) / "
-                        "avg launch; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (= 157.3 TFLOP/s FMA peak / 2). "
+                        "traffic (not HBM); bound = fp32 VALU issue. achieved = 9*N^2 algorithmic lane-ops (SURVEY 8d: the "
+                        "exhaustive bidirectional search the reference runs) / avg launch; peak = 256 CU x 4 SIMD x 32 lanes x "
+                        "2.4 GHz (= 157.3 TFLOP/s FMA peak / 2). The kernel returns the exhaustive search's result bit for bit "
+                        "but EXECUTES only a few percent of those pair evaluations: both clouds are cut into k-d leaf blocks of "
+                        "64 points with boxes and a query looks into the 2-3 blocks its box bounds cannot exclude (the exhaustive "
+                        "kernel it replaces, k_nn_l1, ran the same launch in 21.7 us = frac 0.27; nn_search=1 selects it). "
                         "avg_launch_us = 200 back-to-back launches between two HIP events (includes the launch gap), kernel alone; "
                         "in the timed region the sequences run as two graph branches (3 + 2 problems) on two hardware queues; "
-                        "rocprofv3's kernel trace largely serialises them (2 % of the traced time has two kernels in flight), so "
+                        "rocprofv3's kernel trace largely serialises them, so "
                         "its per-kernel averages are the mean of the standalone 3- and 2-problem launches; "
                         "per-kernel event brackets carry ~7 us of event overhead each, see profiles/ for rocprofv3"}
         out = {"metric": f"registered frames/sec (N={N_POINTS} pts, K={K_CLUSTERS} clusters)", "value": round(world * args.steps / elapsed, 4),
