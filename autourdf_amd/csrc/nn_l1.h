@@ -154,7 +154,7 @@ __device__ __forceinline__ void nn_l1_block(
 }
 
 // ---- exact search over a block-sorted target cloud --------------------------------------------------
-// The targets are laid out in blocks of 64 consecutive slots that are spatially compact (leaves of a k-d tree)
+// The targets are laid out in blocks of 64 * PPL consecutive slots that are spatially compact (leaves of a k-d tree)
 // with an axis-aligned box each: `ts4[slot] = (x, y, z, bits(original index))`, +inf padding slots carry index
 // INT_MAX, `tbox[b] = (lo xyz, hi xyz)`, at most 64 * NB blocks so a wave holds NB boxes per lane.
 // A wave owns 4 queries as in the exhaustive kernel.  Per query: every lane evaluates the L1 distance from the
@@ -166,7 +166,7 @@ __device__ __forceinline__ void nn_l1_block(
 // clouds 2-3 of the 64-80 blocks are visited.
 struct NnBlocks { const float4* ts4; const float* tbox; int nblk; const int* nblk_dev; };
 
-template <int NB, typename Epi>
+template <int NB, int PPL, typename Epi>
 __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int sq, NnBlocks tb, int dir, Epi& epi, int blk) {
     constexpr int QW = 4;
     __shared__ float s_partp[NN_BLOCK / 64];
@@ -213,29 +213,41 @@ __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int s
     }
     bool more = true;
     while (more) {
-        float4 v[QW];
         int b[QW];
         bool act[QW];
 #pragma unroll
-        for (int u = 0; u < QW; ++u) {                        // the loads of all four queries are in flight together
+        for (int u = 0; u < QW; ++u) {
             b[u] = 0; act[u] = false;
 #pragma unroll
             for (int g = NB - 1; g >= 0; --g)
                 if (pend[u][g]) { b[u] = 64 * g + __builtin_ctzll(pend[u][g]); act[u] = true; }
-            v[u] = tb.ts4[(size_t)b[u] * 64 + lane];
+        }
+        float4 v1[QW];
+        if constexpr (PPL == 1) {                             // the loads of all four queries are in flight together
+#pragma unroll
+            for (int u = 0; u < QW; ++u) v1[u] = tb.ts4[(size_t)b[u] * 64 + lane];
         }
         more = false;
 #pragma unroll
         for (int u = 0; u < QW; ++u) {
             if (act[u]) {                                    // wave-uniform
+                float4 v[PPL];
+                if constexpr (PPL == 1) v[0] = v1[u];
+                else {                                       // big clouds: PPL points per lane, enough waves to hide the reads
+#pragma unroll
+                    for (int k = 0; k < PPL; ++k) v[k] = tb.ts4[((size_t)b[u] * PPL + k) * 64 + lane];
+                }
 #pragma unroll
                 for (int g = 0; g < NB; ++g)
                     if ((b[u] >> 6) == g) vis[u][g] |= 1ull << (b[u] & 63);
-                const float d = l1_dist(qx[u], qy[u], qz[u], v[u].x, v[u].y, v[u].z);
-                const int oi = __float_as_int(v[u].w);
-                const bool take = d < bd[u] || (d == bd[u] && oi < bi[u]);
-                bd[u] = take ? d : bd[u]; bi[u] = take ? oi : bi[u];
-                tx[u] = take ? v[u].x : tx[u]; ty[u] = take ? v[u].y : ty[u]; tz[u] = take ? v[u].z : tz[u];
+#pragma unroll
+                for (int k = 0; k < PPL; ++k) {
+                    const float d = l1_dist(qx[u], qy[u], qz[u], v[k].x, v[k].y, v[k].z);
+                    const int oi = __float_as_int(v[k].w);
+                    const bool take = d < bd[u] || (d == bd[u] && oi < bi[u]);
+                    bd[u] = take ? d : bd[u]; bi[u] = take ? oi : bi[u];
+                    tx[u] = take ? v[k].x : tx[u]; ty[u] = take ? v[k].y : ty[u]; tz[u] = take ? v[k].z : tz[u];
+                }
                 wb[u] = wave_min_fast(bd[u]);
 #pragma unroll
                 for (int g = 0; g < NB; ++g) {

@@ -33,7 +33,8 @@ struct Dims {
     int OC;        // o-chunks of k_bwd2
     int nbx, nby;  // NN blocks per direction (= loss partial counts)
     int nyb;       // 64-point blocks of the sorted target frame (0: exhaustive search only)
-    int npb;       // upper bound of the 64-point blocks of the predicted cloud, clusters padded (0: that direction exhaustive)
+    int npb;       // upper bound of the blocks of the predicted cloud, clusters padded (0: that direction exhaustive)
+    int ppl;       // points per lane and block visit: blocks hold 64 * ppl points (1 up to 4096 targets, 4 up to 16384)
 };
 
 struct Hyper {      // uploaded per run
@@ -221,8 +222,9 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, size_t bstride) {
     for (int i = 0; i < 8; ++i) pin[i] = W.pose_in[8 * r + i];
     const int b = W.off[r], e = W.off[r + 1];
     // block-sorted walk (D.npb): cluster r owns the slots of blocks [sb[r], sb[r + 1])
-    const int s0 = D.npb ? 64 * W.sb[r] : 0, s1 = D.npb ? 64 * W.sb[r + 1] : 0;
-    const float4 p_first = D.npb ? W.psl4[min(s0 + (int)threadIdx.x, 64 * D.npb - 1)] : W.pts4[min(b + (int)threadIdx.x, D.NP - 1)];
+    const int BS = 64 * D.ppl;
+    const int s0 = D.npb ? BS * W.sb[r] : 0, s1 = D.npb ? BS * W.sb[r + 1] : 0;
+    const float4 p_first = D.npb ? W.psl4[min(s0 + (int)threadIdx.x, BS * D.npb - 1)] : W.pts4[min(b + (int)threadIdx.x, D.NP - 1)];
     if (wave < NO) {
         const int o = wave;
         const float *w, *a; int n; float bias;
@@ -266,10 +268,14 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, size_t bstride) {
     }
     __syncthreads();
     if (D.npb) {
-        // slot order: a wave covers one 64-slot block per trip, so the block's box is a wave reduction of the
-        // coordinates just computed (exact: the search compares against these very values)
-        for (int sl = s0 + threadIdx.x; sl < s1; sl += 512) {
-            const float4 p = (sl == s0 + (int)threadIdx.x) ? p_first : W.psl4[sl];
+        // slot order: a wave covers 64 consecutive slots per trip, so a block's box is a wave reduction of the
+        // coordinates just computed (exact: the search compares against these very values); with 256-point blocks
+        // the four waves of a block combine through LDS
+        __shared__ float wbox[8][6];
+        for (int base = s0; base < s1; base += 512) {            // trip count uniform over the workgroup
+            const int sl = base + threadIdx.x;
+            const bool in = sl < s1;
+            const float4 p = !in ? make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff)) : (base == s0 ? p_first : W.psl4[sl]);
             const int n = __float_as_int(p.w);
             const bool real = n != 0x7fffffff;
             float o[3];
@@ -279,17 +285,34 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, size_t bstride) {
                 W.pred4[n] = make_float4(o[0], o[1], o[2], 0.f);
                 W.cnt4[n] = make_int4(0, 0, 0, 0);
             }
-            W.ps4[sl] = real ? make_float4(o[0], o[1], o[2], p.w) : make_float4(INFINITY, INFINITY, INFINITY, p.w);
+            if (in) W.ps4[sl] = real ? make_float4(o[0], o[1], o[2], p.w) : make_float4(INFINITY, INFINITY, INFINITY, p.w);
             float bx[6];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 bx[a] = wave_min_fast(real ? o[a] : INFINITY);
                 bx[3 + a] = -wave_min_fast(real ? -o[a] : INFINITY);
             }
-            if (lane == 0) {
-                float* pb = W.pbox + 6 * (sl >> 6);
+            if (D.ppl == 1) {
+                if (lane == 0 && in) {
+                    float* pb = W.pbox + 6 * (sl >> 6);
 #pragma unroll
-                for (int a = 0; a < 6; ++a) pb[a] = bx[a];
+                    for (int a = 0; a < 6; ++a) pb[a] = bx[a];
+                }
+            } else {                                             // 4 waves per block, 2 blocks per trip
+                if (lane == 0) {
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) wbox[wave][a] = bx[a];
+                }
+                __syncthreads();
+                if (threadIdx.x < 12) {
+                    const int hb = threadIdx.x / 6, a = threadIdx.x % 6;
+                    if (base + 256 * hb < s1) {
+                        float v = wbox[4 * hb][a];
+                        for (int w = 1; w < 4; ++w) v = a < 3 ? fminf(v, wbox[4 * hb + w][a]) : fmaxf(v, wbox[4 * hb + w][a]);
+                        W.pbox[6 * ((base >> 8) + hb) + a] = v;
+                    }
+                }
+                __syncthreads();
             }
         }
         return;
@@ -305,50 +328,63 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, size_t bstride) {
 }
 
 // ------------------------------------------------------------------------------------------ target blocks
-// Once per train: the target frame (it does not move during the 300 epochs) cut into blocks of 64 points with an
-// axis-aligned box each, for nn_l1_block_pruned.  The blocks are the leaves of a balanced k-d tree -- sort all
-// slots on x and halve, sort each half on y and halve, ... six levels (x,y,z,x,y,z), i.e. a 4 x 4 x 4 grid in
-// rank space -- so the boxes of different blocks do not overlap and a query usually has to look into one to three
-// of them (Morton-curve blocks, tried first, overlapped enough to need eight).  One workgroup per problem; every
-// level is a bitonic sort of the 4096 slots restricted to segments of 4096 >> level, keys = (order-preserving bits
-// of the coordinate, original index): unique, so the layout is deterministic.  Slots past n_tgt hold +inf keys and
-// stay at the end through every level.  Any permutation gives the same search result -- ties are broken on the
+// Once per train: the target frame (it does not move during the 300 epochs) cut into blocks of BS = 64 * D.ppl
+// points with an axis-aligned box each, for nn_l1_block_pruned.  The blocks are the leaves of a balanced k-d tree
+// -- sort all slots on x and halve, sort each half on y and halve, ... (x,y,z,x,y,z: a 4 x 4 x 4 grid in rank
+// space for 64 leaves) -- so the boxes of different blocks do not overlap and a query usually has to look into one
+// to three of them (Morton-curve blocks, tried first, overlapped enough to need eight).  One workgroup per problem;
+// every level is a bitonic sort of the slots in LDS restricted to segments of npow >> level, keys = (order-preserving
+// bits of the coordinate, original index): unique, so the layout is deterministic.  Slots past n_tgt hold +inf keys
+// and stay at the end through every level.  Any permutation gives the same search result -- ties are broken on the
 // original index stored with the point -- so none of this is visible in the plan's outputs.
-__global__ __launch_bounds__(1024) void k_sort_y(Dims D, Ws W0, size_t bstride) {
+constexpr int PS_MAXB = 128;                   // blocks of the predicted cloud: two boxes per lane in the search
+__device__ __forceinline__ unsigned ordered_bits(float c) {                // total order of the floats, below 0xFFFFFFFF
+    unsigned u = (unsigned)__float_as_int(c);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return u == 0xFFFFFFFFu ? 0xFFFFFFFEu : u;
+}
+// ascending bitonic sort of key[0, npow) restricted to aligned segments of `seg` slots
+__device__ __forceinline__ void bitonic_segments(unsigned long long* key, int npow, int seg, int tid, int nthreads) {
+    for (int size = 2; size <= seg; size <<= 1)
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            for (int t = tid; t < (npow >> 1); t += nthreads) {
+                const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), j = i | stride;
+                const unsigned long long a = key[i], b = key[j];
+                const bool up = size == seg || (i & size) == 0;            // every segment ends ascending
+                if ((a > b) == up) { key[i] = b; key[j] = a; }
+            }
+            __syncthreads();
+        }
+}
+static int pow2_at_least(int n) { int p = 64; while (p < n) p <<= 1; return p; }
+
+__global__ __launch_bounds__(1024) void k_sort_y(Dims D, Ws W0, size_t bstride, int npow) {
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
-    __shared__ unsigned long long key[4096];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned long long* key = (unsigned long long*)smem_raw;               // npow keys
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int j = tid; j < 4096; j += 1024) key[j] = j < D.NT ? (unsigned long long)j : ~0ull;
+    const int BS = 64 * D.ppl;
+    for (int j = tid; j < npow; j += 1024) key[j] = j < D.NT ? (unsigned long long)j : ~0ull;
     __syncthreads();
-    for (int level = 0; level < 6; ++level) {
-        const int seg = 4096 >> level, axis = level % 3;
-        for (int j = tid; j < 4096; j += 1024) {
+    int level = 0;
+    for (int seg = npow; seg > BS; seg >>= 1, ++level) {
+        const int axis = level % 3;
+        for (int j = tid; j < npow; j += 1024) {
             const unsigned long long k = key[j];
             if (k != ~0ull) {
                 const int idx = (int)(k & 0xFFFFull);
                 const float4 p = W.y4[idx];
-                const float c = axis == 0 ? p.x : axis == 1 ? p.y : p.z;
-                unsigned u = (unsigned)__float_as_int(c);
-                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);            // total order of the floats
-                if (u == 0xFFFFFFFFu) u = 0xFFFFFFFEu;                     // keep real keys below the padding key
-                key[j] = ((unsigned long long)u << 32) | (unsigned)idx;
+                key[j] = ((unsigned long long)ordered_bits(axis == 0 ? p.x : axis == 1 ? p.y : p.z) << 32) | (unsigned)idx;
             }
         }
         __syncthreads();
-        for (int size = 2; size <= seg; size <<= 1)
-            for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-                for (int t = tid; t < 2048; t += 1024) {
-                    const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), j = i | stride;
-                    const unsigned long long a = key[i], b = key[j];
-                    const bool up = size == seg || (i & size) == 0;        // every segment ends ascending
-                    if ((a > b) == up) { key[i] = b; key[j] = a; }
-                }
-                __syncthreads();
-            }
+        bitonic_segments(key, npow, seg, tid, 1024);
     }
-    // sorted slots + per-block boxes: wave w writes blocks w, w+16, ...
-    for (int b = wv; b < D.nyb; b += 16) {
-        const unsigned long long k = key[b * 64 + lane];
+    // sorted slots + per-block boxes: wave w handles the 64-slot groups w, w + 16, ...; a block is D.ppl groups
+    float* boxes = (float*)(key + npow);                                   // [group][6] scratch behind the keys
+    const int groups = D.nyb * D.ppl;
+    for (int gq = wv; gq < groups; gq += 16) {
+        const unsigned long long k = key[gq * 64 + lane];
         float4 p = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
         float l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
         if (k != ~0ull) {
@@ -357,7 +393,7 @@ __global__ __launch_bounds__(1024) void k_sort_y(Dims D, Ws W0, size_t bstride) 
             p = make_float4(y.x, y.y, y.z, __int_as_float(j));
             l[0] = h[0] = y.x; l[1] = h[1] = y.y; l[2] = h[2] = y.z;
         }
-        W.ys4[b * 64 + lane] = p;
+        W.ys4[gq * 64 + lane] = p;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             for (int off = 32; off >= 1; off >>= 1) {
@@ -365,106 +401,91 @@ __global__ __launch_bounds__(1024) void k_sort_y(Dims D, Ws W0, size_t bstride) 
                 h[c] = fmaxf(h[c], __shfl_xor(h[c], off, 64));
             }
         if (lane == 0) {
-            float* o = W.ybox + 6 * b;
+            float* o = boxes + 6 * gq;
             o[0] = l[0]; o[1] = l[1]; o[2] = l[2]; o[3] = h[0]; o[4] = h[1]; o[5] = h[2];
         }
+    }
+    __syncthreads();
+    for (int b = tid; b < D.nyb; b += 1024) {
+        float o[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int g = 0; g < D.ppl; ++g)
+            for (int c = 0; c < 3; ++c) {
+                o[c] = fminf(o[c], boxes[6 * (b * D.ppl + g) + c]);
+                o[3 + c] = fmaxf(o[3 + c], boxes[6 * (b * D.ppl + g) + 3 + c]);
+            }
+        for (int c = 0; c < 6; ++c) W.ybox[6 * b + c] = o[c];
     }
 }
 
 // The same for the predicted cloud, whose points move rigidly with their cluster every epoch: each cluster's
-// LOCAL points are cut into k-d leaves of 64 once per train (a cluster of n points owns ceil(n / 64) blocks, the
+// LOCAL points are cut into k-d leaves of BS once per train (a cluster of n points owns ceil(n / BS) blocks, the
 // last one padded), and k_head, which transforms cluster r's points anyway, walks them in slot order and reduces
-// each block's box from the transformed coordinates it has just computed.  All clusters are split at once: one
-// bitonic sort per level over every slot with key = (first block of the slot's segment, coordinate, index) --
-// segments hold exactly 64 * blocks slots, so after the sort each one sits in its own slot range again, ordered on
-// the level's axis, and is halved at a block boundary (padding sorts last inside its segment and so stays in the
-// cluster's last block).  psl4[slot] = (local xyz, bits(point index)), padding = index INT_MAX; sb[c] = first block
-// of cluster c, sb[K] = blocks in use.
-constexpr int PS_MAXB = 128;                   // blocks: two boxes per lane in the search
-__global__ __launch_bounds__(1024) void k_sort_p(Dims D, Ws W0, size_t bstride) {
+// each block's box from the transformed coordinates it has just computed.  One workgroup per cluster; all segments
+// of a level are split by ONE bitonic sort over the cluster's slots with key = (first block of the slot's segment,
+// coordinate, index): segments hold exactly BS * blocks slots, so after the sort each one sits in its own slot range
+// again, ordered on the level's axis, and is halved at a block boundary (padding sorts last inside its segment and
+// so stays in the cluster's last block).  psl4[slot] = (local xyz, bits(point index)), padding = index INT_MAX;
+// sb[c] = first block of cluster c, sb[K] = blocks in use.
+__global__ __launch_bounds__(512) void k_sort_p(Dims D, Ws W0, size_t bstride) {
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    unsigned long long* key = (unsigned long long*)smem_raw;            // PS_MAXB * 64 keys
-    __shared__ unsigned char sf[PS_MAXB], sm[PS_MAXB];                  // per block: its segment's first block, block count
-    __shared__ short blk_cluster[PS_MAXB];
-    __shared__ int s_nb, s_more;
-    const int tid = threadIdx.x;
+    unsigned long long* key = (unsigned long long*)smem_raw;
+    __shared__ unsigned char sf[PS_MAXB], sm[PS_MAXB];                  // per block of this cluster: its segment's first block, block count
+    __shared__ int s_more;
+    const int tid = threadIdx.x, c = blockIdx.x;
+    const int BS = 64 * D.ppl, bshift = D.ppl == 1 ? 6 : 8;
+    int first = 0;                                                       // blocks of the clusters before this one
+    for (int i = 0; i < c; ++i) first += (W.off[i + 1] - W.off[i] + BS - 1) >> bshift;
+    const int p0 = W.off[c], n = W.off[c + 1] - p0, m = (n + BS - 1) >> bshift;
     if (tid == 0) {
-        int nb = 0;
-        for (int c = 0; c < D.K; ++c) {
-            const int n = W.off[c + 1] - W.off[c], m = (n + 63) >> 6;
-            W.sb[c] = nb;
-            for (int i = 0; i < m; ++i) { sf[nb + i] = (unsigned char)nb; sm[nb + i] = (unsigned char)(m > 255 ? 255 : m); blk_cluster[nb + i] = (short)c; }
-            nb += m;
-        }
-        W.sb[D.K] = nb;
-        s_nb = nb;
+        W.sb[c] = first;
+        if (c == D.K - 1) W.sb[D.K] = first + m;
     }
-    __syncthreads();
-    const int nb = s_nb, ns = nb * 64;
+    if (m == 0) return;
+    const int ns = m * BS;
     int npow = 64;
     while (npow < ns) npow <<= 1;
-    // slot -> point index (0x1FFF = padding)
-    for (int sl = tid; sl < npow; sl += 1024) {
-        unsigned long long k = ~0ull;
-        if (sl < ns) {
-            const int b = sl >> 6, c = blk_cluster[b];
-            const int p = sl - 64 * W.sb[c], n = W.off[c + 1] - W.off[c];
-            k = p < n ? (unsigned long long)(W.off[c] + p) : 0x1FFFull;
-        }
-        key[sl] = k;
-    }
+    for (int sl = tid; sl < npow; sl += 512) key[sl] = sl >= ns ? ~0ull : sl < n ? (unsigned long long)(p0 + sl) : 0xFFFFull;
+    for (int b = tid; b < m; b += 512) { sf[b] = 0; sm[b] = (unsigned char)m; }
     __syncthreads();
     for (int level = 0; level < 8; ++level) {
         if (tid == 0) s_more = 0;
         __syncthreads();
-        for (int b = tid; b < nb; b += 1024) if (sm[b] > 1) s_more = 1;
+        for (int b = tid; b < m; b += 512) if (sm[b] > 1) s_more = 1;
         __syncthreads();
         if (!s_more) break;
         const int axis = level % 3;
-        for (int sl = tid; sl < ns; sl += 1024) {
-            const unsigned idx = (unsigned)(key[sl] & 0x1FFFull);
+        for (int sl = tid; sl < ns; sl += 512) {
+            const unsigned idx = (unsigned)(key[sl] & 0xFFFFull);
             unsigned u = 0xFFFFFFFFu;
-            if (idx != 0x1FFFu) {
+            if (idx != 0xFFFFu) {
                 const float4 p = W.pts4[idx];
-                const float c = axis == 0 ? p.x : axis == 1 ? p.y : p.z;
-                u = (unsigned)__float_as_int(c);
-                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-                if (u == 0xFFFFFFFFu) u = 0xFFFFFFFEu;
+                u = ordered_bits(axis == 0 ? p.x : axis == 1 ? p.y : p.z);
             }
-            key[sl] = ((unsigned long long)sf[sl >> 6] << 45) | ((unsigned long long)u << 13) | idx;
+            key[sl] = ((unsigned long long)sf[sl >> bshift] << 48) | ((unsigned long long)u << 16) | idx;
         }
         __syncthreads();
-        for (int size = 2; size <= npow; size <<= 1)
-            for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-                for (int t = tid; t < (npow >> 1); t += 1024) {
-                    const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), j = i | stride;
-                    const unsigned long long a = key[i], b = key[j];
-                    const bool up = (i & size) == 0;
-                    if ((a > b) == up) { key[i] = b; key[j] = a; }
-                }
-                __syncthreads();
-            }
+        bitonic_segments(key, npow, npow, tid, 512);
         unsigned char nf = 0, nm = 0;
-        const bool mine = tid < nb;
+        const bool mine = tid < m;
         if (mine) {
-            const int f = sf[tid], m = sm[tid];
-            nf = (unsigned char)f; nm = (unsigned char)m;
-            if (m >= 2) {
-                const int ml = m >> 1;
+            const int f = sf[tid], mm = sm[tid];
+            nf = (unsigned char)f; nm = (unsigned char)mm;
+            if (mm >= 2) {
+                const int ml = mm >> 1;
                 if (tid < f + ml) nm = (unsigned char)ml;
-                else { nf = (unsigned char)(f + ml); nm = (unsigned char)(m - ml); }
+                else { nf = (unsigned char)(f + ml); nm = (unsigned char)(mm - ml); }
             }
         }
         __syncthreads();
         if (mine) { sf[tid] = nf; sm[tid] = nm; }
         __syncthreads();
     }
-    for (int sl = tid; sl < ns; sl += 1024) {
-        const unsigned idx = (unsigned)(key[sl] & 0x1FFFull);
+    for (int sl = tid; sl < ns; sl += 512) {
+        const unsigned idx = (unsigned)(key[sl] & 0xFFFFull);
         float4 o = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
-        if (idx != 0x1FFFu) { const float4 p = W.pts4[idx]; o = make_float4(p.x, p.y, p.z, __int_as_float((int)idx)); }
-        W.psl4[sl] = o;
+        if (idx != 0xFFFFu) { const float4 p = W.pts4[idx]; o = make_float4(p.x, p.y, p.z, __int_as_float((int)idx)); }
+        W.psl4[(size_t)first * BS + sl] = o;
     }
 }
 
@@ -497,7 +518,7 @@ struct EngineEpi {
 // points (pruned, exact); direction 1 searches the predicted cloud for the target points -- over k_head's
 // block-sorted copy of it (P1) or exhaustively.  Same epilogue, same per-block loss partials as k_nn_l1: the
 // launches are interchangeable bit for bit.
-template <bool P1>
+template <bool P1, int PPL>
 __global__ __launch_bounds__(NN_BLOCK) void k_nn_plan(const float* A, int na, const float* B, int nb, int blocksA,
                                                       int blocksB, EngineEpi epi, NnBlocks yb, NnBlocks pb, size_t zstride) {
     // grid.x = (blocksA + blocksB) * problems, direction 1 (the long blocks when it is exhaustive) of ALL problems
@@ -513,12 +534,12 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_plan(const float* A, int na, co
     yb.ts4 = (const float4*)((const char*)yb.ts4 + zb);
     yb.tbox = (const float*)((const char*)yb.tbox + zb);
     epi.shift(z);
-    if (bx < blocksA) nn_l1_block_pruned<1, EngineEpi>(A, na, 4, yb, 0, epi, bx);
+    if (bx < blocksA) nn_l1_block_pruned<1, PPL, EngineEpi>(A, na, 4, yb, 0, epi, bx);
     else if constexpr (P1) {
         pb.ts4 = (const float4*)((const char*)pb.ts4 + zb);
         pb.tbox = (const float*)((const char*)pb.tbox + zb);
         pb.nblk_dev = (const int*)((const char*)pb.nblk_dev + zb);
-        nn_l1_block_pruned<2, EngineEpi>(B, nb, 4, pb, 1, epi, bx - blocksA);
+        nn_l1_block_pruned<2, PPL, EngineEpi>(B, nb, 4, pb, 1, epi, bx - blocksA);
     } else nn_l1_block<4, int, EngineEpi>(A, na, 4, B, nb, 4, nullptr, nullptr, nullptr, nullptr, blocksA, epi, bx);
 }
 
@@ -933,9 +954,11 @@ static bool make_dims(const creg_train_shape* s, Dims* D) {
     const NnGrid g = nn_grid(D->NP, D->NT, true, true);
     D->nbx = g.blocksA; D->nby = g.blocksB;
     // block-pruned search of the (static) target cloud: one box per lane, 4 queries per wave
-    D->nyb = (s->nn_search == 0 && D->NT <= 64 * 64 && g.qw == 4) ? (D->NT + 63) / 64 : 0;
+    D->ppl = D->NT <= 64 * 64 ? 1 : 4;
+    const int BS = 64 * D->ppl;
+    D->nyb = (s->nn_search == 0 && D->NT <= 64 * BS && g.qw == 4) ? (D->NT + BS - 1) / BS : 0;
     // the other direction: clusters padded to whole blocks, two boxes per lane -> at most 128 blocks
-    D->npb = (s->nn_search == 0 && g.qw == 4 && (D->NP + 63) / 64 + D->K <= PS_MAXB) ? (D->NP + 63) / 64 + D->K : 0;
+    D->npb = (D->nyb && D->NP < 65535 && (D->NP + BS - 1) / BS + D->K <= PS_MAXB) ? (D->NP + BS - 1) / BS + D->K : 0;
     return true;
 }
 
@@ -951,8 +974,9 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     w.m2 = (float*)take(f * 16 * D.K); w.gm2 = (float*)take(f * 16 * D.K);
     w.pts4 = (float4*)take(sizeof(float4) * D.NP); w.y4 = (float4*)take(sizeof(float4) * D.NT);
     w.pred4 = (float4*)take(sizeof(float4) * D.NP);
-    w.ys4 = (float4*)take(sizeof(float4) * 64 * (D.nyb ? D.nyb : 1)); w.ybox = (float*)take(f * 6 * 64);
-    w.psl4 = (float4*)take(sizeof(float4) * 64 * (D.npb ? D.npb : 1)); w.ps4 = (float4*)take(sizeof(float4) * 64 * (D.npb ? D.npb : 1));
+    const size_t bs = 64 * (size_t)D.ppl;
+    w.ys4 = (float4*)take(sizeof(float4) * bs * (D.nyb ? D.nyb : 1)); w.ybox = (float*)take(f * 6 * 64);
+    w.psl4 = (float4*)take(sizeof(float4) * bs * (D.npb ? D.npb : 1)); w.ps4 = (float4*)take(sizeof(float4) * bs * (D.npb ? D.npb : 1));
     w.pbox = (float*)take(f * 6 * 128); w.sb = (int*)take(sizeof(int) * (D.K + 1));
     w.sgn_x = (int*)take(sizeof(int) * D.NP);
     w.cnt4 = (int4*)take(sizeof(int4) * D.NP);
@@ -1005,12 +1029,13 @@ static void launch_nn(const Dims& D, const Ws& W, size_t bstride, int nz, hipStr
     if (D.nyb) {
         const NnGrid g = nn_grid(D.NP, D.NT, true, true);
         const NnBlocks yb{W.ys4, W.ybox, D.nyb, nullptr}, pb{W.ps4, W.pbox, 0, W.sb + D.K};
-        if (D.npb)
-            hipLaunchKernelGGL(k_nn_plan<true>, dim3((g.blocksA + g.blocksB) * nz), dim3(NN_BLOCK), 0, s, (const float*)W.pred4,
-                               D.NP, (const float*)W.y4, D.NT, g.blocksA, g.blocksB, epi, yb, pb, bstride);
-        else
-            hipLaunchKernelGGL(k_nn_plan<false>, dim3((g.blocksA + g.blocksB) * nz), dim3(NN_BLOCK), g.smem, s, (const float*)W.pred4,
-                               D.NP, (const float*)W.y4, D.NT, g.blocksA, g.blocksB, epi, yb, pb, bstride);
+        const dim3 grid((g.blocksA + g.blocksB) * nz);
+        auto go = [&](auto kern, int smem) {
+            hipLaunchKernelGGL(kern, grid, dim3(NN_BLOCK), smem, s, (const float*)W.pred4, D.NP, (const float*)W.y4, D.NT,
+                               g.blocksA, g.blocksB, epi, yb, pb, bstride);
+        };
+        if (D.npb) { if (D.ppl == 1) go(k_nn_plan<true, 1>, 0); else go(k_nn_plan<true, 4>, 0); }
+        else { if (D.ppl == 1) go(k_nn_plan<false, 1>, g.smem); else go(k_nn_plan<false, 4>, g.smem); }
     } else {
         launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
                           true, true, epi, s, nz, bstride);
@@ -1061,15 +1086,16 @@ static int param_map(const Dims& D, ParamMap* pm) {
 }
 
 // After the problems' inputs are staged: the once-per-train block layouts of the two clouds, all problems in one launch each.
-static int ps_sort_smem(const Dims& D) {
-    int npow = 64;
-    while (npow < 64 * D.npb) npow <<= 1;
-    return npow * (int)sizeof(unsigned long long);
+static int ys_sort_npow(const Dims& D) { return pow2_at_least(D.NT); }
+static int ys_sort_smem(const Dims& D) { return ys_sort_npow(D) * 8 + 6 * 4 * D.nyb * D.ppl; }
+static int ps_sort_smem(const Dims& D) {       // a cluster can hold every point
+    const int BS = 64 * D.ppl;
+    return pow2_at_least((D.NP + BS - 1) / BS * BS) * 8;
 }
 static void launch_sorts(Plan* P, hipStream_t s, int nz) {
     const Dims& D = P->D;
-    if (D.nyb) hipLaunchKernelGGL(k_sort_y, dim3(1, 1, nz), dim3(1024), 0, s, D, P->W, P->bstride);
-    if (D.npb) hipLaunchKernelGGL(k_sort_p, dim3(1, 1, nz), dim3(1024), ps_sort_smem(D), s, D, P->W, P->bstride);
+    if (D.nyb) hipLaunchKernelGGL(k_sort_y, dim3(1, 1, nz), dim3(1024), ys_sort_smem(D), s, D, P->W, P->bstride, ys_sort_npow(D));
+    if (D.npb) hipLaunchKernelGGL(k_sort_p, dim3(D.K, 1, nz), dim3(512), ps_sort_smem(D), s, D, P->W, P->bstride);
 }
 
 static int stage_inputs(Plan* P, const creg_train_args* a, hipStream_t s, int b = 0) {
@@ -1133,6 +1159,8 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     CREG_REQUIRE(rc_attr == 0, "creg_train_plan_create: cannot raise the dynamic LDS limit of k_dw");
     if (D.npb && ps_sort_smem(D) >= 60 * 1024)
         CREG_HIP(hipFuncSetAttribute((const void*)k_sort_p, hipFuncAttributeMaxDynamicSharedMemorySize, ps_sort_smem(D)));
+    if (D.nyb && ys_sort_smem(D) >= 60 * 1024)
+        CREG_HIP(hipFuncSetAttribute((const void*)k_sort_y, hipFuncAttributeMaxDynamicSharedMemorySize, ys_sort_smem(D)));
     CREG_REQUIRE(P->smem_bwd2 <= 65536, "creg_train_plan_create: k_bwd2 needs %d B of LDS (K too large)", P->smem_bwd2);
     *plan = (creg_train_plan*)P;
     return CREG_OK;

@@ -234,8 +234,9 @@ typedef struct creg_train_shape {
                                groups whose epochs are captured as independent branches (different hardware queues,
                                so one group's small kernels overlap the other's NN launch).  0 = auto (2 when
                                batch >= 2), 1 = single chain.  Results do not depend on it. */
-    int32_t nn_search;    /* 0 = auto: predicted -> target searches run over the Morton-sorted, boxed target frame
-                             (exact pruning) when n_tgt <= 4096; 1 = exhaustive in both directions.  Results do not
+    int32_t nn_search;    /* 0 = auto: the nearest-neighbour searches run over k-d leaf blocks with boxes (exact
+                             pruning) when n_tgt <= 16384 (and, for the target -> predicted direction, when the
+                             predicted cloud fits 128 blocks); 1 = exhaustive in both directions.  Results do not
                              depend on it. */
 } creg_train_shape;
 

@@ -556,6 +556,10 @@ def test_graph_branches_bench_shape_bit_identical_to_single_runs(dev):
     ("q", 70, 64, 4096, 4096, False),       # 64 + 70 blocks > 128: the target -> predicted direction stays exhaustive
     ("dq", 1, 64, 4096, 3000, False),       # one cluster of 64 blocks: six k-d levels
     ("q", 9, 64, 640, 900, False),          # cluster sizes forced to multiples of 64 below + an empty cluster
+    ("q", 10, 64, 9000, 6000, False),       # > 4096 targets: 256-point blocks, four points per lane and visit
+    ("dq", 40, 64, 16384, 16384, False),    # the franka-shaped config (BASELINE configs[2])
+    ("q", 3, 64, 500, 5000, False),         # big frame, tiny clusters (one padded 256-block each)
+    ("q", 2, 64, 16000, 4097, True),        # lattice ties with 256-point blocks; one cluster of 32 blocks
 ])
 def test_train_pruned_search_bit_identical_to_exhaustive(dev, rot, k, hidden, n_pred, n_tgt, lattice):
     """nn_search 0 (predicted -> target direction over the Morton-sorted, boxed target frame) against nn_search 1
