@@ -1,0 +1,72 @@
+"""Randomised bit-identity stress of the plan's pruned nearest-neighbour search against the exhaustive one.
+
+    python tests/measure/stress_pruned_search.py [n_shapes] [seed]
+
+Every shape draws its own cluster count, cloud sizes (up to 16384, so both block sizes are exercised), cluster
+sizes (empty and whole-block clusters included), duplicated points (exact distance ties) and model; a short train
+is run under nn_search = 0 and 1 and every output tensor compared bit for bit.
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from autourdf_amd import ops          # noqa: E402
+from oracle import models             # noqa: E402  (random-init parameters only)
+
+
+def one(g, dev):
+    rot = "q" if torch.rand((), generator=g) < 0.5 else "dq"
+    big = torch.rand((), generator=g) < 0.3
+    n_tgt = int(torch.randint(1, 16385 if big else 4097, (), generator=g))
+    n_pred = int(torch.randint(1, 16385 if big else 4097, (), generator=g))
+    k = int(torch.randint(1, 41, (), generator=g))
+    k = min(k, n_pred)
+    y = torch.rand(n_tgt, 3, generator=g) * 0.5
+    if torch.rand((), generator=g) < 0.5:                     # duplicates -> exact ties
+        y[torch.randint(0, n_tgt, (n_tgt // 3 + 1,), generator=g)] = y[torch.randint(0, n_tgt, (n_tgt // 3 + 1,), generator=g)]
+    flat = y[torch.randint(0, n_tgt, (n_pred,), generator=g)] + 0.003 * torch.randn(n_pred, 3, generator=g)
+    if torch.rand((), generator=g) < 0.3:
+        flat = torch.round(flat * 64) / 64                     # coarse lattice
+        y = torch.round(y * 64) / 64
+    cuts = sorted(torch.randint(0, n_pred + 1, (k - 1,), generator=g).tolist())       # empty clusters allowed
+    if torch.rand((), generator=g) < 0.3:
+        cuts = sorted(min(n_pred, (c // 64) * 64) for c in cuts)
+    m = torch.eye(4).repeat(k, 1, 1)
+    cl = []
+    for a, z in zip([0] + cuts, cuts + [n_pred]):
+        c = flat[a:z]
+        ctr = c.mean(0) if z > a else torch.zeros(3)
+        m[len(cl), :3, 3] = ctr
+        cl.append(c - ctr)
+    pts, off = ops.pack_clusters(cl, dev)
+    torch.manual_seed(int(torch.randint(0, 1 << 30, (), generator=g)))
+    model, order = (models.QRegMLP(True, 64), ops.Q_PARAM_ORDER) if rot == "q" else (models.DQRegMLP(64), ops.DQ_PARAM_ORDER)
+    outs = []
+    for mode in (0, 1):
+        params = [model.state_dict()[key].clone().to(dev) for key in order]
+        plan = ops.TrainPlan(rot, k, 64, n_pred, n_tgt, epochs=8, use_graph=True, device=dev, nn_search=mode)
+        o = plan.run(m.to(dev), y.to(dev), pts, off, params)
+        outs.append([t.cpu() for t in o] + [t.cpu() for t in params])
+    ok = all(torch.equal(a.nan_to_num(), b.nan_to_num()) for a, b in zip(*outs))
+    return ok, (rot, k, n_pred, n_tgt), bool(torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][2][:1]).all())
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    g = torch.Generator().manual_seed(seed)
+    bad = finite = 0
+    for i in range(n):
+        ok, shape, fin = one(g, "cuda")
+        finite += fin
+        if not ok:
+            bad += 1
+            print("MISMATCH", i, shape, flush=True)
+    print(f"{n} shapes, {bad} mismatches, {finite} with finite poses and loss")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -600,6 +600,22 @@ def test_train_pruned_search_bit_identical_to_exhaustive(dev, rot, k, hidden, n_
     assert torch.isfinite(outs[0][0]).all()
 
 
+def test_train_pruned_search_random_shapes(dev):
+    """20 random shapes of tests/measure/stress_pruned_search.py (sizes up to 16384, empty / whole-block clusters,
+    duplicated points, lattice clouds): pruned and exhaustive plans agree bit for bit (600 shapes were run by hand,
+    profiles/r01_pruned_search_stress.log)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "measure", "stress_pruned_search.py")
+    spec = importlib.util.spec_from_file_location("stress_pruned_search", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = torch.Generator().manual_seed(11)
+    for _ in range(20):
+        ok, shape, finite = mod.one(g, dev)
+        assert ok and finite, shape
+
+
 def test_kmeans_batch_single_launch_bit_identical_to_multi_launch(dev, golden):
     """creg_kmeans_lloyd_batch_f64 (one workgroup per frame, LDS resident, no host sync) against
     creg_kmeans_lloyd_f64 and the sklearn golden: labels, centres, inertia, n_iter all identical."""
