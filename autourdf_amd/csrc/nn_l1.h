@@ -180,7 +180,9 @@ __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int s
     for (int g = 0; g < NB; ++g) {
         const int ng = min(max(nblk - 64 * g, 0), 64);
         valid[g] = ng == 64 ? ~0ull : ((1ull << ng) - 1ull);
-        const float* bx = tb.tbox + 6 * min(64 * g + lane, nblk - 1);
+        // (the box table is allocated for 64 * NB entries: no dependence of these loads on nblk_dev's round trip;
+        //  entries past nblk are masked by `valid`)
+        const float* bx = tb.tbox + 6 * (tb.nblk_dev ? 64 * g + lane : min(64 * g + lane, nblk - 1));
         lox[g] = bx[0]; loy[g] = bx[1]; loz[g] = bx[2]; hix[g] = bx[3]; hiy[g] = bx[4]; hiz[g] = bx[5];
     }
     float qx[QW], qy[QW], qz[QW], lb[QW][NB], bd[QW], tx[QW], ty[QW], tz[QW], wb[QW];
