@@ -808,10 +808,11 @@ __global__ __launch_bounds__(DW_BLOCK, 2) void k_dw(Dims D, Ws W0, int epoch, si
     float* gall = (float*)smem;                     // [4 waves][DW_RPW][K] gradient columns
     float* as = (float*)smem + gsz;                 // staged activations [rc][width]
     const int par = epoch & 1;
-    // block -> row kind.  Blocks: [hidden rows / RPB][output rows / RPB][encoder rows / RPB]
-    const int nb2 = D.H2 / DW_RPB, nb3 = (D.OA + D.OB + DW_RPB - 1) / DW_RPB;
-    const int bkind = (int)blockIdx.x < nb2 ? 0 : ((int)blockIdx.x < nb2 + nb3 ? 1 : 3);   // block-uniform
-    const int row0 = (bkind == 0 ? blockIdx.x : (bkind == 1 ? blockIdx.x - nb2 : blockIdx.x - nb2 - nb3)) * DW_RPB + wib * DW_RPW;
+    // block -> row kind.  Blocks: [encoder rows / RPB][hidden rows / RPB][output rows / RPB] -- the encoder blocks
+    // carry the longest chain (16 partial slabs per gradient, then the next epoch's x1), so they are dispatched first
+    const int nb1 = (D.H + DW_RPB - 1) / DW_RPB, nb2 = D.H2 / DW_RPB;
+    const int bkind = (int)blockIdx.x < nb1 ? 3 : ((int)blockIdx.x < nb1 + nb2 ? 0 : 1);   // block-uniform
+    const int row0 = (bkind == 3 ? blockIdx.x : (bkind == 0 ? blockIdx.x - nb1 : blockIdx.x - nb1 - nb2)) * DW_RPB + wib * DW_RPW;
     const float* x1cur = par ? W.x1[1] : W.x1[0];     // (a runtime index into the shifted struct would go to scratch)
     float* x1next = par ? W.x1[0] : W.x1[1];
     const float* amat = bkind == 0 ? x1cur : (bkind == 1 ? W.h2 : W.enc);
