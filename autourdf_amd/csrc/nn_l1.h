@@ -1,7 +1,9 @@
-// nn_l1.h -- the K=1 L1 nearest-neighbour kernel (K1), shared by the standalone C-ABI entry points
-// (nn_l1.hip) and the fused train plan (train_engine.hip).
+// nn_l1.h -- the K=1 L1 nearest-neighbour kernels (K1), shared by the standalone C-ABI entry points
+// (nn_l1.hip) and the fused train plan (train_engine.hip): the exhaustive search (nn_l1_block / k_nn_l1) and
+// the exact block-pruned search over k-d leaf blocks with boxes (nn_l1_block_pruned, the plan's default; the
+// plan builds the block layouts).  Both return the same (distance, first index) bit for bit.
 //
-// Mapping (N=4096: 256 workgroups = one per CU, 8 waves each):
+// Exhaustive mapping (N=4096: 256 workgroups = one per CU, 8 waves each):
 //   * a workgroup stages the target cloud into LDS once as three coordinate planes (48 KB per 4096
 //     points, chunked for larger clouds) -- without that every wave streamed the whole cloud from
 //     L2 (128 MB per launch at N=4096: the v1 kernel was L2-bandwidth bound);
