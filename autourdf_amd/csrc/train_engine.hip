@@ -1152,16 +1152,19 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     P->smem_bwd2 = (int)(sizeof(float) * (BW2_ROWS * ((D.K + 3) & ~3) + 16 * D.K + 8 * BW2_ROWS));
     P->smem_dw = (int)(sizeof(float) * (((DW_WAVES * DW_RPW * D.K + 3) & ~3) + STAGE_FLOATS + 64 * 4));
     int rc_attr = 0;
+    static int dw_lds_limit[16] = {0};             // per k_dw instantiation: the limit only ever grows (it is per kernel, not per plan)
     by_nc(D.H, [&](auto nc) {
-        if (P->smem_dw > 65536 &&
-            hipFuncSetAttribute((const void*)k_dw<decltype(nc)::value>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                P->smem_dw) != hipSuccess) rc_attr = 1;
+        constexpr int NC = decltype(nc)::value;
+        if (P->smem_dw > 65536 && P->smem_dw > dw_lds_limit[NC]) {
+            if (hipFuncSetAttribute((const void*)k_dw<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, P->smem_dw) != hipSuccess) rc_attr = 1;
+            else dw_lds_limit[NC] = P->smem_dw;
+        }
     });
     CREG_REQUIRE(rc_attr == 0, "creg_train_plan_create: cannot raise the dynamic LDS limit of k_dw");
-    if (D.npb && ps_sort_smem(D) >= 60 * 1024)
-        CREG_HIP(hipFuncSetAttribute((const void*)k_sort_p, hipFuncAttributeMaxDynamicSharedMemorySize, ps_sort_smem(D)));
-    if (D.nyb && ys_sort_smem(D) >= 60 * 1024)
-        CREG_HIP(hipFuncSetAttribute((const void*)k_sort_y, hipFuncAttributeMaxDynamicSharedMemorySize, ys_sort_smem(D)));
+    // the limit is per kernel, not per plan: always raise it to the largest any plan can ask for (16384 keys + boxes),
+    // so that a small plan created later does not lower it under a large one
+    if (D.npb) CREG_HIP(hipFuncSetAttribute((const void*)k_sort_p, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+    if (D.nyb) CREG_HIP(hipFuncSetAttribute((const void*)k_sort_y, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8 + 6 * 4 * 256));
     CREG_REQUIRE(P->smem_bwd2 <= 65536, "creg_train_plan_create: k_bwd2 needs %d B of LDS (K too large)", P->smem_bwd2);
     *plan = (creg_train_plan*)P;
     return CREG_OK;

@@ -600,6 +600,39 @@ def test_train_pruned_search_bit_identical_to_exhaustive(dev, rot, k, hidden, n_
     assert torch.isfinite(outs[0][0]).all()
 
 
+def test_plans_of_different_sizes_coexist(dev):
+    """The dynamic-LDS limit of a kernel is per kernel, not per plan: creating a smaller plan after a larger one must
+    not lower it under the larger one's sort launches (16384-point frame, then 6000, then the first again)."""
+    from autourdf_amd import ops
+    from oracle import models
+    g = torch.Generator().manual_seed(3)
+    torch.manual_seed(3)
+    model = models.QRegMLP(True, 64)
+
+    def make(n_pred, n_tgt, k):
+        y = torch.rand(n_tgt, 3, generator=g)
+        flat = y[torch.randint(0, n_tgt, (n_pred,), generator=g)] + 0.002 * torch.randn(n_pred, 3, generator=g)
+        cl = list(flat.chunk(k))
+        m = torch.eye(4).repeat(k, 1, 1)
+        for i, c in enumerate(cl):
+            m[i, :3, 3] = c.mean(0)
+        pts, off = ops.pack_clusters([c - c.mean(0) for c in cl], dev)
+        plan = ops.TrainPlan("q", k, 64, n_pred, n_tgt, epochs=6, use_graph=True, device=dev)
+        run = lambda: [t.cpu() for t in plan.run(m.to(dev), y.to(dev), pts, off,
+                                                 [model.state_dict()[key].clone().to(dev) for key in ops.Q_PARAM_ORDER])]
+        return run
+
+    big = make(16384, 16384, 8)
+    first = big()
+    mid = make(6000, 6000, 5)
+    mid()
+    small = make(300, 300, 3)
+    small()
+    again = big()
+    for a, b in zip(first, again):
+        assert torch.equal(a.nan_to_num(), b.nan_to_num())
+
+
 def test_train_pruned_search_random_shapes(dev):
     """20 random shapes of tests/measure/stress_pruned_search.py (sizes up to 16384, empty / whole-block clusters,
     duplicated points, lattice clouds): pruned and exhaustive plans agree bit for bit (600 shapes were run by hand,
