@@ -84,11 +84,14 @@ __global__ __launch_bounds__(256) void k_km_center(const double* __restrict__ X,
 __global__ __launch_bounds__(256) void k_km_assign(const double* __restrict__ X, int n,
                                                    const double* __restrict__ B, int k,
                                                    int* __restrict__ labels, const int* __restrict__ prev,
-                                                   KmFlags* __restrict__ f) {
+                                                   KmFlags* __restrict__ f, int raw) {
+    // raw: `B` holds the centres (k,3) and every workgroup derives its (-2c, |c|^2) rows itself -- the standalone
+    // entry point then needs no device scratch (the library never allocates)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sB = (double*)smem;
     if (f && f->done) return;
-    for (int i = threadIdx.x; i < 4 * k; i += 256) sB[i] = B[i];
+    if (raw) { for (int j = threadIdx.x; j < k; j += 256) make_b(B + 3 * j, sB + 4 * j); }
+    else for (int i = threadIdx.x; i < 4 * k; i += 256) sB[i] = B[i];
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     int diff = 0;
@@ -125,7 +128,7 @@ template <int NT>   // centre tiles held in registers (k <= 16 NT); 0: any k, ce
 __global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict__ X, int n,
                                                         const double* __restrict__ B, int k,
                                                         int* __restrict__ labels, const int* __restrict__ prev,
-                                                        KmFlags* __restrict__ f) {
+                                                        KmFlags* __restrict__ f, int raw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sB = (double*)smem;                                  // [kpad][4], rows past k: (0, 0, 0, +inf)
     if (f && f->done) return;
@@ -133,10 +136,17 @@ __global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict
     // C operands as the lanes read them: sC[tile][lane group g][r] = |c|^2 of centre 16 tile + g + 4 r, 32 contiguous
     // bytes per (tile, group) -> two ds_read_b128 per MFMA instead of eight register copies of a resident table
     double* sC = sB + 4 * (size_t)kpad;                          // [ktiles][4][4]
-    for (int i = threadIdx.x; i < 4 * kpad; i += 256) sB[i] = (i >> 2) < k ? B[i] : ((i & 3) == 3 ? INFINITY : 0.0);
+    if (raw) {                                                   // `B` = centres (k,3): build the rows here (see k_km_assign)
+        for (int j = threadIdx.x; j < kpad; j += 256) {
+            if (j < k) make_b(B + 3 * j, sB + 4 * j);
+            else { sB[4 * j] = 0.0; sB[4 * j + 1] = 0.0; sB[4 * j + 2] = 0.0; sB[4 * j + 3] = INFINITY; }
+        }
+        __syncthreads();
+    } else
+        for (int i = threadIdx.x; i < 4 * kpad; i += 256) sB[i] = (i >> 2) < k ? B[i] : ((i & 3) == 3 ? INFINITY : 0.0);
     for (int i = threadIdx.x; i < 16 * ktiles; i += 256) {
         const int t = i >> 4, gg = (i >> 2) & 3, r = i & 3, j = 16 * t + gg + 4 * r;
-        sC[i] = j < k ? B[4 * j + 3] : INFINITY;
+        sC[i] = j >= k ? INFINITY : raw ? sB[4 * j + 3] : B[4 * j + 3];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
@@ -592,11 +602,6 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
 
 static size_t kms_stride(int64_t n, int k) { return align_up(sizeof(double) * (14 * (size_t)k + n), 256); }
 
-__global__ __launch_bounds__(256) void k_make_b(const double* __restrict__ C, int k, double* __restrict__ B) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j < k) make_b(C + 3 * j, B + 4 * j);
-}
-
 // ---- grouping by label + inverse-pose change of frame ------------------------------------------
 __device__ void inv4x4(const double* M, double* I) {      // Gauss-Jordan, partial pivoting
     double a[4][8];
@@ -617,8 +622,7 @@ __device__ void inv4x4(const double* M, double* I) {      // Gauss-Jordan, parti
 }
 
 __global__ __launch_bounds__(1024) void k_group_offsets(const int* __restrict__ labels, int n, int k,
-                                                        int* __restrict__ off, const double* __restrict__ M,
-                                                        double* __restrict__ Minv) {
+                                                        int* __restrict__ off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* cnt = (int*)smem;
     for (int j = threadIdx.x; j <= k; j += 1024) cnt[j] = 0;
@@ -630,17 +634,18 @@ __global__ __launch_bounds__(1024) void k_group_offsets(const int* __restrict__ 
         for (int j = 0; j < k; ++j) { const int c = cnt[j]; off[j] = run; run += c; }
         off[k] = run;
     }
-    for (int j = threadIdx.x; j < k; j += 1024) inv4x4(M + 16 * j, Minv + 16 * j);
 }
 
 // one wave per cluster walks the labels in order: ballot + prefix popcount gives the stable slot
 __global__ __launch_bounds__(64) void k_group_scatter(const double* __restrict__ X, int n,
                                                       const int* __restrict__ labels,
                                                       const int* __restrict__ off,
-                                                      const double* __restrict__ Minv,
+                                                      const double* __restrict__ M,
                                                       double* __restrict__ out) {
     const int j = blockIdx.x, lane = threadIdx.x;
-    const double* I = Minv + 16 * j;
+    __shared__ double I[16];                              // inv(M_j), by one lane (no device scratch)
+    if (lane == 0) inv4x4(M + 16 * j, I);
+    __syncthreads();
     int pos = off[j];
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
@@ -671,20 +676,20 @@ static KmLayout km_layout(int64_t n, int k) {
 }
 
 static void launch_assign(const double* X, int n, const double* B, int k, int* labels, const int* prev,
-                          KmFlags* f, int use_mfma, hipStream_t s) {
+                          KmFlags* f, int use_mfma, hipStream_t s, int raw = 0) {
     if (use_mfma) {
         const int ntile = cdiv(n, 16);
         int blocks = cdiv(ntile, 4);
         if (blocks > 2048) blocks = 2048;                        // a wave then walks several point tiles with its centres in registers
         const size_t smem = sizeof(double) * 5 * ((k + 15) & ~15);          // centre rows + the C-operand table
-        if (k <= 16) hipLaunchKernelGGL(k_km_assign_mfma<1>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f);
-        else if (k <= 32) hipLaunchKernelGGL(k_km_assign_mfma<2>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f);
-        else if (k <= 64) hipLaunchKernelGGL(k_km_assign_mfma<4>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f);
-        else if (k <= 128) hipLaunchKernelGGL(k_km_assign_mfma<8>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f);
-        else hipLaunchKernelGGL(k_km_assign_mfma<0>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f);
+        if (k <= 16) hipLaunchKernelGGL(k_km_assign_mfma<1>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw);
+        else if (k <= 32) hipLaunchKernelGGL(k_km_assign_mfma<2>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw);
+        else if (k <= 64) hipLaunchKernelGGL(k_km_assign_mfma<4>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw);
+        else if (k <= 128) hipLaunchKernelGGL(k_km_assign_mfma<8>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw);
+        else hipLaunchKernelGGL(k_km_assign_mfma<0>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw);
     }
     else
-        hipLaunchKernelGGL(k_km_assign, dim3(cdiv(n, 256)), dim3(256), sizeof(double) * 4 * k, s, X, n, B, k, labels, prev, f);
+        hipLaunchKernelGGL(k_km_assign, dim3(cdiv(n, 256)), dim3(256), sizeof(double) * 4 * k, s, X, n, B, k, labels, prev, f, raw);
 }
 
 }  // namespace creg
@@ -748,13 +753,8 @@ extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* i
 extern "C" int creg_kmeans_assign_f64(const double* X, int64_t n, const double* C, int32_t k, int32_t use_mfma,
                                       int32_t* labels, creg_stream_t stream) {
     CREG_REQUIRE(X && C && labels && n >= 1 && n < (1ll << 31) && k >= 1 && k <= 1024, "creg_kmeans_assign_f64: bad argument");
-    // B is built in a small device buffer carved from the tail of `labels`? No: keep the ABI honest
-    // and stage it in a static per-stream-ordered allocation instead.
-    double* B = nullptr;
-    CREG_HIP(hipMallocAsync((void**)&B, sizeof(double) * 4 * k, (hipStream_t)stream));
-    hipLaunchKernelGGL(k_make_b, dim3(cdiv(k, 256)), dim3(256), 0, (hipStream_t)stream, C, k, B);
-    launch_assign(X, (int)n, B, k, labels, nullptr, nullptr, use_mfma, (hipStream_t)stream);
-    CREG_HIP(hipFreeAsync(B, (hipStream_t)stream));
+    // no device scratch: the kernels derive the (-2c, |c|^2) rows from the centres in their prologue
+    launch_assign(X, (int)n, C, k, labels, nullptr, nullptr, use_mfma, (hipStream_t)stream, 1);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }
@@ -765,11 +765,8 @@ extern "C" int creg_group_to_local_f64(const double* X, int64_t n, const int32_t
     CREG_REQUIRE(X && labels && M && out_local && seg_offsets && n >= 1 && n < (1ll << 31) && k >= 1 && k <= 4096,
                  "creg_group_to_local_f64: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    double* Minv = nullptr;
-    CREG_HIP(hipMallocAsync((void**)&Minv, sizeof(double) * 16 * k, s));
-    hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(1024), sizeof(int) * (k + 1), s, labels, (int)n, k, seg_offsets, M, Minv);
-    hipLaunchKernelGGL(k_group_scatter, dim3(k), dim3(64), 0, s, X, (int)n, labels, seg_offsets, Minv, out_local);
-    CREG_HIP(hipFreeAsync(Minv, s));
+    hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(1024), sizeof(int) * (k + 1), s, labels, (int)n, k, seg_offsets);
+    hipLaunchKernelGGL(k_group_scatter, dim3(k), dim3(64), 0, s, X, (int)n, labels, seg_offsets, M, out_local);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }
