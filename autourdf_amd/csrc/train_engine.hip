@@ -1332,6 +1332,14 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
     CREG_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
     us_out[6] = ms * 1000.f / REP;
     us_out[7] = (float)P->nz;       // problems carried by that launch
+    // us_out[8]: the dW + Adam kernel the same way (each launch is one more Adam step on the plan's copy of the
+    // parameters -- this is a measurement hook, the caller's tensors are not written back)
+    CREG_HIP(hipEventRecord(ev[0], s));
+    for (int i = 0; i < REP; ++i) launch_dw(P, i, s);
+    CREG_HIP(hipEventRecord(ev[1], s));
+    CREG_HIP(hipStreamSynchronize(s));
+    CREG_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    us_out[8] = ms * 1000.f / REP;
     P->nz = P->B;
     for (auto& e : ev) (void)hipEventDestroy(e);
     return CREG_OK;

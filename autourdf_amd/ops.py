@@ -469,11 +469,12 @@ class TrainPlan:
 
     def profile(self, m, y, pts, offsets, params, n_epochs=50):
         """Average event-bracketed microseconds of each of the 6 epoch kernels (synchronises)."""
-        out = (ctypes.c_float * 8)()
+        out = (ctypes.c_float * 10)()
         a = self._args(m, y, pts, offsets, params, 2e-4, 0.7, 5, 200, (None, None, None, None, None))
         _lib.check(self.L.creg_train_plan_profile(self.plan, ctypes.byref(a), n_epochs, out, _stream()),
                    "creg_train_plan_profile")
         d = dict(zip(self.KERNELS, [float(v) for v in out]))
         d["nn_l1_back_to_back"] = float(out[6])
         d["nn_l1_problems_per_launch"] = int(out[7])
+        d["dw_back_to_back"] = float(out[8])
         return d

@@ -279,8 +279,9 @@ int creg_train_plan_probe(creg_train_plan* plan, const creg_train_args* args, fl
 
 /* Measurement hook: run n_epochs eagerly with a HIP event before / after each of the six kernels
  * of an epoch (order: l2, head, nn_l1, gradc, bwd2, dw) on `stream`, synchronise, and write the
- * average microseconds per kernel to us_out (HOST, 8 floats): [0..5] event-bracketed per kernel,
- * [6] the nn_l1 kernel alone as 200 back-to-back launches between two events (kernel + launch gap).  Event-bracketed times
+ * average microseconds per kernel to us_out (HOST, 10 floats): [0..5] event-bracketed per kernel,
+ * [6] the nearest-neighbour kernel alone as 200 back-to-back launches between two events (kernel + launch gap),
+ * [7] the problems that launch carries, [8] the dW + Adam kernel the same way, [9] reserved.  Event-bracketed times
  * include the dispatch latency of the launch, i.e. they are an upper bound of the kernel time. */
 int creg_train_plan_profile(creg_train_plan* plan, const creg_train_args* args, int32_t n_epochs,
                             float* us_out, creg_stream_t stream);
