@@ -343,18 +343,27 @@ __device__ __forceinline__ unsigned ordered_bits(float c) {                // to
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     return u == 0xFFFFFFFFu ? 0xFFFFFFFEu : u;
 }
-// ascending bitonic sort of key[0, npow) restricted to aligned segments of `seg` slots
+// ascending bitonic sort of key[0, npow) restricted to aligned segments of `seg` slots.
+// A wave's 64 compare-exchanges of a stage with stride <= 64 stay inside its own 128 consecutive slots (and so do
+// those of its later trips), so runs of such stages need no workgroup barrier -- the wave's DS instructions execute
+// in order; only stages with a longer stride, and the hand-over to / from them, synchronise the workgroup: 35 barrier
+// pairs instead of 308 stages with one for the six k-d levels of 4096 slots.
 __device__ __forceinline__ void bitonic_segments(unsigned long long* key, int npow, int seg, int tid, int nthreads) {
+    bool wide_before = true;                                   // the caller's writes count as a wide stage
     for (int size = 2; size <= seg; size <<= 1)
         for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            const bool wide = stride > 64;
+            if (wide || wide_before) __syncthreads();
+            else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
             for (int t = tid; t < (npow >> 1); t += nthreads) {
                 const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), j = i | stride;
                 const unsigned long long a = key[i], b = key[j];
                 const bool up = size == seg || (i & size) == 0;            // every segment ends ascending
                 if ((a > b) == up) { key[i] = b; key[j] = a; }
             }
-            __syncthreads();
+            wide_before = wide;
         }
+    __syncthreads();
 }
 static int pow2_at_least(int n) { int p = 64; while (p < n) p <<= 1; return p; }
 
