@@ -1,6 +1,6 @@
 """Randomised bit-identity stress of the plan's pruned nearest-neighbour search against the exhaustive one.
 
-    python tests/measure/stress_pruned_search.py [n_shapes] [seed]
+    python tests/measure/stress_pruned_search.py [n_shapes] [seed] [max_points]
 
 Every shape draws its own cluster count, cloud sizes (up to 16384, so both block sizes are exercised), cluster
 sizes (empty and whole-block clusters included), duplicated points (exact distance ties) and model; a short train
@@ -16,11 +16,12 @@ from autourdf_amd import ops          # noqa: E402
 from oracle import models             # noqa: E402  (random-init parameters only)
 
 
-def one(g, dev):
+def one(g, dev, max_points=None):
     rot = "q" if torch.rand((), generator=g) < 0.5 else "dq"
     big = torch.rand((), generator=g) < 0.3
-    n_tgt = int(torch.randint(1, 16385 if big else 4097, (), generator=g))
-    n_pred = int(torch.randint(1, 16385 if big else 4097, (), generator=g))
+    hi = (max_points + 1) if max_points else (16385 if big else 4097)      # max_points: tiny clouds (single blocks, one point)
+    n_tgt = int(torch.randint(1, hi, (), generator=g))
+    n_pred = int(torch.randint(1, hi, (), generator=g))
     k = int(torch.randint(1, 41, (), generator=g))
     k = min(k, n_pred)
     y = torch.rand(n_tgt, 3, generator=g) * 0.5
@@ -56,10 +57,11 @@ def one(g, dev):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    max_points = int(sys.argv[3]) if len(sys.argv) > 3 else None
     g = torch.Generator().manual_seed(seed)
     bad = finite = 0
     for i in range(n):
-        ok, shape, fin = one(g, "cuda")
+        ok, shape, fin = one(g, "cuda", max_points)
         finite += fin
         if not ok:
             bad += 1
