@@ -62,6 +62,8 @@ struct Ws {         // device pointers into the caller's workspace
     float *lossp_x, *lossp_y;
     float *g_out, *g_h2, *gx1_part;
     TrainState* state;
+    double* bc1;        // [epochs + 1] Adam bias corrections by step, filled once per train by k_prep:
+    float* bc2s;        //   1 - 0.9^t and sqrt(1 - 0.999^t) (two double pow() off the per-epoch critical path)
     float *best_m, *best_pred, *loss_hist, *lr_hist, *result;
     int* off;
     Hyper* hyper;
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(256) void k_prep(Dims D, Ws W, Hyper hy, const floa
         W.y4[j] = make_float4(y[3 * (size_t)j], y[3 * (size_t)j + 1], y[3 * (size_t)j + 2], 0.f);
     for (int i = t; i < D.NPAR; i += stride) { W.AM[i] = 0.f; W.AV[i] = 0.f; }
     for (int i = t; i < D.epochs; i += stride) { W.loss_hist[i] = NAN; W.lr_hist[i] = NAN; }
+    for (int i = t; i <= D.epochs; i += stride) { W.bc1[i] = 1.0 - pow(0.9, (double)i); W.bc2s[i] = (float)sqrt(1.0 - pow(0.999, (double)i)); }
     if (blockIdx.x == 0) {
         for (int r = threadIdx.x; r < D.K; r += 256) {
             const float* M = m + 16 * r;
@@ -556,7 +559,8 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_plan(const float* A, int na, co
 // K blocks.  Every block derives the same loss and the same decisions from the same inputs; block 0
 // advances the double-buffered state.  Then block k reduces cluster k's point gradients to
 // [dL/dR | dL/dt] in a fixed order and thread 0 pulls them back through the pose head.
-__device__ __forceinline__ TrainState advance_state(const TrainState& S, float loss, const Hyper& hy) {
+// bc1 / bc2_sqrt: the bias corrections of step S.step + 1 (k_prep's table)
+__device__ __forceinline__ TrainState advance_state(const TrainState& S, float loss, const Hyper& hy, double bc1, float bc2_sqrt) {
     TrainState N = S;
     const bool improved = loss < S.min_loss;
     N.last_loss = loss;
@@ -566,9 +570,8 @@ __device__ __forceinline__ TrainState advance_state(const TrainState& S, float l
     if (!N.stopped) {
         // optimizer.step() of this epoch uses S.lr (torch.optim.Adam, betas (0.9, 0.999), eps 1e-8)
         N.step = S.step + 1;
-        const double bc1 = 1.0 - pow(0.9, (double)N.step), bc2 = 1.0 - pow(0.999, (double)N.step);
         N.step_size = (float)(S.lr / bc1);
-        N.bc2_sqrt = (float)sqrt(bc2);
+        N.bc2_sqrt = bc2_sqrt;
         // scheduler.step(loss): ReduceLROnPlateau(mode='min', threshold 1e-4 rel, cooldown 0, min_lr 0, eps 1e-8)
         const double cur = (double)loss;
         if (cur < S.sched_best * (1.0 - 1e-4)) { N.sched_best = cur; N.sched_bad = 0; }
@@ -596,6 +599,8 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
     // overlap the loss reduction instead of forming a chain of dependent round trips
     const int b0 = W.off[k], e0 = W.off[k + 1];
     const Hyper hy = *W.hyper;
+    const double bc1_next = W.bc1[min(S.step + 1, D.epochs)];
+    const float bc2s_next = W.bc2s[min(S.step + 1, D.epochs)];
     const int n_first = min(b0 + tid, D.NP - 1);
     const float4 p_first = W.pts4[n_first];
     const int4 c_first = W.cnt4[n_first];
@@ -619,7 +624,7 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
     }
     __syncthreads();
     const float loss = s_loss;
-    const TrainState N = advance_state(S, loss, hy);
+    const TrainState N = advance_state(S, loss, hy, bc1_next, bc2s_next);
     const bool improved = loss < S.min_loss;
     if (improved) {                                     // best_pcd / best_m  (mlp_reg.py:102-106)
         for (int n = b0 + tid; n < e0; n += 256) {
@@ -994,6 +999,7 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     w.g_out = (float*)take(f * 16 * D.K); w.g_h2 = (float*)take(f * D.K * D.H2);
     w.gx1_part = (float*)take(f * (size_t)D.OC * D.K * D.H);
     w.state = (TrainState*)take(sizeof(TrainState) * 2);
+    w.bc1 = (double*)take(sizeof(double) * (D.epochs + 1)); w.bc2s = (float*)take(f * (D.epochs + 1));
     w.best_m = (float*)take(f * 16 * D.K); w.best_pred = (float*)take(f * 3 * D.NP);
     w.loss_hist = (float*)take(f * D.epochs); w.lr_hist = (float*)take(f * D.epochs); w.result = (float*)take(f * 4);
     w.off = (int*)take(sizeof(int) * (D.K + 1)); w.hyper = (Hyper*)take(sizeof(Hyper));
