@@ -466,7 +466,7 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
         const int g = tid >> 8, tg = tid & 255, wg = (tid >> 6) & 3;
         // this thread's points (tg, tg + 256, ...) keep their labels in registers for all ceil(k/4) sweeps, and
         // a sweep is branch-free: adding +0.0 for foreign points leaves every partial sum bit-identical to the
-        // conditional accumulation (the sums start at +0.0 and can never become -0.0)
+        // conditional accumulation (the sums start at +0.0 and can never become -0.0; frames are finite)
         constexpr int KMS_PTS = 20;                            // ceil(5120 / 256)
         int lbl[KMS_PTS];
 #pragma unroll
@@ -479,9 +479,11 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
                 for (int m = 0; m < KMS_PTS; ++m) {
                     if (256 * m >= n) break;                       // block-uniform: no point of this slot exists
                     const int i = min(tg + 256 * m, n - 1);
-                    const bool mine = lbl[m] == j;
+                    // indicator form: fma(1, x, a) = RN(a + x) and fma(0, x, a) = a for finite x (a is never -0), i.e. the
+                    // conditional sum bit for bit with one select + 4 FMAs per point instead of eight selects + 4 adds
+                    const double ind = lbl[m] == j ? 1.0 : 0.0;
                     const double x0 = Xc[3 * i], x1 = Xc[3 * i + 1], x2 = Xc[3 * i + 2];
-                    a0 += mine ? x0 : 0.0; a1 += mine ? x1 : 0.0; a2 += mine ? x2 : 0.0; aw += mine ? 1.0 : 0.0;
+                    a0 = fma(ind, x0, a0); a1 = fma(ind, x1, a1); a2 = fma(ind, x2, a2); aw += ind;
                 }
             }
             a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); aw = wave_sum(aw);
