@@ -89,8 +89,15 @@ __device__ __forceinline__ int seg_of(const int* __restrict__ off, int k, int n)
 }
 
 // ------------------------------------------------------------------------------------------ prep
-__global__ __launch_bounds__(256) void k_prep(Dims D, Ws W, Hyper hy, const float* __restrict__ m,
-                                              const float* __restrict__ y, const float* __restrict__ pts) {
+// per-problem inputs of a batch (grid.z): one launch stages all of them
+constexpr int PREP_MAXB = 64;
+struct PrepBatch { const float* m[PREP_MAXB]; const float* y[PREP_MAXB]; const float* pts[PREP_MAXB]; Hyper hy[PREP_MAXB]; };
+__global__ __launch_bounds__(256) void k_prep(Dims D, Ws W0, size_t bstride, PrepBatch pb) {
+    const Ws W = ws_shift(W0, blockIdx.z * bstride);
+    const Hyper hy = pb.hy[blockIdx.z];
+    const float* __restrict__ m = pb.m[blockIdx.z];
+    const float* __restrict__ y = pb.y[blockIdx.z];
+    const float* __restrict__ pts = pb.pts[blockIdx.z];
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int stride = gridDim.x * 256;
     for (int n = t; n < D.NP; n += stride) {
@@ -141,7 +148,8 @@ __global__ __launch_bounds__(256) void k_prep(Dims D, Ws W, Hyper hy, const floa
 }
 
 // ------------------------------------------------------------------------------------------ layer 1 (epoch 0 only)
-__global__ __launch_bounds__(256) void k_l1(Dims D, Ws W, int par) {
+__global__ __launch_bounds__(256) void k_l1(Dims D, Ws W0, int par, size_t bstride) {
+    const Ws W = ws_shift(W0, blockIdx.z * bstride);
     const int lane = threadIdx.x & 63;
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o >= D.H) return;
@@ -1074,17 +1082,20 @@ static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nu
 
 // One launch copies up to 16 (source, destination, dword count) ranges: a problem's 10 parameter tensors + offsets in,
 // parameters + results out -- instead of one hipMemcpyAsync (a ~2.5 us blit kernel each) per tensor, 270 per frame round.
-struct CopyTable { const unsigned* src[16]; unsigned* dst[16]; int n[16]; int count; };
+constexpr int COPY_MAX = 150;      // ranges per launch (3.1 KB of kernel arguments)
+struct CopyTable { const unsigned* src[COPY_MAX]; unsigned* dst[COPY_MAX]; int n[COPY_MAX]; int count; };
 __global__ __launch_bounds__(256) void k_copy_table(CopyTable T) {
     const unsigned* __restrict__ s = T.src[blockIdx.y]; unsigned* __restrict__ d = T.dst[blockIdx.y];
     const int n = T.n[blockIdx.y];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = s[i];
 }
-static void copy_table_add(CopyTable& T, const void* src, void* dst, size_t bytes) {
-    T.src[T.count] = (const unsigned*)src; T.dst[T.count] = (unsigned*)dst; T.n[T.count] = (int)(bytes / 4); ++T.count;
-}
-static void copy_table_launch(const CopyTable& T, hipStream_t s) {
+static void copy_table_launch(CopyTable& T, hipStream_t s) {
     if (T.count) hipLaunchKernelGGL(k_copy_table, dim3(32, T.count), dim3(256), 0, s, T);
+    T.count = 0;
+}
+static void copy_table_add(CopyTable& T, const void* src, void* dst, size_t bytes, hipStream_t s) {   // launches when full
+    if (T.count == COPY_MAX) copy_table_launch(T, s);
+    T.src[T.count] = (const unsigned*)src; T.dst[T.count] = (unsigned*)dst; T.n[T.count] = (int)(bytes / 4); ++T.count;
 }
 
 struct ParamMap { int off, count; };
@@ -1114,23 +1125,31 @@ static void launch_sorts(Plan* P, hipStream_t s, int nz) {
     if (D.npb) hipLaunchKernelGGL(k_sort_p, dim3(D.K, 1, nz), dim3(512), ps_sort_smem(D), s, D, P->W, P->bstride);
 }
 
-static int stage_inputs(Plan* P, const creg_train_args* a, hipStream_t s, int b = 0) {
-    const Dims& D = P->D; const Ws W = ws_shift(P->W, (size_t)b * P->bstride);
+// Inputs of `n` problems into their workspaces: the parameter / offset copies of all of them in one launch (per
+// COPY_MAX ranges), then one k_prep and one k_l1 launch with the problems in grid.z.
+static int stage_inputs(Plan* P, const creg_train_args* args, int n, hipStream_t s) {
+    const Dims& D = P->D;
     ParamMap pm[10];
     const int np = param_map(D, pm);
     CopyTable T; T.count = 0;
-    for (int i = 0; i < np; ++i) {
-        CREG_REQUIRE(a->params[i], "creg_train: params[%d] is null", i);
-        copy_table_add(T, a->params[i], W.P + pm[i].off, sizeof(float) * pm[i].count);
+    PrepBatch pb;
+    for (int b = 0; b < n; ++b) {
+        const creg_train_args* a = args + b;
+        const Ws W = ws_shift(P->W, (size_t)b * P->bstride);
+        for (int i = 0; i < np; ++i) {
+            CREG_REQUIRE(a->params[i], "creg_train: params[%d] of problem %d is null", i, b);
+            copy_table_add(T, a->params[i], W.P + pm[i].off, sizeof(float) * pm[i].count, s);
+        }
+        copy_table_add(T, a->seg_offsets, W.off, sizeof(int) * (D.K + 1), s);
+        pb.m[b] = a->m; pb.y[b] = a->y; pb.pts[b] = a->local_pts;
+        pb.hy[b] = Hyper{a->lr, a->sched_factor, a->sched_patience, a->stop};
     }
-    copy_table_add(T, a->seg_offsets, W.off, sizeof(int) * (D.K + 1));
     copy_table_launch(T, s);
-    Hyper h = {a->lr, a->sched_factor, a->sched_patience, a->stop};
     const int mx = D.NP > D.NT ? D.NP : D.NT;
     int blocks = cdiv(mx > D.NPAR ? mx : D.NPAR, 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_prep, dim3(blocks), dim3(256), 0, s, D, W, h, a->m, a->y, a->local_pts);
-    hipLaunchKernelGGL(k_l1, dim3(cdiv(D.H, 4)), dim3(256), 0, s, D, W, 0);
+    hipLaunchKernelGGL(k_prep, dim3(blocks, 1, n), dim3(256), 0, s, D, P->W, P->bstride, pb);
+    hipLaunchKernelGGL(k_l1, dim3(cdiv(D.H, 4), 1, n), dim3(256), 0, s, D, P->W, 0, P->bstride);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }
@@ -1196,7 +1215,9 @@ extern "C" int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train
         const creg_train_args* a = args + b;
         CREG_REQUIRE(a->m && a->y && a->local_pts && a->seg_offsets && a->params && a->best_m && a->best_pred && a->result,
                      "creg_train_plan_run_batch: null pointer in problem %d", b);
-        int rc = stage_inputs(P, a, s, b);
+    }
+    {
+        int rc = stage_inputs(P, args, n, s);
         if (rc) return rc;
     }
     launch_sorts(P, s, P->B);
@@ -1266,18 +1287,18 @@ extern "C" int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train
     // results out, parameters back into the callers' tensors
     ParamMap pm[10];
     const int np = param_map(D, pm);
+    CopyTable T; T.count = 0;
     for (int b = 0; b < n; ++b) {
         const creg_train_args* a = args + b;
         const Ws W = ws_shift(P->W, (size_t)b * P->bstride);
-        CopyTable T; T.count = 0;
-        for (int i = 0; i < np; ++i) copy_table_add(T, W.P + pm[i].off, a->params[i], sizeof(float) * pm[i].count);
-        copy_table_add(T, W.best_m, a->best_m, sizeof(float) * 16 * D.K);
-        copy_table_add(T, W.best_pred, a->best_pred, sizeof(float) * 3 * D.NP);
-        copy_table_add(T, W.result, a->result, sizeof(float) * 4);
-        if (a->loss_hist) copy_table_add(T, W.loss_hist, a->loss_hist, sizeof(float) * D.epochs);
-        if (a->lr_hist) copy_table_add(T, W.lr_hist, a->lr_hist, sizeof(float) * D.epochs);
-        copy_table_launch(T, s);
+        for (int i = 0; i < np; ++i) copy_table_add(T, W.P + pm[i].off, a->params[i], sizeof(float) * pm[i].count, s);
+        copy_table_add(T, W.best_m, a->best_m, sizeof(float) * 16 * D.K, s);
+        copy_table_add(T, W.best_pred, a->best_pred, sizeof(float) * 3 * D.NP, s);
+        copy_table_add(T, W.result, a->result, sizeof(float) * 4, s);
+        if (a->loss_hist) copy_table_add(T, W.loss_hist, a->loss_hist, sizeof(float) * D.epochs, s);
+        if (a->lr_hist) copy_table_add(T, W.lr_hist, a->lr_hist, sizeof(float) * D.epochs, s);
     }
+    copy_table_launch(T, s);
     return CREG_OK;
 }
 
@@ -1291,7 +1312,7 @@ extern "C" int creg_train_plan_probe(creg_train_plan* plan, const creg_train_arg
     CREG_REQUIRE(P && a && a->m && a->y && a->local_pts && a->seg_offsets && a->params, "creg_train_plan_probe: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const Dims& D = P->D; const Ws& W = P->W;
-    int rc = stage_inputs(P, a, s);
+    int rc = stage_inputs(P, a, 1, s);
     if (rc) return rc;
     launch_sorts(P, s, 1);
     P->nz = 1;
@@ -1313,7 +1334,7 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
     CREG_REQUIRE(P && a && a->m && a->y && a->local_pts && a->seg_offsets && a->params && us_out && n_epochs >= 1,
                  "creg_train_plan_profile: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    int rc = stage_inputs(P, a, s);
+    int rc = stage_inputs(P, a, 1, s);
     if (rc) return rc;
     launch_sorts(P, s, 1);
     P->nz = 1;
