@@ -47,6 +47,7 @@ SIGNATURES = {
     "creg_kmeans_lloyd_batch_f64": (ctypes.c_int, [vp, i64, vp, i32, i32, i32, f64, vp, vp, vp, vp, vp, sz, vp]),
     "creg_kmeans_assign_f64": (ctypes.c_int, [vp, i64, vp, i32, i32, vp, vp]),
     "creg_group_to_local_f64": (ctypes.c_int, [vp, i64, vp, i32, vp, vp, vp, vp]),
+    "creg_group_to_local_batch_f64": (ctypes.c_int, [vp, i64, vp, i32, vp, i32, vp, vp, vp]),
     "creg_fps_scratch_bytes": (sz, [i64]),
     "creg_fps_f64": (ctypes.c_int, [vp, i64, i64, vp, vp, vp]),
     "creg_se3_to_dq_f32": (ctypes.c_int, [vp, i32, vp, vp]),

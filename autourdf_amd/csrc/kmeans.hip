@@ -623,8 +623,13 @@ __device__ void inv4x4(const double* M, double* I) {      // Gauss-Jordan, parti
     for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) I[4 * r + c] = a[r][4 + c];
 }
 
-__global__ __launch_bounds__(1024) void k_group_offsets(const int* __restrict__ labels, int n, int k,
-                                                        int* __restrict__ off) {
+// grid.y = problem of a batch (the per-frame pointers come from the table)
+constexpr int GRP_MAXB = 16;
+struct GroupBatch { const double* X[GRP_MAXB]; const int* labels[GRP_MAXB]; const double* M[GRP_MAXB]; double* out[GRP_MAXB]; int* off[GRP_MAXB]; };
+
+__global__ __launch_bounds__(1024) void k_group_offsets(GroupBatch G, int n, int k) {
+    const int* __restrict__ labels = G.labels[blockIdx.y];
+    int* __restrict__ off = G.off[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* cnt = (int*)smem;
     for (int j = threadIdx.x; j <= k; j += 1024) cnt[j] = 0;
@@ -639,11 +644,12 @@ __global__ __launch_bounds__(1024) void k_group_offsets(const int* __restrict__ 
 }
 
 // one wave per cluster walks the labels in order: ballot + prefix popcount gives the stable slot
-__global__ __launch_bounds__(64) void k_group_scatter(const double* __restrict__ X, int n,
-                                                      const int* __restrict__ labels,
-                                                      const int* __restrict__ off,
-                                                      const double* __restrict__ M,
-                                                      double* __restrict__ out) {
+__global__ __launch_bounds__(64) void k_group_scatter(GroupBatch G, int n) {
+    const double* __restrict__ X = G.X[blockIdx.y];
+    const int* __restrict__ labels = G.labels[blockIdx.y];
+    const int* __restrict__ off = G.off[blockIdx.y];
+    const double* __restrict__ M = G.M[blockIdx.y];
+    double* __restrict__ out = G.out[blockIdx.y];
     const int j = blockIdx.x, lane = threadIdx.x;
     __shared__ double I[16];                              // inv(M_j), by one lane (no device scratch)
     if (lane == 0) inv4x4(M + 16 * j, I);
@@ -767,8 +773,28 @@ extern "C" int creg_group_to_local_f64(const double* X, int64_t n, const int32_t
     CREG_REQUIRE(X && labels && M && out_local && seg_offsets && n >= 1 && n < (1ll << 31) && k >= 1 && k <= 4096,
                  "creg_group_to_local_f64: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(1024), sizeof(int) * (k + 1), s, labels, (int)n, k, seg_offsets);
-    hipLaunchKernelGGL(k_group_scatter, dim3(k), dim3(64), 0, s, X, (int)n, labels, seg_offsets, M, out_local);
+    GroupBatch G;
+    G.X[0] = X; G.labels[0] = labels; G.M[0] = M; G.out[0] = out_local; G.off[0] = seg_offsets;
+    hipLaunchKernelGGL(k_group_offsets, dim3(1, 1), dim3(1024), sizeof(int) * (k + 1), s, G, (int)n, k);
+    hipLaunchKernelGGL(k_group_scatter, dim3(k, 1), dim3(64), 0, s, G, (int)n);
+    CREG_LAUNCH_CHECK();
+    return CREG_OK;
+}
+
+extern "C" int creg_group_to_local_batch_f64(const double* const* X, int64_t n, const int32_t* const* labels, int32_t k,
+                                             const double* const* M, int32_t batch, double* const* out_local,
+                                             int32_t* const* seg_offsets, creg_stream_t stream) {
+    CREG_REQUIRE(X && labels && M && out_local && seg_offsets && n >= 1 && n < (1ll << 31) && k >= 1 && k <= 4096,
+                 "creg_group_to_local_batch_f64: bad argument");
+    CREG_REQUIRE(batch >= 1 && batch <= GRP_MAXB, "creg_group_to_local_batch_f64: batch must be in 1..%d", GRP_MAXB);
+    GroupBatch G;
+    for (int b = 0; b < batch; ++b) {
+        CREG_REQUIRE(X[b] && labels[b] && M[b] && out_local[b] && seg_offsets[b], "creg_group_to_local_batch_f64: null pointer in problem %d", b);
+        G.X[b] = X[b]; G.labels[b] = labels[b]; G.M[b] = M[b]; G.out[b] = out_local[b]; G.off[b] = seg_offsets[b];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_group_offsets, dim3(1, batch), dim3(1024), sizeof(int) * (k + 1), s, G, (int)n, k);
+    hipLaunchKernelGGL(k_group_scatter, dim3(k, batch), dim3(64), 0, s, G, (int)n);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }

@@ -83,9 +83,13 @@ class BatchRegistrar:
             km = ops.kmeans_lloyd_batch(frames64, inits)
         else:
             km = [ops.kmeans_lloyd(f, c) for f, c in zip(frames64, inits)]
-        for r, f64, o, M64, res in zip(self.seqs, frames64, anchor, M64s, km):
-            m2, labels = o[0], res[1]
-            local, r.off = ops.group_to_local(f64, labels, M64)
+        if self.S <= ops.GROUP_BATCH_MAX and len({f.shape[0] for f in frames64}) == 1:
+            groups = ops.group_to_local_batch(frames64, [res[1] for res in km], M64s)     # all S in one launch pair
+        else:
+            groups = [ops.group_to_local(f, res[1], M) for f, res, M in zip(frames64, km, M64s)]
+        for r, o, (local, off) in zip(self.seqs, anchor, groups):
+            m2 = o[0]
+            r.off = off
             r.local64 = local                        # what resample_cluster returns (the cluster/NNNN.npz contents)
             r.pts, r.m = local.to(torch.float32), m2
             out.append((m2, o[2]))
@@ -109,8 +113,13 @@ def _step_mlp_icp(self, frames64, frames32=None):
     else:
         km = [ops.kmeans_lloyd(f, c) for f, c in zip(frames64, inits)]
     out = []
-    for r, f64, (M, _, _), o, res in zip(self.seqs, frames64, icp, step, km):
-        r.local64, r.off = ops.group_to_local(f64, res[1], M)
+    Ms = [M for M, _, _ in icp]
+    if len(self.seqs) <= ops.GROUP_BATCH_MAX and len({f.shape[0] for f in frames64}) == 1:
+        groups = ops.group_to_local_batch(frames64, [res[1] for res in km], Ms)
+    else:
+        groups = [ops.group_to_local(f, res[1], M) for f, res, M in zip(frames64, km, Ms)]
+    for r, M, o, (local, off) in zip(self.seqs, Ms, step, groups):
+        r.local64, r.off = local, off
         r.pts, r.m = r.local64.to(torch.float32), M.to(torch.float32)
         out.append((M, o[2]))
     return out
@@ -166,8 +175,12 @@ class BatchIcpRegistrar:
             km = ops.kmeans_lloyd_batch(frames64, inits)
         else:
             km = [ops.kmeans_lloyd(f, c) for f, c in zip(frames64, inits)]
-        for r, f, o, kr in zip(self.regs, frames64, res, km):
-            r.local, r.off = ops.group_to_local(f, kr[1], o[0])
+        if len(self.regs) <= ops.GROUP_BATCH_MAX and len({f.shape[0] for f in frames64}) == 1:
+            groups = ops.group_to_local_batch(frames64, [kr[1] for kr in km], [o[0] for o in res])
+        else:
+            groups = [ops.group_to_local(f, kr[1], o[0]) for f, o, kr in zip(frames64, res, km)]
+        for r, o, (local, off) in zip(self.regs, res, groups):
+            r.local, r.off = local, off
             r.M = o[0]
         return res
 

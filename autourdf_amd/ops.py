@@ -181,6 +181,29 @@ def group_to_local(X: torch.Tensor, labels: torch.Tensor, M: torch.Tensor):
     return out, off
 
 
+GROUP_BATCH_MAX = 16
+
+
+def group_to_local_batch(Xs, labels, Ms):
+    """`group_to_local` for a list (<= 16) of frames of identical n and k in one pair of launches.
+    Returns a list of (local (n,3) f64, offsets (k+1) int32)."""
+    L = _lib.load()
+    B = len(Xs)
+    if not 1 <= B <= GROUP_BATCH_MAX or len(labels) != B or len(Ms) != B:
+        raise ValueError(f"group_to_local_batch: 1..{GROUP_BATCH_MAX} problems, one label / pose tensor each")
+    Xs = [_need(x, torch.float64, "X") for x in Xs]
+    labels = [_need(l, torch.int32, "labels") for l in labels]
+    Ms = [_need(m, torch.float64, "M") for m in Ms]
+    n, k = Xs[0].shape[0], Ms[0].shape[0]
+    if any(x.shape[0] != n for x in Xs) or any(m.shape[0] != k for m in Ms) or any(l.shape[0] != n for l in labels):
+        raise ValueError("group_to_local_batch: all problems must share n and k")
+    outs = [(torch.empty_like(x), torch.empty(k + 1, dtype=torch.int32, device=x.device)) for x in Xs]
+    arr = lambda ts: (ctypes.c_void_p * B)(*[t.data_ptr() for t in ts])
+    _lib.check(L.creg_group_to_local_batch_f64(arr(Xs), n, arr(labels), k, arr(Ms), B, arr([o[0] for o in outs]),
+                                               arr([o[1] for o in outs]), _stream()), "creg_group_to_local_batch_f64")
+    return outs
+
+
 def icp_p2p_batch(problems, th: float = 1.0, max_iteration: int = 100000):
     """N3: plain point-to-point ICP (open3d registration_icp semantics) of packed cloud pairs.
     problems: list (<= 16) of (src (n,3) f64, src_offsets (k+1) i32, tgt (m,3) f64, tgt_offsets (k+1) i32,

@@ -113,6 +113,11 @@ int creg_kmeans_assign_f64(const double* X, int64_t n, const double* C, int32_t 
 int creg_group_to_local_f64(const double* X, int64_t n, const int32_t* labels, int32_t k,
                             const double* M, double* out_local, int32_t* seg_offsets,
                             creg_stream_t stream);
+/* The same for `batch` (<= 16) frames of identical n and k in one pair of launches; X, labels, M, out_local and
+ * seg_offsets are HOST arrays of `batch` device pointers.  Identical results to separate calls. */
+int creg_group_to_local_batch_f64(const double* const* X, int64_t n, const int32_t* const* labels, int32_t k,
+                                  const double* const* M, int32_t batch, double* const* out_local,
+                                  int32_t* const* seg_offsets, creg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * N1  farthest-point down-sampling, fp64.  Replaces open3d farthest_point_down_sample as used by

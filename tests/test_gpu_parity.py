@@ -649,6 +649,27 @@ def test_train_pruned_search_random_shapes(dev):
         assert ok and finite, shape
 
 
+def test_group_to_local_batch_equals_separate_calls(dev):
+    """creg_group_to_local_batch_f64 (all frames in one launch pair) against creg_group_to_local_f64 per frame."""
+    from autourdf_amd import ops
+    g = torch.Generator().manual_seed(9)
+    n, k, B = 3001, 17, 5
+    Xs = [torch.rand(n, 3, generator=g, dtype=torch.float64).to(dev) for _ in range(B)]
+    labs = [torch.randint(0, k, (n,), generator=g, dtype=torch.int32).to(dev) for _ in range(B)]
+    labs[2][labs[2] == 4] = 5                                   # an empty cluster
+    Ms = []
+    for _ in range(B):
+        A = torch.linalg.qr(torch.randn(k, 3, 3, generator=g, dtype=torch.float64))[0]
+        M = torch.eye(4, dtype=torch.float64).repeat(k, 1, 1)
+        M[:, :3, :3] = A
+        M[:, :3, 3] = torch.randn(k, 3, generator=g, dtype=torch.float64)
+        Ms.append(M.to(dev))
+    batch = ops.group_to_local_batch(Xs, labs, Ms)
+    for X, l, M, (loc, off) in zip(Xs, labs, Ms, batch):
+        loc1, off1 = ops.group_to_local(X, l, M)
+        assert torch.equal(loc, loc1) and torch.equal(off, off1)
+
+
 def test_kmeans_batch_single_launch_bit_identical_to_multi_launch(dev, golden):
     """creg_kmeans_lloyd_batch_f64 (one workgroup per frame, LDS resident, no host sync) against
     creg_kmeans_lloyd_f64 and the sklearn golden: labels, centres, inertia, n_iter all identical."""
