@@ -165,8 +165,22 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
     // ---- 1. box in float32, exactly as numpy evaluates it on the float32 cluster (min / max: any order) ----
     if (!toff) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = b + tid; i < e; i += ICP_NT)
-        for (int d = 0; d < 3; ++d) { const float v = world[3 * (size_t)i + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
+    if (world) {
+        for (int i = b + tid; i < e; i += ICP_NT)
+            for (int d = 0; d < 3; ++d) { const float v = world[3 * (size_t)i + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
+    } else {
+        // no world clouds given: the cluster in its current pose, evaluated in float32 exactly as
+        // creg_cluster_transform_f32 does on the float32 casts of `local` and `M` (same fma order)
+        float Tf[12];
+        for (int q = 0; q < 12; ++q) Tf[q] = (float)Min[16 * k + q];
+        for (int i = b + tid; i < e; i += ICP_NT) {
+            const float p0 = (float)local[3 * (size_t)i], p1 = (float)local[3 * (size_t)i + 1], p2 = (float)local[3 * (size_t)i + 2];
+            for (int d = 0; d < 3; ++d) {
+                const float v = fmaf(p2, Tf[4 * d + 2], fmaf(p1, Tf[4 * d + 1], p0 * Tf[4 * d])) + Tf[4 * d + 3];
+                lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v);
+            }
+        }
+    }
     {
         __shared__ float wl[ICP_NT / 64][3], wh[ICP_NT / 64][3];
         for (int d = 0; d < 3; ++d) {
@@ -383,7 +397,7 @@ static int icp_launch(const creg_icp_problem* pr, int batch, int64_t n, int32_t 
     IcpBatch B;
     for (int i = 0; i < batch; ++i) {
         const creg_icp_problem& q = pr[i];
-        CREG_REQUIRE(q.local && (q.world || q.tgt_offsets) && q.seg_offsets && q.frame && q.M && q.M_out && q.world_out && q.n_iter_out,
+        CREG_REQUIRE(q.local && q.seg_offsets && q.frame && q.M && q.M_out && q.world_out && q.n_iter_out,
                      "%s: null pointer in problem %d", who, i);
         B.local[i] = q.local; B.world[i] = q.world; B.off[i] = q.seg_offsets; B.frame[i] = q.frame; B.Min[i] = q.M;
         B.toff[i] = q.tgt_offsets;

@@ -162,15 +162,18 @@ class BatchIcpRegistrar:
         self.regs = [IcpRegistrar(mats0, clusters0, device) for _ in range(n_sequences)]
 
     def step(self, frames64):
-        worlds = [ops.cluster_transform(r.local.to(torch.float32), r.off, r.M.to(torch.float32)) for r in self.regs]
-        probs = [(r.local, w, r.off, f, r.M) for r, w, f in zip(self.regs, worlds, frames64)]
-        if len(probs) <= ops.ICP_BATCH_MAX and len({(p[0].shape[0], p[3].shape[0]) for p in probs}) == 1:
-            icp = ops.masked_icp_batch(probs)                  # all sequences' clusters in one launch
+        if len(self.regs) <= ops.ICP_BATCH_MAX and len({(r.local.shape[0], f.shape[0]) for r, f in zip(self.regs, frames64)}) == 1:
+            # all sequences' clusters in one launch; the mask boxes (K3 of the current poses) are evaluated inside it
+            icp = ops.masked_icp_batch([(r.local, None, r.off, f, r.M) for r, f in zip(self.regs, frames64)])
         else:
-            icp = [ops.masked_icp(*p) for p in probs]
-        res = [(M_new, ops.se3_to_dq(M_new.to(torch.float32)), n_it) for M_new, _, n_it in icp]
-        inits = [o[0][:, :3, 3].contiguous() for o in res]
-        k = inits[0].shape[0]
+            icp = [ops.masked_icp(r.local, ops.cluster_transform(r.local.to(torch.float32), r.off, r.M.to(torch.float32)),
+                                  r.off, f, r.M) for r, f in zip(self.regs, frames64)]
+        k = icp[0][0].shape[0]
+        M_all = torch.stack([M_new for M_new, _, _ in icp])                       # (S,K,4,4): one cast, one K5 launch, one slice
+        dq_all = ops.se3_to_dq(M_all.to(torch.float32).reshape(-1, 4, 4)).reshape(len(icp), k, 8)
+        t_all = M_all[:, :, :3, 3].contiguous()
+        res = [(M_new, dq_all[i], n_it) for i, (M_new, _, n_it) in enumerate(icp)]
+        inits = [t_all[i] for i in range(len(icp))]
         if frames64[0].shape[0] <= ops.KMEANS_BATCH_MAX_N and len(self.regs) <= 16 and k <= 128:
             km = ops.kmeans_lloyd_batch(frames64, inits)
         else:

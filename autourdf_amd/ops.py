@@ -335,7 +335,8 @@ ICP_BATCH_MAX = 16
 def masked_icp_batch(problems, scale: float = 1.2, th: float = 1.0, max_iteration: int = 10000, ori: bool = False):
     """`masked_icp` for a list of (local, world, offsets, frame, M) of identical sizes in ONE launch
     (grid clusters x problems); returns a list of (M_out, world_out, iterations), bit-identical to
-    separate calls."""
+    separate calls.  `world` None = the clusters in their current pose (`cluster_transform` of the float32 casts),
+    evaluated inside the kernel."""
     L = _lib.load()
     B = len(problems)
     if not 1 <= B <= ICP_BATCH_MAX:
@@ -344,13 +345,14 @@ def masked_icp_batch(problems, scale: float = 1.2, th: float = 1.0, max_iteratio
     keep, outs = [], []
     n = nf = k = None
     for b, (local, world, offsets, frame, M) in enumerate(problems):
-        local, world = _need(local, torch.float64, "local"), _need(world, torch.float32, "world")
+        local = _need(local, torch.float64, "local")
+        world = None if world is None else _need(world, torch.float32, "world")     # None: boxes of float32(M) . float32(local)
         frame, M = _need(frame, torch.float64, "frame"), _need(M, torch.float64, "M")
         offsets = _need(offsets, torch.int32, "offsets")
         shape = (local.shape[0], frame.shape[0], offsets.shape[0] - 1)
         if b == 0:
             n, nf, k = shape
-        if shape != (n, nf, k) or world.shape[0] != n or M.shape[0] != k:
+        if shape != (n, nf, k) or (world is not None and world.shape[0] != n) or M.shape[0] != k:
             raise ValueError("masked_icp_batch: all problems must share n, nf and k")
         dev = local.device
         M_out = torch.empty(k, 4, 4, dtype=torch.float64, device=dev)

@@ -169,6 +169,9 @@ typedef struct creg_icp_problem {
     const int32_t* tgt_offsets;   /* NULL: masked mode above.  Non-NULL (k+1 offsets into `frame`): point-to-point
                                      mode, cluster i registers to frame[tgt_offsets[i] .. tgt_offsets[i+1]) unmasked,
                                      `world` is ignored and nf is the total number of target points */
+    /* masked mode with world == NULL: the mask boxes are those of the clusters in their CURRENT pose, i.e. of
+       float32(M) applied to float32(local) exactly as creg_cluster_transform_f32 evaluates it -- the caller
+       saves that launch and the two casts */
 } creg_icp_problem;
 size_t creg_icp_batch_workspace_bytes(int64_t n, int64_t nf, int32_t k, int32_t batch);
 int creg_masked_icp_batch_f64(const creg_icp_problem* problems, int32_t batch, int64_t n, int32_t k, int64_t nf,
