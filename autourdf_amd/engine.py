@@ -77,8 +77,10 @@ class BatchRegistrar:
         anchor = self.plan.run_batch([(o[0], y, r.pts_init, r.off_init, r.p_anchor)
                                       for r, y, o in zip(self.seqs, ys, step)], lr=1e-4)
         out = []
-        M64s = [o[0].to(torch.float64) for o in anchor]
-        inits = [M[:, :3, 3].contiguous() for M in M64s]
+        M64_all = torch.stack([o[0] for o in anchor]).to(torch.float64)           # (S,K,4,4): one cast and one slice for all sequences
+        t_all = M64_all[:, :, :3, 3].contiguous()
+        M64s = [M64_all[i] for i in range(self.S)]
+        inits = [t_all[i] for i in range(self.S)]
         if frames64[0].shape[0] <= ops.KMEANS_BATCH_MAX_N and self.S <= 16 and len(self.seqs[0].off) - 1 <= 128:      # all S re-segmentations in one launch
             km = ops.kmeans_lloyd_batch(frames64, inits)
         else:
