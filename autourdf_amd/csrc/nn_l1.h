@@ -158,7 +158,8 @@ __device__ __forceinline__ void nn_l1_block(
 // ---- exact search over a block-sorted target cloud --------------------------------------------------
 // The targets are laid out in blocks of 64 * PPL consecutive slots that are spatially compact (leaves of a k-d tree)
 // with an axis-aligned box each: `ts4[slot] = (x, y, z, bits(original index))`, +inf padding slots carry index
-// INT_MAX, `tbox[b] = (lo xyz, hi xyz)`, at most 64 * NB blocks so a wave holds NB boxes per lane.
+// INT_MAX, boxes as six planes `tbox[c * 64 * NB + b]`, c = lo x,y,z, hi x,y,z (coalesced: a lane reads its box with
+// six loads that each cover consecutive words), at most 64 * NB blocks so a wave holds NB boxes per lane.
 // A wave owns 4 queries as in the exhaustive kernel.  Per query: every lane evaluates the L1 distance from the
 // query to its box(es) -- a lower bound of the distance to every target inside, and in float arithmetic too:
 // each |q - t| is a monotone function of t on either side of the box and rounding is monotone; the block with
@@ -184,8 +185,9 @@ __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int s
         valid[g] = ng == 64 ? ~0ull : ((1ull << ng) - 1ull);
         // (the box table is allocated for 64 * NB entries: no dependence of these loads on nblk_dev's round trip;
         //  entries past nblk are masked by `valid`)
-        const float* bx = tb.tbox + 6 * (tb.nblk_dev ? 64 * g + lane : min(64 * g + lane, nblk - 1));
-        lox[g] = bx[0]; loy[g] = bx[1]; loz[g] = bx[2]; hix[g] = bx[3]; hiy[g] = bx[4]; hiz[g] = bx[5];
+        const float* bx = tb.tbox + (tb.nblk_dev ? 64 * g + lane : min(64 * g + lane, nblk - 1));
+        constexpr int BP = 64 * NB;                             // plane stride
+        lox[g] = bx[0]; loy[g] = bx[BP]; loz[g] = bx[2 * BP]; hix[g] = bx[3 * BP]; hiy[g] = bx[4 * BP]; hiz[g] = bx[5 * BP];
     }
     float qx[QW], qy[QW], qz[QW], lb[QW][NB], bd[QW], tx[QW], ty[QW], tz[QW], wb[QW];
     int bi[QW];

@@ -37,6 +37,8 @@ struct Dims {
     int ppl;       // points per lane and block visit: blocks hold 64 * ppl points (1 up to 4096 targets, 4 up to 16384)
 };
 
+constexpr int PS_MAXB = 128;                   // blocks of the predicted cloud: two boxes per lane in the search
+
 struct Hyper {      // uploaded per run
     float lr, factor;
     int patience, stop;
@@ -305,9 +307,9 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, size_t bstride) {
             }
             if (D.ppl == 1) {
                 if (lane == 0 && in) {
-                    float* pb = W.pbox + 6 * (sl >> 6);
+                    float* pb = W.pbox + (sl >> 6);            // six planes of PS_MAXB boxes
 #pragma unroll
-                    for (int a = 0; a < 6; ++a) pb[a] = bx[a];
+                    for (int a = 0; a < 6; ++a) pb[a * PS_MAXB] = bx[a];
                 }
             } else {                                             // 4 waves per block, 2 blocks per trip
                 if (lane == 0) {
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, size_t bstride) {
                     if (base + 256 * hb < s1) {
                         float v = wbox[4 * hb][a];
                         for (int w = 1; w < 4; ++w) v = a < 3 ? fminf(v, wbox[4 * hb + w][a]) : fmaxf(v, wbox[4 * hb + w][a]);
-                        W.pbox[6 * ((base >> 8) + hb) + a] = v;
+                        W.pbox[a * PS_MAXB + (base >> 8) + hb] = v;
                     }
                 }
                 __syncthreads();
@@ -348,7 +350,6 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, size_t bstride) {
 // bits of the coordinate, original index): unique, so the layout is deterministic.  Slots past n_tgt hold +inf keys
 // and stay at the end through every level.  Any permutation gives the same search result -- ties are broken on the
 // original index stored with the point -- so none of this is visible in the plan's outputs.
-constexpr int PS_MAXB = 128;                   // blocks of the predicted cloud: two boxes per lane in the search
 __device__ __forceinline__ unsigned ordered_bits(float c) {                // total order of the floats, below 0xFFFFFFFF
     unsigned u = (unsigned)__float_as_int(c);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(1024) void k_sort_y(Dims D, Ws W0, size_t bstride, 
                 o[c] = fminf(o[c], boxes[6 * (b * D.ppl + g) + c]);
                 o[3 + c] = fmaxf(o[3 + c], boxes[6 * (b * D.ppl + g) + 3 + c]);
             }
-        for (int c = 0; c < 6; ++c) W.ybox[6 * b + c] = o[c];
+        for (int c = 0; c < 6; ++c) W.ybox[c * 64 + b] = o[c];             // six planes of 64 boxes
     }
 }
 
