@@ -27,7 +27,7 @@ class TrainArgs(ctypes.Structure):
 
 class IcpProblem(ctypes.Structure):
     _fields_ = [("local", vp), ("world", vp), ("seg_offsets", vp), ("frame", vp), ("M", vp),
-                ("M_out", vp), ("world_out", vp), ("n_iter_out", vp), ("tgt_offsets", vp)]
+                ("M_out", vp), ("world_out", vp), ("n_iter_out", vp), ("tgt_offsets", vp), ("world_offsets", vp)]
 
 
 # name -> (restype, argtypes); every symbol include/creg.h declares
@@ -46,8 +46,8 @@ SIGNATURES = {
     "creg_kmeans_batch_workspace_bytes": (sz, [i64, i32, i32]),
     "creg_kmeans_lloyd_batch_f64": (ctypes.c_int, [vp, i64, vp, i32, i32, i32, f64, vp, vp, vp, vp, vp, sz, vp]),
     "creg_kmeans_assign_f64": (ctypes.c_int, [vp, i64, vp, i32, i32, vp, vp]),
-    "creg_group_to_local_f64": (ctypes.c_int, [vp, i64, vp, i32, vp, vp, vp, vp]),
-    "creg_group_to_local_batch_f64": (ctypes.c_int, [vp, i64, vp, i32, vp, i32, vp, vp, vp]),
+    "creg_group_to_local_f64": (ctypes.c_int, [vp, i64, vp, i32, vp, i32, vp, vp, vp]),
+    "creg_group_to_local_batch_f64": (ctypes.c_int, [vp, i64, vp, i32, vp, i32, i32, vp, vp, vp]),
     "creg_fps_scratch_bytes": (sz, [i64]),
     "creg_fps_f64": (ctypes.c_int, [vp, i64, i64, vp, vp, vp]),
     "creg_se3_to_dq_f32": (ctypes.c_int, [vp, i32, vp, vp]),
@@ -60,7 +60,7 @@ SIGNATURES = {
     "creg_matrix_to_quat_f32": (ctypes.c_int, [vp, i32, vp, vp]),
     "creg_quat_to_matrix_f32": (ctypes.c_int, [vp, i32, vp, vp]),
     "creg_icp_workspace_bytes": (sz, [i64, i64, i32]),
-    "creg_masked_icp_f64": (ctypes.c_int, [vp, vp, i64, vp, i32, vp, i64, vp, f64, f64, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "creg_masked_icp_f64": (ctypes.c_int, [vp, vp, vp, i64, vp, i32, vp, i64, vp, f64, f64, i32, i32, vp, vp, vp, vp, sz, vp]),
     "creg_icp_batch_workspace_bytes": (sz, [i64, i64, i32, i32]),
     "creg_masked_icp_batch_f64": (ctypes.c_int, [ctypes.POINTER(IcpProblem), i32, i64, i32, i64, f64, f64, i32, i32, vp, sz, vp]),
     "creg_icp_p2p_f64": (ctypes.c_int, [vp, i64, vp, vp, i64, vp, i32, vp, f64, i32, vp, vp, vp, vp, sz, vp]),

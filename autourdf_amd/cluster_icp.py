@@ -56,6 +56,8 @@ def read_point_cloud(path) -> PointCloud:
         if f.readline().strip() != b"ply":
             raise IOError(f"{path}: not a PLY file")
         fmt, n_vert, props, in_vertex = None, 0, [], False
+        before = []                  # elements declared ahead of `vertex`: [count, [property dtypes] or None if it has a list]
+        seen_vertex = False
         while True:
             line = f.readline()
             if not line:
@@ -68,23 +70,44 @@ def read_point_cloud(path) -> PointCloud:
             elif tok[0] == "element":
                 in_vertex = tok[1] == "vertex"
                 if in_vertex:
-                    n_vert = int(tok[2])
+                    n_vert, seen_vertex = int(tok[2]), True
+                elif not seen_vertex:
+                    before.append([int(tok[2]), []])
             elif tok[0] == "property" and in_vertex:
                 if tok[1] == "list":
                     raise IOError(f"{path}: list property on vertices is not supported")
                 props.append((tok[2], _PLY_TYPES[tok[1]]))
+            elif tok[0] == "property" and not seen_vertex and before:
+                if tok[1] == "list":
+                    before[-1][1] = None
+                elif before[-1][1] is not None:
+                    before[-1][1].append(_PLY_TYPES[tok[1]])
             elif tok[0] == "end_header":
                 break
         names = [p[0] for p in props]
         if not all(a in names for a in "xyz"):
             raise IOError(f"{path}: vertex element lacks x/y/z")
+        if fmt not in ("ascii", "binary_little_endian", "binary_big_endian"):
+            raise IOError(f"{path}: unknown or missing PLY format {fmt!r}")
+        # the vertex records start after every element declared before `vertex`: skip them (fixed-size records only)
+        for count, types in before:
+            if types is None:
+                raise IOError(f"{path}: an element with list properties precedes the vertices; cannot locate them")
+            if fmt == "ascii":
+                for _ in range(count):
+                    f.readline()
+            else:
+                f.seek(count * sum(np.dtype(t).itemsize for t in types), 1)
         if fmt == "ascii":
             data = np.loadtxt(f, max_rows=n_vert, ndmin=2)
             pts = np.stack([data[:, names.index(a)] for a in "xyz"], 1)
         else:
             order = "<" if fmt == "binary_little_endian" else ">"
             dt = np.dtype([(n, order + t) for n, t in props])
-            rec = np.frombuffer(f.read(dt.itemsize * n_vert), dtype=dt, count=n_vert)
+            raw = f.read(dt.itemsize * n_vert)
+            if len(raw) != dt.itemsize * n_vert:
+                raise IOError(f"{path}: truncated vertex data")
+            rec = np.frombuffer(raw, dtype=dt, count=n_vert)
             pts = np.stack([rec[a].astype(np.float64) for a in "xyz"], 1)
     return PointCloud(pts)
 
@@ -168,12 +191,14 @@ def masked_icp(clusters_local, clusters_world, step_pc_np, matrices, visual=Fals
     dev = torch.device("cuda")
     k = len(clusters_local)
     local, off = ops.pack_clusters(clusters_local, dev, torch.float64)
+    # the two lists may be segmented differently: match() --mlp_icp hands the frame-0 clusters as sources and the
+    # trained clouds of the current segmentation as boxes (mlp_reg.py:248,325; only min/max of c_world is used)
     world, off_w = ops.pack_clusters(clusters_world, dev, torch.float32)
-    if not torch.equal(off, off_w):
-        raise ValueError("clusters_local and clusters_world must have matching sizes")
+    if len(clusters_world) != k or len(matrices) != k:
+        raise ValueError("clusters_local, clusters_world and matrices must hold one entry per cluster")
     frame = torch.as_tensor(np.asarray(step_pc_np), dtype=torch.float64, device=dev).contiguous()
     M = torch.as_tensor(np.asarray(matrices), dtype=torch.float64, device=dev).contiguous()
-    M_out, w_out, _ = ops.masked_icp(local, world, off, frame, M, scale, th, max_iteration, ori)
+    M_out, w_out, _ = ops.masked_icp(local, world, off, frame, M, scale, th, max_iteration, ori, world_offsets=off_w)
     off_h = off.cpu().numpy()
     w_h = w_out.cpu().numpy()
     return [w_h[off_h[i]:off_h[i + 1]] for i in range(k)], M_out.cpu().numpy()

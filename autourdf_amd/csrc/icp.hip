@@ -132,6 +132,7 @@ __device__ __forceinline__ void bsum_n(double (&v)[N], double* sc /* [4][N] */) 
 
 struct IcpBatch {
     const double* local[ICP_BATCH_MAX]; const float* world[ICP_BATCH_MAX]; const int* off[ICP_BATCH_MAX];
+    const int* woff[ICP_BATCH_MAX];                    // segment offsets of `world` (the box clouds); null = same as `off`
     const double* frame[ICP_BATCH_MAX]; const double* Min[ICP_BATCH_MAX];
     const int* toff[ICP_BATCH_MAX];                    // point-to-point mode: target segment offsets into `frame`; null = masked mode
     double* Mout[ICP_BATCH_MAX]; double* world_out[ICP_BATCH_MAX]; int* n_iter_out[ICP_BATCH_MAX];
@@ -166,7 +167,11 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
     if (!toff) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (world) {
-        for (int i = b + tid; i < e; i += ICP_NT)
+        // the box cloud of cluster k may have another size than its ICP source (match() --mlp_icp: frame-0 clusters
+        // are the source, the trained clouds of the CURRENT segmentation give the boxes, mlp_reg.py:248,325)
+        const int* __restrict__ woff = P.woff[z] ? P.woff[z] : off;
+        const int wb = woff[k], we = woff[k + 1];
+        for (int i = wb + tid; i < we; i += ICP_NT)
             for (int d = 0; d < 3; ++d) { const float v = world[3 * (size_t)i + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
     } else {
         // no world clouds given: the cluster in its current pose, evaluated in float32 exactly as
@@ -400,7 +405,7 @@ static int icp_launch(const creg_icp_problem* pr, int batch, int64_t n, int32_t 
         CREG_REQUIRE(q.local && q.seg_offsets && q.frame && q.M && q.M_out && q.world_out && q.n_iter_out,
                      "%s: null pointer in problem %d", who, i);
         B.local[i] = q.local; B.world[i] = q.world; B.off[i] = q.seg_offsets; B.frame[i] = q.frame; B.Min[i] = q.M;
-        B.toff[i] = q.tgt_offsets;
+        B.toff[i] = q.tgt_offsets; B.woff[i] = q.world_offsets;
         B.Mout[i] = q.M_out; B.world_out[i] = q.world_out; B.n_iter_out[i] = q.n_iter_out;
     }
     const int lds_cap = (int)(nf < 4096 ? nf : 4096);             // masked targets kept in LDS (28 B each, <= 112 KB)
@@ -417,11 +422,11 @@ static int icp_launch(const creg_icp_problem* pr, int batch, int64_t n, int32_t 
     return CREG_OK;
 }
 
-extern "C" int creg_masked_icp_f64(const double* local, const float* world, int64_t n, const int32_t* seg_offsets, int32_t k,
-                                   const double* frame, int64_t nf, const double* M, double scale, double th,
+extern "C" int creg_masked_icp_f64(const double* local, const float* world, const int32_t* world_offsets, int64_t n,
+                                   const int32_t* seg_offsets, int32_t k, const double* frame, int64_t nf, const double* M, double scale, double th,
                                    int32_t max_iteration, int32_t keep_translation, double* M_out, double* world_out,
                                    int32_t* n_iter_out, void* workspace, size_t workspace_bytes, creg_stream_t stream) {
-    const creg_icp_problem p{local, world, seg_offsets, frame, M, M_out, world_out, n_iter_out, nullptr};
+    const creg_icp_problem p{local, world, seg_offsets, frame, M, M_out, world_out, n_iter_out, nullptr, world_offsets};
     return icp_launch(&p, 1, n, k, nf, scale, th, max_iteration, keep_translation, workspace, workspace_bytes,
                       (hipStream_t)stream, "creg_masked_icp_f64");
 }
@@ -438,7 +443,7 @@ extern "C" int creg_icp_p2p_f64(const double* src, int64_t n_src, const int32_t*
                                 int32_t max_iteration, double* T_out, double* src_out, int32_t* n_iter_out,
                                 void* workspace, size_t workspace_bytes, creg_stream_t stream) {
     CREG_REQUIRE(tgt_offsets, "creg_icp_p2p_f64: null pointer");
-    const creg_icp_problem p{src, nullptr, src_offsets, tgt, init, T_out, src_out, n_iter_out, tgt_offsets};
+    const creg_icp_problem p{src, nullptr, src_offsets, tgt, init, T_out, src_out, n_iter_out, tgt_offsets, nullptr};
     return icp_launch(&p, 1, n_src, k, n_tgt, 1.0, th, max_iteration, 0, workspace, workspace_bytes, (hipStream_t)stream,
                       "creg_icp_p2p_f64");
 }

@@ -644,7 +644,7 @@ __global__ __launch_bounds__(1024) void k_group_offsets(GroupBatch G, int n, int
 }
 
 // one wave per cluster walks the labels in order: ballot + prefix popcount gives the stable slot
-__global__ __launch_bounds__(64) void k_group_scatter(GroupBatch G, int n) {
+__global__ __launch_bounds__(64) void k_group_scatter(GroupBatch G, int n, int m_is_inverse) {
     const double* __restrict__ X = G.X[blockIdx.y];
     const int* __restrict__ labels = G.labels[blockIdx.y];
     const int* __restrict__ off = G.off[blockIdx.y];
@@ -652,7 +652,8 @@ __global__ __launch_bounds__(64) void k_group_scatter(GroupBatch G, int n) {
     double* __restrict__ out = G.out[blockIdx.y];
     const int j = blockIdx.x, lane = threadIdx.x;
     __shared__ double I[16];                              // inv(M_j), by one lane (no device scratch)
-    if (lane == 0) inv4x4(M + 16 * j, I);
+    if (m_is_inverse) { if (lane < 16) I[lane] = M[16 * j + lane]; }     // the caller inverted the pose (np.linalg.inv on the host)
+    else if (lane == 0) inv4x4(M + 16 * j, I);
     __syncthreads();
     int pos = off[j];
     for (int base = 0; base < n; base += 64) {
@@ -768,22 +769,22 @@ extern "C" int creg_kmeans_assign_f64(const double* X, int64_t n, const double* 
 }
 
 extern "C" int creg_group_to_local_f64(const double* X, int64_t n, const int32_t* labels, int32_t k,
-                                       const double* M, double* out_local, int32_t* seg_offsets,
-                                       creg_stream_t stream) {
+                                       const double* M, int32_t m_is_inverse, double* out_local,
+                                       int32_t* seg_offsets, creg_stream_t stream) {
     CREG_REQUIRE(X && labels && M && out_local && seg_offsets && n >= 1 && n < (1ll << 31) && k >= 1 && k <= 4096,
                  "creg_group_to_local_f64: bad argument");
     hipStream_t s = (hipStream_t)stream;
     GroupBatch G;
     G.X[0] = X; G.labels[0] = labels; G.M[0] = M; G.out[0] = out_local; G.off[0] = seg_offsets;
     hipLaunchKernelGGL(k_group_offsets, dim3(1, 1), dim3(1024), sizeof(int) * (k + 1), s, G, (int)n, k);
-    hipLaunchKernelGGL(k_group_scatter, dim3(k, 1), dim3(64), 0, s, G, (int)n);
+    hipLaunchKernelGGL(k_group_scatter, dim3(k, 1), dim3(64), 0, s, G, (int)n, m_is_inverse);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }
 
 extern "C" int creg_group_to_local_batch_f64(const double* const* X, int64_t n, const int32_t* const* labels, int32_t k,
-                                             const double* const* M, int32_t batch, double* const* out_local,
-                                             int32_t* const* seg_offsets, creg_stream_t stream) {
+                                             const double* const* M, int32_t m_is_inverse, int32_t batch,
+                                             double* const* out_local, int32_t* const* seg_offsets, creg_stream_t stream) {
     CREG_REQUIRE(X && labels && M && out_local && seg_offsets && n >= 1 && n < (1ll << 31) && k >= 1 && k <= 4096,
                  "creg_group_to_local_batch_f64: bad argument");
     CREG_REQUIRE(batch >= 1 && batch <= GRP_MAXB, "creg_group_to_local_batch_f64: batch must be in 1..%d", GRP_MAXB);
@@ -794,7 +795,7 @@ extern "C" int creg_group_to_local_batch_f64(const double* const* X, int64_t n, 
     }
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_group_offsets, dim3(1, batch), dim3(1024), sizeof(int) * (k + 1), s, G, (int)n, k);
-    hipLaunchKernelGGL(k_group_scatter, dim3(k, batch), dim3(64), 0, s, G, (int)n);
+    hipLaunchKernelGGL(k_group_scatter, dim3(k, batch), dim3(64), 0, s, G, (int)n, m_is_inverse);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }

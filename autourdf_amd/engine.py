@@ -3,10 +3,35 @@ mlp_reg.py:293-378, default MLP+MLP branch) without the host round trips the ref
 implies (numpy cluster lists, ``loss.item()``), for callers that keep frames in HBM
 (bench.py, the multi-GPU driver).  Arithmetic is identical to ``mlp_reg.register_sequence``:
 the same train plans (A1) and the same k-means / grouping kernels (K2) run in the same order."""
+import numpy as np
 import torch
 
 from . import mlp_reg, ops
 from .model_utils import DQRegMLP, QRegMLP
+
+
+class _HostInverse:
+    """inv(M_k) the way resample_cluster gets it (mlp_reg.py:211): ``np.linalg.inv`` on the HOST in the poses' own
+    dtype (float32 after train, float64 after masked_icp) -- LAPACK's rounding is what the reference's
+    cluster/NNNN.npz carries and it is not reproducible on the device.  The (K,4,4) poses are fetched on a side
+    stream that waits only for the event recorded right after the launch that produced them, so work enqueued in
+    between (the k-means of the same frames) overlaps the round trip; returns the inverses as float64 on the device."""
+
+    def __init__(self, device):
+        self.side = torch.cuda.Stream(device=device)
+
+    def mark(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def __call__(self, M, ev):
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            host = M.to("cpu", non_blocking=True)
+            self.side.synchronize()
+        inv = np.linalg.inv(host.numpy()).astype(np.float64)
+        return torch.from_numpy(inv).to(M.device, non_blocking=True)
 
 
 class SequenceRegistrar:
@@ -33,16 +58,18 @@ class SequenceRegistrar:
         self.m = torch.as_tensor(mats0, dtype=torch.float32).to(self.device).contiguous()
         self.pts, self.off = ops.pack_clusters(clusters0, self.device)
         self.pts_init, self.off_init = self.pts.clone(), self.off.clone()
-        self.local64, _ = ops.pack_clusters(clusters0, self.device, torch.float64)   # step_cluster_np of the reference
+        self.local64, _ = ops.pack_clusters(clusters0, self.device, torch.float64)   # what resample_cluster returned last
+        self.local64_init = self.local64             # step_cluster_np of the reference: assigned once (mlp_reg.py:248/253)
+        self.host_inverse = _HostInverse(self.device)
 
     def step(self, frame64: torch.Tensor, frame32: torch.Tensor = None):
         """Register the next frame ((N,3) fp64 on the device).  Returns (poses (K,4,4) fp32, result (4))."""
         y = frame32 if frame32 is not None else frame64.to(torch.float32)
         m1, _, _, _, _ = self.plan.run(self.m, y, self.pts, self.off, self.p_step, lr=2e-4)            # "Step"
         m2, _, res, _, _ = self.plan.run(m1, y, self.pts_init, self.off_init, self.p_anchor, lr=1e-4)  # "Anchor"
-        M64 = m2.to(torch.float64)
-        _, labels, _, _ = ops.kmeans_lloyd(frame64, M64[:, :3, 3].contiguous())
-        local, self.off = ops.group_to_local(frame64, labels, M64)
+        ev = self.host_inverse.mark()
+        _, labels, _, _ = ops.kmeans_lloyd(frame64, m2[:, :3, 3].to(torch.float64).contiguous())
+        local, self.off = ops.group_to_local(frame64, labels, self.host_inverse(m2, ev), m_is_inverse=True)
         self.pts = local.to(torch.float32)
         self.m = m2
         return m2, res
@@ -59,6 +86,7 @@ class BatchRegistrar:
                  device="cuda", seeds=None, models=None, graph_branches=0, nn_search=0):
         self.device = torch.device(device)
         self.S = n_sequences
+        self.host_inverse = _HostInverse(self.device)
         seeds = list(seeds) if seeds is not None else list(range(n_sequences))
         self.seqs = []
         for s in range(n_sequences):
@@ -70,25 +98,33 @@ class BatchRegistrar:
                                   use_graph=use_graph, device=self.device, batch=n_sequences, graph_branches=graph_branches,
                                  nn_search=nn_search)
 
+    def _train(self, problems, lr):
+        """One batched `train` (mlp_reg.py:17-152) of the S problems (m, y, pts, offsets, params); a seam so the
+        match-level golden test can replay the reference's loop with the deterministic stub the golden was minted
+        with (tests/_match_stub.py).  Returns per problem (best_m, best_pred, result, ...)."""
+        return self.plan.run_batch(problems, lr=lr)
+
     def step(self, frames64, frames32=None):
         """frames64: list of S (N,3) fp64 device tensors (the next frame of every sequence)."""
         ys = frames32 if frames32 is not None else [f.to(torch.float32) for f in frames64]
-        step = self.plan.run_batch([(r.m, y, r.pts, r.off, r.p_step) for r, y in zip(self.seqs, ys)], lr=2e-4)
-        anchor = self.plan.run_batch([(o[0], y, r.pts_init, r.off_init, r.p_anchor)
-                                      for r, y, o in zip(self.seqs, ys, step)], lr=1e-4)
+        step = self._train([(r.m, y, r.pts, r.off, r.p_step) for r, y in zip(self.seqs, ys)], lr=2e-4)
+        anchor = self._train([(o[0], y, r.pts_init, r.off_init, r.p_anchor)
+                              for r, y, o in zip(self.seqs, ys, step)], lr=1e-4)
         out = []
-        M64_all = torch.stack([o[0] for o in anchor]).to(torch.float64)           # (S,K,4,4): one cast and one slice for all sequences
-        t_all = M64_all[:, :, :3, 3].contiguous()
-        M64s = [M64_all[i] for i in range(self.S)]
+        M_all = torch.stack([o[0] for o in anchor])                               # (S,K,4,4) float32: what train returned
+        ev = self.host_inverse.mark()
+        t_all = M_all[:, :, :3, 3].to(torch.float64).contiguous()                 # one cast and one slice for all sequences
         inits = [t_all[i] for i in range(self.S)]
         if frames64[0].shape[0] <= ops.KMEANS_BATCH_MAX_N and self.S <= 16 and len(self.seqs[0].off) - 1 <= 128:      # all S re-segmentations in one launch
             km = ops.kmeans_lloyd_batch(frames64, inits)
         else:
             km = [ops.kmeans_lloyd(f, c) for f, c in zip(frames64, inits)]
+        inv_all = self.host_inverse(M_all, ev)                                    # float32 LAPACK inverse, as mlp_reg.py:211
+        invs = [inv_all[i] for i in range(self.S)]
         if self.S <= ops.GROUP_BATCH_MAX and len({f.shape[0] for f in frames64}) == 1:
-            groups = ops.group_to_local_batch(frames64, [res[1] for res in km], M64s)     # all S in one launch pair
+            groups = ops.group_to_local_batch(frames64, [res[1] for res in km], invs, m_is_inverse=True)     # all S in one launch pair
         else:
-            groups = [ops.group_to_local(f, res[1], M) for f, res, M in zip(frames64, km, M64s)]
+            groups = [ops.group_to_local(f, res[1], I, m_is_inverse=True) for f, res, I in zip(frames64, km, invs)]
         for r, o, (local, off) in zip(self.seqs, anchor, groups):
             m2 = o[0]
             r.off = off
@@ -99,27 +135,33 @@ class BatchRegistrar:
 
 
 def _step_mlp_icp(self, frames64, frames32=None):
-    """The `--mlp_icp` frame of match() (mlp_reg.py:296-332) for all S sequences: ONE batched "Step" train, ONE
-    masked-ICP launch (clusters x sequences) started from the trained poses with the trained clouds as mask
-    boxes, ONE k-means launch.  Returns [(poses (K,4,4) fp64, train result (4))] per sequence."""
+    """The `--mlp_icp` frame of match() (mlp_reg.py:296-332) for all S sequences: ONE batched "Step" train on the
+    current (re-sampled) clusters, ONE masked-ICP launch (clusters x sequences) started from the trained poses whose
+    SOURCES are the frame-0 clusters (the reference never reassigns `step_cluster_np`, mlp_reg.py:248,325) and whose
+    mask boxes are those of the trained clouds of the current segmentation (`pred_pcd_np`), ONE k-means launch.
+    Returns [(poses (K,4,4) fp64, train result (4))] per sequence."""
     ys = frames32 if frames32 is not None else [f.to(torch.float32) for f in frames64]
-    step = self.plan.run_batch([(r.m, y, r.pts, r.off, r.p_step) for r, y in zip(self.seqs, ys)], lr=2e-4)
-    probs = [(r.local64, o[1], r.off, f, o[0].to(torch.float64)) for r, f, o in zip(self.seqs, frames64, step)]
+    step = self._train([(r.m, y, r.pts, r.off, r.p_step) for r, y in zip(self.seqs, ys)], lr=2e-4)
+    probs = [(r.local64_init, o[1], r.off_init, f, o[0].to(torch.float64), r.off) for r, f, o in zip(self.seqs, frames64, step)]
     if len(probs) <= ops.ICP_BATCH_MAX:
         icp = ops.masked_icp_batch(probs)
     else:
         icp = [ops.masked_icp(*p) for p in probs]
-    inits = [M[:, :3, 3].contiguous() for M, _, _ in icp]
+    Ms = [M for M, _, _ in icp]
+    M_all = torch.stack(Ms)                                                       # (S,K,4,4) float64: masked_icp's poses
+    ev = self.host_inverse.mark()
+    inits = [M[:, :3, 3].contiguous() for M in Ms]
     if frames64[0].shape[0] <= ops.KMEANS_BATCH_MAX_N and self.S <= 16 and inits[0].shape[0] <= 128:
         km = ops.kmeans_lloyd_batch(frames64, inits)
     else:
         km = [ops.kmeans_lloyd(f, c) for f, c in zip(frames64, inits)]
     out = []
-    Ms = [M for M, _, _ in icp]
+    inv_all = self.host_inverse(M_all, ev)                                        # float64 LAPACK inverse (mlp_reg.py:211,326)
+    invs = [inv_all[i] for i in range(self.S)]
     if len(self.seqs) <= ops.GROUP_BATCH_MAX and len({f.shape[0] for f in frames64}) == 1:
-        groups = ops.group_to_local_batch(frames64, [res[1] for res in km], Ms)
+        groups = ops.group_to_local_batch(frames64, [res[1] for res in km], invs, m_is_inverse=True)
     else:
-        groups = [ops.group_to_local(f, res[1], M) for f, res, M in zip(frames64, km, Ms)]
+        groups = [ops.group_to_local(f, res[1], I, m_is_inverse=True) for f, res, I in zip(frames64, km, invs)]
     for r, M, o, (local, off) in zip(self.seqs, Ms, step, groups):
         r.local64, r.off = local, off
         r.pts, r.m = r.local64.to(torch.float32), M.to(torch.float32)

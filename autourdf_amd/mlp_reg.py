@@ -142,11 +142,16 @@ def resample_cluster(segments, idx, n_clusters, matrices, normal=False, visual=F
     dev = torch.device("cuda")
     pc_np = np.asarray(segments.pc_list[idx].points)
     X = torch.as_tensor(pc_np, dtype=torch.float64, device=dev).contiguous()
-    M = torch.as_tensor(np.asarray(matrices), device=dev).to(torch.float64).contiguous()
-    if M.shape[0] != n_clusters:
+    matrices = np.asarray(matrices)
+    if matrices.shape[0] != n_clusters:
         raise ValueError("matrices must hold n_clusters poses")
-    _, labels, _, _ = ops.kmeans_lloyd(X, M[:, :3, 3].contiguous())
-    local, off = ops.group_to_local(X, labels, M)
+    init = torch.as_tensor(matrices[:, :3, 3], device=dev).to(torch.float64).contiguous()
+    _, labels, _, _ = ops.kmeans_lloyd(X, init)
+    # mlp_reg.py:211: np.linalg.inv(matrices[i]) in the poses' own dtype (float32 on the default path, float64 after
+    # masked_icp) -- the very same host call, so the inverse has the reference's bits on whatever BLAS numpy carries;
+    # the (N,3) change of frame itself runs on the device
+    inv = np.linalg.inv(matrices).astype(np.float64)          # stacked call: LAPACK ?gesv per (4,4) matrix, the same bits
+    local, off = ops.group_to_local(X, labels, torch.as_tensor(inv, device=dev).contiguous(), m_is_inverse=True)
     off_h, local_h = off.cpu().numpy(), local.cpu().numpy()
     if (np.diff(off_h) == 0).any():
         import warnings
@@ -176,6 +181,7 @@ def register_sequence(seg, step_matrices, step_cluster_np, save_dir=None, mlp_ic
     m_t = torch.tensor(np.asarray(step_matrices), dtype=torch.float32).to(DEVICE)
     cl_t = [torch.tensor(step_cluster_np[i], dtype=torch.float32).to(DEVICE) for i in range(K)]
     cl_init = [c.clone() for c in cl_t]
+    icp_src = step_cluster_np            # mlp_reg.py:248/253: assigned once; masked_icp's source for EVERY frame (:325)
     model, model_rf = models if models is not None else _make_models()
     poses, best_losses = [np.asarray(step_matrices)], []
     for i in range(0, seg.data_size - 1):
@@ -185,7 +191,7 @@ def register_sequence(seg, step_matrices, step_cluster_np, save_dir=None, mlp_ic
             pred_np, _, step_m, best_loss = train(m=m_t, y=target, model=model, clusters=cl_t)
             best_losses.append(best_loss)
             step_m_np = step_m.detach().cpu().numpy()
-            _, matrices = masked_icp(step_cluster_np, pred_np, target_np, step_m_np, False, ori=False)
+            _, matrices = masked_icp(icp_src, pred_np, target_np, step_m_np, False, ori=False)
             new_seg_np = resample_cluster(seg, i + 1, K, matrices)
             m_t = torch.tensor(matrices, dtype=torch.float32).to(DEVICE)
             out_m = matrices
@@ -198,7 +204,6 @@ def register_sequence(seg, step_matrices, step_cluster_np, save_dir=None, mlp_ic
             best_losses.append(best_loss)
             out_m = step_m.detach().cpu().numpy()
             new_seg_np = resample_cluster(seg, i + 1, K, out_m)
-        step_cluster_np = new_seg_np
         cl_t = [torch.tensor(new_seg_np[j], dtype=torch.float32).to(DEVICE) for j in range(K)]
         poses.append(out_m)
         if save_dir is not None:
@@ -270,13 +275,19 @@ def match_all(data_dirs):
         step_matrices, step_cluster_np = np.array(seg0.init_matrix_list), seg0.init_segment_list
     else:
         step_matrices, step_cluster_np = np.load(done[0] + "matrix/0000.npy"), load_pc_npz(done[0] + "cluster/0000.npz")
+    n = len(segs[0].pc_list[0].points)
+    if sum(len(c) for c in step_cluster_np) != n:
+        # the frame-0 state comes from another run / the first raw sequence and holds another point count than these
+        # frames: "Anchor" (n0 points) and "Step" (n points) would need two plan shapes -- match() keys its plans on both
+        for i, d in enumerate(data_dirs):
+            match(d, i)
+        return
     save_dirs = [base + d.split("/")[-2] + "/" for d in data_dirs]
     for sd in save_dirs:
         os.makedirs(sd + "cluster", exist_ok=True)
         os.makedirs(sd + "matrix", exist_ok=True)
         np.save(sd + "matrix/0000.npy", step_matrices)
         save_pc_npz(step_cluster_np, sd + "cluster/0000.npz")
-    n = len(segs[0].pc_list[0].points)
     reg = BatchRegistrar(np.asarray(step_matrices, np.float32), [np.asarray(c, np.float64) for c in step_cluster_np], n,
                          len(segs), ROT, 512, EPOCHS, USE_GRAPH, DEVICE, models=[_make_models() for _ in segs])
     losses = [[] for _ in segs]

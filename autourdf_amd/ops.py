@@ -169,14 +169,15 @@ def kmeans_assign(X: torch.Tensor, C: torch.Tensor, use_mfma: bool = False) -> t
     return labels
 
 
-def group_to_local(X: torch.Tensor, labels: torch.Tensor, M: torch.Tensor):
-    """Stable grouping by label and inv(M_k) change of frame: returns (local (n,3) f64, offsets (k+1) int32)."""
+def group_to_local(X: torch.Tensor, labels: torch.Tensor, M: torch.Tensor, m_is_inverse: bool = False):
+    """Stable grouping by label and inv(M_k) change of frame: returns (local (n,3) f64, offsets (k+1) int32).
+    m_is_inverse: M already holds the inverted poses (the drop-in inverts them on the host like mlp_reg.py:211)."""
     L = _lib.load()
     X, labels, M = _need(X, torch.float64, "X"), _need(labels, torch.int32, "labels"), _need(M, torch.float64, "M")
     k = M.shape[0]
     out = torch.empty_like(X)
     off = torch.empty(k + 1, dtype=torch.int32, device=X.device)
-    _lib.check(L.creg_group_to_local_f64(_p(X), X.shape[0], _p(labels), k, _p(M), _p(out), _p(off), _stream()),
+    _lib.check(L.creg_group_to_local_f64(_p(X), X.shape[0], _p(labels), k, _p(M), int(bool(m_is_inverse)), _p(out), _p(off), _stream()),
                "creg_group_to_local_f64")
     return out, off
 
@@ -184,7 +185,7 @@ def group_to_local(X: torch.Tensor, labels: torch.Tensor, M: torch.Tensor):
 GROUP_BATCH_MAX = 16
 
 
-def group_to_local_batch(Xs, labels, Ms):
+def group_to_local_batch(Xs, labels, Ms, m_is_inverse: bool = False):
     """`group_to_local` for a list (<= 16) of frames of identical n and k in one pair of launches.
     Returns a list of (local (n,3) f64, offsets (k+1) int32)."""
     L = _lib.load()
@@ -199,7 +200,7 @@ def group_to_local_batch(Xs, labels, Ms):
         raise ValueError("group_to_local_batch: all problems must share n and k")
     outs = [(torch.empty_like(x), torch.empty(k + 1, dtype=torch.int32, device=x.device)) for x in Xs]
     arr = lambda ts: (ctypes.c_void_p * B)(*[t.data_ptr() for t in ts])
-    _lib.check(L.creg_group_to_local_batch_f64(arr(Xs), n, arr(labels), k, arr(Ms), B, arr([o[0] for o in outs]),
+    _lib.check(L.creg_group_to_local_batch_f64(arr(Xs), n, arr(labels), k, arr(Ms), int(bool(m_is_inverse)), B, arr([o[0] for o in outs]),
                                                arr([o[1] for o in outs]), _stream()), "creg_group_to_local_batch_f64")
     return outs
 
@@ -228,7 +229,7 @@ def icp_p2p_batch(problems, th: float = 1.0, max_iteration: int = 100000):
         T = torch.empty(k, 4, 4, dtype=torch.float64, device=dev)
         moved = torch.empty(n, 3, dtype=torch.float64, device=dev)
         n_it = torch.empty(k, dtype=torch.int32, device=dev)
-        arr[b] = _lib.IcpProblem(_p(src), None, _p(soff), _p(tgt), _p(init), _p(T), _p(moved), _p(n_it), _p(toff))
+        arr[b] = _lib.IcpProblem(_p(src), None, _p(soff), _p(tgt), _p(init), _p(T), _p(moved), _p(n_it), _p(toff), None)
         keep.append((src, soff, tgt, toff, init))
         outs.append((T, moved, n_it))
     ws_bytes = L.creg_icp_batch_workspace_bytes(n, m, k, B)
@@ -305,10 +306,13 @@ def pose_coords(M: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------ K5 row conversions
 def masked_icp(local: torch.Tensor, world: torch.Tensor, offsets: torch.Tensor, frame: torch.Tensor, M: torch.Tensor,
-               scale: float = 1.2, th: float = 1.0, max_iteration: int = 10000, ori: bool = False):
+               scale: float = 1.2, th: float = 1.0, max_iteration: int = 10000, ori: bool = False,
+               world_offsets: torch.Tensor = None):
     """K4, device resident: AABB-masked point-to-point ICP of every cluster against `frame`, one launch
     (reference cluster_icp.py:118-191 + open3d registration_icp).  local (n,3) f64 cluster-frame
-    points, world (n,3) f32 their current world positions (the mask boxes), offsets (k+1) int32,
+    points (the ICP sources), offsets (k+1) int32; world f32 predicted clusters back to back (the mask boxes) with
+    segment offsets `world_offsets` (None: the same segmentation as `local`; match()'s --mlp_icp branch passes the
+    frame-0 clusters as `local` and the trained clouds of the current segmentation as `world`, mlp_reg.py:325),
     frame (nf,3) f64, M (k,4,4) f64 initial poses.  Returns (M_out (k,4,4) f64, world_out (n,3) f64,
     iterations (k) int32); stream-ordered, no host sync."""
     L = _lib.load()
@@ -316,14 +320,20 @@ def masked_icp(local: torch.Tensor, world: torch.Tensor, offsets: torch.Tensor, 
     frame, M = _need(frame, torch.float64, "frame"), _need(M, torch.float64, "M")
     offsets = _need(offsets, torch.int32, "offsets")
     n, nf, k = local.shape[0], frame.shape[0], offsets.shape[0] - 1
-    if world.shape[0] != n or M.shape[0] != k:
+    if world_offsets is not None:
+        world_offsets = _need(world_offsets, torch.int32, "world_offsets")
+        if world_offsets.shape[0] != k + 1:
+            raise ValueError("world_offsets must hold k+1 entries")
+    elif world.shape[0] != n:
+        raise ValueError("world must have local's size unless world_offsets is given")
+    if M.shape[0] != k:
         raise ValueError("local/world/offsets/M disagree on sizes")
     ws_bytes = L.creg_icp_workspace_bytes(n, nf, k)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=local.device)
     M_out = torch.empty(k, 4, 4, dtype=torch.float64, device=local.device)
     w_out = torch.empty(n, 3, dtype=torch.float64, device=local.device)
     n_it = torch.empty(k, dtype=torch.int32, device=local.device)
-    _lib.check(L.creg_masked_icp_f64(_p(local), _p(world), n, _p(offsets), k, _p(frame), nf, _p(M), float(scale),
+    _lib.check(L.creg_masked_icp_f64(_p(local), _p(world), _p(world_offsets), n, _p(offsets), k, _p(frame), nf, _p(M), float(scale),
                                      float(th), int(max_iteration), int(bool(ori)), _p(M_out), _p(w_out), _p(n_it),
                                      _p(ws), ws_bytes, _stream()), "creg_masked_icp_f64")
     return M_out, w_out, n_it
@@ -333,10 +343,10 @@ ICP_BATCH_MAX = 16
 
 
 def masked_icp_batch(problems, scale: float = 1.2, th: float = 1.0, max_iteration: int = 10000, ori: bool = False):
-    """`masked_icp` for a list of (local, world, offsets, frame, M) of identical sizes in ONE launch
+    """`masked_icp` for a list of (local, world, offsets, frame, M[, world_offsets]) of identical sizes in ONE launch
     (grid clusters x problems); returns a list of (M_out, world_out, iterations), bit-identical to
     separate calls.  `world` None = the clusters in their current pose (`cluster_transform` of the float32 casts),
-    evaluated inside the kernel."""
+    evaluated inside the kernel; `world_offsets` as in `masked_icp`."""
     L = _lib.load()
     B = len(problems)
     if not 1 <= B <= ICP_BATCH_MAX:
@@ -344,7 +354,9 @@ def masked_icp_batch(problems, scale: float = 1.2, th: float = 1.0, max_iteratio
     arr = (_lib.IcpProblem * B)()
     keep, outs = [], []
     n = nf = k = None
-    for b, (local, world, offsets, frame, M) in enumerate(problems):
+    for b, prob in enumerate(problems):
+        local, world, offsets, frame, M = prob[:5]
+        woff = prob[5] if len(prob) > 5 else None
         local = _need(local, torch.float64, "local")
         world = None if world is None else _need(world, torch.float32, "world")     # None: boxes of float32(M) . float32(local)
         frame, M = _need(frame, torch.float64, "frame"), _need(M, torch.float64, "M")
@@ -352,14 +364,21 @@ def masked_icp_batch(problems, scale: float = 1.2, th: float = 1.0, max_iteratio
         shape = (local.shape[0], frame.shape[0], offsets.shape[0] - 1)
         if b == 0:
             n, nf, k = shape
-        if shape != (n, nf, k) or (world is not None and world.shape[0] != n) or M.shape[0] != k:
+        if woff is not None:
+            woff = _need(woff, torch.int32, "world_offsets")
+            if world is None or woff.shape[0] != k + 1:
+                raise ValueError("masked_icp_batch: world_offsets needs world and k+1 entries")
+        elif world is not None and world.shape[0] != n:
+            raise ValueError("masked_icp_batch: world must have local's size unless world_offsets is given")
+        if shape != (n, nf, k) or M.shape[0] != k:
             raise ValueError("masked_icp_batch: all problems must share n, nf and k")
         dev = local.device
         M_out = torch.empty(k, 4, 4, dtype=torch.float64, device=dev)
         w_out = torch.empty(n, 3, dtype=torch.float64, device=dev)
         n_it = torch.empty(k, dtype=torch.int32, device=dev)
-        arr[b] = _lib.IcpProblem(_p(local), _p(world), _p(offsets), _p(frame), _p(M), _p(M_out), _p(w_out), _p(n_it), None)
-        keep.append((local, world, offsets, frame, M))
+        arr[b] = _lib.IcpProblem(_p(local), _p(world), _p(offsets), _p(frame), _p(M), _p(M_out), _p(w_out), _p(n_it), None,
+                                     _p(woff))
+        keep.append((local, world, offsets, frame, M, woff))
         outs.append((M_out, w_out, n_it))
     ws_bytes = L.creg_icp_batch_workspace_bytes(n, nf, k, B)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -425,7 +444,7 @@ class TrainPlan:
         self.plan = ctypes.c_void_p()
         _lib.check(self.L.creg_train_plan_create(ctypes.byref(self.shape), ctypes.c_void_p(base), need,
                                                  ctypes.byref(self.plan)), "creg_train_plan_create")
-        self.k, self.n_pred, self.n_tgt, self.epochs = k, n_pred, n_tgt, epochs
+        self.k, self.n_pred, self.n_tgt, self.epochs, self.hidden = k, n_pred, n_tgt, epochs, hidden
 
     def __del__(self):
         plan = getattr(self, "plan", None)
@@ -439,9 +458,21 @@ class TrainPlan:
             raise ValueError(f"expected {n} parameter tensors, got {len(params)}")
         keep = [_need(m, torch.float32, "m"), _need(y, torch.float32, "y"), _need(pts, torch.float32, "pts"),
                 _need(offsets, torch.int32, "offsets")]
-        for p in params:
+        # the kernels index with the PLAN's sizes: a tensor of another shape would be read out of bounds, not rejected
+        if tuple(keep[0].shape) != (self.k, 4, 4):
+            raise ValueError(f"m must be ({self.k},4,4) for this plan, got {tuple(keep[0].shape)}")
+        if tuple(keep[1].shape) != (self.n_tgt, 3):
+            raise ValueError(f"y must be ({self.n_tgt},3) for this plan, got {tuple(keep[1].shape)}")
+        if tuple(keep[2].shape) != (self.n_pred, 3):
+            raise ValueError(f"pts must be ({self.n_pred},3) for this plan, got {tuple(keep[2].shape)}")
+        if keep[3].numel() != self.k + 1:
+            raise ValueError(f"offsets must hold {self.k + 1} entries, got {keep[3].numel()}")
+        numels = self._param_numels()
+        for p, want in zip(params, numels):
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                 raise TypeError("model parameters must be contiguous fp32 CUDA tensors")
+            if p.numel() != want:
+                raise ValueError(f"parameter tensor of {p.numel()} elements where the plan's model has {want}")
         arr = (ctypes.c_void_p * n)(*[p.data_ptr() for p in params])
         self._keep = getattr(self, "_keep", [])[-64:] + [keep, arr]      # alive until the enqueued work has read them
         a = _lib.TrainArgs()
@@ -450,6 +481,13 @@ class TrainPlan:
         a.lr, a.sched_factor, a.sched_patience, a.stop = lr, factor, patience, stop
         a.best_m, a.best_pred, a.loss_hist, a.lr_hist, a.result = [o.data_ptr() if o is not None else None for o in outs]
         return a
+
+    def _param_numels(self):
+        """Element counts of the model's tensors in Q_PARAM_ORDER / DQ_PARAM_ORDER (model_utils.py:65-168)."""
+        H = self.hidden
+        if self.rot == 0:      # QRegMLP: enc 56->H, dec1 H->H/2->3, dec2 H->H->4
+            return [56 * H, H, H * (H // 2), H // 2, 3 * (H // 2), 3, H * H, H, 4 * H, 4]
+        return [64 * H, H, H * H, H, 8 * H, 8]        # DQRegMLP: enc 64->H, H->H, H->8
 
     def _outs(self):
         dev = self.device

@@ -109,15 +109,20 @@ int creg_kmeans_assign_f64(const double* X, int64_t n, const double* C, int32_t 
 /* Stable grouping of points by label + change of frame, fp64.  Replaces the per-cluster mask /
  * inv(M_k) . [p;1] loop of resample_cluster (mlp_reg.py:208-217) and Segments.k_means_cluster
  * (cluster_icp.py:86-99).  M (k,4,4) fp64 local->world; out_local (n,3) holds the clusters
- * back to back in label order, each keeping the original point order; seg_offsets (k+1) int32. */
+ * back to back in label order, each keeping the original point order; seg_offsets (k+1) int32.
+ * m_is_inverse == 0: M is inverted in the kernel in fp64 (Gauss-Jordan, partial pivoting).
+ * m_is_inverse != 0: M already holds inv(M_k) -- the drop-in resample_cluster inverts each pose on the host with
+ * np.linalg.inv IN THE POSE'S OWN DTYPE exactly as mlp_reg.py:211 does (float32 on the default path: LAPACK sgesv,
+ * whose rounding is BLAS-build specific and is not reproduced on the device), so cluster/NNNN.npz matches the
+ * reference to the rounding of one 4-term fp64 dot product.  out = fma(I2,z, fma(I1,y, I0*x)) + I3 per row. */
 int creg_group_to_local_f64(const double* X, int64_t n, const int32_t* labels, int32_t k,
-                            const double* M, double* out_local, int32_t* seg_offsets,
+                            const double* M, int32_t m_is_inverse, double* out_local, int32_t* seg_offsets,
                             creg_stream_t stream);
 /* The same for `batch` (<= 16) frames of identical n and k in one pair of launches; X, labels, M, out_local and
  * seg_offsets are HOST arrays of `batch` device pointers.  Identical results to separate calls. */
 int creg_group_to_local_batch_f64(const double* const* X, int64_t n, const int32_t* const* labels, int32_t k,
-                                  const double* const* M, int32_t batch, double* const* out_local,
-                                  int32_t* const* seg_offsets, creg_stream_t stream);
+                                  const double* const* M, int32_t m_is_inverse, int32_t batch,
+                                  double* const* out_local, int32_t* const* seg_offsets, creg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * N1  farthest-point down-sampling, fp64.  Replaces open3d farthest_point_down_sample as used by
@@ -149,13 +154,17 @@ int creg_quat_to_matrix_f32(const float* q, int32_t k, float* R, creg_stream_t s
  * K4  masked point-to-point ICP per cluster, fp64.  Replaces masked_icp (cluster_icp.py:118-191)
  * including open3d registration_icp (TransformationEstimationPointToPoint, max_iteration,
  * relative_fitness = relative_rmse = 1e-6).
- * local (n,3) fp64 clusters back to back, world (n,3) fp32 predicted clusters (AABB source),
- * frame (nf,3) fp64 target, M (k,4,4) fp64 initial poses, n = seg_offsets[k] points in total.  M_out (k,4,4) fp64,
- * world_out (n,3) fp64 = M_out applied to local.  keep_translation mirrors `ori`.
+ * local (n,3) fp64 clusters back to back (the ICP sources, n = seg_offsets[k] points in total), world fp32
+ * predicted clusters back to back (only their boxes are used: cluster_icp.py:133-135), frame (nf,3) fp64 target,
+ * M (k,4,4) fp64 initial poses.  world_offsets (k+1, DEVICE) are the segment offsets of `world`; NULL = the same
+ * as seg_offsets.  They differ in match()'s --mlp_icp branch: `clusters_local` is the frame-0 segmentation for the
+ * whole sequence (mlp_reg.py:248, never reassigned), `clusters_world` the trained clouds of the current, re-sampled
+ * one (mlp_reg.py:301-306,325), so cluster i has another point count in the two lists from frame 2 on.
+ * M_out (k,4,4) fp64, world_out (n,3) fp64 = M_out applied to local.  keep_translation mirrors `ori`.
  * workspace: creg_icp_workspace_bytes(n, nf, k). */
 size_t creg_icp_workspace_bytes(int64_t n, int64_t nf, int32_t k);
-int creg_masked_icp_f64(const double* local, const float* world, int64_t n, const int32_t* seg_offsets,
-                        int32_t k, const double* frame, int64_t nf, const double* M,
+int creg_masked_icp_f64(const double* local, const float* world, const int32_t* world_offsets, int64_t n,
+                        const int32_t* seg_offsets, int32_t k, const double* frame, int64_t nf, const double* M,
                         double scale, double th, int32_t max_iteration, int32_t keep_translation,
                         double* M_out, double* world_out, int32_t* n_iter_out,
                         void* workspace, size_t workspace_bytes, creg_stream_t stream);
@@ -169,6 +178,7 @@ typedef struct creg_icp_problem {
     const int32_t* tgt_offsets;   /* NULL: masked mode above.  Non-NULL (k+1 offsets into `frame`): point-to-point
                                      mode, cluster i registers to frame[tgt_offsets[i] .. tgt_offsets[i+1]) unmasked,
                                      `world` is ignored and nf is the total number of target points */
+    const int32_t* world_offsets; /* masked mode: (k+1) segment offsets of `world`; NULL = seg_offsets */
     /* masked mode with world == NULL: the mask boxes are those of the clusters in their CURRENT pose, i.e. of
        float32(M) applied to float32(local) exactly as creg_cluster_transform_f32 evaluates it -- the caller
        saves that launch and the two casts */

@@ -83,3 +83,44 @@ def resample_cluster(pc_np, n_clusters, matrices):
         inv = np.linalg.inv(matrices[i])
         out.append((inv @ np.hstack([pts, np.ones((len(pts), 1))]).T)[:3].T)
     return out, labels
+
+
+def match_sequence(frames, step_matrices, step_cluster_np, train_fn, mlp_icp=False, models=("model", "model_rf")):
+    """Loop body of ``match`` (mlp_reg.py:265-378) on arrays: frames list of (N,3) f64, frame-0 poses (K,4,4) and
+    local clusters.  ``train_fn`` has ``train``'s signature (the real loop above, or the deterministic stub the
+    match-level golden was minted with).  Returns ([matrices per frame incl. frame 0], [clusters per frame], losses).
+
+    The details that matter: ``step_cluster_np`` is assigned ONCE (:248/253) -- it is masked_icp's source cloud for
+    every frame (:325) while the boxes come from ``pred_pcd_np`` of the re-sampled clusters; "Anchor" always trains
+    on the frame-0 clusters (:353); the default branch saves float32 poses, --mlp_icp float64 ones."""
+    from .icp import masked_icp
+    K = len(step_cluster_np)
+    m_t = torch.tensor(np.asarray(step_matrices), dtype=torch.float32)
+    cl_t = [torch.tensor(step_cluster_np[i], dtype=torch.float32) for i in range(K)]
+    cl_init = [torch.tensor(step_cluster_np[i], dtype=torch.float32) for i in range(K)]
+    model, model_rf = models
+    mats, clusters, losses = [np.asarray(step_matrices)], [list(step_cluster_np)], []
+    for i in range(len(frames) - 1):
+        target_np = np.array(frames[i + 1])
+        target = torch.tensor(target_np, dtype=torch.float32)
+        if mlp_icp:
+            pred_np, _, step_m, best = train_fn(m=m_t, y=target, model=model, clusters=cl_t)
+            losses.append(best)
+            step_m_np = step_m.detach().cpu().numpy()
+            _, matrices = masked_icp(step_cluster_np, pred_np, target_np, step_m_np, ori=False)
+            new_seg, _ = resample_cluster(target_np, K, matrices)
+            cl_t = [torch.tensor(new_seg[j], dtype=torch.float32) for j in range(K)]
+            m_t = torch.tensor(matrices, dtype=torch.float32)
+            mats.append(matrices)
+        else:
+            _, _, step_m, _ = train_fn(m=m_t, y=target, model=model, clusters=cl_t)
+            m_t = step_m.detach().clone()
+            _, _, step_m, best = train_fn(m=m_t, y=target, model=model_rf, clusters=cl_init, learning_rate=0.0001)
+            m_t = step_m.detach().clone()
+            losses.append(best)
+            step_m_np = step_m.detach().cpu().numpy()
+            new_seg, _ = resample_cluster(target_np, K, step_m_np)
+            cl_t = [torch.tensor(new_seg[j], dtype=torch.float32) for j in range(K)]
+            mats.append(step_m_np)
+        clusters.append(new_seg)
+    return mats, clusters, losses

@@ -68,7 +68,15 @@ def install():
         TransformationEstimationPointToPoint=lambda: None,
         ICPConvergenceCriteria=lambda max_iteration=30: types.SimpleNamespace(max_iteration=max_iteration))
     o3d.pipelines = types.SimpleNamespace(registration=reg)
-    o3d.io = types.SimpleNamespace(read_point_cloud=lambda p: (_ for _ in ()).throw(IOError(p)))
+    def read_point_cloud(path):
+        """ascii PLY with x y z vertex properties only (what tests/_ply.write_ascii_ply writes)."""
+        with open(path) as f:
+            lines = f.read().split("\n")
+        end = lines.index("end_header")
+        n = int([l for l in lines[:end] if l.startswith("element vertex")][0].split()[2])
+        return _PointCloud(np.array([[float(v) for v in l.split()[:3]] for l in lines[end + 1:end + 1 + n]], np.float64))
+
+    o3d.io = types.SimpleNamespace(read_point_cloud=read_point_cloud)
     o3d.visualization = types.SimpleNamespace(draw_geometries=lambda *a, **k: None)
     sys.modules["open3d"] = o3d
 

@@ -1,0 +1,105 @@
+"""GPU: the product's match() loop against the reference-minted match-level golden (match_reference.npz: the
+reference's own match(), mlp_reg.py:240-386, run on disk with the deterministic train stub of tests/_match_stub.py,
+both branches, 4 frames).  Pins the COMPOSITION around train(): masked_icp's sources stay the frame-0 clusters while
+its boxes follow the re-sampled segmentation (mlp_reg.py:248,325), Anchor trains on the frame-0 clusters (:353),
+resample_cluster inverts the poses in their own dtype (:211), dtypes / contents of the files written."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests._match_stub import TrainStub
+from tests._ply import write_sequence
+from tests.test_match_golden_cpu import T, _split, check_against_golden
+
+pytestmark = pytest.mark.gpu
+K = 5
+
+
+@pytest.mark.parametrize("tag,flags", [("mlp", []), ("icp", ["--mlp_icp"])])
+def test_match_replays_reference_golden(golden, tmp_path, monkeypatch, tag, flags):
+    """The drop-in surface on disk: Segments (PLY) -> match() -> matrix/NNNN.npy, cluster/NNNN.npz, loss.txt."""
+    from autourdf_amd import mlp_reg
+    g = golden("match_reference.npz")
+    raw = "data/raw/toy/4_deg_20_cams/"
+    monkeypatch.chdir(tmp_path)
+    write_sequence(raw + "V0000/", list(g["frames"]))
+    write_sequence(raw + "V0001/", list(g["frames"]))
+    json.dump({"toy": {"num_seg": K, "dof": 5}}, open("parameters.json", "w"))
+    first = "data/part/toy_5_seg/4_deg_20_cams/V0000/"
+    os.makedirs(first + "matrix"), os.makedirs(first + "cluster")
+    np.save(first + "matrix/0000.npy", g["mats0"])
+    np.savez(first + "cluster/0000.npz", **{str(i): c for i, c in enumerate(_split(g["clusters0"], g["offsets0"]))})
+    stub = TrainStub()
+    monkeypatch.setattr(mlp_reg, "train", stub)
+    mlp_reg.main(["--robot", "toy", "--num_video", "0", "--loss"] + flags)       # sets the module globals, runs nothing
+    mlp_reg.match(raw + "V0001/", 1)
+    out = "data/part/toy_5_seg/4_deg_20_cams/V0001/"
+    mats, clusters = [], []
+    for t in range(T):
+        mats.append(np.load(out + f"matrix/{t:04}.npy"))
+        with np.load(out + f"cluster/{t:04}.npz") as z:
+            assert list(z.keys()) == [str(i) for i in range(K)]
+            clusters.append([z[k] for k in z.keys()])
+    # mlp: float32 LAPACK inverse of the poses on another host CPU + the stub's float32 rounding of perturbed inputs;
+    # icp: the golden's ICP is the numpy oracle (SVD) against the kernel's Horn/Jacobi solve
+    check_against_golden(g, tag, mats, clusters, np.loadtxt(out + "loss.txt"), stub.log_arrays(), 2e-6, 2e-6)
+
+
+@pytest.mark.parametrize("tag,mlp_icp", [("mlp", False), ("icp", True)])
+def test_batch_registrar_replays_reference_golden(golden, tag, mlp_icp):
+    """The device-resident lock-step engine (match_all / bench.py) with its train seam replaced by the stub:
+    two identical sequences, each must reproduce the reference's files."""
+    from autourdf_amd.engine import BatchRegistrar
+    dev = torch.device("cuda")
+    g = golden("match_reference.npz")
+    frames = list(g["frames"])
+    clusters0 = _split(g["clusters0"], g["offsets0"])
+    S = 2
+    reg = BatchRegistrar(np.asarray(g["mats0"], np.float32), clusters0, frames[0].shape[0], S, "q", 64, 2, True, dev)
+    stubs = [TrainStub() for _ in range(S)]
+
+    def stub_train(problems, lr):
+        outs = []
+        for r, st, (m, y, pts, off, params) in zip(reg.seqs, stubs, problems):
+            o = off.cpu().numpy()
+            model = r.model if params is r.p_step else r.model_rf
+            assert params is r.p_step or params is r.p_anchor
+            pred, _, best_m, loss = st(m, y, model, [pts[o[i]:o[i + 1]] for i in range(len(o) - 1)], learning_rate=lr)
+            outs.append((best_m, torch.from_numpy(np.concatenate(pred)).to(dev),
+                         torch.tensor([loss, 2.0, lr, 0.0], dtype=torch.float32, device=dev), None, None))
+        return outs
+
+    reg._train = stub_train
+    mats = [[np.asarray(g["mats0"])] for _ in range(S)]
+    clusters = [[clusters0] for _ in range(S)]
+    losses = [[] for _ in range(S)]
+    for t in range(1, T):
+        f64 = [torch.as_tensor(frames[t], dtype=torch.float64, device=dev) for _ in range(S)]
+        out = reg.step_mlp_icp(f64) if mlp_icp else reg.step(f64)
+        for s, (r, (m2, res)) in enumerate(zip(reg.seqs, out)):
+            off, local = r.off.cpu().numpy(), r.local64.cpu().numpy()
+            mats[s].append(m2.cpu().numpy())
+            clusters[s].append([local[off[j]:off[j + 1]] for j in range(K)])
+            losses[s].append(float(res[0]))
+    for s in range(S):
+        check_against_golden(g, tag, mats[s], clusters[s], losses[s], stubs[s].log_arrays(), 2e-6, 2e-6)
+
+
+def test_masked_icp_accepts_differently_segmented_boxes(golden):
+    """cluster_icp.masked_icp with clusters_local / clusters_world of different per-cluster sizes (frame 2 of the
+    --mlp_icp branch) against the oracle."""
+    from autourdf_amd.cluster_icp import masked_icp
+    from oracle import icp as oicp
+    g = golden("match_reference.npz")
+    src = _split(g["clusters0"], g["offsets0"])
+    cur = _split(g["icp_cluster1"], g["icp_offsets1"])
+    M = g["icp_matrix1"]
+    world = [(c @ m[:3, :3].T + m[:3, 3]).astype(np.float32) for c, m in zip(cur, M)]
+    assert [len(a) for a in src] != [len(b) for b in world]
+    w, new_m = masked_icp(src, world, g["frames"][2], M.astype(np.float32))
+    ow, om = oicp.masked_icp(src, world, g["frames"][2], M.astype(np.float32))
+    np.testing.assert_allclose(new_m, om, atol=1e-8)
+    np.testing.assert_allclose(np.concatenate(w), np.concatenate(ow), atol=1e-8)
