@@ -38,13 +38,14 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "creg.h"))
     hipcc = _hipcc()
+    extra = os.environ.get("CREG_EXTRA_FLAGS", "").split()      # e.g. -DCREG_BACK_STAMPS for tools/back_stamps.py
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

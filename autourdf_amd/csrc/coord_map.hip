@@ -168,11 +168,8 @@ extern "C" int creg_coord_dist_map_f64(const double* M, int32_t T, int32_t K, do
     hipStream_t s = (hipStream_t)stream;
     const int Tn = diff ? T - 1 : T;
     const size_t smem = sizeof(double) * ((size_t)17 * K + (K <= CM_LDS_K ? 2 * (size_t)K * K : 0));
-    static bool attr_set = false;
-    if (!attr_set) {
-        CREG_HIP(hipFuncSetAttribute((const void*)k_coord_dist_map, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        attr_set = true;
-    }
+    // per device, not per process: set on every call (a cached flag would leave a second GPU at the 64 KB default)
+    CREG_HIP(hipFuncSetAttribute((const void*)k_coord_dist_map, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     hipLaunchKernelGGL(k_coord_dist_map, dim3(Tn), dim3(K <= 32 ? 256 : CM_NT), smem, s, M, T, K, 1.0 / (bounding_box * 2.0),
                        1.0 / 3.14159265358979323846, diff ? 1 : 0, d_map, (double*)workspace);
     CREG_LAUNCH_CHECK();

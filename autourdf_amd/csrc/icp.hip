@@ -410,12 +410,9 @@ static int icp_launch(const creg_icp_problem* pr, int batch, int64_t n, int32_t 
     }
     const int lds_cap = (int)(nf < 4096 ? nf : 4096);             // masked targets kept in LDS (28 B each, <= 112 KB)
     const int smem = lds_cap * 28 + ICP_SRC_LDS * 28;
-    static bool attr_set = false;
-    if (!attr_set) {
-        CREG_HIP(hipFuncSetAttribute((const void*)k_masked_icp, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     4096 * 28 + ICP_SRC_LDS * 28));
-        attr_set = true;
-    }
+    // per device, not per process: set on every call (a cached flag would leave a second GPU at the 64 KB default)
+    CREG_HIP(hipFuncSetAttribute((const void*)k_masked_icp, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 4096 * 28 + ICP_SRC_LDS * 28));
     hipLaunchKernelGGL(k_masked_icp, dim3(k, batch), dim3(ICP_NT), smem, s, B, (int)nf, (float)(0.5 * scale), th,
                        max_iteration, keep_translation, (char*)workspace, L.total, L.srcw, L.tidx, L.nn, lds_cap);
     CREG_LAUNCH_CHECK();

@@ -823,11 +823,8 @@ extern "C" int creg_kmeans_lloyd_batch_f64(const double* const* X, int64_t n, co
     const int with_c = ((smem + 7) & ~7) + (int)sizeof(double) * 14 * k;
     const int c_in_lds = with_c <= 5120 * 28 + 128 * 32;           // the limit requested from the runtime below
     if (c_in_lds) smem = with_c;
-    static bool attr_set = false;
-    if (!attr_set) {
-        CREG_HIP(hipFuncSetAttribute((const void*)k_km_small, hipFuncAttributeMaxDynamicSharedMemorySize, 5120 * 28 + 128 * 32));
-        attr_set = true;
-    }
+    // per device, not per process: set on every call (a cached flag would leave a second GPU at the 64 KB default)
+    CREG_HIP(hipFuncSetAttribute((const void*)k_km_small, hipFuncAttributeMaxDynamicSharedMemorySize, 5120 * 28 + 128 * 32));
     hipLaunchKernelGGL(k_km_small, dim3(batch), dim3(1024), smem, (hipStream_t)stream, A, (int)n, k, max_iter, tol_rel,
                        (char*)workspace, kms_stride(n, k), c_in_lds);
     CREG_LAUNCH_CHECK();

@@ -1158,6 +1158,74 @@ static int stage_inputs(Plan* P, const creg_train_args* args, int n, hipStream_t
 }  // namespace creg
 using namespace creg;
 
+// EPG consecutive epochs captured as one graph (G independent branches over contiguous groups of problems).  On any
+// failure the capture is ended, and every stream / event / graph created here is destroyed before returning.
+static int capture_epochs(Plan* P, int epg) {
+    // captured on a private stream (torch's current stream is usually the null stream, which cannot be captured); the
+    // instantiated graph is then launched on the caller's stream.
+    const int G = P->branches;
+    hipStream_t cs = nullptr, cs2[16] = {nullptr};
+    hipEvent_t ef = nullptr, ej[16] = {nullptr};
+    hipGraph_t g = nullptr;
+    bool capturing = false;
+    const Ws Wall = P->W;
+    const int nz_all = P->nz;
+    hipError_t err = hipSuccess;
+    const char* what = "";
+#define CAP_TRY(call) do { if (err == hipSuccess) { err = (call); if (err != hipSuccess) what = #call; } } while (0)
+    CAP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    CAP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    capturing = err == hipSuccess;
+    if (G > 1) {
+        // fork / join through events, so the instantiated graph has parallel chains: the runtime feeds them to
+        // different hardware queues and the latency-bound kernels of one group overlap the long launches of the
+        // other.  Problems never interact, so results do not depend on G (stress-tested: tests/test_gpu_parity.py).
+        CAP_TRY(hipEventCreateWithFlags(&ef, hipEventDisableTiming));
+        CAP_TRY(hipEventRecord(ef, cs));
+        int first = 0;
+        for (int gi = 0; gi < G && err == hipSuccess; ++gi) {
+            const int cnt = P->B / G + (gi < P->B % G ? 1 : 0);
+            hipStream_t st = cs;
+            if (gi > 0) {
+                CAP_TRY(hipStreamCreateWithFlags(&cs2[gi], hipStreamNonBlocking));
+                CAP_TRY(hipStreamWaitEvent(cs2[gi], ef, 0));
+                st = cs2[gi];
+            }
+            if (err != hipSuccess) break;
+            P->W = ws_shift(Wall, (size_t)first * P->bstride); P->nz = cnt;
+            for (int i = 0; i < epg; ++i) enqueue_epoch(P, i, st);
+            if (gi > 0) {
+                CAP_TRY(hipEventCreateWithFlags(&ej[gi], hipEventDisableTiming));
+                CAP_TRY(hipEventRecord(ej[gi], st));
+            }
+            first += cnt;
+        }
+        P->W = Wall; P->nz = nz_all;
+        for (int gi = 1; gi < G; ++gi) if (ej[gi]) CAP_TRY(hipStreamWaitEvent(cs, ej[gi], 0));
+    } else {
+        if (err == hipSuccess) for (int i = 0; i < epg; ++i) enqueue_epoch(P, i, cs);
+    }
+    if (capturing) {
+        const hipError_t e2 = hipStreamEndCapture(cs, &g);          // always end the capture, also after a failure
+        if (err == hipSuccess && e2 != hipSuccess) { err = e2; what = "hipStreamEndCapture"; }
+    }
+    CAP_TRY(hipGraphInstantiate(&P->gexec, g, nullptr, nullptr, 0));
+#undef CAP_TRY
+    if (g) (void)hipGraphDestroy(g);
+    for (int gi = 1; gi < 16; ++gi) { if (cs2[gi]) (void)hipStreamDestroy(cs2[gi]); if (ej[gi]) (void)hipEventDestroy(ej[gi]); }
+    if (ef) (void)hipEventDestroy(ef);
+    if (cs) (void)hipStreamDestroy(cs);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        if (P->gexec) { (void)hipGraphExecDestroy(P->gexec); P->gexec = nullptr; }
+        creg::set_error("creg_train_plan_run_batch: graph capture failed: %s: %s", what, hipGetErrorString(err));
+        return CREG_EHIP;
+    }
+    P->graph_ready = true;
+    P->graph_epochs = epg;
+    return CREG_OK;
+}
+
 static int batch_of(const creg_train_shape* s) { return s->batch >= 1 ? s->batch : 1; }
 
 extern "C" size_t creg_train_workspace_bytes(const creg_train_shape* shape) {
@@ -1187,13 +1255,12 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     P->smem_bwd2 = (int)(sizeof(float) * (BW2_ROWS * ((D.K + 3) & ~3) + 16 * D.K + 8 * BW2_ROWS));
     P->smem_dw = (int)(sizeof(float) * (((DW_WAVES * DW_RPW * D.K + 3) & ~3) + STAGE_FLOATS + 64 * 4));
     int rc_attr = 0;
-    static int dw_lds_limit[16] = {0};             // per k_dw instantiation: the limit only ever grows (it is per kernel, not per plan)
+    // the dynamic-LDS limit is per kernel AND per device: raise it at every plan creation (a process may drive several
+    // GPUs; a cached "already set" flag would leave the second device at 64 KB) to the most any plan can ask for
     by_nc(D.H, [&](auto nc) {
         constexpr int NC = decltype(nc)::value;
-        if (P->smem_dw > 65536 && P->smem_dw > dw_lds_limit[NC]) {
-            if (hipFuncSetAttribute((const void*)k_dw<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, P->smem_dw) != hipSuccess) rc_attr = 1;
-            else dw_lds_limit[NC] = P->smem_dw;
-        }
+        constexpr int DW_LDS_MAX = (int)(sizeof(float) * (((DW_WAVES * DW_RPW * 160 + 3) & ~3) + STAGE_FLOATS + 64 * 4));
+        if (hipFuncSetAttribute((const void*)k_dw<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_MAX) != hipSuccess) rc_attr = 1;
     });
     CREG_REQUIRE(rc_attr == 0, "creg_train_plan_create: cannot raise the dynamic LDS limit of k_dw");
     // the limit is per kernel, not per plan: always raise it to the largest any plan can ask for (16384 keys + boxes),
@@ -1232,54 +1299,8 @@ extern "C" int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train
         if (epg > D.epochs) epg = D.epochs;
         epg &= ~1;
         if (!P->graph_ready) {
-            // captured on a private stream (torch's current stream is usually the null stream, which
-            // cannot be captured); the instantiated graph is then launched on the caller's stream.
-            hipGraph_t g;
-            hipStream_t cs;
-            CREG_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-            CREG_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-            const int G = P->branches;
-            if (G > 1) {
-                // G independent branches over contiguous groups of problems (fork / join through events, so the
-                // instantiated graph has parallel chains): the runtime feeds them to different hardware queues
-                // and the latency-bound kernels of one group overlap the NN launch of the other.  Problems
-                // never interact, so results do not depend on G (stress-tested: tests/test_gpu_parity.py).
-                // Measured at B = 5: G = 2 +8 %, 3 +5 %, 5 -27 %.
-                hipStream_t cs2[16]; hipEvent_t ef, ej[16];
-                CREG_HIP(hipEventCreateWithFlags(&ef, hipEventDisableTiming));
-                CREG_HIP(hipEventRecord(ef, cs));
-                const Ws Wall = P->W;
-                int first = 0;
-                for (int gi = 0; gi < G; ++gi) {
-                    const int cnt = P->B / G + (gi < P->B % G ? 1 : 0);
-                    hipStream_t st = cs;
-                    if (gi > 0) {
-                        CREG_HIP(hipStreamCreateWithFlags(&cs2[gi], hipStreamNonBlocking));
-                        CREG_HIP(hipStreamWaitEvent(cs2[gi], ef, 0));
-                        st = cs2[gi];
-                    }
-                    P->W = ws_shift(Wall, (size_t)first * P->bstride); P->nz = cnt;
-                    for (int i = 0; i < epg; ++i) enqueue_epoch(P, i, st);
-                    if (gi > 0) {
-                        CREG_HIP(hipEventCreateWithFlags(&ej[gi], hipEventDisableTiming));
-                        CREG_HIP(hipEventRecord(ej[gi], st));
-                    }
-                    first += cnt;
-                }
-                P->W = Wall; P->nz = P->B;
-                for (int gi = 1; gi < G; ++gi) CREG_HIP(hipStreamWaitEvent(cs, ej[gi], 0));
-                CREG_HIP(hipStreamEndCapture(cs, &g));
-                for (int gi = 1; gi < G; ++gi) { CREG_HIP(hipStreamDestroy(cs2[gi])); CREG_HIP(hipEventDestroy(ej[gi])); }
-                CREG_HIP(hipEventDestroy(ef));
-            } else {
-                for (int i = 0; i < epg; ++i) enqueue_epoch(P, i, cs);
-                CREG_HIP(hipStreamEndCapture(cs, &g));
-            }
-            CREG_HIP(hipGraphInstantiate(&P->gexec, g, nullptr, nullptr, 0));
-            CREG_HIP(hipGraphDestroy(g));
-            CREG_HIP(hipStreamDestroy(cs));
-            P->graph_ready = true;
-            P->graph_epochs = epg;
+            const int rc = capture_epochs(P, epg);
+            if (rc) return rc;
         }
         for (; e + P->graph_epochs <= D.epochs; e += P->graph_epochs) CREG_HIP(hipGraphLaunch(P->gexec, s));
     }
