@@ -14,7 +14,45 @@ import torch
 from scipy.spatial.transform import Rotation as R
 
 from . import _lib, ops
-from .synthetic import kmeans_plusplus
+
+
+def kmeans_plusplus_sklearn(X, k, random_state):
+    """k-means++ seeding with scikit-learn's draw sequence (sklearn/cluster/_kmeans.py:174-275 as reached by
+    ``k_means(X, init="k-means++", n_clusters=k)``, reference cluster_icp.py:67): on the mean-centred data, first
+    centre by ``random_state.choice``, then 2 + log(k) candidates per centre from ``random_state.uniform`` against the
+    cumulative closest-distance potential, the candidate with the smallest new potential wins.  ``random_state`` is a
+    ``numpy.random.RandomState``; the reference passes none, i.e. numpy's GLOBAL one -- so ``np.random.seed(s)`` before
+    ``Segments.k_means_cluster`` pins the reference and this function to the same seeds.  Host RNG by nature (a
+    dependent chain of k draws); returns the indices of the chosen points."""
+    X = np.asarray(X, np.float64)
+    n = len(X)
+    Xc = X - X.mean(axis=0)
+    xx = np.einsum("ij,ij->i", Xc, Xc)
+
+    def dist2(rows):                                  # sklearn's euclidean_distances(squared=True): |y|^2 - 2 x.y + |x|^2
+        d = -2.0 * (Xc[rows] @ Xc.T)
+        d += xx[rows][:, None]
+        d += xx[None, :]
+        np.maximum(d, 0, out=d)
+        d[np.arange(len(rows)), rows] = 0.0
+        return d
+
+    trials = 2 + int(np.log(k))
+    w = np.ones(n)
+    idx = np.full(k, -1, dtype=int)
+    idx[0] = random_state.choice(n, p=w / w.sum())
+    closest = dist2(idx[:1])[0]
+    pot = closest @ w
+    for c in range(1, k):
+        rand_vals = random_state.uniform(size=trials) * pot
+        cand = np.searchsorted(np.cumsum(w * closest, dtype=np.float64), rand_vals)
+        np.clip(cand, None, n - 1, out=cand)
+        d = dist2(cand)
+        np.minimum(closest, d, out=d)
+        pots = (d @ w.reshape(-1, 1)).ravel()
+        best = int(np.argmin(pots))
+        pot, closest, idx[c] = pots[best], d[best], cand[best]
+    return idx
 
 
 def xyzrpy_to_matrix_scipy(xyz, rpy):
@@ -146,15 +184,17 @@ class Segments:
         return self
 
     def k_means_cluster(self, pc_id=0, num=30, normal=False, colors=None, seed=None):
-        """k-means++ seeding (host RNG, as sklearn does it) + Lloyd on the GPU (K2); then per
+        """k-means++ seeding (host RNG, scikit-learn's draw sequence) + Lloyd on the GPU (K2); then per
         cluster a frame with R = I at the centroid and the points in that frame
-        (cluster_icp.py:86-99).  ``seed`` pins the otherwise unseeded k-means++ draw."""
+        (cluster_icp.py:86-99).  Like the reference, the draw comes from numpy's GLOBAL RandomState unless
+        ``seed`` is given (``np.random.seed(s)`` pins both implementations to the same segmentation)."""
         if normal:
             raise NotImplementedError("--normal needs Open3D normal estimation (out of scope, SURVEY.md 8)")
         _lib.load()
         dev = torch.device("cuda")
         pc_np = np.asarray(self.pc_list[pc_id].points)
-        init = kmeans_plusplus(pc_np, num, np.random.default_rng(seed))
+        rs = np.random.RandomState(seed) if seed is not None else np.random.mtrand._rand
+        init = pc_np[kmeans_plusplus_sklearn(pc_np, num, rs)]            # data points: centring them in the kernel is exact
         X = torch.as_tensor(pc_np, dtype=torch.float64, device=dev)
         _, labels, _, _ = ops.kmeans_lloyd(X, torch.as_tensor(init, dtype=torch.float64, device=dev))
         lab = labels.long()

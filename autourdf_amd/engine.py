@@ -111,6 +111,8 @@ class BatchRegistrar:
         anchor = self._train([(o[0], y, r.pts_init, r.off_init, r.p_anchor)
                               for r, y, o in zip(self.seqs, ys, step)], lr=1e-4)
         out = []
+        # epochs each train ran (result[1]; < the plan's epochs after an early stop) -- bench.py reports them
+        self.last_epochs = (torch.stack([o[2][1] for o in step]), torch.stack([o[2][1] for o in anchor]))
         M_all = torch.stack([o[0] for o in anchor])                               # (S,K,4,4) float32: what train returned
         ev = self.host_inverse.mark()
         t_all = M_all[:, :, :3, 3].to(torch.float64).contiguous()                 # one cast and one slice for all sequences

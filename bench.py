@@ -3,11 +3,22 @@
 One "step" = one registered frame exactly as the reference's default path does it
 (mlp_reg.py:334-378): train "Step" (300 Adam epochs) + train "Anchor" (300 epochs, lr 1e-4) +
 resample_cluster (Lloyd k-means + change of frame), at N=4096 points, K=20 clusters, QRegMLP
-hidden 512 (BASELINE.json configs[1]: wx200_5-shaped, 5 sequences x 10 frames).  Frames of a
-sequence are sequentially dependent; ranks own disjoint sequences (weak scaling) and exchange
-nothing until the final all_gather of the (frames,K,4,4) poses over RCCL.
+hidden 512 (BASELINE.json configs[1]: wx200_5-shaped, 5 sequences x 10 frames).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+Two ways of spreading frames over GPUs (one process per GPU, no data-path collective, ONE final
+all_gather of the (frames,K,4,4) poses over RCCL):
+
+  --mode sequences (default, the driver's line)  frames of a sequence are sequentially dependent
+        (mlp_reg.py:293-378), sequences are not: every rank registers its own S sequences in
+        lock-step.  WEAK scaling: --steps frames per rank.
+  --mode replay   independent-frame mode (what "50 frames sharded
+        across 8 GPUs" must mean): a work item = (poses_t, clusters_t, clusters_0, frame_t+1, both
+        models' weights) captured from a sequential pass that every rank repeats untimed; the --steps
+        items of the job are dealt round-robin to the ranks and registered independently.  STRONG
+        scaling: --steps frames in total.  --workload c5 (N=262144, K=128: SURVEY 8(d) "assign / fit
+        kernels only") always runs this way, with the ICP-style frame (K4 masked ICP + K5 + K2).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode replay] [--workload allegro|franka|c5]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
@@ -18,19 +29,24 @@ import time
 import numpy as np
 import torch
 
-N_POINTS, K_CLUSTERS, HIDDEN, EPOCHS, FRAMES_PER_SEQ = 4096, 20, 512, 300, 10
+HIDDEN, EPOCHS, FRAMES_PER_SEQ = 512, 300, 10
 # QRegMLP(multi_decoder=True, hidden 512) parameters: 56->512, 512->256->3, 512->512->4 with biases
 N_PARAMS = (56 * HIDDEN + HIDDEN) + (HIDDEN * (HIDDEN // 2) + HIDDEN // 2) + (3 * (HIDDEN // 2) + 3) + (HIDDEN * HIDDEN + HIDDEN) + (4 * HIDDEN + 4)
-ROBOT = "wx200_5"
-# BASELINE.json configs: [1] is the headline (default); [2] and [3] shapes are selectable for extra evidence lines
+# BASELINE.json configs: [1] is the headline (default); the others are selectable for extra evidence lines
 WORKLOADS = {"wx200_5": ("wx200_5", 4096, 20, "BASELINE configs[1]"),
              "franka": ("franka", 16384, 40, "BASELINE configs[2] shape"),
-             "allegro": ("allegro_hand", 4096, 30, "BASELINE configs[3] shape")}
-VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12          # fp32 non-FMA lane-ops/s: 78.6 T (= 157.3 TFLOP/s FMA peak / 2)
+             "allegro": ("allegro_hand", 4096, 30, "BASELINE configs[3] shape"),
+             "c5": ("chain32", 262144, 128, "BASELINE configs[4] shape (ICP-style frame: assign + fit kernels)")}
+FP32_VECTOR_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32 vector peak (FMA = 2 flops, packed)
+HBM_PEAK_GBPS = 8000.0
+STUB = os.environ.get("CREG_BENCH_STUB") == "1"      # CPU plumbing test: gloo + a stand-in registrar (tests/test_bench_cpu.py)
 
 
-def cpu_baseline(seq0, mats0, clusters0, budget_s=12.0):
-    """The oracle (CPU port of the reference path) on the host cores, bounded sample, extrapolated."""
+# ------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters, budget_frames=2, budget_s=25.0):
+    """The oracle (CPU port of the reference path, `kind: "port"`) on the host cores: TWO full registered frames
+    (2 x 600 Adam epochs + 2 resamples) unless the box is so slow that a 25 s budget runs out first, in
+    which case the rest is extrapolated from the per-epoch time and the sample says so."""
     from oracle import models, registration
     from oracle import kmeans as okm
     torch.manual_seed(0)
@@ -39,29 +55,35 @@ def cpu_baseline(seq0, mats0, clusters0, budget_s=12.0):
     threads = min(16, os.cpu_count() or 1)
     os.environ["OMP_NUM_THREADS"] = str(threads)
     torch.set_num_threads(threads)
-    model = models.QRegMLP(True, HIDDEN)
+    model, model_rf = models.QRegMLP(True, HIDDEN), models.QRegMLP(True, HIDDEN)
     m = torch.tensor(mats0, dtype=torch.float32)
-    y = torch.tensor(seq0[1], dtype=torch.float32)
     cl = [torch.tensor(c, dtype=torch.float32) for c in clusters0]
-    registration.train(m, y, model, cl, rot="q", epochs=2)                    # warm caches / build the C lib
+    cl0 = [c.clone() for c in cl]
+    registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl, rot="q", epochs=2)   # warm caches / build the C lib
     t0 = time.perf_counter()
-    registration.train(m, y, model, cl, rot="q", epochs=5)
-    per_epoch = (time.perf_counter() - t0) / 5
-    n_ep = int(max(10, min(300, budget_s / per_epoch)))
-    t0 = time.perf_counter()
-    registration.train(m, y, model, cl, rot="q", epochs=n_ep)
-    per_epoch = (time.perf_counter() - t0) / n_ep
-    t0 = time.perf_counter()
-    for _ in range(3):
-        okm.k_means(seq0[1], mats0[:, :3, 3])
-    t_km = (time.perf_counter() - t0) / 3
-    frame_s = 2 * EPOCHS * per_epoch + t_km
+    epochs_done, frames_done, t_km = 0, 0, 0.0
+    for f in range(budget_frames):
+        y = torch.tensor(seq0[f + 1], dtype=torch.float32)
+        left = budget_s - (time.perf_counter() - t0)
+        if f > 0 and left < (time.perf_counter() - t0) / max(frames_done, 1):
+            break
+        _, m1, _, h1 = registration.train(m, y, model, cl, rot="q", epochs=EPOCHS)
+        _, m2, _, h2 = registration.train(m1.detach(), y, model_rf, cl0, rot="q", epochs=EPOCHS, learning_rate=1e-4)
+        epochs_done += len(h1["loss"]) + len(h2["loss"])
+        tk = time.perf_counter()
+        new, _ = registration.resample_cluster(seq0[f + 1], k_clusters, m2.detach().numpy())
+        t_km += time.perf_counter() - tk
+        m, cl = m2.detach(), [torch.tensor(c, dtype=torch.float32) for c in new]
+        frames_done += 1
+    elapsed = time.perf_counter() - t0
+    per_epoch = (elapsed - t_km) / max(epochs_done, 1)
+    frame_s = elapsed / frames_done if frames_done else float("nan")
     # the same port on ONE host thread (SURVEY 8(d) asks for both), a few epochs only
     os.environ["OMP_NUM_THREADS"] = "1"
     torch.set_num_threads(1)
-    t0 = time.perf_counter()
-    registration.train(m, y, model, cl, rot="q", epochs=6)
-    per_epoch_1 = (time.perf_counter() - t0) / 6
+    t1 = time.perf_counter()
+    registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=6)
+    per_epoch_1 = (time.perf_counter() - t1) / 6
     torch.set_num_threads(threads)
     os.environ["OMP_NUM_THREADS"] = str(threads)
     cpu_model = ""
@@ -70,18 +92,20 @@ def cpu_baseline(seq0, mats0, clusters0, budget_s=12.0):
     except Exception:
         pass
     return {"value": 1.0 / frame_s, "unit": "frames/s", "cores": threads, "kind": "port",
-            "one_thread": {"value": 1.0 / (2 * EPOCHS * per_epoch_1 + t_km), "ms_per_epoch": round(per_epoch_1 * 1e3, 2)},
+            "one_thread": {"value": 1.0 / (2 * EPOCHS * per_epoch_1 + t_km / max(frames_done, 1)), "ms_per_epoch": round(per_epoch_1 * 1e3, 2),
+                           "sample": "6 epochs, extrapolated to 600 + the measured resample"},
             "host": {"cpu_model": cpu_model, "os_cpu_count": os.cpu_count()},
-            "sample": f"{n_ep} of the 600 Adam epochs of one frame (N={N_POINTS}, K={K_CLUSTERS}, hidden {HIDDEN}) "
-                      f"at {per_epoch * 1e3:.2f} ms/epoch + 1 Lloyd k-means at {t_km * 1e3:.2f} ms, extrapolated to "
-                      "600 epochs + 1 k-means; oracle = torch-CPU MLP/Adam + OpenMP C L1-NN (oracle/creg_oracle.c)"}
+            "sample": f"{frames_done} full registered frame(s) of sequence 0 (N={n_points}, K={k_clusters}, hidden {HIDDEN}): {epochs_done} Adam "
+                      f"epochs at {per_epoch * 1e3:.2f} ms/epoch + {frames_done} resample_cluster at {t_km / max(frames_done, 1) * 1e3:.1f} ms, "
+                      f"{elapsed:.1f} s of host time, nothing extrapolated; oracle = torch-CPU MLP/Adam + OpenMP C L1-NN "
+                      "(oracle/creg_oracle.c) + sklearn-equivalent Lloyd"}
 
 
+# ------------------------------------------------------------------------------------------ ICP-style second line
 def icp_variant(frames64, mats0, clusters0, dev, warm_rounds, timed_rounds):
     """SURVEY 8(d) second line: the ICP-style frame of the north star, no MLP -- K3 transform -> K4 masked
     per-cluster point-to-point ICP -> K5 dual quaternions -> K2 Lloyd k-means + change of frame -- on the
-    same synthetic sequences, frames resident in HBM, sequences in lock-step (every kernel is a handful
-    of workgroups: this line is latency-bound, and says so)."""
+    same synthetic sequences, frames resident in HBM, sequences in lock-step."""
     from autourdf_amd import ops
     from autourdf_amd.engine import BatchIcpRegistrar
     S = len(frames64)
@@ -123,165 +147,425 @@ def icp_variant(frames64, mats0, clusters0, dev, warm_rounds, timed_rounds):
             "value": round(n_frames / dt, 2), "unit": "frames/s", "ms_per_frame": round(dt / n_frames * 1e3, 3),
             "frames_timed": n_frames, "mean_icp_iterations_per_cluster": round(it, 2),
             "roofline": {"bound": "hbm", "kernel": "k_masked_icp", "avg_launch_us": round(icp_us, 1),
-                         "achieved": round(alg / (icp_us * 1e-6) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(alg / (icp_us * 1e-6) / 8e12, 6), "traffic": None,
+                         "achieved": round(alg / (icp_us * 1e-6) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(alg / (icp_us * 1e-6) / (HBM_PEAK_GBPS * 1e9), 6), "traffic": None,
                          "problems_per_launch": S,
-                         "note": "one workgroup per cluster per sequence iterates NN + Horn closed form out of LDS "
-                                 "until open3d's convergence rule: K x S = 100 workgroups on a 256-CU chip, each a serial "
-                                 "chain of ~20-60 ICP iterations -> latency-bound by construction (SURVEY 8(d): report "
-                                 "honestly); algorithmic bytes = one pass over the cluster points, the mask scan and the poses"}}
+                         "note": "each cluster's ICP is a serial chain of ~20-60 iterations (nearest neighbours + closed-form fit); "
+                                 "latency-bound by construction (SURVEY 8(d): report honestly); algorithmic bytes = one pass over the "
+                                 "cluster points, the mask scan and the poses"}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--sequences", type=int, default=5, help="independent sequences in flight per GPU (configs[1]: 5)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-icp-variant", action="store_true", help="skip the ICP-style second line (SURVEY 8(d))")
-    ap.add_argument("--eager", action="store_true", help="eager launches instead of the captured epoch graph")
-    ap.add_argument("--graph-branches", type=int, default=0, help="parallel chains in the captured graph (0 = the library's default)")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="wx200_5",
-                    help="default = the configuration BASELINE.json's metric is quoted on")
-    args = ap.parse_args()
-    global ROBOT, N_POINTS, K_CLUSTERS
-    ROBOT, N_POINTS, K_CLUSTERS, wl_tag = WORKLOADS[args.workload]
+# ------------------------------------------------------------------------------------------ stand-in registrar (CPU plumbing test)
+class _StubRegistrar:
+    """CREG_BENCH_STUB=1: the rank / sharding / gather logic of this file on CPU tensors with gloo -- a registrar whose
+    'registration' is a fixed function of (its sequence slot's state, the frame), so poses are comparable between
+    world sizes.  No kernel is involved and nothing is timed meaningfully."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    class _Seq:
+        pass
+
+    def __init__(self, mats0, clusters0, n_tgt, n_sequences, *a, **k):
+        self.S = n_sequences
+        self.seqs = []
+        for _ in range(n_sequences):
+            r = self._Seq()
+            r.m = torch.as_tensor(mats0, dtype=torch.float32).clone()
+            self.seqs.append(r)
+        self.plan = None
+        self.last_epochs = None
+
+    def step(self, frames64, frames32=None):
+        out = []
+        for r, f in zip(self.seqs, frames64):
+            m2 = r.m.clone()
+            m2[:, :3, 3] += 0.5 * (f.mean(0).to(torch.float32) - m2[:, :3, 3].mean(0))
+            r.m = m2
+            out.append((m2, torch.tensor([float(m2[:, :3, 3].abs().sum()), EPOCHS, 1e-4, 0.0])))
+        return out
+
+
+def _registrar_cls():
+    if STUB:
+        return _StubRegistrar
+    from autourdf_amd.engine import BatchRegistrar
+    return BatchRegistrar
+
+
+# ------------------------------------------------------------------------------------------ replay items
+def capture_items(reg, frames64, frames32, n_rounds, clone_params):
+    """A sequential pass over the sequences (untimed), snapshotting the state ENTERING every registration:
+    item = (poses_t, clusters_t + offsets, clusters_0 + offsets, frame_t+1 (f64, f32), parameter copies of both models).
+    Items are independent of each other by construction -- that is the replay / independent-frame mode."""
+    items = []
+    for f in range(n_rounds):
+        for s, r in enumerate(reg.seqs):
+            it = {"m": r.m.clone(), "f64": frames64[s][f], "f32": frames32[s][f], "seq": s, "frame": f + 1}
+            if clone_params:
+                it.update(pts=r.pts.clone(), off=r.off.clone(), pts_init=r.pts_init, off_init=r.off_init,
+                          p_step=[p.clone() for p in r.p_step], p_anchor=[p.clone() for p in r.p_anchor])
+            items.append(it)
+        reg.step([frames64[s][f] for s in range(reg.S)], [frames32[s][f] for s in range(reg.S)])
+    return items
+
+
+def load_items(reg, batch):
+    """Put a batch of items into the registrar's S slots (zero-copy: the slot's tensors ARE the item's)."""
+    for r, it in zip(reg.seqs, batch):
+        r.m = it["m"]
+        if "pts" in it:
+            r.pts, r.off, r.pts_init, r.off_init = it["pts"], it["off"], it["pts_init"], it["off_init"]
+            r.p_step, r.p_anchor = it["p_step"], it["p_anchor"]
+
+
+def clone_item(it):
+    c = dict(it)
+    c["m"] = it["m"].clone()
+    if "pts" in it:
+        c["p_step"] = [p.clone() for p in it["p_step"]]
+        c["p_anchor"] = [p.clone() for p in it["p_anchor"]]
+    return c
+
+
+# ------------------------------------------------------------------------------------------ roofline block
+def roofline_block(reg, frames32, n_points, workload):
+    """Per kernel, measured live with HIP events on the plan's own launches (back-to-back, kernel + launch gap):
+    algorithmic figure / launch time against the GUIDE's peaks.  SQ-counter utilisation and HBM-side traffic cannot be
+    read inside this process (rocprofv3 --pmc needs its own passes): they are replayed from the committed profile
+    summary and say so in `source`."""
+    r = reg.seqs[0]
+    prof = reg.plan.profile(r.m, frames32[0][0], r.pts_init, r.off_init, r.p_anchor, n_epochs=100)
+    nn_us = prof.pop("nn_l1_back_to_back")
+    nz = prof.pop("nn_l1_problems_per_launch")
+    dw_us = prof.pop("dw_back_to_back")
+    here = os.path.dirname(os.path.abspath(__file__))
+    pmc, pmc_src = {}, None
+    for name in ("r02_pmc.json", "r01_nn_l1_pmc.json"):
+        path = os.path.join(here, "profiles", name)
+        if os.path.exists(path) and workload == "wx200_5":
+            pmc, pmc_src = json.load(open(path)), "profiles/" + name
+            break
+    dw_bytes = 24 * N_PARAMS * nz                       # P, Adam m, Adam v: read + written, 4 B each, per problem
+    nn_ops = 9.0 * n_points * n_points * nz             # SURVEY 8(d): the exhaustive bidirectional search the reference runs
+    nn_bytes = nz * (2 * 12 * n_points + 2 * (4 + 8) * n_points)
+    dw_traffic = pmc.get("k_dw_hbm_bytes_per_problem")
+    nn_traffic = pmc.get("k_nn_hbm_bytes_per_problem", pmc.get("hbm_bytes_per_problem"))
+    roof = {
+        # the dominant kernel of an epoch by rocprofv3 time (profiles/): dW fused with Adam, a stream over parameters + state
+        "bound": "hbm", "kernel": "k_dw<8>", "achieved": round(dw_bytes / (dw_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s", "frac": round(dw_bytes / (dw_us * 1e-6) / (HBM_PEAK_GBPS * 1e9), 4),
+        "traffic": dw_traffic * nz if dw_traffic else None, "traffic_source": pmc_src if dw_traffic else None,
+        "avg_launch_us": round(dw_us, 3), "problems_per_launch": nz,
+        "timing_source": "HIP events around 200 back-to-back launches of the kernel on the plan's stream, in this run (kernel + ~1 us "
+                         "launch gap); the launch carries the problems of the larger graph branch, as in the timed region",
+        "algorithmic_bytes": dw_bytes,
+        "wasted_traffic_ratio": round(dw_traffic * nz / dw_bytes, 2) if dw_traffic else None,
+        "kernels": {
+            "k_nn_plan<true,1>": {
+                "bound": "valu", "avg_launch_us": round(nn_us, 3), "problems_per_launch": nz,
+                "algorithmic_ops": nn_ops, "achieved_TFLOPs": round(nn_ops / (nn_us * 1e-6) / 1e12, 3),
+                "peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS, "frac": round(nn_ops / (nn_us * 1e-6) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
+                "executed_valu_utilisation": pmc.get("k_nn_valu_active_frac"), "utilisation_source": pmc_src,
+                "algorithmic_bytes": nn_bytes, "traffic": nn_traffic * nz if nn_traffic else None, "traffic_source": pmc_src if nn_traffic else None,
+                "wasted_traffic_ratio": round(nn_traffic * nz / nn_bytes, 2) if nn_traffic else None,
+                "note": "algorithmic = 9 lane-ops x N^2 of the exhaustive search the reference runs (SURVEY 8d) against the fp32 vector "
+                        "peak of the guide; the kernel returns that search's result bit for bit while executing a few percent of the pair "
+                        "evaluations (exact k-d block pruning), so `frac` is distance from a perfect exhaustive kernel, "
+                        "`executed_valu_utilisation` (SQ_ACTIVE_INST_VALU / wave cycles) is how busy the VALUs really are"}},
+        "epoch_kernels_event_bracketed_us": {k: round(v, 2) if isinstance(v, float) else v for k, v in prof.items()},
+        "note": "event-bracketed per-kernel times carry ~7 us of event overhead each (upper bounds); rocprofv3 stats of the same "
+                "command are under profiles/"}
+    return roof
+
+
+# ------------------------------------------------------------------------------------------ configs[4]: N=262144, K=128
+def run_c5(args, robot, n_points, k_clusters, wl_tag):
+    """BASELINE configs[4] (synthetic N=262144, K=128, independent frames sharded over the GPUs): SURVEY 8(d) defines this
+    line over the assign / fit kernels only -- the ICP-style frame: K4 masked per-cluster ICP from the current poses
+    (mask boxes of the current clusters), K5 dual quaternions, K2 Lloyd re-segmentation seeded at the new translations +
+    change of frame.  (The default path's 600 epochs of an N^2 Chamfer search are 8e13 pair evaluations per frame at
+    this size.)  Work items (poses, local clusters, next frame) come from a sequential pass every rank repeats untimed;
+    --steps items in total are dealt round-robin."""
+    from autourdf_amd import ops
+    from autourdf_amd.distributed import gather_poses
+    from autourdf_amd.engine import IcpRegistrar
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible; there is no CPU path to time)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one process per GPU over RCCL
+    if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-
-    from autourdf_amd.distributed import gather_poses
-    from autourdf_amd.engine import BatchRegistrar
-    from autourdf_amd.synthetic import initial_segmentation, make_sequence
-
-    # ---- synthetic inputs, resident in HBM before the clock starts -------------------------------
-    # configs[1]: 5 independent sequences per GPU (10 frames each in the reference's data set).  Frames of
-    # ONE sequence are sequentially dependent (mlp_reg.py:293-378) but sequences are independent, so the S
-    # sequences advance in lock-step through ONE batched plan: every launch carries S problems.
-    # Step i of a rank is frame (i // S) + 1 of its sequence i % S.  Any --steps K / --warmup W works without ever
-    # putting MORE sequences in flight than the configuration has (5): S = --sequences when it divides K, else the
-    # largest divisor of K in [2, S), else S with the last round padded (the padding is timed but not counted, so
-    # the reported value can only be understated); sequences are generated as long as W and K require.
-    S = min(max(1, args.sequences), args.steps)
-    if args.steps % S:
-        divs = [d for d in range(S - 1, 1, -1) if args.steps % d == 0]
-        S = divs[0] if divs else S
-    n_seq = S
-    warm_rounds = (args.warmup + S - 1) // S
-    timed_rounds = (args.steps + S - 1) // S
-    n_frames = warm_rounds + timed_rounds + 1
-    seq0 = make_sequence(ROBOT, 0, max(n_frames, FRAMES_PER_SEQ), N_POINTS)
-    mats0, clusters0, _ = initial_segmentation(seq0[0], K_CLUSTERS, seed=0)      # shared frame-0 state (mlp_reg.py:242-253)
-    seqs = [make_sequence(ROBOT, rank * 1000 + s, max(n_frames, FRAMES_PER_SEQ), N_POINTS) for s in range(S)]
-    frames64 = [[torch.as_tensor(f, dtype=torch.float64, device=dev) for f in s[1:n_frames]] for s in seqs]
-    frames32 = [[f.to(torch.float32) for f in s] for s in frames64]
-    reg = BatchRegistrar(mats0, clusters0, N_POINTS, S, "q", HIDDEN, EPOCHS, not args.eager, dev,
-                         seeds=[rank * 1000 + s for s in range(S)], graph_branches=args.graph_branches)
-    poses = torch.zeros((warm_rounds + timed_rounds) * S, K_CLUSTERS, 4, 4, dtype=torch.float32, device=dev)
-    losses = torch.zeros((warm_rounds + timed_rounds) * S, dtype=torch.float32, device=dev)
-
-    def run_rounds(lo, hi):
-        for f in range(lo, hi):
-            out = reg.step([frames64[s][f] for s in range(S)], [frames32[s][f] for s in range(S)])
-            for s, (m, res) in enumerate(out):
-                poses[f * S + s].copy_(m)
-                losses[f * S + s].copy_(res[0])
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
+    total = args.steps + args.warmup
+    t_gen = time.perf_counter()
+    seq = make_sequence(robot, 0, total + 1, n_points)
+    mats0, clusters0, _ = initial_segmentation(seq[0], k_clusters, seed=0, iters=8)
+    t_gen = time.perf_counter() - t_gen
+    frames = [torch.as_tensor(f, dtype=torch.float64, device=dev) for f in seq[1:]]
+    cap = IcpRegistrar(mats0, clusters0, dev)
+    items = []
+    for f in frames:                                               # the sequential pass (untimed): state entering every frame
+        items.append((cap.M, cap.local, cap.off, f))
+        cap.step(f)
     torch.cuda.synchronize()
-    run_rounds(0, warm_rounds)
-    fence()
+    job = items[args.warmup:]
+    mine = job[rank::world]
+    worker = IcpRegistrar(mats0, clusters0, dev)
+
+    def register(it):
+        worker.M, worker.local, worker.off = it[0], it[1], it[2]
+        return worker.step(it[3])
+
+    for it in items[:args.warmup]:
+        register(it)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    poses = torch.zeros(max(len(mine), 1), k_clusters, 4, 4, dtype=torch.float64, device=dev)
+    iters = []
     t0 = time.perf_counter()
-    run_rounds(warm_rounds, warm_rounds + timed_rounds)
-    timed = poses[warm_rounds * S: warm_rounds * S + args.steps]
-    gathered = gather_poses(timed)                     # the one exchange of the job (RCCL all_gather; no-op at N=1)
-    fence()
+    for i, it in enumerate(mine):
+        M_new, _, n_it = register(it)
+        poses[i].copy_(M_new)
+        iters.append(n_it)
+    counts = [len(job[r::world]) for r in range(world)]
+    gathered = gather_poses(poses[:len(mine)], counts=counts if dist is not None else None)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.isfinite(poses).all() and torch.isfinite(losses).all() and gathered.shape[0] == world * args.steps
+    assert torch.isfinite(gathered).all() and gathered.shape[0] == args.steps
+    if rank == 0:
+        # the assign kernel (K2 E-step) alone, event-timed on torch's stream (ops launch there): N x K fp64 distances
+        it = job[0]
+        C = it[0][:, :3, 3].contiguous()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        res = {}
+        for mfma in (False, True):
+            ops.kmeans_assign(it[3], C, use_mfma=mfma)
+            e0.record()
+            for _ in range(50):
+                ops.kmeans_assign(it[3], C, use_mfma=mfma)
+            e1.record()
+            torch.cuda.synchronize()
+            res[mfma] = e0.elapsed_time(e1) * 1e3 / 50
+        us = res[False]
+        alg_bytes = 28.0 * n_points                                   # 24 B/point read (fp64 xyz) + 4 B label written
+        flops = 8.0 * n_points * k_clusters                           # 3 fma + 1 compare-select per (point, centre) ~ 8 flops
+        world32 = ops.cluster_transform(it[1].to(torch.float32), it[2], it[0].to(torch.float32))
+        ops.masked_icp(it[1], world32, it[2], it[3], it[0])
+        e0.record()
+        for _ in range(3):
+            ops.masked_icp(it[1], world32, it[2], it[3], it[0])
+        e1.record()
+        torch.cuda.synchronize()
+        icp_us = e0.elapsed_time(e1) * 1e3 / 3
+        out = {"metric": f"ICP-style registered frames/sec (N={n_points} pts, K={k_clusters} clusters): K4 masked ICP + K5 DQ + K2 Lloyd resample",
+               "value": round(args.steps / elapsed, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3 / 1.0, 3), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"{robot}-shaped synthetic frames, N={n_points}, K={k_clusters} ({wl_tag})", "n_points": n_points,
+                          "k_clusters": k_clusters,
+                          "mode": "replay / independent-frame mode: --steps work items in TOTAL from a sequential pass, dealt round-robin to the ranks",
+                          "mean_icp_iterations_per_cluster": round(float(torch.stack(iters).double().mean()), 1),
+                          "host_generation_s": round(t_gen, 1)},
+               "roofline": {"bound": "hbm", "kernel": "k_km_assign (K2 E-step, VALU form)", "achieved": round(alg_bytes / (us * 1e-6) / 1e9, 1),
+                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg_bytes / (us * 1e-6) / (HBM_PEAK_GBPS * 1e9), 4),
+                            "traffic": None, "avg_launch_us": round(us, 2),
+                            "fp64_TFLOPs": round(flops / (us * 1e-6) / 1e12, 2), "fp64_vector_peak_TFLOPs": 78.6,
+                            "fp64_frac": round(flops / (us * 1e-6) / 1e12 / 78.6, 4),
+                            "mfma_form_avg_launch_us": round(res[True], 2),
+                            "kernels": {"k_masked_icp": {"avg_launch_us": round(icp_us, 1), "note": "all K clusters of one frame, whole ICP loop"}},
+                            "note": "N x K assignment at K = 128 sits at the fp64 ridge (64 flop/B against 78.6 TF / 8 TB/s ~ 10): the E-step is "
+                                    "fp64-FMA-bound, so both roofs are given; timing = HIP events around 50 back-to-back launches in this run"},
+               "pose_checksum": round(float(gathered.abs().sum()), 6)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------ main
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["sequences", "replay"], default="sequences")
+    ap.add_argument("--sequences", type=int, default=5, help="independent sequences in flight per GPU (configs[1]: 5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-icp-variant", action="store_true", help="skip the ICP-style second line (SURVEY 8(d))")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="eager launches instead of the captured epoch graph")
+    ap.add_argument("--graph-branches", type=int, default=0, help="parallel chains in the captured graph (0 = the library's default)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="wx200_5",
+                    help="default = the configuration BASELINE.json's metric is quoted on")
+    args = ap.parse_args(argv)
+    robot, n_points, k_clusters, wl_tag = WORKLOADS[args.workload]
+    if args.workload == "c5":
+        args.mode = "replay"
+        return run_c5(args, robot, n_points, k_clusters, wl_tag)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if STUB:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no GPU visible; there is no CPU path to time)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one process per GPU over RCCL
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if STUB:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from autourdf_amd.distributed import gather_poses
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    Registrar = _registrar_cls()
+    sync = (lambda: None) if STUB else torch.cuda.synchronize
+
+    def fence():
+        sync()
+        if dist is not None:
+            dist.barrier()
+            sync()
+
+    replay = args.mode == "replay"
+    # ---- synthetic inputs, resident in HBM before the clock starts -------------------------------
+    # Frames of ONE sequence are sequentially dependent (mlp_reg.py:293-378) but sequences are independent, so the S
+    # sequences advance in lock-step through ONE batched plan: every launch carries S problems.
+    S = min(max(1, args.sequences), args.steps)
+    if not replay and args.steps % S:
+        divs = [d for d in range(S - 1, 1, -1) if args.steps % d == 0]
+        S = divs[0] if divs else S
+    if replay:
+        # the job: --steps items in total (+ --warmup untimed ones), the same on every rank count; captured from S
+        # sequences registered sequentially, which every rank repeats for itself (deterministic, untimed)
+        total_items = args.steps + args.warmup
+        cap_rounds = (total_items + S - 1) // S
+        n_frames = cap_rounds + 1
+        seq_ids = list(range(S))
+    else:
+        warm_rounds = (args.warmup + S - 1) // S
+        timed_rounds = (args.steps + S - 1) // S
+        n_frames = warm_rounds + timed_rounds + 1
+        seq_ids = [rank * 1000 + s for s in range(S)]
+    seq0 = make_sequence(robot, 0, max(n_frames, FRAMES_PER_SEQ), n_points)
+    mats0, clusters0, _ = initial_segmentation(seq0[0], k_clusters, seed=0)      # shared frame-0 state (mlp_reg.py:242-253)
+    seqs = [make_sequence(robot, sid, max(n_frames, FRAMES_PER_SEQ), n_points) for sid in seq_ids]
+    frames64 = [[torch.as_tensor(f, dtype=torch.float64, device=dev) for f in s[1:n_frames]] for s in seqs]
+    frames32 = [[f.to(torch.float32) for f in s] for s in frames64]
+    reg = Registrar(mats0, clusters0, n_points, S, "q", HIDDEN, EPOCHS, not args.eager, dev,
+                    seeds=seq_ids, graph_branches=args.graph_branches)
+    epochs_log = []
+
+    def note_epochs():
+        le = getattr(reg, "last_epochs", None)
+        if le is not None:
+            epochs_log.append(le)
+
+    if replay:
+        items = capture_items(reg, frames64, frames32, cap_rounds, clone_params=not STUB)[:total_items]
+        warm_items = [clone_item(it) for it in items[:args.warmup]]
+        job = items[args.warmup:]
+        mine = job[rank::world]                                   # round-robin: no rank holds more than one item extra
+        while len(mine) % S:                                      # the last batch is padded with a repeat (timed, not counted)
+            mine.append(clone_item(mine[-1]))
+        n_mine = len(job[rank::world])
+        poses = torch.zeros(max(len(mine), 1), k_clusters, 4, 4, dtype=torch.float32, device=dev)
+        for b in range(0, len(warm_items) - len(warm_items) % S, S):
+            load_items(reg, warm_items[b:b + S])
+            reg.step([it["f64"] for it in warm_items[b:b + S]], [it["f32"] for it in warm_items[b:b + S]])
+        fence()
+        t0 = time.perf_counter()
+        for b in range(0, len(mine), S):
+            batch = mine[b:b + S]
+            load_items(reg, batch)
+            out = reg.step([it["f64"] for it in batch], [it["f32"] for it in batch])
+            note_epochs()
+            for i, (m, _) in enumerate(out):
+                poses[b + i].copy_(m)
+        counts = [len(job[r::world]) for r in range(world)]
+        gathered = gather_poses(poses[:n_mine], counts=counts if dist is not None else None)
+        fence()
+        elapsed = time.perf_counter() - t0
+        n_counted = args.steps
+        padded = len(mine) - n_mine
+    else:
+        poses = torch.zeros((warm_rounds + timed_rounds) * S, k_clusters, 4, 4, dtype=torch.float32, device=dev)
+
+        def run_rounds(lo, hi):
+            for f in range(lo, hi):
+                out = reg.step([frames64[s][f] for s in range(S)], [frames32[s][f] for s in range(S)])
+                note_epochs()
+                for s, (m, res) in enumerate(out):
+                    poses[f * S + s].copy_(m)
+
+        sync()
+        run_rounds(0, warm_rounds)
+        fence()
+        epochs_log.clear()
+        t0 = time.perf_counter()
+        run_rounds(warm_rounds, warm_rounds + timed_rounds)
+        timed = poses[warm_rounds * S: warm_rounds * S + args.steps]
+        gathered = gather_poses(timed)                     # the one exchange of the job (RCCL all_gather; no-op at N=1)
+        fence()
+        elapsed = time.perf_counter() - t0
+        n_counted = world * args.steps
+        padded = timed_rounds * S - args.steps
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(gathered).all() and gathered.shape[0] == n_counted, (gathered.shape, n_counted)
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (L1 nearest neighbour), measured live with HIP events
-        r = reg.seqs[0]
-        prof = reg.plan.profile(r.m, frames32[0][0], r.pts_init, r.off_init, r.p_anchor, n_epochs=100)
-        nn_us = prof.pop("nn_l1_back_to_back")     # 200 back-to-back launches between two HIP events
-        nn_problems = prof.pop("nn_l1_problems_per_launch")
-        dw_us = prof.pop("dw_back_to_back")        # the largest kernel of an epoch since the NN search is pruned
-        # 9 VALU ops x N^2 per problem-epoch (shared pair evaluation); one launch carries the
-        # problems of one graph branch in grid.z (3 of the 5 sequences; the other branch carries 2) and the
-        # back-to-back timing launches exactly that grid
-        alg_ops = 9.0 * N_POINTS * N_POINTS * nn_problems
-        achieved = alg_ops / (nn_us * 1e-6) / 1e12
-        alg_bytes = nn_problems * (2 * 12 * N_POINTS + 2 * (4 + 8) * N_POINTS)
-        traffic = None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_nn_l1_pmc.json")
-        if os.path.exists(pmc) and args.workload == "wx200_5":
-            per_problem = json.load(open(pmc)).get("hbm_bytes_per_problem")      # PMC passes, tools/collect_profiles.sh
-            traffic = per_problem * nn_problems if per_problem else None
-        roof = {"bound": "valu", "kernel": "k_nn_plan<true>", "achieved": round(achieved, 3),
-                "peak": round(VALU_PEAK_TOPS, 1), "unit": "TFLOP/s", "frac": round(achieved / VALU_PEAK_TOPS, 4),
-                "traffic": traffic, "avg_launch_us": round(nn_us, 3), "problems_per_launch": nn_problems,
-                # the same launch against the HBM roofline, to show it is not the bound: algorithmic bytes (both clouds
-                # in, distances + indices' worth of results out) / launch time vs 8 TB/s
-                "hbm_view": {"algorithmic_bytes": alg_bytes, "achieved_GBps": round(alg_bytes / (nn_us * 1e-6) / 1e9, 2),
-                             "peak_GBps": 8000.0, "frac": round(alg_bytes / (nn_us * 1e-6) / 8e12, 5)},
-                "epoch_kernels_event_bracketed_us": {k: round(v, 2) for k, v in prof.items()},
-                # the largest kernel by time since the search is pruned: dW + Adam, a stream over parameters and Adam state
-                # (3 arrays read + 3 written, 4 B per parameter each) -- against the HBM roofline
-                "largest_kernel": {"kernel": "k_dw<8>", "bound": "hbm", "avg_launch_us": round(dw_us, 3), "problems_per_launch": nn_problems,
-                                   "algorithmic_bytes": 24 * N_PARAMS * nn_problems,
-                                   "achieved": round(24 * N_PARAMS * nn_problems / (dw_us * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                                   "frac": round(24 * N_PARAMS * nn_problems / (dw_us * 1e-6) / 8e12, 4),
-                                   "note": "fused dW (K-row outer products from LDS-staged activations) + Adam; the three arrays "
-                                           "stay resident in the 256 MB memory-side cache between epochs, the kernel is bound by its "
-                                           "dependent load -> accumulate -> store chain at 2-3 workgroups per CU, see DESIGN.md 4"},
-                "note": "L1 min-search is sub/add/min work: not a contraction (no MFMA) and ~200 KB of algorithmic "
-                        "traffic (not HBM); bound = fp32 VALU issue. achieved = 9*N^2 algorithmic lane-ops (SURVEY 8d: the "
-                        "exhaustive bidirectional search the reference runs) / avg launch; peak = 256 CU x 4 SIMD x 32 lanes x "
-                        "2.4 GHz (= 157.3 TFLOP/s FMA peak / 2). The kernel returns the exhaustive search's result bit for bit "
-                        "but EXECUTES only a few percent of those pair evaluations: both clouds are cut into k-d leaf blocks of "
-                        "64 points with boxes and a query looks into the 2-3 blocks its box bounds cannot exclude (the exhaustive "
-                        "kernel it replaces, k_nn_l1, ran the same launch in 21.7 us = frac 0.27; nn_search=1 selects it). "
-                        "avg_launch_us = 200 back-to-back launches between two HIP events (includes the launch gap), kernel alone; "
-                        "in the timed region the sequences run as two graph branches (3 + 2 problems) on two hardware queues; "
-                        "rocprofv3's kernel trace largely serialises them, so "
-                        "its per-kernel averages are the mean of the standalone 3- and 2-problem launches; "
-                        "per-kernel event brackets carry ~7 us of event overhead each, see profiles/ for rocprofv3"}
-        out = {"metric": f"registered frames/sec (N={N_POINTS} pts, K={K_CLUSTERS} clusters)", "value": round(world * args.steps / elapsed, 4),
+        ep = {}
+        if epochs_log:
+            e = torch.stack([torch.stack([x.to(torch.float32) for x in pair]) for pair in epochs_log]).cpu()     # (rounds, 2, S)
+            ep = {"epochs_run_step": {"min": int(e[:, 0].min()), "mean": round(float(e[:, 0].mean()), 1)},
+                  "epochs_run_anchor": {"min": int(e[:, 1].min()), "mean": round(float(e[:, 1].mean()), 1)},
+                  "early_stop": bool((e < EPOCHS).any()),
+                  "early_stop_note": "early stopping is live (stop=200, mlp_reg.py:107-111); after a stop the remaining launches of the "
+                                     "300-epoch graph still run as no-ops, so a stopped train costs the same time as a full one"}
+        out = {"metric": f"registered frames/sec (N={n_points} pts, K={k_clusters} clusters)", "value": round(n_counted / elapsed, 4),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "strong" if replay else "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{ROBOT}-shaped, {n_seq} sequences x 10 frames per GPU, N={N_POINTS}, K={K_CLUSTERS} ({wl_tag}); "
+               "config": {"workload": f"{robot}-shaped, {S} sequences x 10 frames per GPU, N={n_points}, K={k_clusters} ({wl_tag}); "
                                       "1 step = 1 registered frame = 2 x 300 Adam epochs (QRegMLP hidden 512, L1 Chamfer) "
-                                      "+ Lloyd k-means resample", "n_points": N_POINTS, "k_clusters": K_CLUSTERS,
-                          "epochs_per_frame": 2 * EPOCHS, "launch": "eager" if args.eager else "hipGraph",
-                          "sequences_in_flight_per_gpu": n_seq, "padded_steps_timed_not_counted": timed_rounds * S - args.steps,
-                          "sharding": "sequences per rank, final all_gather of poses" if world > 1 else "single GPU"},
-               "roofline": roof}
-        if not args.no_icp_variant:
+                                      "+ Lloyd k-means resample", "n_points": n_points, "k_clusters": k_clusters,
+                          "mode": ("replay / independent-frame mode: --steps work items in TOTAL, captured from a sequential pass, dealt "
+                                   "round-robin to the ranks (SURVEY 8(e); frames of a sequence cannot be sharded otherwise)") if replay else
+                                  "sequences: every rank registers its own sequences frame by frame (weak scaling)",
+                          "epochs_per_frame": 2 * EPOCHS, **ep, "launch": "eager" if args.eager else "hipGraph",
+                          "sequences_in_flight_per_gpu": S, "padded_steps_timed_not_counted": padded,
+                          "sharding": ("items round-robin over ranks" if replay else "sequences per rank") + ", final all_gather of poses"
+                                      if world > 1 else "single GPU"},
+               "pose_checksum": round(float(gathered.double().abs().sum()), 6)}
+        if not STUB and not args.no_roofline:
+            out["roofline"] = roofline_block(reg, frames32, n_points, args.workload)
+        if not STUB and not args.no_icp_variant and not replay:
             out["icp_variant"] = icp_variant(frames64, mats0, clusters0, dev, warm_rounds, timed_rounds)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(seq0, mats0, clusters0)
+        if not STUB and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters)
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
     if dist is not None:

@@ -159,8 +159,39 @@ def g_resample():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         local = ref_reg.resample_cluster(_Seg(seq), 1, 8, mats32)
+    # ... and with ROTATED float32 poses (what train() returns from frame 1 on): mlp_reg.py:211 inverts the float32
+    # matrix with np.linalg.inv, i.e. in float32 -- identity rotations (above) cannot see that
+    rng = np.random.default_rng(33)
+    rot = mats.copy()
+    rot[:, :3, :3] = Rotation.from_rotvec(rng.normal(scale=0.35, size=(8, 3))).as_matrix()
+    rot[:, :3, 3] += rng.normal(scale=0.01, size=(8, 3))
+    rot32 = rot.astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        local_r = ref_reg.resample_cluster(_Seg(seq), 1, 8, rot32)
+    rot64 = rot32.astype(np.float64)                       # the --mlp_icp path hands float64 poses (mlp_reg.py:326)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        local_r64 = ref_reg.resample_cluster(_Seg(seq), 1, 8, rot64)
     save("resample_reference.npz", frame=seq[1], mats=mats32,
-         offsets=np.cumsum([0] + [len(c) for c in local]), local=np.concatenate(local))
+         offsets=np.cumsum([0] + [len(c) for c in local]), local=np.concatenate(local),
+         rot_mats=rot32, rot_offsets=np.cumsum([0] + [len(c) for c in local_r]), rot_local=np.concatenate(local_r),
+         rot64_offsets=np.cumsum([0] + [len(c) for c in local_r64]), rot64_local=np.concatenate(local_r64))
+
+
+def g_segments():
+    """reference Segments.k_means_cluster (cluster_icp.py:47-107) with the global numpy RandomState seeded: sklearn's
+    k_means(init="k-means++", random_state=None) draws from it, so the otherwise unseeded frame-0 segmentation is
+    reproducible -> centroid frames, local segments."""
+    seq = make_sequence("wx200_5", seq=9, n_frames=1, n_points=1024)
+    seg = ref_icp.Segments.__new__(ref_icp.Segments)
+    seg.pc_list = [ref_shims._PointCloud(seq[0])]
+    seg.init_coord_list, seg.init_matrix_list, seg.init_segment_list = [], [], []
+    np.random.seed(11)
+    seg.k_means_cluster(0, 8)
+    save("segments_reference.npz", frame=seq[0], seed=np.int64(11), matrices=np.array(seg.init_matrix_list),
+         coords=np.array(seg.init_coord_list), offsets=np.cumsum([0] + [len(c) for c in seg.init_segment_list]),
+         segments=np.concatenate(seg.init_segment_list))
 
 
 def g_masked_icp():
@@ -203,4 +234,4 @@ def g_chamfer():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    g_dq(); g_models(); g_calc_pc(); g_train(); g_resample(); g_masked_icp(); g_kmeans(); g_chamfer()
+    g_dq(); g_models(); g_calc_pc(); g_train(); g_resample(); g_segments(); g_masked_icp(); g_kmeans(); g_chamfer()

@@ -51,7 +51,15 @@ def install():
     sys.modules.update({"pytorch3d": p3d, "pytorch3d.transforms": tr, "pytorch3d.loss": loss})
 
     o3d = types.ModuleType("open3d")
-    o3d.geometry = types.SimpleNamespace(PointCloud=_PointCloud)
+    class _Mesh:                                     # coordinate-frame gizmos the reference builds for its viewer calls
+        def transform(self, T):
+            return self
+
+        def paint_uniform_color(self, c):
+            return self
+
+    o3d.geometry = types.SimpleNamespace(PointCloud=_PointCloud, TriangleMesh=types.SimpleNamespace(
+        create_coordinate_frame=lambda size=1.0, origin=None: _Mesh()))
     o3d.utility = types.SimpleNamespace(Vector3dVector=lambda a: np.asarray(a, np.float64))
 
     class _Result:

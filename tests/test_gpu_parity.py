@@ -188,6 +188,38 @@ def test_resample_group_to_local_vs_reference_golden(dev, golden):
     np.testing.assert_allclose(local.cpu().numpy(), g["local"], atol=1e-12)
 
 
+@pytest.mark.parametrize("tag,dtype,tol", [("rot", np.float32, 2e-7), ("rot64", np.float64, 1e-12)])
+def test_resample_cluster_rotated_poses_vs_reference_golden(dev, golden, tag, dtype, tol):
+    """The drop-in resample_cluster with rotated poses against the reference function's output: the pose inverse is
+    the reference's own host call in the pose's dtype (float32 LAPACK after train: the last bits depend on the BLAS
+    build of the host, hence 2e-7; float64 after masked_icp), the labels and the change of frame run on the GPU."""
+    from autourdf_amd import mlp_reg
+    from autourdf_amd.cluster_icp import Segments
+    g = golden("resample_reference.npz")
+    seg = Segments.from_arrays([g["frame"], g["frame"]])
+    local = mlp_reg.resample_cluster(seg, 1, 8, g["rot_mats"].astype(dtype))
+    np.testing.assert_array_equal(np.cumsum([0] + [len(c) for c in local]), g[f"{tag}_offsets"])
+    assert all(c.dtype == np.float64 for c in local)
+    np.testing.assert_allclose(np.concatenate(local), g[f"{tag}_local"], rtol=0, atol=tol)
+
+
+def test_segments_k_means_cluster_vs_reference_golden(dev, golden):
+    """Frame-0 segmentation: reference Segments.k_means_cluster (cluster_icp.py:47-107) under np.random.seed against
+    the drop-in with the same seed -- sklearn's k-means++ draw sequence on the host, Lloyd + grouping on the GPU."""
+    from autourdf_amd.cluster_icp import Segments
+    g = golden("segments_reference.npz")
+    seg = Segments.from_arrays([g["frame"]])
+    np.random.seed(int(g["seed"]))
+    seg.k_means_cluster(0, 8)
+    np.testing.assert_array_equal(np.cumsum([0] + [len(c) for c in seg.init_segment_list]), g["offsets"])
+    np.testing.assert_allclose(np.array(seg.init_matrix_list), g["matrices"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(np.array(seg.init_coord_list), g["coords"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(np.concatenate(seg.init_segment_list), g["segments"], rtol=0, atol=1e-14)
+    seg2 = Segments.from_arrays([g["frame"]])                       # explicit seed = the same draw
+    seg2.k_means_cluster(0, 8, seed=int(g["seed"]))
+    np.testing.assert_array_equal(np.array(seg2.init_matrix_list), np.array(seg.init_matrix_list))
+
+
 # ------------------------------------------------------------------------------------------ K5
 def test_dq_rows_vs_reference_golden(dev, golden):
     from autourdf_amd import ops

@@ -149,3 +149,28 @@ def test_synthetic_sequences_are_seeded_and_sized():
     assert mats.shape == (20, 4, 4) and sum(len(c) for c in clusters) == 4096 and lab.dtype == np.int32
     for r in ("franka", "allegro", "chain32"):
         assert make_sequence(r, 0, 1, 512)[0].shape == (512, 3)
+
+
+def test_kmeans_plusplus_follows_sklearns_draw_sequence(golden):
+    """Segments.k_means_cluster seeds like scikit-learn does (global RandomState, k-means++ on centred data): with the
+    same np.random.seed, live sklearn's k_means(init="k-means++") and our seeding + Lloyd give identical labels, and
+    the reference-minted segmentation golden (reference Segments.k_means_cluster under np.random.seed) is reproduced."""
+    import numpy as np
+    from sklearn.cluster import k_means
+    from autourdf_amd.cluster_icp import kmeans_plusplus_sklearn
+    from oracle import kmeans as okm
+    g = golden("segments_reference.npz")
+    X = g["frame"]
+    for seed in (int(g["seed"]), 0, 5):
+        np.random.seed(seed)
+        _, lab, _ = k_means(X.copy(), init="k-means++", n_clusters=8)
+        np.random.seed(seed)
+        idx = kmeans_plusplus_sklearn(X, 8, np.random.mtrand._rand)
+        _, olab, _, _ = okm.k_means(X, X[idx])
+        np.testing.assert_array_equal(lab, olab)
+    np.random.seed(int(g["seed"]))
+    idx = kmeans_plusplus_sklearn(X, 8, np.random.mtrand._rand)
+    _, olab, _, _ = okm.k_means(X, X[idx])
+    np.testing.assert_array_equal(np.cumsum([0] + list(np.bincount(olab, minlength=8))), g["offsets"])
+    for i in range(8):
+        np.testing.assert_allclose(X[olab == i].mean(0), g["matrices"][i][:3, 3], atol=1e-14)

@@ -260,3 +260,16 @@ def test_link_refine_oracle_vs_reference_golden(golden):
         assert len(moved[t]) == dof + 1
         for i in range(dof + 1):
             np.testing.assert_allclose(moved[t][i], g[f"out.{t}.{i}"], atol=1e-12)
+
+
+@pytest.mark.parametrize("tag,dtype", [("rot", np.float32), ("rot64", np.float64)])
+def test_resample_rotated_poses_match_reference(golden, tag, dtype):
+    """resample_cluster with ROTATED poses: the reference inverts each pose in its own dtype (float32 after train,
+    mlp_reg.py:211,371; float64 after masked_icp, :326).  The oracle makes the same numpy call; across machines the
+    float32 LAPACK inverse may differ in the last bits (BLAS build), hence 2e-7 on coordinates of ~0.1 m."""
+    g = golden("resample_reference.npz")
+    local, _ = registration.resample_cluster(g["frame"], 8, g["rot_mats"].astype(dtype))
+    np.testing.assert_array_equal(np.cumsum([0] + [len(c) for c in local]), g[f"{tag}_offsets"])
+    np.testing.assert_allclose(np.concatenate(local), g[f"{tag}_local"], rtol=0, atol=2e-7 if dtype == np.float32 else 1e-12)
+    # the float32 inverse is visible: the two goldens differ by more than the float64 tolerance
+    assert np.abs(g["rot_local"] - g["rot64_local"]).max() > 1e-9
