@@ -376,17 +376,318 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
     }
 }
 
+
+// =================================================================================================================
+// Large regime (clusters of more than ICP_SRC_LDS points, or frames whose masked targets do not fit a CU's LDS: the
+// BASELINE configs[4] shape has 2048-point clusters against ~3000 masked targets each): the same ICP as k_masked_icp,
+// iteration by iteration over MANY workgroups instead of one workgroup per cluster running out of global memory:
+//   k_icp_mask   (cluster)            box, ordered compaction of the frame indices inside it
+//   k_icp_init   (cluster)            sources into the world frame with the initial pose
+//   k_icp_nn     (256-source chunk)   nearest masked target of every source point: tiles of the cluster's targets staged in
+//                                     LDS, sequential-equivalent first minimum (strict '<' in ascending target order)
+//   k_icp_fit    (cluster)            fitness / RMSE of the new correspondences, open3d's convergence test against the
+//                                     previous ones, else Horn's closed form from them, pose and source update
+//   k_icp_finish (cluster)            outputs
+// The host enqueues [fit, nn] in batches of 16 and reads one "clusters still running" word between batches.
+struct IcpLarge {                          // per problem
+    const double* local; const float* world; const int* off; const int* woff; const double* frame; const double* Min;
+    double* Mout; double* world_out; int* n_iter_out;
+    double* srcw; int* tidx; int* tcount; float* box; int* nn; double* d2; double* state; int* running;
+    int* chunk0;                               // [k + 1] first source chunk of every cluster (k_icp_nn's block -> cluster map)
+};
+constexpr int ICP_CH = 256;                // sources per k_icp_nn workgroup
+constexpr int ICP_ST = 48;                 // doubles of per-cluster state: T[16] Vp[16] prev_fit prev_rmse done n_updates ...
+
+__global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float half_scale, int from_pose) {
+    __shared__ float wl[16][3], wh[16][3];
+    __shared__ float s_lo[3], s_hi[3];
+    __shared__ int s_wofs[16];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = P.off[k], e = P.off[k + 1];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (!from_pose) {
+        const int* woff = P.woff ? P.woff : P.off;
+        for (int i = woff[k] + tid; i < woff[k + 1]; i += 1024)
+            for (int d = 0; d < 3; ++d) { const float v = P.world[3 * (size_t)i + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
+    } else {                                   // boxes of float32(M) . float32(local), creg_cluster_transform_f32's arithmetic
+        float Tf[12];
+        for (int q = 0; q < 12; ++q) Tf[q] = (float)P.Min[16 * k + q];
+        for (int i = b + tid; i < e; i += 1024) {
+            const float p0 = (float)P.local[3 * (size_t)i], p1 = (float)P.local[3 * (size_t)i + 1], p2 = (float)P.local[3 * (size_t)i + 2];
+            for (int d = 0; d < 3; ++d) {
+                const float v = fmaf(p2, Tf[4 * d + 2], fmaf(p1, Tf[4 * d + 1], p0 * Tf[4 * d])) + Tf[4 * d + 3];
+                lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v);
+            }
+        }
+    }
+    for (int d = 0; d < 3; ++d) {
+        for (int o = 32; o >= 1; o >>= 1) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64)); }
+        if (lane == 0) { wl[wv][d] = lo[d]; wh[wv][d] = hi[d]; }
+    }
+    __syncthreads();
+    if (tid < 3) {
+        const int d = tid;
+        float l = wl[0][d], h = wh[0][d];
+        for (int w = 1; w < 16; ++w) { l = fminf(l, wl[w][d]); h = fmaxf(h, wh[w][d]); }
+        const float c = (l + h) / 2.0f, sz = h - l;
+        s_lo[d] = c - half_scale * sz; s_hi[d] = c + half_scale * sz;
+        if (P.box) { P.box[6 * k + d] = s_lo[d]; P.box[6 * k + 3 + d] = s_hi[d]; }
+    }
+    __syncthreads();
+    const double blo0 = (double)s_lo[0], blo1 = (double)s_lo[1], blo2 = (double)s_lo[2];
+    const double bhi0 = (double)s_hi[0], bhi1 = (double)s_hi[1], bhi2 = (double)s_hi[2];
+    int* tidx = P.tidx + (size_t)k * nf;
+    int run = 0;
+    for (int base = 0; base < nf; base += 1024) {
+        const int j = base + tid;
+        bool in = false;
+        if (j < nf && e > b) {
+            const double x = P.frame[3 * (size_t)j], y = P.frame[3 * (size_t)j + 1], z = P.frame[3 * (size_t)j + 2];
+            in = x > blo0 && x < bhi0 && y > blo1 && y < bhi1 && z > blo2 && z < bhi2;
+        }
+        const unsigned long long m = __ballot(in);
+        __syncthreads();
+        if (lane == 0) s_wofs[wv] = __popcll(m);
+        __syncthreads();
+        int before = run, total = 0;
+        for (int w = 0; w < 16; ++w) { const int c = s_wofs[w]; before += w < wv ? c : 0; total += c; }
+        if (in) tidx[before + __popcll(m & ((1ull << lane) - 1ull))] = j;
+        run += total;
+    }
+    if (tid == 0) P.tcount[k] = run;
+}
+
+__global__ __launch_bounds__(256) void k_icp_init(IcpLarge P, int k_total) {
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int b = P.off[k], e = P.off[k + 1];
+    double T[12];
+    for (int q = 0; q < 12; ++q) T[q] = P.Min[16 * k + q];
+    for (int i = b + tid; i < e; i += 256) {
+        const double p0 = P.local[3 * (size_t)i], p1 = P.local[3 * (size_t)i + 1], p2 = P.local[3 * (size_t)i + 2];
+        for (int a = 0; a < 3; ++a) P.srcw[3 * (size_t)i + a] = fma(T[4 * a + 2], p2, fma(T[4 * a + 1], p1, T[4 * a] * p0)) + T[4 * a + 3];
+    }
+    if (tid < 16) { P.state[ICP_ST * k + tid] = P.Min[16 * k + tid]; P.state[ICP_ST * k + 16 + tid] = (tid % 5 == 0) ? 1.0 : 0.0; }
+    if (tid == 0) {
+        double* st = P.state + ICP_ST * k;
+        st[32] = 0.0; st[33] = 0.0; st[34] = 0.0; st[35] = 0.0;       // prev fitness, prev rmse, done, updates applied
+        if (k == 0) {
+            *P.running = k_total;
+            int c = 0;                                                // chunks of ICP_CH sources, never across clusters
+            for (int j = 0; j < k_total; ++j) { P.chunk0[j] = c; c += (P.off[j + 1] - P.off[j] + ICP_CH - 1) / ICP_CH; }
+            P.chunk0[k_total] = c;
+        }
+    }
+}
+
+// Block = one chunk of ICP_CH = 256 sources of ONE cluster (chunk0 maps blocks to clusters; blocks past the last chunk
+// exit), one source per thread: every thread of the block scans the same target list, staged tile by tile in LDS.
+// (Measured at N = 262144, K = 128: blocks over the concatenated sources that straddle two clusters 51 ms per frame's ICP,
+//  cluster-aligned chunks 32 ms, two sources per thread -- half the LDS broadcast reads per pair, half the waves -- 41 ms.)
+__global__ __launch_bounds__(256) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2) {
+    __shared__ double tx[256], ty[256], tz[256];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    if (blk >= P.chunk0[k_total]) return;
+    int lo = 0, hi = k_total;                                         // cluster c with chunk0[c] <= blk < chunk0[c + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P.chunk0[mid] <= blk) lo = mid; else hi = mid; }
+    const int c = lo;
+    if (P.state[ICP_ST * c + 34] != 0.0) return;                      // converged cluster: its correspondences stay
+    const int i = P.off[c] + (blk - P.chunk0[c]) * ICP_CH + tid;
+    const bool live = i < P.off[c + 1];
+    double s0 = 0, s1 = 0, s2 = 0;
+    if (live) { s0 = P.srcw[3 * (size_t)i]; s1 = P.srcw[3 * (size_t)i + 1]; s2 = P.srcw[3 * (size_t)i + 2]; }
+    double best = INFINITY; int bm = -1;
+    const int nt = P.tcount[c];
+    const int* tidx = P.tidx + (size_t)c * nf;
+    for (int t0 = 0; t0 < nt; t0 += 256) {
+        __syncthreads();
+        if (t0 + tid < nt) {
+            const int j = tidx[t0 + tid];
+            tx[tid] = P.frame[3 * (size_t)j]; ty[tid] = P.frame[3 * (size_t)j + 1]; tz[tid] = P.frame[3 * (size_t)j + 2];
+        }
+        __syncthreads();
+        const int cnt = min(256, nt - t0);
+#pragma unroll 8
+        for (int t = 0; t < cnt; ++t) {
+            const double dx = s0 - tx[t], dy = s1 - ty[t], dz = s2 - tz[t];
+            const double d = (dx * dx + dy * dy) + dz * dz;
+            if (d < best) { best = d; bm = t0 + t; }                  // the slot; its frame index is looked up once at the end
+        }
+    }
+    if (live) {
+        const bool ok = bm >= 0 && best <= th2;
+        P.nn[i] = ok ? tidx[bm] : -1;
+        P.d2[i] = ok ? best : 0.0;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void bsum512(double (&v)[N], double* sc /* [8][N] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = wave_sum_fast(v[i]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) sc[wv * N + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) { double r = 0.0; for (int w = 0; w < 8; ++w) r += sc[w * N + i]; v[i] = r; }
+}
+
+__global__ __launch_bounds__(512) void k_icp_fit(IcpLarge P, int max_iter) {
+    __shared__ double sc[8 * 9];
+    __shared__ double T[16], U[16], Vp[16];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    double* st = P.state + ICP_ST * k;
+    if (st[34] != 0.0) return;                                        // done
+    const int b = P.off[k], e = P.off[k + 1], ns = e - b;
+    // fitness / inlier RMSE of the correspondences the last k_icp_nn produced (registration_icp's GetRegistrationResult)
+    double ce[2] = {0, 0};
+    for (int i = b + tid; i < e; i += 512) if (P.nn[i] >= 0) { ce[0] += 1.0; ce[1] += P.d2[i]; }
+    bsum512<2>(ce, sc);
+    const double ncorr = ce[0];
+    const double fit = ns > 0 ? ce[0] / (double)ns : 0.0, rmse = ce[0] > 0 ? sqrt(ce[1] / ce[0]) : 0.0;
+    const double pf = st[32], pr = st[33];
+    const int updates = (int)st[35];
+    const bool converged = updates >= 1 && fabs(pf - fit) < 1e-6 && fabs(pr - rmse) < 1e-6;
+    if (converged || updates >= max_iter) {
+        __syncthreads();
+        if (tid == 0) { st[34] = 1.0; atomicSub(P.running, 1); }
+        return;
+    }
+    if (tid < 16) { T[tid] = st[tid]; Vp[tid] = st[16 + tid]; }
+    double mm[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = b + tid; i < e; i += 512) {
+        const int m = P.nn[i];
+        if (m < 0) continue;
+        for (int a = 0; a < 3; ++a) { mm[a] += P.srcw[3 * (size_t)i + a]; mm[3 + a] += P.frame[3 * (size_t)m + a]; }
+    }
+    bsum512<6>(mm, sc);
+    if (ncorr > 0) for (int a = 0; a < 6; ++a) mm[a] /= ncorr;
+    const double* ms = mm; const double* md = mm + 3;
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = b + tid; i < e; i += 512) {
+        const int m = P.nn[i];
+        if (m < 0) continue;
+        double sv[3], dv[3];
+        for (int a = 0; a < 3; ++a) { sv[a] = P.srcw[3 * (size_t)i + a] - ms[a]; dv[a] = P.frame[3 * (size_t)m + a] - md[a]; }
+        for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) C[3 * a + c] = fma(sv[a], dv[c], C[3 * a + c]);
+    }
+    bsum512<9>(C, sc);
+    if (tid == 0) {
+        for (int i = 0; i < 16; ++i) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        if (ncorr > 0) {
+            const double Sxx = C[0], Sxy = C[1], Sxz = C[2], Syx = C[3], Syy = C[4], Syz = C[5], Szx = C[6], Szy = C[7], Szz = C[8];
+            double N[4][4] = {{Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx},
+                              {Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz},
+                              {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
+                              {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
+            double q[4], R[9];
+            sym4_max_eigvec(N, q, Vp);
+            quat_to_matrix(q, R);
+            for (int a = 0; a < 3; ++a) {
+                U[4 * a] = R[3 * a]; U[4 * a + 1] = R[3 * a + 1]; U[4 * a + 2] = R[3 * a + 2];
+                U[4 * a + 3] = md[a] - (R[3 * a] * ms[0] + R[3 * a + 1] * ms[1] + R[3 * a + 2] * ms[2]);
+            }
+        }
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) {
+            double s = 0;
+            for (int m = 0; m < 4; ++m) s = fma(U[4 * r + m], T[4 * m + c], s);
+            st[4 * r + c] = s;
+        }
+        for (int i = 0; i < 16; ++i) st[16 + i] = Vp[i];
+        st[32] = fit; st[33] = rmse; st[35] = (double)(updates + 1);
+    }
+    __syncthreads();
+    for (int i = b + tid; i < e; i += 512) {
+        const double p0 = P.srcw[3 * (size_t)i], p1 = P.srcw[3 * (size_t)i + 1], p2 = P.srcw[3 * (size_t)i + 2];
+        for (int a = 0; a < 3; ++a) P.srcw[3 * (size_t)i + a] = fma(U[4 * a + 2], p2, fma(U[4 * a + 1], p1, U[4 * a] * p0)) + U[4 * a + 3];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_icp_finish(IcpLarge P, int keep_t) {
+    __shared__ double T[16];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const double* st = P.state + ICP_ST * k;
+    if (tid < 16) T[tid] = st[tid];
+    __syncthreads();
+    if (tid == 0 && keep_t) { T[3] = P.Min[16 * k + 3]; T[7] = P.Min[16 * k + 7]; T[11] = P.Min[16 * k + 11]; }
+    __syncthreads();
+    if (tid < 16) P.Mout[16 * k + tid] = T[tid];
+    if (tid == 0) P.n_iter_out[k] = (int)st[35];
+    const int b = P.off[k], e = P.off[k + 1];
+    for (int i = b + tid; i < e; i += 256) {
+        const double* p = P.local + 3 * (size_t)i;
+        for (int a = 0; a < 3; ++a)
+            P.world_out[3 * (size_t)i + a] = fma(T[4 * a + 2], p[2], fma(T[4 * a + 1], p[1], T[4 * a] * p[0])) + T[4 * a + 3];
+    }
+}
+
+struct IcpLargeLayout { size_t srcw, tidx, tcount, box, nn, d2, state, running, chunk0, total; };
+static IcpLargeLayout icp_large_layout(int64_t n, int64_t nf, int k) {
+    IcpLargeLayout L; size_t o = 0;
+    auto take = [&](size_t b) { size_t r = o; o = align_up(o + b, 256); return r; };
+    L.srcw = take(sizeof(double) * 3 * n); L.tidx = take(sizeof(int) * (size_t)k * nf); L.tcount = take(sizeof(int) * k);
+    L.box = take(sizeof(float) * 6 * k); L.nn = take(sizeof(int) * n); L.d2 = take(sizeof(double) * n);
+    L.state = take(sizeof(double) * ICP_ST * k); L.running = take(sizeof(int) * 4); L.chunk0 = take(sizeof(int) * (k + 1)); L.total = o;
+    return L;
+}
+// the regime switch (host-side sizes only): average cluster above the LDS source budget, or a frame too large for the
+// LDS target table to matter
+static bool icp_large_regime(int64_t n, int64_t nf, int k) { return n / (k > 0 ? k : 1) > ICP_SRC_LDS || nf > 65536; }
+
 }  // namespace creg
 using namespace creg;
 
+static size_t icp_ws_one(int64_t n, int64_t nf, int k) {
+    const size_t a = icp_layout(n, nf, k).total, b = icp_large_layout(n, nf, k).total;
+    return a > b ? a : b;
+}
+
 extern "C" size_t creg_icp_workspace_bytes(int64_t n, int64_t nf, int32_t k) {
     if (n < 1 || nf < 1 || k < 1) return 0;
-    return icp_layout(n, nf, k).total;
+    return icp_ws_one(n, nf, k);
 }
 
 extern "C" size_t creg_icp_batch_workspace_bytes(int64_t n, int64_t nf, int32_t k, int32_t batch) {
     if (n < 1 || nf < 1 || k < 1 || batch < 1) return 0;
-    return icp_layout(n, nf, k).total * (size_t)batch;
+    return icp_ws_one(n, nf, k) * (size_t)batch;
+}
+
+// One problem through the multi-launch path.  Synchronises the stream between batches of iterations.
+static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_t nf, double scale, double th,
+                         int32_t max_iteration, int32_t keep_translation, char* ws, hipStream_t s) {
+    const IcpLargeLayout L = icp_large_layout(n, nf, k);
+    IcpLarge P;
+    P.local = q.local; P.world = q.world; P.off = q.seg_offsets; P.woff = q.world_offsets; P.frame = q.frame; P.Min = q.M;
+    P.Mout = q.M_out; P.world_out = q.world_out; P.n_iter_out = q.n_iter_out;
+    P.srcw = (double*)(ws + L.srcw); P.tidx = (int*)(ws + L.tidx); P.tcount = (int*)(ws + L.tcount); P.box = (float*)(ws + L.box);
+    P.nn = (int*)(ws + L.nn); P.d2 = (double*)(ws + L.d2); P.state = (double*)(ws + L.state); P.running = (int*)(ws + L.running); P.chunk0 = (int*)(ws + L.chunk0);
+    if (q.tgt_offsets) {
+        set_error("creg_masked_icp: point-to-point mode (tgt_offsets) is not available in the large-cluster regime");
+        return CREG_EINVAL;
+    }
+    hipLaunchKernelGGL(k_icp_mask, dim3(k), dim3(1024), 0, s, P, (int)nf, (float)(0.5 * scale), q.world ? 0 : 1);
+    hipLaunchKernelGGL(k_icp_init, dim3(k), dim3(256), 0, s, P, k);
+    const int nblk = cdiv(n, ICP_CH) + k;                // an upper bound of sum_c ceil(ns_c / ICP_CH); the surplus blocks exit
+    hipLaunchKernelGGL(k_icp_nn, dim3(nblk), dim3(256), 0, s, P, (int)n, k, (int)nf, th * th);
+    CREG_LAUNCH_CHECK();
+    int running = k;
+    // every k_icp_fit call is one convergence test + (unless converged) one update; max_iteration updates need one call more
+    for (int64_t done = 0; running > 0 && done <= (int64_t)max_iteration; ) {
+        const int batch = 16;
+        for (int b = 0; b < batch; ++b, ++done) {
+            hipLaunchKernelGGL(k_icp_fit, dim3(k), dim3(512), 0, s, P, max_iteration);
+            hipLaunchKernelGGL(k_icp_nn, dim3(nblk), dim3(256), 0, s, P, (int)n, k, (int)nf, th * th);
+        }
+        CREG_LAUNCH_CHECK();
+        CREG_HIP(hipMemcpyAsync(&running, P.running, sizeof(int), hipMemcpyDeviceToHost, s));
+        CREG_HIP(hipStreamSynchronize(s));
+    }
+    hipLaunchKernelGGL(k_icp_finish, dim3(k), dim3(256), 0, s, P, keep_translation);
+    CREG_LAUNCH_CHECK();
+    return CREG_OK;
 }
 
 static int icp_launch(const creg_icp_problem* pr, int batch, int64_t n, int32_t k, int64_t nf, double scale, double th,
@@ -397,8 +698,20 @@ static int icp_launch(const creg_icp_problem* pr, int batch, int64_t n, int32_t 
     CREG_REQUIRE(k >= 1 && nf >= 1 && nf < (1ll << 31) && max_iteration >= 1, "%s: bad size", who);
     CREG_REQUIRE(n >= 1 && n < (1ll << 31), "%s: no source points", who);
     const IcpLayout L = icp_layout(n, nf, k);
-    CREG_REQUIRE(workspace_bytes >= L.total * (size_t)batch, "%s: workspace too small (%zu < %zu)", who, workspace_bytes,
-                 L.total * (size_t)batch);
+    const size_t one = icp_ws_one(n, nf, k);
+    CREG_REQUIRE(workspace_bytes >= one * (size_t)batch, "%s: workspace too small (%zu < %zu)", who, workspace_bytes,
+                 one * (size_t)batch);
+    if (icp_large_regime(n, nf, k) && !pr[0].tgt_offsets) {
+        // clusters / frames beyond what one CU's LDS holds: many workgroups per iteration instead of one per cluster
+        for (int i = 0; i < batch; ++i) {
+            const creg_icp_problem& q = pr[i];
+            CREG_REQUIRE(q.local && q.seg_offsets && q.frame && q.M && q.M_out && q.world_out && q.n_iter_out,
+                         "%s: null pointer in problem %d", who, i);
+            const int rc = icp_large_run(q, n, k, nf, scale, th, max_iteration, keep_translation, (char*)workspace + one * (size_t)i, s);
+            if (rc) return rc;
+        }
+        return CREG_OK;
+    }
     IcpBatch B;
     for (int i = 0; i < batch; ++i) {
         const creg_icp_problem& q = pr[i];
@@ -414,7 +727,7 @@ static int icp_launch(const creg_icp_problem* pr, int batch, int64_t n, int32_t 
     CREG_HIP(hipFuncSetAttribute((const void*)k_masked_icp, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  4096 * 28 + ICP_SRC_LDS * 28));
     hipLaunchKernelGGL(k_masked_icp, dim3(k, batch), dim3(ICP_NT), smem, s, B, (int)nf, (float)(0.5 * scale), th,
-                       max_iteration, keep_translation, (char*)workspace, L.total, L.srcw, L.tidx, L.nn, lds_cap);
+                       max_iteration, keep_translation, (char*)workspace, one, L.srcw, L.tidx, L.nn, lds_cap);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }
@@ -433,6 +746,18 @@ extern "C" int creg_masked_icp_batch_f64(const creg_icp_problem* problems, int32
                                          void* workspace, size_t workspace_bytes, creg_stream_t stream) {
     return icp_launch(problems, batch, n, k, nf, scale, th, max_iteration, keep_translation,
                       workspace, workspace_bytes, (hipStream_t)stream, "creg_masked_icp_batch_f64");
+}
+
+extern "C" int creg_aabb_mask_f64(const float* world, const int32_t* world_offsets, int32_t k, const double* frame, int64_t nf,
+                                  double scale, int32_t* mask_idx, int32_t* mask_count, float* boxes, creg_stream_t stream) {
+    CREG_REQUIRE(world && world_offsets && frame && mask_idx && mask_count && k >= 1 && nf >= 1 && nf < (1ll << 31),
+                 "creg_aabb_mask_f64: bad argument");
+    IcpLarge P{};
+    P.world = world; P.off = world_offsets; P.woff = world_offsets; P.frame = frame;
+    P.tidx = mask_idx; P.tcount = mask_count; P.box = boxes;
+    hipLaunchKernelGGL(k_icp_mask, dim3(k), dim3(1024), 0, (hipStream_t)stream, P, (int)nf, (float)(0.5 * scale), 0);
+    CREG_LAUNCH_CHECK();
+    return CREG_OK;
 }
 
 extern "C" int creg_icp_p2p_f64(const double* src, int64_t n_src, const int32_t* src_offsets, const double* tgt,

@@ -2,11 +2,16 @@
 // n_init=1) semantics (reference mlp_reg.py:204, cluster_icp.py:67), plus the stable grouping /
 // change-of-frame step that follows it (mlp_reg.py:208-217).
 //
-// Per Lloyd iteration three small launches, all with fixed reduction orders (bit-reproducible):
-//   k_assign[_mfma]  labels = first argmin_k fma(x2,b2,fma(x1,b1,fma(x0,b0,|c|^2))),  b = -2c
-//   k_accumulate     grid (k, S): per-cluster sums over a segment of the points, strided + tree
-//   k_finalize       1 block: reduce segments, relocate empty clusters, average (x 1/w), centre
-//                    shift, convergence (strict label equality first, then tol), next b/|c|^2
+// Per Lloyd iteration two small launches (bit-reproducible):
+//   k_assign[_mfma]  labels = first argmin_k fma(x2,b2,fma(x1,b1,fma(x0,b0,|c|^2))),  b = -2c; the per-cluster sums of
+//                    the M-step in the same pass: every point adds its FIXED-POINT coordinates (int64, scale 2^s chosen per
+//                    call so that n points cannot overflow) and a count to a table in LDS, the table goes to global
+//                    accumulators with integer atomics.  Integer sums are exact, hence order-independent: atomics without
+//                    losing determinism, and no second pass over the labels (a (cluster, segment) sweep that re-read every
+//                    label k times used to cost 1.7x the E-step at n = 262144, k = 128).  A point is rounded to a grid
+//                    of range * 2^-43 at that size (2^-49 at n = 4096): below the error of any float64 summation order.
+//   k_finalize       1 block: sums -> centres (x 1/w), relocate empty clusters, centre shift, convergence (strict label
+//                    equality first, then tol), next b/|c|^2, accumulators cleared for the next iteration
 // The host enqueues iterations in batches and reads the `done` word between batches; kernels of
 // iterations after convergence return immediately.
 #include "creg_common.h"
@@ -25,7 +30,18 @@ struct KmFlags {
     double tol;
     double shift_tot;
     double inertia;
+    double fix_scale, fix_inv;   // fixed-point scale 2^s of the M-step accumulators and its inverse
 };
+
+// scale 2^s with n * range * 2^s < 2^62: the int64 sums of n fixed-point coordinates cannot overflow
+__device__ __forceinline__ double km_fix_scale(double range, int n) {
+    if (!(range > 0.0)) return 1.0;
+    int e;
+    frexp(range, &e);                                    // range < 2^e
+    const int nb = 32 - __clz(n);                        // n < 2^nb
+    return ldexp(1.0, 62 - nb - e);
+}
+__device__ __forceinline__ unsigned long long km_fix(double x, double scale) { return (unsigned long long)__double2ll_rn(x * scale); }
 
 typedef double double4v __attribute__((ext_vector_type(4)));
 
@@ -46,14 +62,22 @@ __global__ __launch_bounds__(1024) void k_km_stats(const double* __restrict__ X,
         if (threadIdx.x == 0) mean[d] = s / (double)n;
     }
     __syncthreads();
-    double var = 0;
+    double var = 0, amax = 0;
     for (int d = 0; d < 3; ++d) {
         double s = 0;
-        for (int i = threadIdx.x; i < n; i += 1024) { const double t = X[3 * (size_t)i + d] - mean[d]; s = fma(t, t, s); }
+        for (int i = threadIdx.x; i < n; i += 1024) { const double t = X[3 * (size_t)i + d] - mean[d]; s = fma(t, t, s); amax = fmax(amax, fabs(t)); }
         s = block_sum<double, 1024>(s, sc);
         if (threadIdx.x == 0) var += s / (double)n;
     }
+    __shared__ double s_amax[16];
+    for (int off = 32; off >= 1; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_amax[threadIdx.x >> 6] = amax;
+    __syncthreads();
     if (threadIdx.x == 0) {
+        double r = 0;
+        for (int w = 0; w < 16; ++w) r = fmax(r, s_amax[w]);
+        f->fix_scale = km_fix_scale(r, n); f->fix_inv = 1.0 / f->fix_scale;
         f->mean[0] = mean[0]; f->mean[1] = mean[1]; f->mean[2] = mean[2];
         f->tol = (var / 3.0) * tol_rel;
         f->changed = 0; f->done = 0; f->strict = 0; f->n_iter = 0; f->cur = 0;
@@ -84,14 +108,18 @@ __global__ __launch_bounds__(256) void k_km_center(const double* __restrict__ X,
 __global__ __launch_bounds__(256) void k_km_assign(const double* __restrict__ X, int n,
                                                    const double* __restrict__ B, int k,
                                                    int* __restrict__ labels, const int* __restrict__ prev,
-                                                   KmFlags* __restrict__ f, int raw) {
+                                                   KmFlags* __restrict__ f, int raw, unsigned long long* __restrict__ acc) {
     // raw: `B` holds the centres (k,3) and every workgroup derives its (-2c, |c|^2) rows itself -- the standalone
     // entry point then needs no device scratch (the library never allocates)
+    // acc (Lloyd only): global [k][4] int64 accumulators of the M-step (fixed-point x, y, z and the count)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sB = (double*)smem;
+    unsigned long long* sA = (unsigned long long*)(sB + 4 * k);
     if (f && f->done) return;
     if (raw) { for (int j = threadIdx.x; j < k; j += 256) make_b(B + 3 * j, sB + 4 * j); }
     else for (int i = threadIdx.x; i < 4 * k; i += 256) sB[i] = B[i];
+    if (acc) for (int i = threadIdx.x; i < 4 * k; i += 256) sA[i] = 0ull;
+    const double fscale = acc ? f->fix_scale : 0.0;
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     int diff = 0;
@@ -105,10 +133,18 @@ __global__ __launch_bounds__(256) void k_km_assign(const double* __restrict__ X,
         }
         labels[i] = lab;
         if (prev) diff = (prev[i] != lab);
+        if (acc) {
+            atomicAdd(&sA[4 * lab], km_fix(x0, fscale)); atomicAdd(&sA[4 * lab + 1], km_fix(x1, fscale));
+            atomicAdd(&sA[4 * lab + 2], km_fix(x2, fscale)); atomicAdd(&sA[4 * lab + 3], 1ull);
+        }
     }
     if (prev && f) {
         const unsigned long long m = __ballot(diff);
         if ((threadIdx.x & 63) == 0 && m) atomicAdd(&f->changed, __popcll(m));
+    }
+    if (acc) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * k; i += 256) { const unsigned long long v = sA[i]; if (v) atomicAdd(&acc[i], v); }
     }
 }
 
@@ -128,11 +164,14 @@ template <int NT>   // centre tiles held in registers (k <= 16 NT); 0: any k, ce
 __global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict__ X, int n,
                                                         const double* __restrict__ B, int k,
                                                         int* __restrict__ labels, const int* __restrict__ prev,
-                                                        KmFlags* __restrict__ f, int raw) {
+                                                        KmFlags* __restrict__ f, int raw, unsigned long long* __restrict__ acc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sB = (double*)smem;                                  // [kpad][4], rows past k: (0, 0, 0, +inf)
     if (f && f->done) return;
     const int kpad = (k + 15) & ~15, ktiles = kpad / 16;
+    unsigned long long* sA = (unsigned long long*)(sB + 5 * (size_t)kpad);       // [k][4] M-step sums (behind sB and sC)
+    if (acc) for (int i = threadIdx.x; i < 4 * k; i += 256) sA[i] = 0ull;
+    const double fscale = acc ? f->fix_scale : 0.0;
     // C operands as the lanes read them: sC[tile][lane group g][r] = |c|^2 of centre 16 tile + g + 4 r, 32 contiguous
     // bytes per (tile, group) -> two ds_read_b128 per MFMA instead of eight register copies of a resident table
     double* sC = sB + 4 * (size_t)kpad;                          // [ktiles][4][4]
@@ -210,38 +249,22 @@ __global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict
         }
         const int i = tile * 16 + col;
         if (g == 0 && i < n) { labels[i] = lab; if (prev) diff += (prev[i] != lab); }
+        // the point's lane groups hold x, y, z (b) and nothing: one LDS atomic each -- coordinate g, or the count
+        if (acc && i < n) atomicAdd(&sA[4 * lab + g], g < 3 ? km_fix(b, fscale) : 1ull);
     }
     if (prev && f) {
         diff = wave_sum(diff);
         if (lane == 0 && diff) atomicAdd(&f->changed, diff);
     }
+    if (acc) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * k; i += 256) { const unsigned long long v = sA[i]; if (v) atomicAdd(&acc[i], v); }
+    }
 }
 
-// grid (k, S): block (j, s) sums the points of cluster j inside segment s.
-__global__ __launch_bounds__(256) void k_km_accumulate(const double* __restrict__ X, int n,
-                                                       const int* __restrict__ labels, int k, int S,
-                                                       double* __restrict__ part, const KmFlags* __restrict__ f) {
-    // one block per (cluster, segment): every label is read k times, but 2048 small blocks hide the latency;
-    // an 8-clusters-per-block variant that reads each label once (bit-identical sums) measured SLOWER at
-    // n = 262144, k = 128 (51 vs 45 us): one block per CU cannot hide its own round trips
-    __shared__ double sc[4];
-    if (f->done) return;
-    const int j = blockIdx.x, s = blockIdx.y;
-    const int seg = (n + S - 1) / S, b = s * seg, e = min(n, b + seg);
-    double a0 = 0, a1 = 0, a2 = 0, w = 0;
-    for (int i = b + threadIdx.x; i < e; i += 256) {
-        if (labels[i] == j) { a0 += X[3 * (size_t)i]; a1 += X[3 * (size_t)i + 1]; a2 += X[3 * (size_t)i + 2]; w += 1.0; }
-    }
-    a0 = block_sum<double, 256>(a0, sc); a1 = block_sum<double, 256>(a1, sc);
-    a2 = block_sum<double, 256>(a2, sc); w = block_sum<double, 256>(w, sc);
-    if (threadIdx.x == 0) {
-        double* p = part + 4 * ((size_t)s * k + j);
-        p[0] = a0; p[1] = a1; p[2] = a2; p[3] = w;
-    }
-}
 __global__ __launch_bounds__(1024) void k_km_finalize(const double* __restrict__ X, int n,
-                                                      const int* __restrict__ labels, int k, int S,
-                                                      const double* __restrict__ part, double* __restrict__ C2,
+                                                      const int* __restrict__ labels, int k,
+                                                      unsigned long long* __restrict__ acc, double* __restrict__ C2,
                                                       double* __restrict__ B, double* __restrict__ Cw,
                                                       double* __restrict__ far_d, KmFlags* __restrict__ f) {
     __shared__ double sc[16];
@@ -255,21 +278,12 @@ __global__ __launch_bounds__(1024) void k_km_finalize(const double* __restrict__
     //  40 of this kernel's 48 us at k = 128.  Same sums in the same order; only who scans changed.)
     if (threadIdx.x == 0) s_nempty = 0;
     __syncthreads();
+    const double finv = f->fix_inv;
     for (int j = threadIdx.x; j < k; j += 1024) {
-        double a[4] = {0, 0, 0, 0};
-        for (int s0 = 0; s0 < S; s0 += 8) {                       // 8 segments' partials in flight, added in segment order
-            double v[8][4];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int d = 0; d < 4; ++d) v[u][d] = part[4 * ((size_t)min(s0 + u, S - 1) * k + j) + d];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (s0 + u < S)
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) a[d] += v[u][d];
-        }
-        for (int d = 0; d < 4; ++d) Cw[4 * j + d] = a[d];
+        double a[4];
+        for (int d = 0; d < 3; ++d) a[d] = (double)(long long)acc[4 * j + d] * finv;     // exact integer sums of the E-step
+        a[3] = (double)(long long)acc[4 * j + 3];
+        for (int d = 0; d < 4; ++d) { Cw[4 * j + d] = a[d]; acc[4 * j + d] = 0ull; }     // cleared for the next iteration
         if (a[3] == 0.0) atomicAdd(&s_nempty, 1);                 // integer count: order independent
     }
     __syncthreads();
@@ -398,7 +412,8 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
     double* Xc = (double*)smem;                               // [n][3] centred points
     __shared__ double sc[16];
     __shared__ double s_mean[3], s_tol;
-    __shared__ double gpart[4][4][4];                         // [group][wave in group][x,y,z,w]
+    __shared__ unsigned long long accI[4 * 128];              // M-step sums: fixed-point x, y, z and the count per cluster (k <= 128)
+    __shared__ double s_fscale, s_finv;
     __shared__ int s_changed, s_done, s_strict, s_it, s_nempty, s_argmax;
     __shared__ double s_dmax, s_fv[16];
     __shared__ int s_fi[16];
@@ -425,13 +440,24 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
         if (tid == 0) s_mean[d] = s / (double)n;
     }
     __syncthreads();
+    double amax = 0;
     for (int d = 0; d < 3; ++d) {
         double s = 0;
-        for (int i = tid; i < n; i += 1024) { const double t = X[3 * (size_t)i + d] - s_mean[d]; s = fma(t, t, s); }
+        for (int i = tid; i < n; i += 1024) { const double t = X[3 * (size_t)i + d] - s_mean[d]; s = fma(t, t, s); amax = fmax(amax, fabs(t)); }
         s = block_sum<double, 1024>(s, sc);
         if (tid == 0) var += s / (double)n;
     }
-    if (tid == 0) { s_tol = (var / 3.0) * tol_rel; s_done = 0; s_strict = 0; s_it = 0; s_changed = 0; }
+    for (int off = 32; off >= 1; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
+    __syncthreads();
+    if (lane == 0) s_fv[wv] = amax;
+    if (tid < 4 * k) accI[tid] = 0ull;
+    __syncthreads();
+    if (tid == 0) {
+        double r = 0;
+        for (int q = 0; q < 16; ++q) r = fmax(r, s_fv[q]);
+        s_fscale = km_fix_scale(r, n); s_finv = 1.0 / s_fscale;
+        s_tol = (var / 3.0) * tol_rel; s_done = 0; s_strict = 0; s_it = 0; s_changed = 0;
+    }
     // ---- centre (k_km_center) ----
     for (int i = tid; i < 3 * n; i += 1024) Xc[i] = X[i] - s_mean[i % 3];
     for (int i = tid; i < n; i += 1024) lab[1][i] = 0xFFFF;    // iteration 0 compares against lab[1] = "no label"
@@ -458,45 +484,20 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
             }
             lcur[i] = (unsigned short)lb;
             diff += ((int)lprev[i] != lb);
+            atomicAdd(&accI[4 * lb], km_fix(x0, s_fscale)); atomicAdd(&accI[4 * lb + 1], km_fix(x1, s_fscale));
+            atomicAdd(&accI[4 * lb + 2], km_fix(x2, s_fscale)); atomicAdd(&accI[4 * lb + 3], 1ull);
         }
         if (diff) atomicAdd(&s_changed, diff);
         __threadfence_block();
         __syncthreads();
-        // ---- per-cluster sums in k_km_accumulate's order: groups of 256 threads emulate its blocks ----
-        const int g = tid >> 8, tg = tid & 255, wg = (tid >> 6) & 3;
-        // this thread's points (tg, tg + 256, ...) keep their labels in registers for all ceil(k/4) sweeps, and
-        // a sweep is branch-free: adding +0.0 for foreign points leaves every partial sum bit-identical to the
-        // conditional accumulation (the sums start at +0.0 and can never become -0.0; frames are finite)
-        constexpr int KMS_PTS = 20;                            // ceil(5120 / 256)
-        int lbl[KMS_PTS];
-#pragma unroll
-        for (int m = 0; m < KMS_PTS; ++m) { const int i = tg + 256 * m; lbl[m] = i < n ? (int)lcur[i] : -1; }
-        for (int j0 = 0; j0 < k; j0 += 4) {
-            const int j = j0 + g;
-            double a0 = 0, a1 = 0, a2 = 0, aw = 0;
-            if (j < k) {
-#pragma unroll
-                for (int m = 0; m < KMS_PTS; ++m) {
-                    if (256 * m >= n) break;                       // block-uniform: no point of this slot exists
-                    const int i = min(tg + 256 * m, n - 1);
-                    // indicator form: fma(1, x, a) = RN(a + x) and fma(0, x, a) = a for finite x (a is never -0), i.e. the
-                    // conditional sum bit for bit with one select + 4 FMAs per point instead of eight selects + 4 adds
-                    const double ind = lbl[m] == j ? 1.0 : 0.0;
-                    const double x0 = Xc[3 * i], x1 = Xc[3 * i + 1], x2 = Xc[3 * i + 2];
-                    a0 = fma(ind, x0, a0); a1 = fma(ind, x1, a1); a2 = fma(ind, x2, a2); aw += ind;
-                }
-            }
-            a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); aw = wave_sum(aw);
-            if (lane == 0) { gpart[g][wg][0] = a0; gpart[g][wg][1] = a1; gpart[g][wg][2] = a2; gpart[g][wg][3] = aw; }
-            __syncthreads();
-            if (tg == 0 && j < k)
-                for (int d = 0; d < 4; ++d) {
-                    double r = 0;
-                    for (int q = 0; q < 4; ++q) r += gpart[g][q][d];
-                    Cw[4 * j + d] = r;                          // S = 1 segment: finalize's sum over segments is this value
-                }
-            __syncthreads();
+        // ---- per-cluster sums: the exact integer sums the E-step above added to accI (see the file header) ----
+        if (tid < 4 * k) {
+            const long long v = (long long)accI[tid];
+            Cw[tid] = (tid & 3) == 3 ? (double)v : (double)v * s_finv;
+            accI[tid] = 0ull;
         }
+        __threadfence_block();
+        __syncthreads();
         // ---- k_km_finalize ----
         const double* Cold = C2 + (size_t)cur * 3 * k;
         double* Cnew = C2 + (size_t)(cur ^ 1) * 3 * k;
@@ -678,27 +679,27 @@ static KmLayout km_layout(int64_t n, int k) {
     KmLayout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     L.xc = take(sizeof(double) * 3 * n); L.c2 = take(sizeof(double) * 6 * k); L.b = take(sizeof(double) * 4 * k);
-    L.cw = take(sizeof(double) * 4 * k); L.part = take(sizeof(double) * 4 * k * seg_count(n));
+    L.cw = take(sizeof(double) * 4 * k); L.part = take(sizeof(unsigned long long) * 4 * k);      // part: the int64 accumulators
     L.far = take(sizeof(double) * n); L.prev = take(sizeof(int) * n); L.lab2 = take(sizeof(int) * n);
     L.flags = take(sizeof(KmFlags)); L.total = o;
     return L;
 }
 
 static void launch_assign(const double* X, int n, const double* B, int k, int* labels, const int* prev,
-                          KmFlags* f, int use_mfma, hipStream_t s, int raw = 0) {
+                          KmFlags* f, int use_mfma, hipStream_t s, int raw = 0, unsigned long long* acc = nullptr) {
     if (use_mfma) {
         const int ntile = cdiv(n, 16);
         int blocks = cdiv(ntile, 4);
         if (blocks > 2048) blocks = 2048;                        // a wave then walks several point tiles with its centres in registers
-        const size_t smem = sizeof(double) * 5 * ((k + 15) & ~15);          // centre rows + the C-operand table
-        if (k <= 16) hipLaunchKernelGGL(k_km_assign_mfma<1>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw);
-        else if (k <= 32) hipLaunchKernelGGL(k_km_assign_mfma<2>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw);
-        else if (k <= 64) hipLaunchKernelGGL(k_km_assign_mfma<4>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw);
-        else if (k <= 128) hipLaunchKernelGGL(k_km_assign_mfma<8>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw);
-        else hipLaunchKernelGGL(k_km_assign_mfma<0>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw);
+        const size_t smem = sizeof(double) * 5 * ((k + 15) & ~15) + sizeof(unsigned long long) * 4 * k;   // centre rows + the C-operand table + M-step sums
+        if (k <= 16) hipLaunchKernelGGL(k_km_assign_mfma<1>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw, acc);
+        else if (k <= 32) hipLaunchKernelGGL(k_km_assign_mfma<2>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw, acc);
+        else if (k <= 64) hipLaunchKernelGGL(k_km_assign_mfma<4>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw, acc);
+        else if (k <= 128) hipLaunchKernelGGL(k_km_assign_mfma<8>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw, acc);
+        else hipLaunchKernelGGL(k_km_assign_mfma<0>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw, acc);
     }
     else
-        hipLaunchKernelGGL(k_km_assign, dim3(cdiv(n, 256)), dim3(256), sizeof(double) * 4 * k, s, X, n, B, k, labels, prev, f, raw);
+        hipLaunchKernelGGL(k_km_assign, dim3(cdiv(n, 256)), dim3(256), sizeof(double) * 8 * k, s, X, n, B, k, labels, prev, f, raw, acc);
 }
 
 }  // namespace creg
@@ -721,11 +722,12 @@ extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* i
     hipStream_t s = (hipStream_t)stream;
     char* w = (char*)workspace;
     double* Xc = (double*)(w + L.xc); double* C2 = (double*)(w + L.c2); double* B = (double*)(w + L.b);
-    double* Cw = (double*)(w + L.cw); double* part = (double*)(w + L.part); double* far_d = (double*)(w + L.far);
+    double* Cw = (double*)(w + L.cw); unsigned long long* acc = (unsigned long long*)(w + L.part); double* far_d = (double*)(w + L.far);
     int* lab[2] = {labels, (int*)(w + L.lab2)};
     int* prev0 = (int*)(w + L.prev);
     KmFlags* f = (KmFlags*)(w + L.flags);
-    const int S = seg_count(n), ni = (int)n;
+    const int ni = (int)n;
+    CREG_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * 4 * k, s));
 
     hipLaunchKernelGGL(k_km_stats, dim3(1), dim3(1024), 0, s, X, ni, tol_rel, f);
     hipLaunchKernelGGL(k_km_center, dim3(cdiv(n > k ? n : k, 256)), dim3(256), 0, s, X, ni, init, k, f, Xc, C2, B, prev0);
@@ -739,9 +741,8 @@ extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* i
         for (int b = 0; b < batch; ++b, ++it) {
             int* cur = lab[it & 1];
             const int* prev = it == 0 ? prev0 : lab[(it - 1) & 1];
-            launch_assign(Xc, ni, B, k, cur, prev, f, use_mfma, s);
-            hipLaunchKernelGGL(k_km_accumulate, dim3(k, S), dim3(256), 0, s, Xc, ni, cur, k, S, part, f);
-            hipLaunchKernelGGL(k_km_finalize, dim3(1), dim3(1024), 0, s, Xc, ni, cur, k, S, part, C2, B, Cw, far_d, f);
+            launch_assign(Xc, ni, B, k, cur, prev, f, use_mfma, s, 0, acc);
+            hipLaunchKernelGGL(k_km_finalize, dim3(1), dim3(1024), 0, s, Xc, ni, cur, k, acc, C2, B, Cw, far_d, f);
         }
         CREG_LAUNCH_CHECK();
         CREG_HIP(hipMemcpyAsync(&host, f, sizeof(KmFlags), hipMemcpyDeviceToHost, s));

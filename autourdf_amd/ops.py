@@ -342,6 +342,22 @@ def masked_icp(local: torch.Tensor, world: torch.Tensor, offsets: torch.Tensor, 
 ICP_BATCH_MAX = 16
 
 
+def aabb_mask(world: torch.Tensor, world_offsets: torch.Tensor, frame: torch.Tensor, scale: float = 1.2):
+    """Step 1 of masked_icp (cluster_icp.py:133-146): per cluster the scaled float32 box of its world points and the
+    frame points strictly inside it.  Returns (mask_idx (k, nf) int32 -- row c holds count[c] ascending indices --,
+    count (k) int32, boxes (k,6) fp32)."""
+    L = _lib.load()
+    world, frame = _need(world, torch.float32, "world"), _need(frame, torch.float64, "frame")
+    world_offsets = _need(world_offsets, torch.int32, "world_offsets")
+    k, nf = world_offsets.shape[0] - 1, frame.shape[0]
+    idx = torch.empty(k, nf, dtype=torch.int32, device=frame.device)
+    cnt = torch.empty(k, dtype=torch.int32, device=frame.device)
+    boxes = torch.empty(k, 6, dtype=torch.float32, device=frame.device)
+    _lib.check(L.creg_aabb_mask_f64(_p(world), _p(world_offsets), k, _p(frame), nf, float(scale), _p(idx), _p(cnt), _p(boxes),
+                                    _stream()), "creg_aabb_mask_f64")
+    return idx, cnt, boxes
+
+
 def masked_icp_batch(problems, scale: float = 1.2, th: float = 1.0, max_iteration: int = 10000, ori: bool = False):
     """`masked_icp` for a list of (local, world, offsets, frame, M[, world_offsets]) of identical sizes in ONE launch
     (grid clusters x problems); returns a list of (M_out, world_out, iterations), bit-identical to

@@ -161,6 +161,10 @@ int creg_quat_to_matrix_f32(const float* q, int32_t k, float* R, creg_stream_t s
  * whole sequence (mlp_reg.py:248, never reassigned), `clusters_world` the trained clouds of the current, re-sampled
  * one (mlp_reg.py:301-306,325), so cluster i has another point count in the two lists from frame 2 on.
  * M_out (k,4,4) fp64, world_out (n,3) fp64 = M_out applied to local.  keep_translation mirrors `ori`.
+ * Two regimes, same arithmetic: clusters a CU can hold (<= 1024 points on average, frames <= 65536 points) run the whole
+ * loop in ONE asynchronous launch; larger ones (BASELINE configs[4]: 2048-point clusters, 262144-point frames) run it
+ * iteration by iteration over many workgroups and synchronise the stream every 16 iterations to read the number of
+ * clusters still iterating.
  * workspace: creg_icp_workspace_bytes(n, nf, k). */
 size_t creg_icp_workspace_bytes(int64_t n, int64_t nf, int32_t k);
 int creg_masked_icp_f64(const double* local, const float* world, const int32_t* world_offsets, int64_t n,
@@ -187,6 +191,14 @@ size_t creg_icp_batch_workspace_bytes(int64_t n, int64_t nf, int32_t k, int32_t 
 int creg_masked_icp_batch_f64(const creg_icp_problem* problems, int32_t batch, int64_t n, int32_t k, int64_t nf,
                               double scale, double th, int32_t max_iteration, int32_t keep_translation,
                               void* workspace, size_t workspace_bytes, creg_stream_t stream);
+
+/* Step 1 of masked_icp on its own (cluster_icp.py:133-146): per cluster the float32 axis-aligned box of its predicted
+ * world points scaled about its centre, and the indices of the frame points strictly inside it, ascending.
+ * world fp32 clusters back to back with offsets world_offsets (k+1), frame (nf,3) fp64.  mask_idx (k, nf) int32: row c
+ * holds mask_count[c] indices; boxes (k,6) fp32 [lo xyz | hi xyz] or NULL.  The same kernel as the large-cluster regime
+ * of creg_masked_icp_f64 runs first. */
+int creg_aabb_mask_f64(const float* world, const int32_t* world_offsets, int32_t k, const double* frame, int64_t nf,
+                       double scale, int32_t* mask_idx, int32_t* mask_count, float* boxes, creg_stream_t stream);
 
 /* N3  plain point-to-point ICP of k independent (source, target) cloud pairs in one launch: the
  * registration_icp(source, target, threshold, init, TransformationEstimationPointToPoint,

@@ -198,10 +198,29 @@ def g_masked_icp():
     seq = make_sequence("wx200_5", seq=4, n_frames=2, n_points=768)
     mats, clusters, _ = initial_segmentation(seq[0], 6, seed=4)
     world = [(c @ M[:3, :3].T + M[:3, 3]).astype(np.float32) for c, M in zip(clusters, mats)]
-    w_np, new_m = ref_icp.masked_icp(clusters, world, seq[1], mats.astype(np.float32))
+    # G9: the exact AABB mask of every cluster.  masked_icp does not return it, so the targets it hands to
+    # registration_icp (cluster_icp.py:146-157: step_pc_np[mask]) are recorded on the way and mapped back to frame indices
+    import open3d as o3d_stub
+    seen = []
+    orig = o3d_stub.pipelines.registration.registration_icp
+
+    def spy(source, target, *a, **k):
+        seen.append(np.asarray(target.points).copy())
+        return orig(source, target, *a, **k)
+
+    o3d_stub.pipelines.registration.registration_icp = spy
+    try:
+        w_np, new_m = ref_icp.masked_icp(clusters, world, seq[1], mats.astype(np.float32))
+    finally:
+        o3d_stub.pipelines.registration.registration_icp = orig
+    key = {tuple(p): i for i, p in enumerate(seq[1])}
+    assert len(key) == len(seq[1])                           # no duplicate points: rows identify frame indices
+    masks = [np.array([key[tuple(p)] for p in t], np.int32) for t in seen]
+    assert all((np.diff(m) > 0).all() for m in masks if len(m) > 1)
     save("masked_icp_reference.npz", frame=seq[1], mats=mats.astype(np.float32),
          offsets=np.cumsum([0] + [len(c) for c in clusters]), local=np.concatenate(clusters),
-         world_pred=np.concatenate(world), new_mats=new_m, new_world=np.concatenate(w_np))
+         world_pred=np.concatenate(world), new_mats=new_m, new_world=np.concatenate(w_np),
+         mask_idx=np.concatenate(masks), mask_offsets=np.cumsum([0] + [len(m) for m in masks]).astype(np.int32))
 
 
 def g_kmeans():

@@ -263,6 +263,49 @@ def test_masked_icp_vs_reference_golden(dev, golden):
     np.testing.assert_allclose(np.concatenate(w), g["new_world"], atol=1e-8)
 
 
+def test_aabb_mask_indices_vs_reference_golden(dev, golden):
+    """G9: exact mask membership per cluster -- float32 box scaled about its centre, strict inequalities
+    (cluster_icp.py:133-146) -- against what the reference's masked_icp handed to registration_icp."""
+    from autourdf_amd import ops
+    g = golden("masked_icp_reference.npz")
+    off = torch.as_tensor(g["offsets"].astype(np.int32), device=dev)
+    idx, cnt, boxes = ops.aabb_mask(_cuda(g["world_pred"], dev), off, _cuda(g["frame"], dev))
+    cnt_h, idx_h = cnt.cpu().numpy(), idx.cpu().numpy()
+    np.testing.assert_array_equal(cnt_h, np.diff(g["mask_offsets"]))
+    for c in range(len(cnt_h)):
+        np.testing.assert_array_equal(idx_h[c, :cnt_h[c]], g["mask_idx"][g["mask_offsets"][c]:g["mask_offsets"][c + 1]])
+    w = _split(g["world_pred"], g["offsets"])
+    lo = np.array([x.min(0) for x in w]); hi = np.array([x.max(0) for x in w])
+    ctr, sz = (lo + hi) / np.float32(2), hi - lo
+    np.testing.assert_array_equal(boxes.cpu().numpy(), np.concatenate([ctr - np.float32(0.6) * sz, ctr + np.float32(0.6) * sz], 1))
+
+
+@pytest.mark.parametrize("from_pose", [False, True])
+def test_masked_icp_large_cluster_regime_vs_oracle(dev, from_pose):
+    """Clusters above the LDS source budget (the BASELINE configs[4] regime: 2048-point clusters) run the ICP iteration
+    by iteration over many workgroups; same poses / iteration counts as the oracle's open3d-style loop, and the same as the
+    single-launch kernel gives on the same problem cut into the small regime's limits."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    from oracle import icp as oicp
+    seq = make_sequence("wx200_5", 21, 2, 4600)
+    mats, clusters, _ = initial_segmentation(seq[0], 4, seed=1)          # ~1150 points per cluster > 1024
+    assert sum(len(c) for c in clusters) // 4 > 1024
+    local, off = ops.pack_clusters(clusters, dev, torch.float64)
+    M = _cuda(mats, dev)
+    frame = _cuda(seq[1], dev)
+    world32 = ops.cluster_transform(local.to(torch.float32), off, M.to(torch.float32))
+    if from_pose:
+        M_out, w_out, n_it = ops.masked_icp_batch([(local, None, off, frame, M)])[0]
+    else:
+        M_out, w_out, n_it = ops.masked_icp(local, world32, off, frame, M)
+    world_h = _split(world32.cpu().numpy(), off.cpu().numpy())
+    ow, om = oicp.masked_icp(clusters, world_h, seq[1], mats)
+    np.testing.assert_allclose(M_out.cpu().numpy(), om, atol=1e-8)
+    np.testing.assert_allclose(w_out.cpu().numpy(), np.concatenate(ow), atol=1e-8)
+    assert (n_it.cpu().numpy() >= 1).all()
+
+
 def test_icp_registrar_two_frames_vs_oracle(dev):
     """The ICP-style frame (K3 -> K4 -> K5 -> K2) device resident, against the oracle's composition
     of the same reference steps; labels bit-exact, poses far inside 1e-5."""

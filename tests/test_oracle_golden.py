@@ -273,3 +273,13 @@ def test_resample_rotated_poses_match_reference(golden, tag, dtype):
     np.testing.assert_allclose(np.concatenate(local), g[f"{tag}_local"], rtol=0, atol=2e-7 if dtype == np.float32 else 1e-12)
     # the float32 inverse is visible: the two goldens differ by more than the float64 tolerance
     assert np.abs(g["rot_local"] - g["rot64_local"]).max() > 1e-9
+
+
+def test_aabb_mask_indices_match_reference(golden):
+    """G9: the exact mask membership of every cluster (cluster_icp.py:133-146) as the reference's masked_icp handed it
+    to registration_icp."""
+    g = golden("masked_icp_reference.npz")
+    world = _split(g["world_pred"], g["offsets"])
+    for c, w in enumerate(world):
+        idx = np.nonzero(icp.aabb_mask(w, g["frame"], 1.2))[0]
+        np.testing.assert_array_equal(idx, g["mask_idx"][g["mask_offsets"][c]:g["mask_offsets"][c + 1]])
