@@ -407,9 +407,13 @@ struct KmBatch {
 };
 
 __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int max_iter, double tol_rel,
-                                                   char* __restrict__ ws, size_t ws_stride, int c_in_lds) {
+                                                   char* __restrict__ ws, size_t ws_stride, int c_in_lds, int x_in_lds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* Xc = (double*)smem;                               // [n][3] centred points
+    // x_in_lds: the centred frame lives in LDS (n <= 5120); else (n <= 16384: franka-sized frames) every use re-reads the
+    // frame from global memory -- it stays in this XCD's L2 for the whole launch -- and subtracts the mean on the fly (the
+    // same subtraction, the same bits), so those frames' k_means() is one asynchronous launch too
+    double* Xc = (double*)smem;                               // [n][3] centred points (x_in_lds)
+    const int nx = x_in_lds ? n : 0;
     __shared__ double sc[16];
     __shared__ double s_mean[3], s_tol;
     __shared__ unsigned long long accI[4 * 128];              // M-step sums: fixed-point x, y, z and the count per cluster (k <= 128)
@@ -424,12 +428,12 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
     // LDS: Xc [3n] | (-2c, |c|^2) rows [4k] | labels ping-pong as 16-bit values [2n] (k <= 128 here).  The
     // E-step reads every centre row and the accumulation sweeps read every label ceil(k/4) times per
     // iteration; from global memory each of those reads was a dependent round trip.
-    double* Bm = Xc + 3 * (size_t)n;
+    double* Bm = Xc + 3 * (size_t)nx;
     unsigned short* lab[2] = {(unsigned short*)(Bm + 4 * k), (unsigned short*)(Bm + 4 * k) + n};
     // centre ping-pong C2 [2][k][3] (+ spare) and per-cluster sums Cw [k][4]: in LDS when they fit next to the
     // frame (every Lloyd iteration reads and writes them several times between barriers -- from global memory
     // each of those was a dependent ~1 us round trip inside the workgroup), else in the global scratch
-    double* C2 = c_in_lds ? (double*)(smem + (((size_t)(3 * n + 4 * k) * 8 + 4 * (size_t)n + 7) & ~(size_t)7)) : (double*)w;
+    double* C2 = c_in_lds ? (double*)(smem + (((size_t)(3 * nx + 4 * k) * 8 + 4 * (size_t)n + 7) & ~(size_t)7)) : (double*)w;
     double* Cw = C2 + 10 * k;
     // ---- mean / tol (k_km_stats) ----
     double var = 0;
@@ -459,7 +463,9 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
         s_tol = (var / 3.0) * tol_rel; s_done = 0; s_strict = 0; s_it = 0; s_changed = 0;
     }
     // ---- centre (k_km_center) ----
-    for (int i = tid; i < 3 * n; i += 1024) Xc[i] = X[i] - s_mean[i % 3];
+    if (x_in_lds) for (int i = tid; i < 3 * n; i += 1024) Xc[i] = X[i] - s_mean[i % 3];
+    const double mean0 = s_mean[0], mean1 = s_mean[1], mean2 = s_mean[2];
+    auto xc = [&](int i, int d) -> double { return x_in_lds ? Xc[3 * i + d] : X[3 * (size_t)i + d] - (d == 0 ? mean0 : d == 1 ? mean1 : mean2); };
     for (int i = tid; i < n; i += 1024) lab[1][i] = 0xFFFF;    // iteration 0 compares against lab[1] = "no label"
     if (tid < k) {
         double c[3];
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
         // ---- E-step (k_km_assign) ----
         int diff = 0;
         for (int i = tid; i < n; i += 1024) {
-            const double x0 = Xc[3 * i], x1 = Xc[3 * i + 1], x2 = Xc[3 * i + 2];
+            const double x0 = xc(i, 0), x1 = xc(i, 1), x2 = xc(i, 2);
             double best = fma(x2, Bm[2], fma(x1, Bm[1], fma(x0, Bm[0], Bm[3])));
             int lb = 0;
             for (int j = 1; j < k; ++j) {
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
             double dmax = 0;
             for (int i = tid; i < n; i += 1024) {
                 const double* c = Cold + 3 * lcur[i];
-                const double a = Xc[3 * i] - c[0], b = Xc[3 * i + 1] - c[1], e = Xc[3 * i + 2] - c[2];
+                const double a = xc(i, 0) - c[0], b = xc(i, 1) - c[1], e = xc(i, 2) - c[2];
                 const double d = (a * a + b * b) + e * e;
                 far_d[i] = d;
                 dmax = fmax(dmax, d);
@@ -534,7 +540,7 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
                         for (int q = 0; q < 16; ++q) if (s_fv[q] > bv || (s_fv[q] == bv && s_fi[q] < bi)) { bv = s_fv[q]; bi = s_fi[q]; }
                         far_d[bi] = -2;
                         const int old = lcur[bi];
-                        for (int d = 0; d < 3; ++d) { Cw[4 * old + d] -= Xc[3 * bi + d]; Cw[4 * j + d] = Xc[3 * bi + d]; }
+                        for (int d = 0; d < 3; ++d) { Cw[4 * old + d] -= xc(bi, d); Cw[4 * j + d] = xc(bi, d); }
                         Cw[4 * j + 3] = 1.0; Cw[4 * old + 3] -= 1.0;
                     }
                     __threadfence_block();
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
     unsigned short* last = lab[(s_it - 1) & 1];
     if (!s_strict) {
         for (int i = tid; i < n; i += 1024) {
-            const double x0 = Xc[3 * i], x1 = Xc[3 * i + 1], x2 = Xc[3 * i + 2];
+            const double x0 = xc(i, 0), x1 = xc(i, 1), x2 = xc(i, 2);
             double best = fma(x2, Bm[2], fma(x1, Bm[1], fma(x0, Bm[0], Bm[3])));
             int lb = 0;
             for (int j = 1; j < k; ++j) {
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
     double s = 0;
     for (int i = tid; i < n; i += 1024) {
         const double* c = C + 3 * last[i];
-        const double a = Xc[3 * i] - c[0], b = Xc[3 * i + 1] - c[1], e = Xc[3 * i + 2] - c[2];
+        const double a = xc(i, 0) - c[0], b = xc(i, 1) - c[1], e = xc(i, 2) - c[2];
         s += (a * a + b * b) + e * e;
     }
     s = block_sum<double, 1024>(s, sc);
@@ -812,22 +818,23 @@ extern "C" int creg_kmeans_lloyd_batch_f64(const double* const* X, int64_t n, co
                                            void* workspace, size_t workspace_bytes, creg_stream_t stream) {
     CREG_REQUIRE(X && init && centers && labels && inertia && n_iter && workspace, "creg_kmeans_lloyd_batch_f64: null pointer");
     CREG_REQUIRE(batch >= 1 && batch <= KMS_MAXB, "creg_kmeans_lloyd_batch_f64: batch must be in [1, %d]", KMS_MAXB);
-    CREG_REQUIRE(n >= 1 && n <= 5120 && k >= 1 && k <= 128 && max_iter >= 1,
-                 "creg_kmeans_lloyd_batch_f64: needs n <= 5120 and k <= 128 (frame, centres and labels resident in LDS); use creg_kmeans_lloyd_f64 otherwise");
+    CREG_REQUIRE(n >= 1 && n <= 16384 && k >= 1 && k <= 128 && max_iter >= 1,
+                 "creg_kmeans_lloyd_batch_f64: needs n <= 16384 and k <= 128 (centres and labels resident in LDS; the frame too up to 5120 points); use creg_kmeans_lloyd_f64 otherwise");
     CREG_REQUIRE(workspace_bytes >= kms_stride(n, k) * (size_t)batch, "creg_kmeans_lloyd_batch_f64: workspace too small");
     KmBatch A;
     for (int b = 0; b < batch; ++b) {
         CREG_REQUIRE(X[b] && init[b] && centers[b] && labels[b] && inertia[b] && n_iter[b], "creg_kmeans_lloyd_batch_f64: null pointer in problem %d", b);
         A.X[b] = X[b]; A.init[b] = init[b]; A.centers[b] = centers[b]; A.labels[b] = labels[b]; A.inertia[b] = inertia[b]; A.n_iter[b] = n_iter[b];
     }
-    int smem = (int)(sizeof(double) * (3 * n + 4 * k) + 2 * sizeof(unsigned short) * n);
+    const int x_in_lds = n <= 5120;
+    int smem = (int)(sizeof(double) * ((x_in_lds ? 3 * n : 0) + 4 * k) + 2 * sizeof(unsigned short) * n);
     const int with_c = ((smem + 7) & ~7) + (int)sizeof(double) * 14 * k;
     const int c_in_lds = with_c <= 5120 * 28 + 128 * 32;           // the limit requested from the runtime below
     if (c_in_lds) smem = with_c;
     // per device, not per process: set on every call (a cached flag would leave a second GPU at the 64 KB default)
     CREG_HIP(hipFuncSetAttribute((const void*)k_km_small, hipFuncAttributeMaxDynamicSharedMemorySize, 5120 * 28 + 128 * 32));
     hipLaunchKernelGGL(k_km_small, dim3(batch), dim3(1024), smem, (hipStream_t)stream, A, (int)n, k, max_iter, tol_rel,
-                       (char*)workspace, kms_stride(n, k), c_in_lds);
+                       (char*)workspace, kms_stride(n, k), c_in_lds, x_in_lds);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }

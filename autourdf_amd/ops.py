@@ -136,12 +136,12 @@ def kmeans_lloyd(X: torch.Tensor, init: torch.Tensor, max_iter: int = 300, tol: 
     return centers, labels, inertia, n_iter
 
 
-KMEANS_BATCH_MAX_N = 5120          # frame (24 B/pt) + two 16-bit label arrays must fit one CU's LDS
+KMEANS_BATCH_MAX_N = 16384         # labels + centres in one CU's LDS; the frame too up to 5120 points, from L2 above
 
 
 def kmeans_lloyd_batch(Xs, inits, max_iter: int = 300, tol: float = 1e-4):
     """k_means() for a list of same-sized frames in ONE asynchronous launch (one workgroup per frame,
-    n <= 5120).  Returns a list of (centers, labels, inertia, n_iter) like `kmeans_lloyd`."""
+    n <= 16384).  Returns a list of (centers, labels, inertia, n_iter) like `kmeans_lloyd`."""
     L = _lib.load()
     Xs = [_need(x, torch.float64, "X") for x in Xs]
     inits = [_need(c, torch.float64, "init") for c in inits]

@@ -94,7 +94,8 @@ int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* init, int32_
                           double* centers, int32_t* labels, double* inertia, int32_t* n_iter,
                           void* workspace, size_t workspace_bytes, creg_stream_t stream);
 /* The same k_means() for `batch` (<= 16) independent frames of identical size in ONE launch, one
- * workgroup per frame, the centred frame, centres and labels resident in LDS (n <= 5120, k <= 128), fully asynchronous (no host
+ * workgroup per frame, centres and labels resident in LDS (n <= 16384, k <= 128; the centred frame too up to 5120 points, read from
+ * L2 above that), fully asynchronous (no host
  * synchronisation at all).  Bit-identical to creg_kmeans_lloyd_f64.  X, init, centers, labels, inertia,
  * n_iter are HOST arrays of `batch` device pointers. */
 size_t creg_kmeans_batch_workspace_bytes(int64_t n, int32_t k, int32_t batch);

@@ -767,6 +767,30 @@ def test_kmeans_batch_single_launch_bit_identical_to_multi_launch(dev, golden):
     np.testing.assert_array_equal(o2[1][1].cpu().numpy(), g["small_labels"])
 
 
+def test_kmeans_batch_franka_sized_frames_from_l2(dev):
+    """Frames above the LDS budget (5120 < n <= 16384: BASELINE configs[2], N=16384, K=40) take the same one-launch
+    path with the frame read from L2: identical to the multi-launch path (which syncs with the host) and to the
+    oracle's labels, incl. a forced empty cluster."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    from oracle import kmeans as okm
+    Xs, inits, hosts = [], [], []
+    for s in range(2):
+        seq = make_sequence("franka", 50 + s, 2, 16384 if s == 0 else 9000)
+        mats, _, _ = initial_segmentation(seq[0], 40, seed=s, iters=3)
+        c0 = mats[:, :3, 3].copy()
+        if s == 1:
+            c0[5] = [7.0, 7.0, 7.0]                               # forces an empty cluster
+        Xs.append(_cuda(seq[1], dev)); inits.append(_cuda(c0, dev)); hosts.append((seq[1], c0))
+    for X, c0, (Xh, ch) in zip(Xs, inits, hosts):
+        o = ops.kmeans_lloyd_batch([X, X], [c0, c0])
+        c, lab, inertia, n_iter = ops.kmeans_lloyd(X, c0)
+        for b in range(2):
+            assert torch.equal(o[b][1], lab) and torch.equal(o[b][0], c) and torch.equal(o[b][2], inertia) and torch.equal(o[b][3], n_iter)
+        _, olab, _, _ = okm.k_means(Xh, ch)
+        np.testing.assert_array_equal(lab.cpu().numpy(), olab)
+
+
 # ------------------------------------------------------------------------------------------ full-size properties
 def test_full_size_c5_nn_and_kmeans_properties(dev):
     """BASELINE configs[4] sizes (N=262144, K=128): too big for the CPU oracle end to end, so
