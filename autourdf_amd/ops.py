@@ -275,6 +275,24 @@ def sample_mesh(tri, cum_area, tri_link, link_T, u, with_links: bool = False):
     return (out, links) if with_links else out
 
 
+def visibility(tri, tri_link, link_T, cams, pts, fov_deg=60.0, aspect=1.0, near=0.1, far=4.0, width=800, height=800,
+               eps=0.004, return_depth=False):
+    """Camera-ring visibility (creg_visibility_f64): tri (F,3,3) f64 link-frame triangles, tri_link (F) i32, link_T (L,4,4)
+    f64, cams (C,12) f64 = eye | forward | right | up, pts (n,3) f64 world points -> (n) bool tensor (and the (C,H,W) f64
+    depth buffers when return_depth)."""
+    L = _lib.load()
+    tri, link_T, cams, pts = (_need(t, torch.float64, nm) for t, nm in ((tri, "tri"), (link_T, "link_T"), (cams, "cams"), (pts, "pts")))
+    tri_link = _need(tri_link, torch.int32, "tri_link")
+    C, n = cams.shape[0], pts.shape[0]
+    ws_bytes = L.creg_visibility_workspace_bytes(C, width, height)
+    ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=pts.device)
+    vis = torch.empty(n, dtype=torch.uint8, device=pts.device)
+    _lib.check(L.creg_visibility_f64(_p(tri), _p(tri_link), tri.shape[0], _p(link_T), link_T.shape[0], _p(cams), C, float(fov_deg),
+                                     float(aspect), float(near), float(far), int(width), int(height), _p(pts), n, float(eps), _p(vis),
+                                     _p(ws), ws_bytes, _stream()), "creg_visibility_f64")
+    return (vis.bool(), ws.reshape(C, height, width)) if return_depth else vis.bool()
+
+
 # ------------------------------------------------------------------------------ N2 pose distance maps
 def coord_dist_map(M: torch.Tensor, bounding_box: float, diff: bool = True):
     """CoordMap.coord_dist_map (coord_map.py:230-307) for poses M (T,K,4,4) f64 on the device:

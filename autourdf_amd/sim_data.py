@@ -87,14 +87,125 @@ def _load_obj(path):
     return v[np.asarray(tris, np.int64)] if tris else np.zeros((0, 3, 3))
 
 
+def _dae_node_matrix(node, ns):
+    """Local transform of a COLLADA <node>: its <matrix> / <translate> / <rotate> / <scale> children composed in
+    document order (COLLADA 1.4.1, 5.5 'node': post-multiplied in the order listed)."""
+    M = np.eye(4)
+    for ch in node:
+        tag = ch.tag[len(ns):] if ch.tag.startswith(ns) else ch.tag
+        if tag not in ("matrix", "translate", "rotate", "scale") or ch.text is None:
+            continue
+        v = [float(x) for x in ch.text.split()]
+        T = np.eye(4)
+        if tag == "matrix":
+            T = np.asarray(v, np.float64).reshape(4, 4)          # row-major in the document
+        elif tag == "translate":
+            T[:3, 3] = v[:3]
+        elif tag == "scale":
+            T[0, 0], T[1, 1], T[2, 2] = v[:3]
+        else:                                                    # rotate: axis x y z, angle in degrees
+            T[:3, :3] = _axis_angle(v[:3], np.deg2rad(v[3])) if np.linalg.norm(v[:3]) > 0 else np.eye(3)
+        M = M @ T
+    return M
+
+
+def _load_dae(path):
+    """Triangles of a COLLADA 1.4 document: every <instance_geometry> of the visual scene with its node transforms,
+    <triangles> / <polylist> / <polygons> primitives (polygons fan-triangulated), the asset's unit (metres per unit) and
+    up axis applied the way PyBullet's URDF importer does (Y_UP -> +90 degrees about x, X_UP -> -90 degrees about y;
+    Bullet LoadMeshFromCollada.cpp).  Materials, normals and texture coordinates are not needed for surface sampling."""
+    root = ET.parse(path).getroot()
+    ns = root.tag[: root.tag.index("}") + 1] if root.tag.startswith("{") else ""
+    f = lambda e, q: e.find(q.replace("c:", ns))
+    fa = lambda e, q: e.findall(q.replace("c:", ns))
+    unit, up = 1.0, "Y_UP"                                       # COLLADA's defaults
+    asset = f(root, "c:asset")
+    if asset is not None:
+        u = f(asset, "c:unit")
+        if u is not None and u.get("meter"):
+            unit = float(u.get("meter"))
+        a = f(asset, "c:up_axis")
+        if a is not None and a.text:
+            up = a.text.strip()
+    geoms = {}
+    for g in fa(root, "c:library_geometries/c:geometry"):
+        mesh = f(g, "c:mesh")
+        if mesh is None:
+            continue
+        sources = {}
+        for src in fa(mesh, "c:source"):
+            fa_ = f(src, "c:float_array")
+            acc = f(src, "c:technique_common/c:accessor")
+            if fa_ is None or fa_.text is None:
+                continue
+            stride = int(acc.get("stride", "3")) if acc is not None else 3
+            sources["#" + src.get("id")] = np.asarray(fa_.text.split(), np.float64).reshape(-1, stride)
+        verts = {}
+        for v in fa(mesh, "c:vertices"):
+            for inp in fa(v, "c:input"):
+                if inp.get("semantic") == "POSITION":
+                    verts["#" + v.get("id")] = sources[inp.get("source")]
+        tris = []
+        for prim in list(fa(mesh, "c:triangles")) + list(fa(mesh, "c:polylist")) + list(fa(mesh, "c:polygons")):
+            inputs = fa(prim, "c:input")
+            stride = max(int(i.get("offset", "0")) for i in inputs) + 1
+            vin = next(i for i in inputs if i.get("semantic") == "VERTEX")
+            pos, voff = verts[vin.get("source")][:, :3], int(vin.get("offset", "0"))
+            kind = prim.tag[len(ns):]
+            plists = [np.asarray(p_.text.split(), np.int64) for p_ in fa(prim, "c:p") if p_.text]
+            if kind == "triangles":
+                idx = np.concatenate(plists)[voff::stride] if plists else np.zeros(0, np.int64)
+                tris.append(pos[idx].reshape(-1, 3, 3))
+            else:
+                if kind == "polylist":
+                    counts = np.asarray(f(prim, "c:vcount").text.split(), np.int64)
+                    idx = plists[0][voff::stride]
+                    polys, at = [], 0
+                    for c in counts:
+                        polys.append(idx[at:at + c]); at += c
+                else:
+                    polys = [pl[voff::stride] for pl in plists]
+                for poly in polys:
+                    for a in range(1, len(poly) - 1):
+                        tris.append(pos[[poly[0], poly[a], poly[a + 1]]][None])
+        geoms["#" + g.get("id")] = np.concatenate(tris) if tris else np.zeros((0, 3, 3))
+    out = []
+
+    def walk(node, M):
+        M = M @ _dae_node_matrix(node, ns)
+        for ig in fa(node, "c:instance_geometry"):
+            t = geoms.get(ig.get("url"))
+            if t is not None and len(t):
+                out.append(t @ M[:3, :3].T + M[:3, 3])
+        for ch in fa(node, "c:node"):
+            walk(ch, M)
+
+    scenes = fa(root, "c:library_visual_scenes/c:visual_scene")
+    for sc in scenes:
+        for node in fa(sc, "c:node"):
+            walk(node, np.eye(4))
+    if not out:                                                  # no scene graph: every geometry as it stands
+        out = [t for t in geoms.values() if len(t)]
+    if not out:
+        raise IOError(f"{path}: no triangle geometry found")
+    tri = np.concatenate(out) * unit
+    if up == "Y_UP":
+        tri = tri @ np.array([[1.0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]]).T      # (x, y, z) -> (x, -z, y)
+    elif up == "X_UP":
+        tri = tri @ np.array([[0, 0, -1.0], [0, 1.0, 0], [1.0, 0, 0]]).T     # (x, y, z) -> (-z, y, x)
+    return tri
+
+
 def load_mesh(path):
-    """(F,3,3) float64 triangles of an STL or OBJ file."""
+    """(F,3,3) float64 triangles of an STL, OBJ or COLLADA (.dae) file."""
     ext = os.path.splitext(path)[1].lower()
     if ext == ".stl":
         return _load_stl(path)
     if ext == ".obj":
         return _load_obj(path)
-    raise NotImplementedError(f"{path}: only STL and OBJ visuals are supported (COLLADA needs a scene-graph reader)")
+    if ext == ".dae":
+        return _load_dae(path)
+    raise NotImplementedError(f"{path}: only STL, OBJ and COLLADA visuals are supported")
 
 
 def _primitive(geom):
@@ -270,6 +381,47 @@ class SimEnv:
         self.dof_list = self.joint_list[:dof]
         self.joint_limits = np.array([self.joint_params[j] for j in self.dof_list])
         self._dev = None
+        self._setup_cameras(radius, num_cameras)
+
+    def _setup_cameras(self, radius, num_cameras=20, cam_angle=20):
+        """The reference's camera ring (sim_data.py:88-116): fewer than 20 cameras evenly on a circle at `cam_angle` degrees
+        elevation; 20 or more drawn from numpy's GLOBAL RandomState like the reference (uniform azimuth, elevation in
+        [0, pi/2)); all on a sphere of `radius` looking at the origin, +z up, fov 60, aspect 1, near 0.1, far 4.
+        `self.cameras` keeps the reference's dict list; `self.cam_frames` (C,12) = eye | forward | right | up."""
+        if num_cameras < 20:
+            theta = np.linspace(0, 2 * np.pi, num_cameras, endpoint=False)
+            phi = np.pi * np.array([cam_angle] * num_cameras) / 180
+        else:
+            theta = np.random.rand(num_cameras) * 2 * np.pi
+            phi = np.random.rand(num_cameras) * np.pi / 2
+        xs, ys, zs = radius * np.cos(theta) * np.cos(phi), radius * np.sin(theta) * np.cos(phi), radius * np.sin(phi)
+        self.cameras = [{'camera_pos': [x, y, z], 'target_pos': [0, 0, 0], 'up_vector': [0, 0, 1], 'fov': 60, 'aspect': 1.0,
+                         'near_val': 0.1, 'far_val': 4} for x, y, z in zip(xs, ys, zs)]
+        frames = []
+        for c in self.cameras:
+            e = np.asarray(c['camera_pos'], np.float64)
+            f = (np.asarray(c['target_pos'], np.float64) - e)
+            f = f / np.linalg.norm(f)
+            s_ = np.cross(f, np.asarray(c['up_vector'], np.float64))
+            s_ = s_ / np.linalg.norm(s_)
+            frames.append(np.concatenate([e, f, s_, np.cross(s_, f)]))
+        self.cam_frames = np.asarray(frames)
+
+    def visible(self, joint_positions, pts, width=800, height=800, eps=0.004):
+        """Which of `pts` (n,3 world points, device tensor) some camera of the ring sees (creg_visibility_f64)."""
+        tri, _, own = self._device_mesh()
+        T = torch.as_tensor(self.robot.fk(joint_positions, self.base), device=tri.device)
+        cams = torch.as_tensor(self.cam_frames, device=tri.device)
+        c = self.cameras[0]
+        return ops.visibility(tri, own, T, cams, pts, c['fov'], c['aspect'], c['near_val'], c['far_val'], width, height, eps)
+
+    def _device_mesh(self):
+        if self._dev is None:
+            d = torch.device("cuda")
+            r = self.robot
+            self._dev = (torch.as_tensor(r.tri, device=d).contiguous(), torch.as_tensor(r.cum_area, device=d),
+                         torch.as_tensor(r.tri_link, device=d))
+        return self._dev
 
     def set_joint_positions(self, commands, manual_positions=0):
         """Joint name -> position: commanded for the driven joints, mid range (+ manual offset) for the others.
@@ -282,12 +434,7 @@ class SimEnv:
 
     def sample_surface(self, joint_positions, n, rng):
         """n area-weighted surface points of the posed robot, on the GPU (creg_sample_mesh_f64)."""
-        if self._dev is None:
-            d = torch.device("cuda")
-            r = self.robot
-            self._dev = (torch.as_tensor(r.tri, device=d).contiguous(), torch.as_tensor(r.cum_area, device=d),
-                         torch.as_tensor(r.tri_link, device=d))
-        tri, cum, own = self._dev
+        tri, cum, own = self._device_mesh()
         T = torch.as_tensor(self.robot.fk(joint_positions, self.base), device=tri.device)
         u = torch.as_tensor(rng.random((n, 3)), device=tri.device)
         return ops.sample_mesh(tri, cum, own, T, u)
@@ -313,10 +460,12 @@ def save_step_data(step_id, combined_pcds, joint_positions, data_path, dof_list)
 
 
 def data_collection(env, data_path=None, width=800, height=800, visualize=False, angle_list=None, ground_flag=False,
-                    noise_flag=False, num_points=5000, collision_flag=False, oversample=4, seed=0):
-    """One sequence: for every row of ``angle_list`` pose the robot, sample ``oversample * num_points`` surface
-    points, add the reference's noise (translation N(0, 0.01) per frame and N(0, 0.0005) per point, not on the
-    first frame; sim_data.py:333-343), farthest-point down-sample to ``num_points`` (:346,349) and save.
+                    noise_flag=False, num_points=5000, collision_flag=False, oversample=4, seed=0, occlusion=True):
+    """One sequence: for every row of ``angle_list`` pose the robot, sample surface points, keep those that at least one
+    camera of the ring sees (``occlusion``: depth buffers of ``width`` x ``height`` like the reference's rendered images,
+    sim_data.py:286-306; more samples are drawn until ``oversample * num_points`` visible ones exist), add the
+    reference's noise (translation N(0, 0.01) per frame and N(0, 0.0005) per point, not on the first frame;
+    sim_data.py:333-343), farthest-point down-sample to ``num_points`` (:346,349) and save.
     Returns (collision=False, list of PointCloud) like the reference (self-collision checking is PyBullet's)."""
     if visualize:
         raise NotImplementedError("visualize=True needs Open3D's viewer (out of scope)")
@@ -324,7 +473,18 @@ def data_collection(env, data_path=None, width=800, height=800, visualize=False,
     noise, record = [], []
     for jp_id, cmd in enumerate(np.asarray(angle_list)):
         q = env.set_joint_positions(cmd)
-        pts = env.sample_surface(q, oversample * num_points, rng)
+        want = oversample * num_points
+        pts = env.sample_surface(q, want, rng)
+        if occlusion:
+            kept = pts[env.visible(q, pts, width, height)]
+            draws = 1
+            while kept.shape[0] < want and draws < 16:            # interior / hidden surfaces: draw until enough are visible
+                more = env.sample_surface(q, want, rng)
+                kept = torch.cat([kept, more[env.visible(q, more, width, height)]])
+                draws += 1
+            if kept.shape[0] < num_points:
+                raise RuntimeError(f"only {kept.shape[0]} of the sampled surface points are visible from the camera ring")
+            pts = kept[:max(want, num_points)] if kept.shape[0] >= want else kept
         if noise_flag and jp_id != 0:
             pos_noise = rng.normal(0, 0.01, size=3)
             noise.append(pos_noise)
@@ -350,8 +510,9 @@ def collect(robot, robot_params, num_step=10, step_size=4, epochs=5, scale=0.9, 
     for seed in range(epochs):
         data_path = os.path.join(root, f"data/raw/{robot}/{step_size}_deg_{num_cameras}_cams/V{seed:04}/")
         os.makedirs(data_path, exist_ok=True)
+        np.random.seed(seed)                                       # the ring of >= 20 cameras draws from the global state
         env = SimEnv(os.path.join(root, robot_params["gt"]), base_orientation=robot_params.get("sim_ori", [0, 0, 0]),
-                     dof=robot_params["dof"])
+                     dof=robot_params["dof"], radius=robot_params.get("cam_dist", 1.5), num_cameras=num_cameras)
         a_list = angle_list(num_step, step_size, robot_params["dof"], env.joint_limits, np.array([scale] * robot_params["dof"]), seed)
         data_collection(env, data_path=data_path, angle_list=a_list, noise_flag=noise, num_points=num_points, seed=seed)
         env.reset()

@@ -239,6 +239,18 @@ int creg_sample_mesh_f64(const double* tri, const double* cum_area, const int32_
                          const double* link_T, int32_t n_links, const double* u, int64_t n, double* out,
                          int32_t* link_out, creg_stream_t stream);
 
+/* Camera-ring visibility of sampled surface points: what the reference's rendered depth cameras impose on its frames
+ * (Sim/sim_data.py:88-116 camera ring, :246-306 depth images -> point clouds).  The posed triangles are rasterised into one
+ * fp64 depth buffer per camera (width x height, pinhole, vertical fov `fov_deg`, linear depth along the view axis, minimum at
+ * the pixel centres); visible[i] = 1 when point i projects into some camera's image between near and far and lies no more
+ * than `eps` behind that camera's buffer at its pixel.  cams (n_cams,12) fp64 = eye | forward | right | up.
+ * workspace: creg_visibility_workspace_bytes(n_cams, width, height) (the depth buffers). */
+size_t creg_visibility_workspace_bytes(int32_t n_cams, int32_t width, int32_t height);
+int creg_visibility_f64(const double* tri, const int32_t* tri_link, int32_t n_tri, const double* link_T, int32_t n_links,
+                        const double* cams, int32_t n_cams, double fov_deg, double aspect, double near_val, double far_val,
+                        int32_t width, int32_t height, const double* pts, int64_t n, double eps, uint8_t* visible,
+                        void* workspace, size_t workspace_bytes, creg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * A1  the whole `train` loop (mlp_reg.py:17-152) as one device-resident plan: per epoch
  * pose -> sin/cos features -> MLP -> pose -> calculate_pc -> L1 Chamfer -> backward -> Adam ->

@@ -89,3 +89,48 @@ def test_collect_layout_and_registration_smoke(tmp_path):
     reg = IcpRegistrar(np.array(seg.init_matrix_list), seg.init_segment_list, "cuda")
     M, dq, n_it = reg.step(torch.as_tensor(np.asarray(seg.pc_list[1].points), device="cuda"))
     assert torch.isfinite(M).all() and torch.isfinite(dq).all() and (n_it >= 1).all()
+
+
+def test_camera_visibility_depth_buffers_bit_exact_vs_oracle(tmp_path):
+    """creg_visibility_f64: per-camera fp64 depth buffers of the posed triangles and the visibility flags of sampled
+    surface points against the numpy restatement (same operation order: identical buffers); and the geometry of it --
+    every camera sees something, hidden faces exist, and a point survives exactly when some camera's buffer says so."""
+    from autourdf_amd import ops
+    from autourdf_amd.sim_data import SimEnv
+    from oracle import sim_data as osim
+    path, _, _ = write_toy_robot(str(tmp_path))
+    env = SimEnv(path, dof=3, radius=1.2, num_cameras=3)
+    q = env.set_joint_positions([0.4, -0.6, 0.9])
+    rng = np.random.default_rng(2)
+    pts = env.sample_surface(q, 6000, rng)
+    dev = pts.device
+    r = env.robot
+    T = env.robot.fk(q, env.base)
+    vis, depth = ops.visibility(torch.as_tensor(r.tri, device=dev), torch.as_tensor(r.tri_link, device=dev), torch.as_tensor(T, device=dev),
+                                torch.as_tensor(env.cam_frames, device=dev), pts, width=96, height=96, eps=0.004, return_depth=True)
+    ovis, odepth = osim.visibility(r.tri, r.tri_link, T, env.cam_frames, pts.cpu().numpy(), width=96, height=96, eps=0.004)
+    np.testing.assert_array_equal(depth.cpu().numpy(), odepth)
+    np.testing.assert_array_equal(vis.cpu().numpy(), ovis)
+    finite = np.isfinite(odepth)
+    assert finite.reshape(3, -1).any(1).all() and (odepth[finite] > 0.8).all() and (odepth[finite] < 1.6).all()
+    frac = ovis.mean()
+    assert 0.5 < frac < 0.98                                        # the base plate's underside and inner faces are hidden
+    # the underside of the base box (z = 0 in the base frame) cannot be seen from cameras above the ground plane -- away
+    # from its rim, where a point is less than eps behind the side face a camera does see
+    ph = pts.cpu().numpy()
+    under = np.isclose(ph[:, 2], 0.0, atol=1e-12) & (np.abs(ph[:, 0]) < 0.08) & (np.abs(ph[:, 1]) < 0.08)
+    assert under.sum() > 50 and not ovis[under].any()
+
+
+def test_data_collection_with_occlusion_keeps_only_visible_surface(tmp_path):
+    from autourdf_amd.sim_data import SimEnv, angle_list, data_collection
+    path, _, _ = write_toy_robot(str(tmp_path / "robot"))
+    env = SimEnv(path, dof=3, radius=1.2, num_cameras=4)
+    a = angle_list(2, 4, 3, env.joint_limits, np.array([0.9] * 3), seed_i=0)
+    _, rec_occ = data_collection(env, angle_list=a, noise_flag=False, num_points=500, seed=1, width=200, height=200)
+    _, rec_all = data_collection(env, angle_list=a, noise_flag=False, num_points=500, seed=1, occlusion=False)
+    assert all(len(c.points) == 500 for c in rec_occ)
+    # no point of the occluded frames lies on the underside of the base plate (away from its rim); the unculled ones do
+    inner = lambda c: np.isclose(np.asarray(c.points)[:, 2], 0.0, atol=1e-9) & (np.abs(np.asarray(c.points)[:, :2]) < 0.08).all(1)
+    assert not inner(rec_occ[0]).any()
+    assert inner(rec_all[0]).any()
