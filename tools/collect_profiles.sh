@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repository root: bench lines + rocprofv3 evidence into gpurun_out/final/.
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh'
-# then here:  python tools/summarize_profiles.py gpurun_out/final r01
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
+# then here:  python tools/summarize_profiles.py gpurun_out/final r02
 set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
@@ -12,12 +12,17 @@ python $R/bench.py --sequences 1 --steps 8 --warmup 2 --no-cpu-baseline --no-icp
 python $R/bench.py --sequences 8 --steps 40 --warmup 8 --no-cpu-baseline --no-icp-variant > $O/bench_b8.log 2>/dev/null
 python $R/bench.py --workload franka --steps 10 --warmup 5 --no-cpu-baseline --no-icp-variant > $O/bench_franka.log 2>/dev/null
 python $R/bench.py --workload allegro --steps 20 --warmup 5 --no-cpu-baseline --no-icp-variant > $O/bench_allegro.log 2>/dev/null
-CMD="python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-icp-variant"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -o r01 -- $CMD > $O/prof_run.log 2>&1
+# BASELINE configs[3] / [4] in replay (independent-frame) mode, one GPU: the items an 8-GPU job would deal out
+python $R/bench.py --mode replay --workload allegro --steps 50 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_replay_allegro.log 2>/dev/null
+python $R/bench.py --workload c5 --steps 12 --warmup 2 > $O/bench_c5.log 2>/dev/null
+python $R/tests/measure/bench_c5_resegment.py > $O/c5_resegment.log 2>/dev/null
+CMD="python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o r02 -- $CMD > $O/prof_run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o c5 -- python $R/bench.py --workload c5 --steps 4 --warmup 1 > $O/prof_c5.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O -o pmc_$c -- python $R/bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-icp-variant > $O/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O -o pmc_$c -- python $R/bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline > $O/pmc_$c.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O -o pmc_sq -- python $R/bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-icp-variant > $O/pmc_sq.log 2>&1
-rm -f $O/*_kernel_trace.csv.bak
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O -o pmc_sq -- python $R/bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline > $O/pmc_sq.log 2>&1
+rm -f $O/*_kernel_trace.csv $O/*_agent_info.csv $O/*_domain_stats.csv
 ls -la $O | head -40
 tail -c 600 $O/bench.log

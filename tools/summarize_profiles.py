@@ -1,6 +1,6 @@
 """Turn the rocprofv3 outputs of a gpurun (gpurun_out/final/) into the tracked summaries under profiles/.
 
-    python tools/summarize_profiles.py gpurun_out/final r01
+    python tools/summarize_profiles.py gpurun_out/final r02
 """
 import collections
 import csv
@@ -24,7 +24,7 @@ def main(src, tag):
     w = agg(f"{src}/pmc_WRITE_SIZE_counter_collection.csv")
     sq = agg(f"{src}/pmc_sq_counter_collection.csv")
     lines, out = [], {}
-    for k in ["k_l2<8>", "k_head<8>", "k_nn_plan", "k_gradc", "k_bwd2<8, 48>", "k_dw<8>", "k_km_small", "k_sort_y", "k_sort_p"]:
+    for k in ["k_l2<8>", "k_head<8>", "k_nn_plan", "k_gradc", "k_bwd2<8, 48>", "k_dw<8>", "k_km_small", "k_sort_y", "k_sort_p", "k_masked_icp"]:
         if k not in f:
             continue
         fs = sum(f[k]["FETCH_SIZE"]) / len(f[k]["FETCH_SIZE"])
@@ -43,18 +43,31 @@ def main(src, tag):
               "double it for the dwordx4 / LDS-DMA streams (k_nn_plan block reads, k_dw, k_l2 staging); dword-wide reads are uncorrected.\n")
     open(f"profiles/{tag}_pmc_summary.txt", "w").write(header + "\n".join(lines) + "\n")
     fs, ws = out["k_nn_plan"]
-    json.dump({"kernel": "k_nn_plan<true>", "problems_per_launch_avg": 2.5, "FETCH_SIZE_KB": fs, "WRITE_SIZE_KB": ws,
-               "hbm_bytes_per_launch_avg": (2 * fs + ws) * 1024, "hbm_bytes_per_problem": (2 * fs + ws) * 1024 / 2.5,
-               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 5 --warmup 5 --no-cpu-baseline), "
-                         "averaged over all launches of the kernel; FETCH_SIZE doubled per MI355X_MICROARCH.md (the block reads are 16 B/lane coalesced), "
-                         "WRITE_SIZE uncorrected",
-               "algorithmic_bytes_per_problem": 2 * 16 * 4096 + 16 * 4096 + 4 * 4096}, open(f"profiles/{tag}_nn_l1_pmc.json", "w"), indent=1)
-    shutil.copy(f"{src}/r01_kernel_stats.csv", f"profiles/{tag}_final_kernel_stats.csv")
+    dfs, dws = out["k_dw<8>"]
+    nnm = {c: sum(v) / len(v) for c, v in sq["k_nn_plan"].items()}
+    dwm = {c: sum(v) / len(v) for c, v in sq["k_dw<8>"].items()}
+    n_params = 425991
+    json.dump({"source": f"rocprofv3 --kernel-trace --pmc, separate passes for FETCH_SIZE / WRITE_SIZE / the SQ set, `bench.py --steps 5 --warmup 5 "
+                         "--no-cpu-baseline --no-icp-variant --no-roofline` (tools/collect_profiles.sh); averages over all launches of a kernel, which carry "
+                         "3 or 2 problems (2.5 on average); FETCH_SIZE doubled per MI355X_MICROARCH.md for the 16 B/lane coalesced streams, WRITE_SIZE raw",
+               "problems_per_launch_avg": 2.5,
+               "k_nn_FETCH_SIZE_KB": fs, "k_nn_WRITE_SIZE_KB": ws, "k_nn_hbm_bytes_per_problem": (2 * fs + ws) * 1024 / 2.5,
+               "k_nn_algorithmic_bytes_per_problem": 2 * 16 * 4096 + 16 * 4096 + 4 * 4096,
+               "k_nn_valu_active_frac": nnm["SQ_ACTIVE_INST_VALU"] / nnm["SQ_WAVE_CYCLES"],
+               "k_nn_wait_any_frac": nnm["SQ_WAIT_ANY"] / nnm["SQ_WAVE_CYCLES"],
+               "k_dw_FETCH_SIZE_KB": dfs, "k_dw_WRITE_SIZE_KB": dws, "k_dw_hbm_bytes_per_problem": (2 * dfs + dws) * 1024 / 2.5,
+               "k_dw_algorithmic_bytes_per_problem": 24 * n_params,
+               "k_dw_valu_active_frac": dwm["SQ_ACTIVE_INST_VALU"] / dwm["SQ_WAVE_CYCLES"]},
+              open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+    shutil.copy(f"{src}/{tag}_kernel_stats.csv", f"profiles/{tag}_final_kernel_stats.csv")
+    shutil.copy(f"{src}/c5_kernel_stats.csv", f"profiles/{tag}_c5_kernel_stats.csv")
     shutil.copy(f"{src}/bench.log", f"profiles/{tag}_final_bench.log")
     open(f"profiles/{tag}_final_bench_b1_b8.log", "w").write(open(f"{src}/bench_b1.log").read() + open(f"{src}/bench_b8.log").read())
     open(f"profiles/{tag}_final_bench_other_workloads.log", "w").write(open(f"{src}/bench_franka.log").read() + open(f"{src}/bench_allegro.log").read())
+    open(f"profiles/{tag}_final_bench_replay_and_c5.log", "w").write(open(f"{src}/bench_replay_allegro.log").read() + open(f"{src}/bench_c5.log").read())
+    shutil.copy(f"{src}/c5_resegment.log", f"profiles/{tag}_c5_resegment_bench.log")
     print("\n".join(lines))
-    for r in list(csv.DictReader(open(f"{src}/r01_kernel_stats.csv")))[:8]:
+    for r in list(csv.DictReader(open(f"{src}/{tag}_kernel_stats.csv")))[:8]:
         print(r["Name"][:50], r["Calls"], round(float(r["AverageNs"]) / 1e3, 2), r["Percentage"])
 
 
