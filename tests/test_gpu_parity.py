@@ -828,3 +828,36 @@ def test_full_size_c5_nn_and_kmeans_properties(dev):
     assert torch.equal(ops.kmeans_assign(X, c2), lab2)
     local, off = ops.group_to_local(X, lab, torch.eye(4, dtype=torch.float64, device=dev).repeat(k, 1, 1).contiguous())
     assert off[-1].item() == n and torch.equal(torch.sort(local[:, 0])[0], torch.sort(X[:, 0])[0])     # a permutation
+
+
+def test_full_size_c5_masked_icp_spot_check_vs_oracle(dev):
+    """K4 at the BASELINE configs[4] shape (N=262144, K=128: ~2048-point clusters against a few thousand masked targets
+    each -- the large-cluster regime, many workgroups per ICP iteration): the whole frame on the GPU, three clusters
+    re-run by the oracle's open3d-style loop on their own masked targets; plus properties that hold for every cluster
+    (rigid poses, world_out = pose . local, at least one iteration)."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import make_sequence
+    from oracle import icp as oicp
+    n, k = 262144, 128
+    fr = make_sequence("chain32", 0, 2, n)
+    X0, X1 = _cuda(fr[0], dev), _cuda(fr[1], dev)
+    init = X0[torch.as_tensor(np.random.default_rng(1).choice(n, k, replace=False), device=dev)].clone()
+    c, lab, _, _ = ops.kmeans_lloyd(X0, init, max_iter=20)
+    M = torch.eye(4, dtype=torch.float64, device=dev).repeat(k, 1, 1)
+    M[:, :3, 3] = c
+    local, off = ops.group_to_local(X0, lab, M.contiguous())
+    world32 = ops.cluster_transform(local.to(torch.float32), off, M.to(torch.float32))
+    M_out, w_out, n_it = ops.masked_icp(local, world32, off, X1, M.contiguous())
+    Mh, offh, localh = M_out.cpu().numpy(), off.cpu().numpy(), local.cpu().numpy()
+    R = Mh[:, :3, :3]
+    np.testing.assert_allclose(R @ R.transpose(0, 2, 1), np.tile(np.eye(3), (k, 1, 1)), atol=1e-12)
+    np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=1e-12)
+    assert (n_it.cpu().numpy() >= 1).all() and np.isfinite(Mh).all()
+    wh = w_out.cpu().numpy()
+    for j in (0, 57, 127):
+        src = localh[offh[j]:offh[j + 1]]
+        np.testing.assert_allclose(wh[offh[j]:offh[j + 1]], src @ Mh[j, :3, :3].T + Mh[j, :3, 3], atol=1e-12)
+        mask = oicp.aabb_mask(world32.cpu().numpy()[offh[j]:offh[j + 1]], fr[1], 1.2)
+        T, _, _, it = oicp.registration_icp(src, fr[1][mask], 1.0, M[j].cpu().numpy())
+        np.testing.assert_allclose(Mh[j], T, atol=1e-8)
+        assert int(n_it[j]) == it
