@@ -130,6 +130,16 @@ __device__ __forceinline__ void bsum_n(double (&v)[N], double* sc /* [4][N] */) 
     for (int i = 0; i < N; ++i) { double r = 0.0; for (int w = 0; w < ICP_ROWS / 64; ++w) r += sc[w * N + i]; v[i] = r; }
 }
 
+#ifdef CREG_STAMPS
+// debug build only (CREG_EXTRA_FLAGS=-DCREG_STAMPS, tests/measure/icp_stamps.py): shader-clock cycles of the phases of
+// workgroup (0, 0), accumulated over its iterations: [0] mask+setup [1] NN scan [2] combine + fitness [3] sums [4] Horn
+// on lane 0 [5] move [6] iterations
+__device__ unsigned long long g_icp_stamps[512 * 8];      // [workgroup (x + gridDim.x * y) % 512][slot]
+#define ICP_STAMP(slot) do { if (stamp_on && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_icp_stamps[stamp_b * 8 + slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
+#else
+#define ICP_STAMP(slot) do { } while (0)
+#endif
+
 struct IcpBatch {
     const double* local[ICP_BATCH_MAX]; const float* world[ICP_BATCH_MAX]; const int* off[ICP_BATCH_MAX];
     const int* woff[ICP_BATCH_MAX];                    // segment offsets of `world` (the box clouds); null = same as `off`
@@ -153,6 +163,11 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
     __shared__ double sB[ICP_PARTS][ICP_ROWS];         // per part: best squared distance of the round's points
     __shared__ int sM[ICP_PARTS][ICP_ROWS];            //           and its target
     const int z = blockIdx.y;
+#ifdef CREG_STAMPS
+    const bool stamp_on = true;
+    const int stamp_b = (blockIdx.x + gridDim.x * blockIdx.y) % 512;
+    unsigned long long stamp_t = clock64();
+#endif
     const double* __restrict__ local = P.local[z]; const float* __restrict__ world = P.world[z];
     const int* __restrict__ off = P.off[z]; const double* __restrict__ frame = P.frame[z];
     const double* __restrict__ Min = P.Min[z];
@@ -267,6 +282,7 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
     auto correspond = [&](double& fitness, double& rm) {
         double ce[2] = {0, 0};
         __syncthreads();                              // the row threads' moves of S are visible
+        ICP_STAMP(5);
         for (int r0 = 0; r0 < ns; r0 += ICP_ROWS) {
             const int i = r0 + pi;
             double best = INFINITY; int bm = -1;
@@ -290,6 +306,7 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
             }
             sB[part][pi] = best; sM[part][pi] = bm;
             __syncthreads();
+            ICP_STAMP(1);
             if (row && i < ns) {                      // quarters in ascending target order, strict '<': first minimum
                 best = sB[0][pi]; bm = sM[0][pi];
 #pragma unroll
@@ -299,10 +316,12 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
             if (r0 + ICP_ROWS < ns) __syncthreads();  // sB / sM are rewritten by the next round
         }
         bsum_n<2>(ce, sc);
+        ICP_STAMP(2);
         fitness = ns > 0 ? ce[0] / (double)ns : 0.0;
         rm = ce[0] > 0 ? sqrt(ce[1] / ce[0]) : 0.0;
         return ce[0];
     };
+    ICP_STAMP(0);
     double ncorr = correspond(fit, rmse);
     for (it = 1; it <= max_iter; ++it) {
         // best rigid update from the current correspondences
@@ -326,6 +345,7 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
                 for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) C[3 * a + c] = fma(sv[a], dv[c], C[3 * a + c]);
             }
         bsum_n<9>(C, sc);
+        ICP_STAMP(3);
         if (tid == 0) {
             for (int i = 0; i < 16; ++i) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
             if (ncorr > 0) {
@@ -351,6 +371,10 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
             for (int i = 0; i < 16; ++i) T[i] = Tn[i];
         }
         __syncthreads();
+        ICP_STAMP(4);
+#ifdef CREG_STAMPS
+        if (stamp_on && tid == 0) g_icp_stamps[stamp_b * 8 + 6] += 1;
+#endif
         if (row)
             for (int i = tid; i < ns; i += ICP_ROWS) {
                 const double p0 = S[3 * i], p1 = S[3 * i + 1], p2 = S[3 * i + 2];
@@ -769,3 +793,11 @@ extern "C" int creg_icp_p2p_f64(const double* src, int64_t n_src, const int32_t*
     return icp_launch(&p, 1, n_src, k, n_tgt, 1.0, th, max_iteration, 0, workspace, workspace_bytes, (hipStream_t)stream,
                       "creg_icp_p2p_f64");
 }
+
+#ifdef CREG_STAMPS
+extern "C" int creg_debug_icp_stamps(unsigned long long* out8, int reset) {
+    if (out8) CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_icp_stamps), sizeof(unsigned long long) * 512 * 8));
+    if (reset) { static unsigned long long z[512 * 8]; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_icp_stamps), z, sizeof(z))); }
+    return CREG_OK;
+}
+#endif

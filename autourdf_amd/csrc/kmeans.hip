@@ -2,18 +2,22 @@
 // n_init=1) semantics (reference mlp_reg.py:204, cluster_icp.py:67), plus the stable grouping /
 // change-of-frame step that follows it (mlp_reg.py:208-217).
 //
-// Per Lloyd iteration two small launches (bit-reproducible):
+// Per Lloyd iteration ONE launch (bit-reproducible):
 //   k_assign[_mfma]  labels = first argmin_k fma(x2,b2,fma(x1,b1,fma(x0,b0,|c|^2))),  b = -2c; the per-cluster sums of
-//                    the M-step in the same pass: every point adds its FIXED-POINT coordinates (int64, scale 2^s chosen per
-//                    call so that n points cannot overflow) and a count to a table in LDS, the table goes to global
-//                    accumulators with integer atomics.  Integer sums are exact, hence order-independent: atomics without
-//                    losing determinism, and no second pass over the labels (a (cluster, segment) sweep that re-read every
-//                    label k times used to cost 1.7x the E-step at n = 262144, k = 128).  A point is rounded to a grid
-//                    of range * 2^-43 at that size (2^-49 at n = 4096): below the error of any float64 summation order.
-//   k_finalize       1 block: sums -> centres (x 1/w), relocate empty clusters, centre shift, convergence (strict label
-//                    equality first, then tol), next b/|c|^2, accumulators cleared for the next iteration
-// The host enqueues iterations in batches and reads the `done` word between batches; kernels of
+//                    the M-step in the same pass, as EXACT integers: a point's coordinates enter as int64 fixed point
+//                    (scale 2^s chosen per call so that n points cannot overflow; a grid of range * 2^-43 at n = 262144,
+//                    2^-49 at n = 4096: below the error of any float64 summation order).  Integer sums are exact, hence
+//                    order-independent -- atomics without losing determinism -- and INCREMENTAL: the accumulators persist
+//                    over the iterations and only a point whose label changed moves its coordinates from the old
+//                    cluster's sum to the new one's (no drift: integers).  After the first few Lloyd iterations a handful of
+//                    points change, so the M-step costs next to nothing; per-workgroup tables in LDS, non-zero entries
+//                    flushed to the global accumulators with integer atomics.
+//                    The LAST workgroup to arrive (release fence -> counter -> acquire) runs the M-step tail in the same
+//                    launch: sums -> centres (x 1/w), relocation of empty clusters, centre shift, convergence (strict
+//                    label equality first, then tol), next b / |c|^2 rows.
+// The host enqueues iterations in batches of 32 and reads the `done` word between batches; launches of
 // iterations after convergence return immediately.
+#include <cstdlib>
 #include "creg_common.h"
 #include "creg_dev.h"
 
@@ -25,7 +29,10 @@ struct KmFlags {
     int strict;       // converged by label equality (no final E-step needed)
     int n_iter;       // iterations executed (i + 1 of the breaking iteration)
     int cur;          // which centre buffer holds the current centres
-    int pad[3];
+    int arrive;       // workgroups of the running E-step launch that have flushed their sums (last one runs the M-step tail)
+    int reloc;        // an empty cluster was found: the NEXT launch runs the M-step tail (with the relocation) instead of an E-step
+    int pad[1];
+    int arrive8[8];   // first-level arrival counters (workgroup index mod 8)
     double mean[3];
     double tol;
     double shift_tot;
@@ -55,19 +62,25 @@ __global__ __launch_bounds__(1024) void k_km_stats(const double* __restrict__ X,
                                                    KmFlags* __restrict__ f) {
     __shared__ double sc[16];
     __shared__ double mean[3];
-    for (int d = 0; d < 3; ++d) {
-        double s = 0;
-        for (int i = threadIdx.x; i < n; i += 1024) s += X[3 * (size_t)i + d];
-        s = block_sum<double, 1024>(s, sc);
-        if (threadIdx.x == 0) mean[d] = s / (double)n;
+    // the three coordinate sums of a pass run side by side (each keeps its own order: 1024 strided partials + tree)
+    {
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int i = threadIdx.x; i < n; i += 1024) { s0 += X[3 * (size_t)i]; s1 += X[3 * (size_t)i + 1]; s2 += X[3 * (size_t)i + 2]; }
+        s0 = block_sum<double, 1024>(s0, sc); s1 = block_sum<double, 1024>(s1, sc); s2 = block_sum<double, 1024>(s2, sc);
+        if (threadIdx.x == 0) { mean[0] = s0 / (double)n; mean[1] = s1 / (double)n; mean[2] = s2 / (double)n; }
     }
     __syncthreads();
     double var = 0, amax = 0;
-    for (int d = 0; d < 3; ++d) {
-        double s = 0;
-        for (int i = threadIdx.x; i < n; i += 1024) { const double t = X[3 * (size_t)i + d] - mean[d]; s = fma(t, t, s); amax = fmax(amax, fabs(t)); }
-        s = block_sum<double, 1024>(s, sc);
-        if (threadIdx.x == 0) var += s / (double)n;
+    {
+        const double m0 = mean[0], m1 = mean[1], m2 = mean[2];
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const double t0 = X[3 * (size_t)i] - m0, t1 = X[3 * (size_t)i + 1] - m1, t2 = X[3 * (size_t)i + 2] - m2;
+            s0 = fma(t0, t0, s0); s1 = fma(t1, t1, s1); s2 = fma(t2, t2, s2);
+            amax = fmax(amax, fmax(fabs(t0), fmax(fabs(t1), fabs(t2))));
+        }
+        s0 = block_sum<double, 1024>(s0, sc); s1 = block_sum<double, 1024>(s1, sc); s2 = block_sum<double, 1024>(s2, sc);
+        if (threadIdx.x == 0) { var += s0 / (double)n; var += s1 / (double)n; var += s2 / (double)n; }
     }
     __shared__ double s_amax[16];
     for (int off = 32; off >= 1; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
@@ -80,7 +93,8 @@ __global__ __launch_bounds__(1024) void k_km_stats(const double* __restrict__ X,
         f->fix_scale = km_fix_scale(r, n); f->fix_inv = 1.0 / f->fix_scale;
         f->mean[0] = mean[0]; f->mean[1] = mean[1]; f->mean[2] = mean[2];
         f->tol = (var / 3.0) * tol_rel;
-        f->changed = 0; f->done = 0; f->strict = 0; f->n_iter = 0; f->cur = 0;
+        f->changed = 0; f->done = 0; f->strict = 0; f->n_iter = 0; f->cur = 0; f->arrive = 0; f->reloc = 0;
+        for (int i = 0; i < 8; ++i) f->arrive8[i] = 0;
         f->shift_tot = 0; f->inertia = 0;
     }
 }
@@ -104,48 +118,291 @@ __global__ __launch_bounds__(256) void k_km_center(const double* __restrict__ X,
     }
 }
 
-// E-step, VALU form: one thread per point, centres broadcast from LDS.
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(double* p, double v) {
+    __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct KmTailSh { double fv[16]; int fi[16]; int nempty, argmax, last, bi; double bv; };
+
+// (value descending, index ascending) maximum over the block; the result is returned to every thread.  Two barriers.
+template <int NT>
+__device__ __forceinline__ void km_block_argmax(double& bv, int& bi, KmTailSh& S) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(bv, off, 64); const int oi = __shfl_xor(bi, off, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    __syncthreads();                                             // previous readers of S.bv / S.bi are done
+    if (lane == 0) { S.fv[wv] = bv; S.fi[wv] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 0; w < NT / 64; ++w) if (S.fv[w] > bv || (S.fv[w] == bv && S.fi[w] < bi)) { bv = S.fv[w]; bi = S.fi[w]; }
+        S.bv = bv; S.bi = bi;
+    }
+    __syncthreads();
+    bv = S.bv; bi = S.bi;
+}
+
+// Every workgroup of a launch calls this once after its global atomics / agent-scope stores (they have completed: the barrier
+// waits for vmcnt(0)); true in the last workgroup to arrive.  Two levels -- 8 shard counters, then one -- so that a few
+// hundred workgroups finishing together do not queue on one word (MI355X_MICROARCH.md: ~12 ns per arrival on one counter).
+__device__ __forceinline__ bool km_arrive_last(KmFlags* __restrict__ f, KmTailSh& S) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int sh = blockIdx.x & 7, in_shard = ((int)gridDim.x - sh + 7) >> 3, shards = min(8, (int)gridDim.x);
+        int last = 0;
+        if (atomicAdd(&f->arrive8[sh], 1) == in_shard - 1) last = atomicAdd(&f->arrive, 1) == shards - 1;
+        S.last = last;
+    }
+    __syncthreads();
+    return S.last != 0;
+}
+__device__ __forceinline__ void km_arrive_reset(KmFlags* __restrict__ f) {
+    for (int i = 0; i < 8; ++i) f->arrive8[i] = 0;
+    f->arrive = 0;
+}
+
+// M-step tail of one Lloyd iteration, run by ONE workgroup of NT threads (the last one of its launch to arrive):
+// sums -> centres, _relocate_empty_clusters_dense, centre shift, convergence flags, next (-2c, |c|^2) rows.
+// `acc` are the exact integer sums of the CURRENT labels (they persist: the E-step moves a point between sums when
+// its label changes); `shift` is >= 4 k doubles of LDS scratch.
+// Everything read here that another workgroup wrote in THIS launch goes through agent-scope atomics on both sides (the
+// sums, the changed-label count; on the relocation path the per-point distances and the per-segment maxima), so neither side
+// needs a fence (MI355X_MICROARCH.md: "8-B agent atomics both sides").
+// relocate = false (the tail of an E-step launch): an empty cluster defers the tail -- the relocation needs the distance of
+// every point to its centre, i.e. the labels the other workgroups have just stored with plain stores.  `reloc` is set and
+// the NEXT launch does it (km_reloc_pass in every workgroup, then this function with relocate = true in the last one).
+template <int NT>
+__device__ void km_mstep_tail(const double* __restrict__ X, int n, const int* __restrict__ labels, int k,
+                              const unsigned long long* __restrict__ acc, double* __restrict__ C2, double* B,
+                              double* __restrict__ Cw, double* far_d, double* segv, int* segi, int segsz, int nseg,
+                              KmFlags* __restrict__ f, KmTailSh& S, double* __restrict__ shift, bool relocate) {
+    const int tid = threadIdx.x;
+    const int cur = f->cur;
+    const double finv = f->fix_inv, tol = f->tol;
+    const double* Cold = C2 + (size_t)cur * 3 * k;
+    double* Cnew = C2 + (size_t)(cur ^ 1) * 3 * k;
+    double* cpark = shift + k;                                  // [k][3] (the scratch holds 4 k doubles)
+    if (tid == 0) S.nempty = 0;
+    __syncthreads();
+    for (int j = tid; j < k; j += NT) {
+        double a[4];
+        for (int d = 0; d < 3; ++d) a[d] = (double)(long long)ld_agent(acc + 4 * j + d) * finv;
+        a[3] = (double)(long long)ld_agent(acc + 4 * j + 3);
+        if (a[3] == 0.0) atomicAdd(&S.nempty, 1);                  // integer count: order independent
+        if (relocate) for (int d = 0; d < 4; ++d) Cw[4 * j + d] = a[d];
+        else {
+            // common path: straight to the centre, parked in LDS until the barrier says "no empty cluster" (an empty
+            // cluster defers the whole tail, nothing is kept)
+            double s2 = 0;
+            const double alpha = 1.0 / a[3];
+            for (int d = 0; d < 3; ++d) { const double c = a[d] * alpha; cpark[3 * j + d] = c; const double t = c - Cold[3 * j + d]; s2 += t * t; }
+            const double sh = sqrt(s2);
+            shift[j] = sh * sh;
+        }
+    }
+    __syncthreads();
+    if (!relocate) {
+        if (S.nempty > 0) {                                      // block-uniform; rare: defer
+            if (tid == 0) { f->reloc = 1; km_arrive_reset(f); }
+            return;
+        }
+        for (int j = tid; j < k; j += NT) {
+            const double c[3] = {cpark[3 * j], cpark[3 * j + 1], cpark[3 * j + 2]};
+            for (int d = 0; d < 3; ++d) Cnew[3 * j + d] = c[d];
+            make_b(c, B + 4 * j);
+        }
+    } else {
+        if (S.nempty > 0) {
+            // _relocate_empty_clusters_dense: the farthest points (descending distance, ties to the lower index) seed the
+            // empty clusters and leave their old ones.  Two levels: the maxima of the nseg segments km_reloc_pass left,
+            // then a rescan of the winner's segment only.
+            double dv = -1; int di = 0x7fffffff;
+            for (int sg = tid; sg < nseg; sg += NT) { const double v = ld_agent(segv + sg); const int i = ld_agent(segi + sg); if (v > dv || (v == dv && i < di)) { dv = v; di = i; } }
+            km_block_argmax<NT>(dv, di, S);
+            if (dv > 0) {                                        // the largest distance: all zero -> nothing moves (sklearn)
+                for (int j = 0; j < k; ++j) {
+                    if (Cw[4 * j + 3] != 0.0) continue;          // uniform: Cw only changes under barriers
+                    double bv = -1; int bi = 0x7fffffff;
+                    for (int sg = tid; sg < nseg; sg += NT) { const double v = ld_agent(segv + sg); const int i = ld_agent(segi + sg); if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; } }
+                    km_block_argmax<NT>(bv, bi, S);
+                    const int sb = bi / segsz;
+                    if (tid == 0) {
+                        st_agent(far_d + bi, -2.0);
+                        const int old = labels[bi];
+                        for (int d = 0; d < 3; ++d) { Cw[4 * old + d] -= X[3 * (size_t)bi + d]; Cw[4 * j + d] = X[3 * (size_t)bi + d]; }
+                        Cw[4 * j + 3] = 1.0; Cw[4 * old + 3] -= 1.0;
+                    }
+                    __syncthreads();
+                    double rv = -3; int ri = 0x7fffffff;          // the segment's new maximum (taken points hold -2)
+                    for (int i = sb * segsz + tid; i < min(n, (sb + 1) * segsz); i += NT) { const double v = ld_agent(far_d + i); if (v > rv || (v == rv && i < ri)) { rv = v; ri = i; } }
+                    km_block_argmax<NT>(rv, ri, S);
+                    if (tid == 0) { st_agent(segv + sb, rv); st_agent(segi + sb, ri); }
+                    __syncthreads();
+                }
+            }
+            // first cluster of maximal weight (weight desc, index asc): the centre a still-empty cluster takes
+            if (tid == 0) { int am = 0; for (int j = 1; j < k; ++j) if (Cw[4 * j + 3] > Cw[4 * am + 3]) am = j; S.argmax = am; }
+            __syncthreads();
+        }
+        for (int j = tid; j < k; j += NT) {
+            const double w = Cw[4 * j + 3];
+            double c[3];
+            if (w > 0) { const double alpha = 1.0 / w; for (int d = 0; d < 3; ++d) c[d] = Cw[4 * j + d] * alpha; }
+            else { const double wa = Cw[4 * S.argmax + 3]; const double alpha = 1.0 / wa;
+                   for (int d = 0; d < 3; ++d) c[d] = Cw[4 * S.argmax + d] * alpha; }
+            double s2 = 0;
+            for (int d = 0; d < 3; ++d) { Cnew[3 * j + d] = c[d]; const double t = c[d] - Cold[3 * j + d]; s2 += t * t; }
+            const double sh = sqrt(s2);
+            shift[j] = sh * sh;
+            make_b(c, B + 4 * j);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int changed = ld_agent(&f->changed);
+        double tot = 0;
+        for (int j0 = 0; j0 < k; j0 += 8) {                      // fixed order (cluster index); a group's loads are issued together
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = shift[min(j0 + u, k - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (j0 + u < k) tot += v[u];
+        }
+        f->shift_tot = tot;
+        f->cur = cur ^ 1;
+        f->n_iter += 1;
+        if (changed == 0) { f->strict = 1; f->done = 1; }
+        else if (tot <= tol) { f->done = 1; }
+        f->changed = 0;
+        f->reloc = 0;
+        km_arrive_reset(f);
+    }
+}
+
+// a point whose label changed moves from the old cluster's sums to the new one's (prev < 0: first iteration, add only)
+__device__ __forceinline__ void km_move(unsigned long long* sA, int lab, int pv, double x0, double x1, double x2, double fscale) {
+    const unsigned long long v0 = km_fix(x0, fscale), v1 = km_fix(x1, fscale), v2 = km_fix(x2, fscale);
+    atomicAdd(&sA[4 * lab], v0); atomicAdd(&sA[4 * lab + 1], v1); atomicAdd(&sA[4 * lab + 2], v2); atomicAdd(&sA[4 * lab + 3], 1ull);
+    if (pv >= 0) {
+        atomicAdd(&sA[4 * pv], 0ull - v0); atomicAdd(&sA[4 * pv + 1], 0ull - v1); atomicAdd(&sA[4 * pv + 2], 0ull - v2);
+        atomicAdd(&sA[4 * pv + 3], ~0ull);
+    }
+}
+
+// Lloyd launches only: the M-step tail's operands (B = the rows `B` points at, writable), the relocation scratch (far: n
+// doubles, segv / segi: one entry per workgroup) and the label buffers.  A launch works on iteration t = f->n_iter: it
+// writes lab[t & 1] and compares with lab[(t - 1) & 1] (prev0 = "no label" at t = 0).
+struct KmTail { double* B; double* C2; double* Cw; double* far_d; double* segv; int* segi; int* lab[2]; const int* prev0; int max_iter; };
+
+// The workgroup's table of sums goes to the global accumulators; the last workgroup of the launch to have done so runs
+// the M-step tail.
+template <int NT>
+__device__ __forceinline__ void km_flush_and_tail(const unsigned long long* sA, const double* __restrict__ X, int n,
+                                                  int k, unsigned long long* __restrict__ acc,
+                                                  KmFlags* __restrict__ f, const KmTail& T, double* lds_scratch) {
+    __shared__ KmTailSh S;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * k; i += NT) { const unsigned long long v = sA[i]; if (v) atomicAdd(&acc[i], v); }
+    if (!km_arrive_last(f, S)) return;
+    km_mstep_tail<NT>(X, n, nullptr, k, acc, T.C2, T.B, T.Cw, T.far_d, T.segv, T.segi, 0, 0, f, S, lds_scratch, false);
+}
+
+// Entry of a Lloyd launch: done / budget spent -> nothing; a deferred M-step tail pending -> this launch does the
+// relocation instead of an E-step: every workgroup computes its segment's point-to-centre distances and their maximum
+// (the labels of the previous launch are visible now), the last one to arrive runs the tail.  Returns true when the
+// launch should run its E-step, with the iteration's label buffers selected.
+template <int NT>
+__device__ __forceinline__ bool km_lloyd_entry(const double* __restrict__ X, int n, int k, unsigned long long* __restrict__ acc,
+                                               KmFlags* __restrict__ f, const KmTail& T, double* lds_scratch,
+                                               int*& labels, const int*& prev) {
+    if (f->done) return false;
+    const int t = f->n_iter;
+    if (t >= T.max_iter) return false;
+    labels = (t & 1) ? T.lab[1] : T.lab[0];
+    prev = t == 0 ? T.prev0 : ((t & 1) ? T.lab[0] : T.lab[1]);
+    if (!f->reloc) return true;
+    __shared__ KmTailSh S;
+    const int nseg = gridDim.x, segsz = (n + nseg - 1) / nseg, sg = blockIdx.x;
+    const double* Cold = T.C2 + (size_t)f->cur * 3 * k;
+    double bv = -1; int bi = 0x7fffffff;
+    for (int i = sg * segsz + threadIdx.x; i < min(n, (sg + 1) * segsz); i += NT) {
+        const double* c = Cold + 3 * labels[i];
+        const double a = X[3 * (size_t)i] - c[0], b = X[3 * (size_t)i + 1] - c[1], e = X[3 * (size_t)i + 2] - c[2];
+        const double d = (a * a + b * b) + e * e;
+        st_agent(T.far_d + i, d);
+        if (d > bv) { bv = d; bi = i; }                          // ascending i: the first maximum stays
+    }
+    km_block_argmax<NT>(bv, bi, S);
+    if (threadIdx.x == 0) { st_agent(T.segv + sg, bv); st_agent(T.segi + sg, bi); }
+    if (km_arrive_last(f, S))
+        km_mstep_tail<NT>(X, n, labels, k, acc, T.C2, T.B, T.Cw, T.far_d, T.segv, T.segi, segsz, nseg, f, S, lds_scratch, true);
+    return false;
+}
+
+// E-step, VALU form: PT points per thread (the centre rows are read from LDS once for all of them), 256 threads.
+template <int PT>
 __global__ __launch_bounds__(256) void k_km_assign(const double* __restrict__ X, int n,
-                                                   const double* __restrict__ B, int k,
-                                                   int* __restrict__ labels, const int* __restrict__ prev,
-                                                   KmFlags* __restrict__ f, int raw, unsigned long long* __restrict__ acc) {
+                                                   const double* B, int k,
+                                                   int* labels_in, const int* prev_in,
+                                                   KmFlags* __restrict__ f, int raw, unsigned long long* __restrict__ acc, KmTail T) {
     // raw: `B` holds the centres (k,3) and every workgroup derives its (-2c, |c|^2) rows itself -- the standalone
     // entry point then needs no device scratch (the library never allocates)
-    // acc (Lloyd only): global [k][4] int64 accumulators of the M-step (fixed-point x, y, z and the count)
+    // acc (Lloyd only): global [k][4] int64 sums of the M-step (fixed-point x, y, z and the count) of the labels in `prev`
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sB = (double*)smem;
     unsigned long long* sA = (unsigned long long*)(sB + 4 * k);
-    if (f && f->done) return;
+    int* labels = labels_in;
+    const int* prev = prev_in;
+    if (f && !km_lloyd_entry<256>(X, n, k, acc, f, T, sB, labels, prev)) return;      // Lloyd launch: buffers of iteration f->n_iter
     if (raw) { for (int j = threadIdx.x; j < k; j += 256) make_b(B + 3 * j, sB + 4 * j); }
     else for (int i = threadIdx.x; i < 4 * k; i += 256) sB[i] = B[i];
     if (acc) for (int i = threadIdx.x; i < 4 * k; i += 256) sA[i] = 0ull;
     const double fscale = acc ? f->fix_scale : 0.0;
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    int diff = 0;
-    if (i < n) {
-        const double x0 = X[3 * (size_t)i], x1 = X[3 * (size_t)i + 1], x2 = X[3 * (size_t)i + 2];
-        double best = fma(x2, sB[2], fma(x1, sB[1], fma(x0, sB[0], sB[3])));
-        int lab = 0;
-        for (int j = 1; j < k; ++j) {
-            const double d = fma(x2, sB[4 * j + 2], fma(x1, sB[4 * j + 1], fma(x0, sB[4 * j], sB[4 * j + 3])));
-            if (d < best) { best = d; lab = j; }
+    const int i0 = blockIdx.x * (256 * PT) + threadIdx.x;
+    double x[PT][3], best[PT];
+    int lab[PT];
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int i = min(i0 + 256 * q, n - 1);
+        x[q][0] = X[3 * (size_t)i]; x[q][1] = X[3 * (size_t)i + 1]; x[q][2] = X[3 * (size_t)i + 2];
+        best[q] = fma(x[q][2], sB[2], fma(x[q][1], sB[1], fma(x[q][0], sB[0], sB[3])));
+        lab[q] = 0;
+    }
+    for (int j = 1; j < k; ++j) {
+        const double b0 = sB[4 * j], b1 = sB[4 * j + 1], b2 = sB[4 * j + 2], b3 = sB[4 * j + 3];
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            const double d = fma(x[q][2], b2, fma(x[q][1], b1, fma(x[q][0], b0, b3)));
+            if (d < best[q]) { best[q] = d; lab[q] = j; }
         }
-        labels[i] = lab;
-        if (prev) diff = (prev[i] != lab);
-        if (acc) {
-            atomicAdd(&sA[4 * lab], km_fix(x0, fscale)); atomicAdd(&sA[4 * lab + 1], km_fix(x1, fscale));
-            atomicAdd(&sA[4 * lab + 2], km_fix(x2, fscale)); atomicAdd(&sA[4 * lab + 3], 1ull);
+    }
+    int diff = 0;
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int i = i0 + 256 * q;
+        if (i < n) {
+            labels[i] = lab[q];
+            if (prev) {
+                const int pv = prev[i];
+                if (pv != lab[q]) { ++diff; if (acc) km_move(sA, lab[q], pv, x[q][0], x[q][1], x[q][2], fscale); }
+            }
         }
     }
     if (prev && f) {
-        const unsigned long long m = __ballot(diff);
-        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&f->changed, __popcll(m));
+        diff = wave_sum(diff);
+        if ((threadIdx.x & 63) == 0 && diff) atomicAdd(&f->changed, diff);
     }
-    if (acc) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 4 * k; i += 256) { const unsigned long long v = sA[i]; if (v) atomicAdd(&acc[i], v); }
-    }
+    if (acc) km_flush_and_tail<256>(sA, X, n, k, acc, f, T, sB);
 }
 
 // E-step, matrix-core form: v_mfma_f64_16x16x4_f64 evaluates a 16-centre x 16-point tile of |c|^2 - 2 x.c as
@@ -162,12 +419,14 @@ __global__ __launch_bounds__(256) void k_km_assign(const double* __restrict__ X,
 // only draws level here; kept selectable because the north star asks for it).
 template <int NT>   // centre tiles held in registers (k <= 16 NT); 0: any k, centre operands re-read from LDS per tile
 __global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict__ X, int n,
-                                                        const double* __restrict__ B, int k,
-                                                        int* __restrict__ labels, const int* __restrict__ prev,
-                                                        KmFlags* __restrict__ f, int raw, unsigned long long* __restrict__ acc) {
+                                                        const double* B, int k,
+                                                        int* labels_in, const int* prev_in,
+                                                        KmFlags* __restrict__ f, int raw, unsigned long long* __restrict__ acc, KmTail T) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sB = (double*)smem;                                  // [kpad][4], rows past k: (0, 0, 0, +inf)
-    if (f && f->done) return;
+    int* labels = labels_in;
+    const int* prev = prev_in;
+    if (f && !km_lloyd_entry<256>(X, n, k, acc, f, T, sB, labels, prev)) return;
     const int kpad = (k + 15) & ~15, ktiles = kpad / 16;
     unsigned long long* sA = (unsigned long long*)(sB + 5 * (size_t)kpad);       // [k][4] M-step sums (behind sB and sC)
     if (acc) for (int i = threadIdx.x; i < 4 * k; i += 256) sA[i] = 0ull;
@@ -248,130 +507,28 @@ __global__ __launch_bounds__(256) void k_km_assign_mfma(const double* __restrict
             best = take ? ov : best; lab = take ? oi : lab;
         }
         const int i = tile * 16 + col;
-        if (g == 0 && i < n) { labels[i] = lab; if (prev) diff += (prev[i] != lab); }
-        // the point's lane groups hold x, y, z (b) and nothing: one LDS atomic each -- coordinate g, or the count
-        if (acc && i < n) atomicAdd(&sA[4 * lab + g], g < 3 ? km_fix(b, fscale) : 1ull);
+        if (i < n) {
+            if (g == 0) labels[i] = lab;
+            if (prev) {
+                // the point's lane groups hold x, y, z (b) and nothing: when its label changed, group g moves coordinate g
+                // (or the count) from the old cluster's sum to the new one's -- one LDS atomic pair each
+                const int pv = prev[i];
+                if (pv != lab) {
+                    if (g == 0) ++diff;
+                    if (acc) {
+                        const unsigned long long v = g < 3 ? km_fix(b, fscale) : 1ull;
+                        atomicAdd(&sA[4 * lab + g], v);
+                        if (pv >= 0) atomicAdd(&sA[4 * pv + g], 0ull - v);
+                    }
+                }
+            }
+        }
     }
     if (prev && f) {
         diff = wave_sum(diff);
         if (lane == 0 && diff) atomicAdd(&f->changed, diff);
     }
-    if (acc) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 4 * k; i += 256) { const unsigned long long v = sA[i]; if (v) atomicAdd(&acc[i], v); }
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_km_finalize(const double* __restrict__ X, int n,
-                                                      const int* __restrict__ labels, int k,
-                                                      unsigned long long* __restrict__ acc, double* __restrict__ C2,
-                                                      double* __restrict__ B, double* __restrict__ Cw,
-                                                      double* __restrict__ far_d, KmFlags* __restrict__ f) {
-    __shared__ double sc[16];
-    __shared__ int s_nempty, s_argmax;
-    __shared__ double s_dmax;
-    if (f->done) return;
-    const int cur = f->cur;
-    const double* Cold = C2 + (size_t)cur * 3 * k;
-    double* Cnew = C2 + (size_t)(cur ^ 1) * 3 * k;
-    // (v1 let thread 0 walk Cw in global memory for the empty count and the arg-max: 2 k dependent round trips,
-    //  40 of this kernel's 48 us at k = 128.  Same sums in the same order; only who scans changed.)
-    if (threadIdx.x == 0) s_nempty = 0;
-    __syncthreads();
-    const double finv = f->fix_inv;
-    for (int j = threadIdx.x; j < k; j += 1024) {
-        double a[4];
-        for (int d = 0; d < 3; ++d) a[d] = (double)(long long)acc[4 * j + d] * finv;     // exact integer sums of the E-step
-        a[3] = (double)(long long)acc[4 * j + 3];
-        for (int d = 0; d < 4; ++d) { Cw[4 * j + d] = a[d]; acc[4 * j + d] = 0ull; }     // cleared for the next iteration
-        if (a[3] == 0.0) atomicAdd(&s_nempty, 1);                 // integer count: order independent
-    }
-    __syncthreads();
-    if (s_nempty > 0) {
-        // _relocate_empty_clusters_dense: farthest points (descending distance, ties to the lower
-        // index) seed the empty clusters and leave their old ones.  Rare path, whole block scans.
-        double dmax = 0;
-        for (int i = threadIdx.x; i < n; i += 1024) {
-            const double* c = Cold + 3 * labels[i];
-            const double a = X[3 * (size_t)i] - c[0], b = X[3 * (size_t)i + 1] - c[1], e = X[3 * (size_t)i + 2] - c[2];
-            const double d = (a * a + b * b) + e * e;
-            far_d[i] = d;
-            dmax = fmax(dmax, d);
-        }
-        for (int off = 32; off >= 1; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = dmax;
-        __syncthreads();
-        if (threadIdx.x == 0) { double m = 0; for (int i = 0; i < 16; ++i) m = fmax(m, sc[i]); s_dmax = m; }
-        __syncthreads();
-        if (s_dmax > 0) {
-            for (int j = 0; j < k; ++j) {
-                if (Cw[4 * j + 3] != 0.0) continue;            // uniform: Cw only changes under barriers
-                double bv = -1; int bi = 0x7fffffff;
-                for (int i = threadIdx.x; i < n; i += 1024) if (far_d[i] > bv) { bv = far_d[i]; bi = i; }
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const double ov = __shfl_xor(bv, off, 64); const int oi = __shfl_xor(bi, off, 64);
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                }
-                __shared__ double s_v[16]; __shared__ int s_i[16];
-                __syncthreads();
-                if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = bv; s_i[threadIdx.x >> 6] = bi; }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    for (int w = 0; w < 16; ++w) if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) { bv = s_v[w]; bi = s_i[w]; }
-                    far_d[bi] = -2;
-                    const int old = labels[bi];
-                    for (int d = 0; d < 3; ++d) { Cw[4 * old + d] -= X[3 * (size_t)bi + d]; Cw[4 * j + d] = X[3 * (size_t)bi + d]; }
-                    Cw[4 * j + 3] = 1.0; Cw[4 * old + 3] -= 1.0;
-                }
-                __syncthreads();
-            }
-        }
-    }
-    {   // first cluster of maximal weight (k <= 1024: one candidate per thread), block-wide (weight desc, index asc)
-        double bw = threadIdx.x < k ? Cw[4 * threadIdx.x + 3] : -1.0;
-        int bj = threadIdx.x < k ? (int)threadIdx.x : 0x7fffffff;
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ow = __shfl_xor(bw, off, 64); const int oj = __shfl_xor(bj, off, 64);
-            if (ow > bw || (ow == bw && oj < bj)) { bw = ow; bj = oj; }
-        }
-        __shared__ double s_w[16]; __shared__ int s_j[16];
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = bw; s_j[threadIdx.x >> 6] = bj; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < 16; ++w) if (s_w[w] > bw || (s_w[w] == bw && s_j[w] < bj)) { bw = s_w[w]; bj = s_j[w]; }
-            s_argmax = bj;
-        }
-    }
-    __syncthreads();
-    double shift = 0;
-    for (int j = threadIdx.x; j < k; j += 1024) {
-        const double w = Cw[4 * j + 3];
-        double c[3];
-        if (w > 0) { const double alpha = 1.0 / w; for (int d = 0; d < 3; ++d) c[d] = Cw[4 * j + d] * alpha; }
-        else { const double wa = Cw[4 * s_argmax + 3]; const double alpha = 1.0 / wa;
-               for (int d = 0; d < 3; ++d) c[d] = Cw[4 * s_argmax + d] * alpha; }
-        double s = 0;
-        for (int d = 0; d < 3; ++d) { Cnew[3 * j + d] = c[d]; const double t = c[d] - Cold[3 * j + d]; s += t * t; }
-        const double sh = sqrt(s);
-        shift += sh * sh;
-        make_b(c, B + 4 * j);
-    }
-    // fixed order: per-thread value for j = tid (k <= 1024), summed by thread 0 in index order
-    __shared__ double s_shift[1024];
-    s_shift[threadIdx.x] = shift;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot = 0;
-        for (int j = 0; j < min(k, 1024); ++j) tot += s_shift[j];
-        f->shift_tot = tot;
-        f->cur = cur ^ 1;
-        f->n_iter += 1;
-        if (f->changed == 0) { f->strict = 1; f->done = 1; }
-        else if (tot <= f->tol) { f->done = 1; }
-        f->changed = 0;
-    }
+    if (acc) km_flush_and_tail<256>(sA, X, n, k, acc, f, T, sB);
 }
 
 __global__ __launch_bounds__(1024) void k_km_finish(const double* __restrict__ X, int n,
@@ -435,21 +592,26 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
     // each of those was a dependent ~1 us round trip inside the workgroup), else in the global scratch
     double* C2 = c_in_lds ? (double*)(smem + (((size_t)(3 * nx + 4 * k) * 8 + 4 * (size_t)n + 7) & ~(size_t)7)) : (double*)w;
     double* Cw = C2 + 10 * k;
-    // ---- mean / tol (k_km_stats) ----
+    // ---- mean / tol (k_km_stats: the same sums in the same order) ----
     double var = 0;
-    for (int d = 0; d < 3; ++d) {
-        double s = 0;
-        for (int i = tid; i < n; i += 1024) s += X[3 * (size_t)i + d];
-        s = block_sum<double, 1024>(s, sc);
-        if (tid == 0) s_mean[d] = s / (double)n;
+    {
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int i = tid; i < n; i += 1024) { s0 += X[3 * (size_t)i]; s1 += X[3 * (size_t)i + 1]; s2 += X[3 * (size_t)i + 2]; }
+        s0 = block_sum<double, 1024>(s0, sc); s1 = block_sum<double, 1024>(s1, sc); s2 = block_sum<double, 1024>(s2, sc);
+        if (tid == 0) { s_mean[0] = s0 / (double)n; s_mean[1] = s1 / (double)n; s_mean[2] = s2 / (double)n; }
     }
     __syncthreads();
     double amax = 0;
-    for (int d = 0; d < 3; ++d) {
-        double s = 0;
-        for (int i = tid; i < n; i += 1024) { const double t = X[3 * (size_t)i + d] - s_mean[d]; s = fma(t, t, s); amax = fmax(amax, fabs(t)); }
-        s = block_sum<double, 1024>(s, sc);
-        if (tid == 0) var += s / (double)n;
+    {
+        const double m0 = s_mean[0], m1 = s_mean[1], m2 = s_mean[2];
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int i = tid; i < n; i += 1024) {
+            const double t0 = X[3 * (size_t)i] - m0, t1 = X[3 * (size_t)i + 1] - m1, t2 = X[3 * (size_t)i + 2] - m2;
+            s0 = fma(t0, t0, s0); s1 = fma(t1, t1, s1); s2 = fma(t2, t2, s2);
+            amax = fmax(amax, fmax(fabs(t0), fmax(fabs(t1), fabs(t2))));
+        }
+        s0 = block_sum<double, 1024>(s0, sc); s1 = block_sum<double, 1024>(s1, sc); s2 = block_sum<double, 1024>(s2, sc);
+        if (tid == 0) { var += s0 / (double)n; var += s1 / (double)n; var += s2 / (double)n; }
     }
     for (int off = 32; off >= 1; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
     __syncthreads();
@@ -460,7 +622,7 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
         double r = 0;
         for (int q = 0; q < 16; ++q) r = fmax(r, s_fv[q]);
         s_fscale = km_fix_scale(r, n); s_finv = 1.0 / s_fscale;
-        s_tol = (var / 3.0) * tol_rel; s_done = 0; s_strict = 0; s_it = 0; s_changed = 0;
+        s_tol = (var / 3.0) * tol_rel; s_done = 0; s_strict = 0; s_it = 0; s_changed = 0; s_nempty = 0;
     }
     // ---- centre (k_km_center) ----
     if (x_in_lds) for (int i = tid; i < 3 * n; i += 1024) Xc[i] = X[i] - s_mean[i % 3];
@@ -475,41 +637,57 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
     __threadfence_block();
     __syncthreads();
     int cur = 0;                                             // centre buffer holding the current centres
+    __shared__ double s_sh[128];
     for (int it = 0; it < max_iter; ++it) {
         unsigned short* lcur = lab[it & 1];
         const unsigned short* lprev = lab[(it + 1) & 1];
-        // ---- E-step (k_km_assign) ----
+        // ---- E-step (k_km_assign): four points per thread share every centre row read; a point whose label changed
+        //      moves from the old cluster's exact integer sums to the new one's (accI persists over the iterations)
         int diff = 0;
-        for (int i = tid; i < n; i += 1024) {
-            const double x0 = xc(i, 0), x1 = xc(i, 1), x2 = xc(i, 2);
-            double best = fma(x2, Bm[2], fma(x1, Bm[1], fma(x0, Bm[0], Bm[3])));
-            int lb = 0;
-            for (int j = 1; j < k; ++j) {
-                const double d = fma(x2, Bm[4 * j + 2], fma(x1, Bm[4 * j + 1], fma(x0, Bm[4 * j], Bm[4 * j + 3])));
-                if (d < best) { best = d; lb = j; }
+        for (int i0 = 0; i0 < n; i0 += 4096) {
+            double x[4][3], best[4];
+            int lb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = min(i0 + 1024 * q + tid, n - 1);
+                x[q][0] = xc(i, 0); x[q][1] = xc(i, 1); x[q][2] = xc(i, 2);
+                best[q] = fma(x[q][2], Bm[2], fma(x[q][1], Bm[1], fma(x[q][0], Bm[0], Bm[3])));
+                lb[q] = 0;
             }
-            lcur[i] = (unsigned short)lb;
-            diff += ((int)lprev[i] != lb);
-            atomicAdd(&accI[4 * lb], km_fix(x0, s_fscale)); atomicAdd(&accI[4 * lb + 1], km_fix(x1, s_fscale));
-            atomicAdd(&accI[4 * lb + 2], km_fix(x2, s_fscale)); atomicAdd(&accI[4 * lb + 3], 1ull);
+            for (int j = 1; j < k; ++j) {
+                const double b0 = Bm[4 * j], b1 = Bm[4 * j + 1], b2 = Bm[4 * j + 2], b3 = Bm[4 * j + 3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double d = fma(x[q][2], b2, fma(x[q][1], b1, fma(x[q][0], b0, b3)));
+                    if (d < best[q]) { best[q] = d; lb[q] = j; }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + 1024 * q + tid;
+                if (i < n) {
+                    const int pv = lprev[i];
+                    lcur[i] = (unsigned short)lb[q];
+                    if (pv != lb[q]) { ++diff; km_move(accI, lb[q], pv == 0xFFFF ? -1 : pv, x[q][0], x[q][1], x[q][2], s_fscale); }
+                }
+            }
         }
         if (diff) atomicAdd(&s_changed, diff);
         __threadfence_block();
         __syncthreads();
-        // ---- per-cluster sums: the exact integer sums the E-step above added to accI (see the file header) ----
-        if (tid < 4 * k) {
-            const long long v = (long long)accI[tid];
-            Cw[tid] = (tid & 3) == 3 ? (double)v : (double)v * s_finv;
-            accI[tid] = 0ull;
+        // ---- M-step tail (km_mstep_tail): thread j owns cluster j (k <= 128) ----
+        const double* Cold = C2 + (size_t)cur * 3 * k;
+        double* Cnew = C2 + (size_t)(cur ^ 1) * 3 * k;
+        double a4[4] = {0, 0, 0, 1};
+        if (tid < k) {
+            for (int d = 0; d < 3; ++d) a4[d] = (double)(long long)accI[4 * tid + d] * s_finv;
+            a4[3] = (double)(long long)accI[4 * tid + 3];
+            for (int d = 0; d < 4; ++d) Cw[4 * tid + d] = a4[d];
+            if (a4[3] == 0.0) atomicAdd(&s_nempty, 1);
         }
         __threadfence_block();
         __syncthreads();
-        // ---- k_km_finalize ----
-        const double* Cold = C2 + (size_t)cur * 3 * k;
-        double* Cnew = C2 + (size_t)(cur ^ 1) * 3 * k;
-        if (tid == 0) { int ne = 0; for (int j = 0; j < k; ++j) ne += (Cw[4 * j + 3] == 0.0); s_nempty = ne; }
-        __syncthreads();
-        if (s_nempty > 0) {
+        if (s_nempty > 0) {                                    // block-uniform; rare
             double dmax = 0;
             for (int i = tid; i < n; i += 1024) {
                 const double* c = Cold + 3 * lcur[i];
@@ -547,33 +725,37 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
                     __syncthreads();
                 }
             }
+            if (tid == 0) { int am = 0; for (int j = 1; j < k; ++j) if (Cw[4 * j + 3] > Cw[4 * am + 3]) am = j; s_argmax = am; }
+            __threadfence_block();
+            __syncthreads();
+            if (tid < k) for (int d = 0; d < 4; ++d) a4[d] = Cw[4 * tid + d];
         }
-        if (tid == 0) { int am = 0; for (int j = 1; j < k; ++j) if (Cw[4 * j + 3] > Cw[4 * am + 3]) am = j; s_argmax = am; }
-        __syncthreads();
-        __shared__ double s_sh[1024];
-        double shift = 0;
         if (tid < k) {
             const int j = tid;
-            const double wj = Cw[4 * j + 3];
             double c[3];
-            if (wj > 0) { const double alpha = 1.0 / wj; for (int d = 0; d < 3; ++d) c[d] = Cw[4 * j + d] * alpha; }
+            if (a4[3] > 0) { const double alpha = 1.0 / a4[3]; for (int d = 0; d < 3; ++d) c[d] = a4[d] * alpha; }
             else { const double alpha = 1.0 / Cw[4 * s_argmax + 3]; for (int d = 0; d < 3; ++d) c[d] = Cw[4 * s_argmax + d] * alpha; }
             double s = 0;
             for (int d = 0; d < 3; ++d) { Cnew[3 * j + d] = c[d]; const double t = c[d] - Cold[3 * j + d]; s += t * t; }
             const double sh = sqrt(s);
-            shift = sh * sh;
+            s_sh[j] = sh * sh;
             make_b(c, Bm + 4 * j);
         }
-        s_sh[tid] = shift;
         __threadfence_block();
         __syncthreads();
         if (tid == 0) {
             double tot = 0;
-            for (int j = 0; j < k; ++j) tot += s_sh[j];
+            for (int j0 = 0; j0 < k; j0 += 8) {                 // fixed order (cluster index); loads of a group issued together
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = s_sh[min(j0 + u, 127)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (j0 + u < k) tot += v[u];
+            }
             s_it = it + 1;
             if (s_changed == 0) { s_strict = 1; s_done = 1; }
             else if (tot <= s_tol) s_done = 1;
-            s_changed = 0;
+            s_changed = 0; s_nempty = 0;
         }
         cur ^= 1;
         __syncthreads();
@@ -678,34 +860,133 @@ __global__ __launch_bounds__(64) void k_group_scatter(GroupBatch G, int n, int m
     }
 }
 
+// ---- the same grouping for large frames (n > 16384): counts over many workgroups, one 1024-thread workgroup per cluster
+// for the ordered compaction (the one-wave-per-cluster walk above took 1.85 ms at n = 262144, k = 128) ----
+__global__ __launch_bounds__(1024) void k_group_count(const int* __restrict__ labels, int n, int k, int* __restrict__ off) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* cnt = (int*)smem;
+    for (int j = threadIdx.x; j < k; j += 1024) cnt[j] = 0;
+    __syncthreads();
+    const int i0 = blockIdx.x * 4096 + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int i = i0 + 1024 * q; if (i < n) atomicAdd(&cnt[labels[i]], 1); }
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += 1024) { const int c = cnt[j]; if (c) atomicAdd(&off[j + 1], c); }      // integers: order independent
+}
+
+// off[0] = 0, off[j + 1] = count of cluster j  ->  off[j + 1] = sum of the counts up to j  (k <= 4096: four per thread)
+__global__ __launch_bounds__(1024) void k_group_excl(int* __restrict__ off, int k) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int c[4], run = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int j = 4 * tid + q; c[q] = j < k ? off[j + 1] : 0; run += c[q]; }
+    int inc = run;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = inc - run;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int j = 4 * tid + q; base += c[q]; if (j < k) off[j + 1] = base; }
+    if (tid == 0) off[0] = 0;
+}
+
+__global__ __launch_bounds__(1024) void k_group_scatter_big(const double* __restrict__ X, int n, const int* __restrict__ labels,
+                                                            const int* __restrict__ off, const double* __restrict__ M,
+                                                            double* __restrict__ out, int m_is_inverse) {
+    const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ double I[16];
+    __shared__ int wtot[2][16];
+    if (m_is_inverse) { if (tid < 16) I[tid] = M[16 * j + tid]; }
+    else if (tid == 0) inv4x4(M + 16 * j, I);
+    __syncthreads();
+    int pos = off[j];
+    for (int base = 0, r = 0; base < n; base += 4096, ++r) {
+        const int i0 = base + 4 * tid;                        // four consecutive points per thread: slots stay in index order
+        bool fl[4];
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { fl[q] = (i0 + q < n) && labels[min(i0 + q, n - 1)] == j; c += fl[q]; }
+        int inc = c;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wtot[r & 1][wv] = inc;
+        __syncthreads();                                      // one barrier per round: the table alternates
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int v = wtot[r & 1][w]; before += w < wv ? v : 0; total += v; }
+        int slot = pos + before + inc - c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (fl[q]) {
+                const size_t i = (size_t)(i0 + q);
+                const double p0 = X[3 * i], p1 = X[3 * i + 1], p2 = X[3 * i + 2];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    out[3 * (size_t)slot + a] = fma(I[4 * a + 2], p2, fma(I[4 * a + 1], p1, I[4 * a] * p0)) + I[4 * a + 3];
+                ++slot;
+            }
+        pos += total;
+    }
+}
+
 static int seg_count(int64_t n) { int s = (int)((n + 16383) / 16384); return s < 1 ? 1 : (s > 64 ? 64 : s); }
 
-struct KmLayout { size_t xc, c2, b, cw, part, far, prev, lab2, flags, total; };
+struct KmLayout { size_t xc, c2, b, cw, part, far, segv, segi, prev, lab2, flags, total; };
 static KmLayout km_layout(int64_t n, int k) {
     KmLayout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     L.xc = take(sizeof(double) * 3 * n); L.c2 = take(sizeof(double) * 6 * k); L.b = take(sizeof(double) * 4 * k);
     L.cw = take(sizeof(double) * 4 * k); L.part = take(sizeof(unsigned long long) * 4 * k);      // part: the int64 accumulators
-    L.far = take(sizeof(double) * n); L.prev = take(sizeof(int) * n); L.lab2 = take(sizeof(int) * n);
+    L.far = take(sizeof(double) * n);
+    const size_t nseg = (size_t)((n + 63) / 64);                 // relocation pass: one entry per workgroup of the E-step launch (at most n / 64: the matrix-core form)
+    L.segv = take(sizeof(double) * nseg); L.segi = take(sizeof(int) * nseg);
+    L.prev = take(sizeof(int) * n); L.lab2 = take(sizeof(int) * n);
     L.flags = take(sizeof(KmFlags)); L.total = o;
     return L;
 }
 
-static void launch_assign(const double* X, int n, const double* B, int k, int* labels, const int* prev,
-                          KmFlags* f, int use_mfma, hipStream_t s, int raw = 0, unsigned long long* acc = nullptr) {
+static int km_points_per_thread(int n) {
+    static int forced = -1;                                      // measurement knob (tests/measure): CREG_KM_PT = 1 | 2 | 4
+    if (forced < 0) { const char* e = getenv("CREG_KM_PT"); forced = e ? atoi(e) : 0; }
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    return n >= 32768 ? 2 : 1;                                  // measured at n = 262144, k = 128: 13.5 / 11.7 / 15.0 us for 1 / 2 / 4
+}
+
+static int launch_assign(const double* X, int n, const double* B, int k, int* labels, const int* prev,
+                         KmFlags* f, int use_mfma, hipStream_t s, int raw = 0, unsigned long long* acc = nullptr,
+                         KmTail T = KmTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr}, nullptr, 0}) {
+    constexpr int LDS_MAX = 128 * 1024;
     if (use_mfma) {
         const int ntile = cdiv(n, 16);
         int blocks = cdiv(ntile, 4);
         if (blocks > 2048) blocks = 2048;                        // a wave then walks several point tiles with its centres in registers
         const size_t smem = sizeof(double) * 5 * ((k + 15) & ~15) + sizeof(unsigned long long) * 4 * k;   // centre rows + the C-operand table + M-step sums
-        if (k <= 16) hipLaunchKernelGGL(k_km_assign_mfma<1>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw, acc);
-        else if (k <= 32) hipLaunchKernelGGL(k_km_assign_mfma<2>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw, acc);
-        else if (k <= 64) hipLaunchKernelGGL(k_km_assign_mfma<4>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw, acc);
-        else if (k <= 128) hipLaunchKernelGGL(k_km_assign_mfma<8>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw, acc);
-        else hipLaunchKernelGGL(k_km_assign_mfma<0>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw, acc);
+#define CREG_KM_MFMA(NT_)                                                                                                        \
+        do {                                                                                                                      \
+            if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_km_assign_mfma<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess) return 1; \
+            hipLaunchKernelGGL(k_km_assign_mfma<NT_>, dim3(blocks), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw, acc, T);  \
+        } while (0)
+        if (k <= 16) CREG_KM_MFMA(1);
+        else if (k <= 32) CREG_KM_MFMA(2);
+        else if (k <= 64) CREG_KM_MFMA(4);
+        else if (k <= 128) CREG_KM_MFMA(8);
+        else CREG_KM_MFMA(0);
+#undef CREG_KM_MFMA
+    } else {
+        const size_t smem = sizeof(double) * 8 * k;
+        const int pt = km_points_per_thread(n);
+#define CREG_KM_VALU(PT_)                                                                                                        \
+        do {                                                                                                                      \
+            if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_km_assign<PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess) return 1; \
+            hipLaunchKernelGGL(k_km_assign<PT_>, dim3(cdiv(n, 256 * PT_)), dim3(256), smem, s, X, n, B, k, labels, prev, f, raw, acc, T); \
+        } while (0)
+        if (pt == 4) CREG_KM_VALU(4);
+        else if (pt == 2) CREG_KM_VALU(2);
+        else CREG_KM_VALU(1);
+#undef CREG_KM_VALU
     }
-    else
-        hipLaunchKernelGGL(k_km_assign, dim3(cdiv(n, 256)), dim3(256), sizeof(double) * 8 * k, s, X, n, B, k, labels, prev, f, raw, acc);
+    return 0;
 }
 
 }  // namespace creg
@@ -740,25 +1021,25 @@ extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* i
     CREG_LAUNCH_CHECK();
     // labels ping-pong between the caller's buffer and lab2 so "previous labels" needs no copy;
     // iteration `it` writes lab[it & 1] and compares with the buffer written by it - 1.
-    int it = 0, done = 0;
+    int done = 0, n_done = 0;
     KmFlags host;
-    while (it < max_iter && !done) {
-        const int batch = (max_iter - it) < 8 ? (max_iter - it) : 8;
-        for (int b = 0; b < batch; ++b, ++it) {
-            int* cur = lab[it & 1];
-            const int* prev = it == 0 ? prev0 : lab[(it - 1) & 1];
-            launch_assign(Xc, ni, B, k, cur, prev, f, use_mfma, s, 0, acc);
-            hipLaunchKernelGGL(k_km_finalize, dim3(1), dim3(1024), 0, s, Xc, ni, cur, k, acc, C2, B, Cw, far_d, f);
-        }
+    const KmTail T{B, C2, Cw, far_d, (double*)(w + L.segv), (int*)(w + L.segi), {lab[0], lab[1]}, prev0, max_iter};
+    while (n_done < max_iter && !done) {
+        // 32 launches per host round trip.  A launch runs the E-step of iteration f->n_iter with the exact incremental sums, and
+        // its last workgroup the M-step tail; launches after convergence (or after max_iter iterations) return at once, and a
+        // launch that follows the discovery of an empty cluster runs the deferred tail instead (see km_lloyd_entry).
+        for (int b = 0; b < 32; ++b)
+            CREG_REQUIRE(launch_assign(Xc, ni, B, k, nullptr, nullptr, f, use_mfma, s, 0, acc, T) == 0,
+                         "creg_kmeans_lloyd_f64: cannot raise the dynamic LDS limit of the E-step");
         CREG_LAUNCH_CHECK();
         CREG_HIP(hipMemcpyAsync(&host, f, sizeof(KmFlags), hipMemcpyDeviceToHost, s));
         CREG_HIP(hipStreamSynchronize(s));
-        done = host.done;
+        done = host.done; n_done = host.n_iter;
     }
     // which buffer holds the labels of the last executed iteration
     int* last = lab[(host.n_iter - 1) & 1];
     if (!host.strict) {      // rerun the E-step so labels match the final centres (_kmeans.py:736-748)
-        launch_assign(Xc, ni, B, k, last, nullptr, nullptr, use_mfma, s);
+        CREG_REQUIRE(launch_assign(Xc, ni, B, k, last, nullptr, nullptr, use_mfma, s) == 0, "creg_kmeans_lloyd_f64: E-step launch failed");
     }
     if (last != labels) CREG_HIP(hipMemcpyAsync(labels, last, sizeof(int) * n, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_km_finish, dim3(1), dim3(1024), 0, s, Xc, ni, labels, k, C2, f, centers, inertia, n_iter);
@@ -770,7 +1051,7 @@ extern "C" int creg_kmeans_assign_f64(const double* X, int64_t n, const double* 
                                       int32_t* labels, creg_stream_t stream) {
     CREG_REQUIRE(X && C && labels && n >= 1 && n < (1ll << 31) && k >= 1 && k <= 1024, "creg_kmeans_assign_f64: bad argument");
     // no device scratch: the kernels derive the (-2c, |c|^2) rows from the centres in their prologue
-    launch_assign(X, (int)n, C, k, labels, nullptr, nullptr, use_mfma, (hipStream_t)stream, 1);
+    CREG_REQUIRE(launch_assign(X, (int)n, C, k, labels, nullptr, nullptr, use_mfma, (hipStream_t)stream, 1) == 0, "creg_kmeans_assign_f64: E-step launch failed");
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }
@@ -783,6 +1064,14 @@ extern "C" int creg_group_to_local_f64(const double* X, int64_t n, const int32_t
     hipStream_t s = (hipStream_t)stream;
     GroupBatch G;
     G.X[0] = X; G.labels[0] = labels; G.M[0] = M; G.out[0] = out_local; G.off[0] = seg_offsets;
+    if (n > 16384) {                                           // large frames: many-workgroup count, workgroup-per-cluster compaction
+        CREG_HIP(hipMemsetAsync(seg_offsets, 0, sizeof(int) * ((size_t)k + 1), s));
+        hipLaunchKernelGGL(k_group_count, dim3(cdiv(n, 4096)), dim3(1024), sizeof(int) * k, s, labels, (int)n, k, seg_offsets);
+        hipLaunchKernelGGL(k_group_excl, dim3(1), dim3(1024), 0, s, seg_offsets, k);
+        hipLaunchKernelGGL(k_group_scatter_big, dim3(k), dim3(1024), 0, s, X, (int)n, labels, seg_offsets, M, out_local, m_is_inverse);
+        CREG_LAUNCH_CHECK();
+        return CREG_OK;
+    }
     hipLaunchKernelGGL(k_group_offsets, dim3(1, 1), dim3(1024), sizeof(int) * (k + 1), s, G, (int)n, k);
     hipLaunchKernelGGL(k_group_scatter, dim3(k, 1), dim3(64), 0, s, G, (int)n, m_is_inverse);
     CREG_LAUNCH_CHECK();
