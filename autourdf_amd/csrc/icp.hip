@@ -94,6 +94,101 @@ __device__ void sym4_max_eigvec(const double N[4][4], double q[4], double* Vp) {
     q[0] = sg * v0 / n; q[1] = sg * v1 / n; q[2] = sg * v2 / n; q[3] = sg * v3 / n;
 }
 
+// adjugate of a symmetric 4x4 (Laplace expansion over the 2x2 minors of its row pairs): adj(M) = det(M) inv(M), and for a
+// singular M with a one-dimensional null space, adj(M) = (product of the non-zero eigenvalues) v v^T with v the null vector.
+__device__ __forceinline__ void adj4(const double (&a)[4][4], double (&r)[4][4]) {
+    const double s0 = a[0][0] * a[1][1] - a[0][1] * a[1][0], s1 = a[0][0] * a[1][2] - a[0][2] * a[1][0], s2 = a[0][0] * a[1][3] - a[0][3] * a[1][0];
+    const double s3 = a[0][1] * a[1][2] - a[0][2] * a[1][1], s4 = a[0][1] * a[1][3] - a[0][3] * a[1][1], s5 = a[0][2] * a[1][3] - a[0][3] * a[1][2];
+    const double c5 = a[2][2] * a[3][3] - a[2][3] * a[3][2], c4 = a[2][1] * a[3][3] - a[2][3] * a[3][1], c3 = a[2][1] * a[3][2] - a[2][2] * a[3][1];
+    const double c2 = a[2][0] * a[3][3] - a[2][3] * a[3][0], c1 = a[2][0] * a[3][2] - a[2][2] * a[3][0], c0 = a[2][0] * a[3][1] - a[2][1] * a[3][0];
+    r[0][0] = (a[1][1] * c5 - a[1][2] * c4) + a[1][3] * c3;  r[0][1] = (-a[0][1] * c5 + a[0][2] * c4) - a[0][3] * c3;
+    r[0][2] = (a[3][1] * s5 - a[3][2] * s4) + a[3][3] * s3;  r[0][3] = (-a[2][1] * s5 + a[2][2] * s4) - a[2][3] * s3;
+    r[1][0] = (-a[1][0] * c5 + a[1][2] * c2) - a[1][3] * c1; r[1][1] = (a[0][0] * c5 - a[0][2] * c2) + a[0][3] * c1;
+    r[1][2] = (-a[3][0] * s5 + a[3][2] * s2) - a[3][3] * s1; r[1][3] = (a[2][0] * s5 - a[2][2] * s2) + a[2][3] * s1;
+    r[2][0] = (a[1][0] * c4 - a[1][1] * c2) + a[1][3] * c0;  r[2][1] = (-a[0][0] * c4 + a[0][1] * c2) - a[0][3] * c0;
+    r[2][2] = (a[3][0] * s4 - a[3][1] * s2) + a[3][3] * s0;  r[2][3] = (-a[2][0] * s4 + a[2][1] * s2) - a[2][3] * s0;
+    r[3][0] = (-a[1][0] * c3 + a[1][1] * c1) - a[1][2] * c0; r[3][1] = (a[0][0] * c3 - a[0][1] * c1) + a[0][2] * c0;
+    r[3][2] = (-a[3][0] * s3 + a[3][1] * s1) - a[3][2] * s0; r[3][3] = (a[2][0] * s3 - a[2][1] * s1) + a[2][2] * s0;
+}
+
+// Dominant eigenvector of Horn's symmetric, traceless 4x4 profile matrix as a unit quaternion (q0 >= 0).
+// Fast path (a few hundred mostly independent flops instead of the serial Jacobi chain, which was 6-7 us of every ICP iteration
+// on one lane): the largest root of the characteristic polynomial  l^4 + c2 l^2 + c1 l + c0  by Newton from the upper bound
+// sqrt(-1.5 c2) (monotone from above), then  v = a column of adj(N - l I),  refined by Rayleigh-quotient rounds
+// (l <- v^T N v / v^T v, new adjugate) until l stops moving at the 1e-15 level: each round squares the eigenvalue error, so
+// two or three rounds reach what the conditioning of the eigenvector (eps / gap) allows.  When the dominant eigenvalue is
+// (nearly) repeated -- too few or degenerate correspondences -- the adjugate vanishes and the warm-started Jacobi sweep
+// below takes over.
+__device__ void horn_max_eigvec(const double N[4][4], double q[4], double* Vp) {
+    double nn2 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nn2 = fma(N[i][j], N[i][j], nn2);
+    bool ok = nn2 > 0 && nn2 < 1e300;
+    if (ok) {
+        double A[4][4], R[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) A[i][j] = N[i][j];
+        // characteristic polynomial of a traceless symmetric matrix: c2 = -tr(N^2)/2, c1 = -tr(N^3)/3, c0 = det N
+        const double c2 = -0.5 * nn2;
+        double t3 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double n2ij = fma(N[i][3], N[3][j], fma(N[i][2], N[2][j], fma(N[i][1], N[1][j], N[i][0] * N[0][j])));
+                t3 = fma(n2ij, N[j][i], t3);
+            }
+        const double c1 = -t3 / 3.0;
+        adj4(A, R);
+        const double c0 = fma(N[0][3], R[3][0], fma(N[0][2], R[2][0], fma(N[0][1], R[1][0], N[0][0] * R[0][0])));   // det = row 0 . column 0 of adj
+        double lam = sqrt(-1.5 * c2) * (1.0 + 1e-12);
+        for (int it = 0; it < 16; ++it) {                       // ~8 steps; the Rayleigh rounds below finish the job
+            const double l2 = lam * lam;
+            const double P = fma(fma(l2 + c2, lam, c1), lam, c0), dP = fma(fma(4.0, l2, 2.0 * c2), lam, c1);
+            if (!(dP > 0)) break;
+            const double step = P * fast_rcp(dP);             // Newton corrects itself: a few-ulp quotient is as good
+            lam -= step;
+            if (fabs(step) <= 1e-11 * fabs(lam)) break;
+        }
+        const double thr = 1e-9 * nn2 * sqrt(nn2);          // |adj| ~ (product of the gaps to the other three eigenvalues)
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        for (int round = 0; round < 6 && ok; ++round) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A[i][i] = N[i][i] - lam;
+            adj4(A, R);
+            // the column of the largest diagonal cofactor (static indices only)
+            double d = fabs(R[0][0]);
+            v0 = R[0][0]; v1 = R[1][0]; v2 = R[2][0]; v3 = R[3][0];
+#pragma unroll
+            for (int c = 1; c < 4; ++c) {
+                const bool gt = fabs(R[c][c]) > d;
+                d = gt ? fabs(R[c][c]) : d;
+                v0 = gt ? R[0][c] : v0; v1 = gt ? R[1][c] : v1; v2 = gt ? R[2][c] : v2; v3 = gt ? R[3][c] : v3;
+            }
+            if (!(d > thr)) { ok = false; break; }
+            const double w0 = fma(N[0][3], v3, fma(N[0][2], v2, fma(N[0][1], v1, N[0][0] * v0)));
+            const double w1 = fma(N[1][3], v3, fma(N[1][2], v2, fma(N[1][1], v1, N[1][0] * v0)));
+            const double w2 = fma(N[2][3], v3, fma(N[2][2], v2, fma(N[2][1], v1, N[2][0] * v0)));
+            const double w3 = fma(N[3][3], v3, fma(N[3][2], v2, fma(N[3][1], v1, N[3][0] * v0)));
+            const double vv = fma(v3, v3, fma(v2, v2, fma(v1, v1, v0 * v0)));
+            const double ray = fma(v3, w3, fma(v2, w2, fma(v1, w1, v0 * w0))) * fast_rcp(vv);
+            const bool settled = fabs(ray - lam) <= 1e-15 * fabs(ray);
+            lam = ray;
+            if (settled) break;
+        }
+        if (ok) {
+            const double rn = (v0 < 0 ? -1.0 : 1.0) * fast_rsqrt(((v0 * v0 + v1 * v1) + v2 * v2) + v3 * v3);
+            q[0] = v0 * rn; q[1] = v1 * rn; q[2] = v2 * rn; q[3] = v3 * rn;
+            return;
+        }
+    }
+    sym4_max_eigvec(N, q, Vp);
+}
+
 struct IcpLayout { size_t srcw, tidx, nn, total; };
 static IcpLayout icp_layout(int64_t n, int64_t nf, int k) {
     IcpLayout L; size_t o = 0;
@@ -105,37 +200,85 @@ static IcpLayout icp_layout(int64_t n, int64_t nf, int k) {
     return L;
 }
 
-constexpr int ICP_NT = 512;                           // threads per workgroup (16 waves)
-constexpr int ICP_ROWS = 256;                          // threads that own source points ("row" threads)
-constexpr int ICP_PARTS = ICP_NT / ICP_ROWS;           // the target list is split this many ways per source point
+constexpr int ICP_NT = 512;                           // threads per workgroup
+constexpr int ICP_WAVES = ICP_NT / 64;                // 8 waves
+constexpr int ICP_ROWS = 256;                         // fallback path: threads that own source points ("row" threads)
+constexpr int ICP_PARTS = ICP_NT / ICP_ROWS;          // fallback path: the target list is split this many ways per source point
 constexpr int ICP_BATCH_MAX = 16;
-constexpr int ICP_SRC_LDS = 1024;                      // source points of a cluster kept in LDS (28 B each)
+constexpr int ICP_SRC_LDS = 1024;                     // source points of a cluster kept in LDS (28 B each)
+constexpr int ICP_NSLAB = 64;                         // slabs along the cluster's longest axis (targets and sources are binned by them)
 
-// Sum N values held by the row threads (waves 0..3) over the block, result in every thread.
-// Fixed association: DPP wave sum per wave, then 0 + w0 + w1 + w2 + w3.
+// Sum N values held by the threads over the block, result in every thread.  `mine` (wave-uniform): this wave holds
+// contributions; a wave without any contributes exact zeros and skips its DPP sums.
+// Fixed association: DPP wave sum per wave, then 0 + w0 + w1 + ... + w7 (by N lanes of wave 0), read back by all.
 template <int N>
-__device__ __forceinline__ void bsum_n(double (&v)[N], double* sc /* [4][N] */) {
+__device__ __forceinline__ void bsum_n(double (&v)[N], double* sc /* [ICP_WAVES + 1][N] */, bool mine = true) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (wv < ICP_ROWS / 64) {
+    if (mine) {
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = wave_sum_fast(v[i]);
     }
     __syncthreads();                                   // previous readers of sc are done
-    if (lane == 0 && wv < ICP_ROWS / 64) {
+    if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) sc[wv * N + i] = v[i];
+        for (int i = 0; i < N; ++i) sc[wv * N + i] = mine ? v[i] : 0.0;
     }
     __syncthreads();
+    if (threadIdx.x < N) { double r = 0.0; for (int w = 0; w < ICP_WAVES; ++w) r += sc[w * N + threadIdx.x]; sc[ICP_WAVES * N + threadIdx.x] = r; }
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < N; ++i) { double r = 0.0; for (int w = 0; w < ICP_ROWS / 64; ++w) r += sc[w * N + i]; v[i] = r; }
+    for (int i = 0; i < N; ++i) v[i] = sc[ICP_WAVES * N + i];
+}
+
+// one v_min_f64 (fmin() lowers to canonicalising v_max pairs around it); neither operand is ever NaN here
+__device__ __forceinline__ double vmin_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// wave-uniform minimum / maximum through the DPP row moves of wave_sum_fast (no LDS-crossbar permutes)
+__device__ __forceinline__ double vmax_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#define CREG_DPP_MINMAX_F64(v, ctrl, mask, OP)                                                                                    \
+    {                                                                                                                             \
+        const int lo_ = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), ctrl, mask, 0xF, false);                  \
+        const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), ctrl, mask, 0xF, false);                  \
+        v = OP(v, __hiloint2double(hi_, lo_));                                                                                    \
+    }
+__device__ __forceinline__ double wave_min_fast(double v) {
+    CREG_DPP_MINMAX_F64(v, 0xB1, 0xF, vmin_f64) CREG_DPP_MINMAX_F64(v, 0x4E, 0xF, vmin_f64) CREG_DPP_MINMAX_F64(v, 0x141, 0xF, vmin_f64)
+    CREG_DPP_MINMAX_F64(v, 0x140, 0xF, vmin_f64) CREG_DPP_MINMAX_F64(v, 0x142, 0xA, vmin_f64) CREG_DPP_MINMAX_F64(v, 0x143, 0xC, vmin_f64)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ double wave_max_fast(double v) {
+    CREG_DPP_MINMAX_F64(v, 0xB1, 0xF, vmax_f64) CREG_DPP_MINMAX_F64(v, 0x4E, 0xF, vmax_f64) CREG_DPP_MINMAX_F64(v, 0x141, 0xF, vmax_f64)
+    CREG_DPP_MINMAX_F64(v, 0x140, 0xF, vmax_f64) CREG_DPP_MINMAX_F64(v, 0x142, 0xA, vmax_f64) CREG_DPP_MINMAX_F64(v, 0x143, 0xC, vmax_f64)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// slab of a coordinate along the binning axis: monotone in x (the same expression bins targets, sources and search bounds)
+__device__ __forceinline__ int icp_slab(double x, double x0, double inv_w) {
+    return (int)fmin(fmax((x - x0) * inv_w, 0.0), (double)(ICP_NSLAB - 1));
 }
 
 #ifdef CREG_STAMPS
 // debug build only (CREG_EXTRA_FLAGS=-DCREG_STAMPS, tests/measure/icp_stamps.py): shader-clock cycles of the phases of
-// workgroup (0, 0), accumulated over its iterations: [0] mask+setup [1] NN scan [2] combine + fitness [3] sums [4] Horn
-// on lane 0 [5] move [6] iterations
-__device__ unsigned long long g_icp_stamps[512 * 8];      // [workgroup (x + gridDim.x * y) % 512][slot]
-#define ICP_STAMP(slot) do { if (stamp_on && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_icp_stamps[stamp_b * 8 + slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
+// every workgroup, accumulated over its iterations: [0] mask + setup [1] NN scan [2] combine + sums of the means [3]
+// covariance sums [4] Horn on lane 0 [5] move [6] iterations [7] targets scanned per wave and iteration (fast path)
+__device__ unsigned long long g_icp_stamps[512 * 16];     // [workgroup (x + gridDim.x * y) % 512][slot]; 8.. = finer split of the NN scan (wave 0's view): [8] bounds + range [9] scan [10] rescans [11] wait for the other waves
+#define ICP_STAMP(slot) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_icp_stamps[stamp_b * 16 + slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
 #else
 #define ICP_STAMP(slot) do { } while (0)
 #endif
@@ -148,23 +291,34 @@ struct IcpBatch {
     double* Mout[ICP_BATCH_MAX]; double* world_out[ICP_BATCH_MAX]; int* n_iter_out[ICP_BATCH_MAX];
 };
 
-// grid (k, batch): one 1024-thread workgroup per cluster per problem.  Masked targets (<= lds_cap) and the
-// cluster's moving source points (<= ICP_SRC_LDS) live in LDS for the whole loop; larger ones fall back to
-// the workspace in global memory through the same (flat) pointers.  Threads 0..255 own the source points
-// (sums, moves); the nearest-target search of a point is split over 4 threads (quarters of the target list,
-// ascending, combined with strict '<' so the first minimum wins exactly as a sequential scan).
+// grid (k, batch): one 512-thread workgroup per cluster per problem; the whole ICP loop of the cluster runs in it.
+//
+// Fast path (<= lds_cap masked targets and <= ICP_SRC_LDS source points: every cluster of the reference's frames): targets
+// and the moving source points live in LDS, both BINNED into ICP_NSLAB slabs along the longest axis of the mask box
+// (targets: counting sort while compacting; sources: stable counting sort, once, at their initial pose -- a rigid motion
+// of a few degrees keeps them nearly sorted).  A wave owns 64 consecutive sorted sources; the nearest target of a source is
+// at most as far as the target it matched in the previous iteration, so the wave scans only the slabs its sources'
+// [x - r, x + r] intervals touch -- a fraction of the list once the cluster is near its pose.  The search is exact: every
+// target at least as near as the previous match lies in the scanned slabs; among equidistant candidates the lowest frame
+// index wins (the sequential scan's first minimum), detected lazily (an equality seen during the scan triggers a rescan
+// with the lexicographic comparison).  The sources of a small cluster are split over several waves by target range.
+// Fallback (larger clusters of a ragged segmentation, or more masked targets than fit): the unbinned lists, sources or
+// targets read through flat pointers from the workspace.
 __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float half_scale, double th, int max_iter,
                                                        int keep_t, char* __restrict__ ws, size_t ws_stride, size_t o_srcw,
                                                        size_t o_tidx, size_t o_nn, int lds_cap) {
-    __shared__ double sc[4 * 9];
+    __shared__ double sc[(ICP_WAVES + 1) * 17];
     __shared__ float s_lo[3], s_hi[3];
-    __shared__ int s_wofs[ICP_NT / 64];
+    __shared__ int s_wofs[ICP_WAVES];
     __shared__ double T[16], U[16], Vp[16];
-    __shared__ double sB[ICP_PARTS][ICP_ROWS];         // per part: best squared distance of the round's points
-    __shared__ int sM[ICP_PARTS][ICP_ROWS];            //           and its target
+    __shared__ double sB[ICP_NT];                      // per (part, source): best squared distance of the round
+    __shared__ int sM[ICP_NT];                         //                     and its target
+    __shared__ int tstart[ICP_NSLAB + 1], tfill[ICP_NSLAB], s_sbase[ICP_NSLAB];
+    __shared__ int wcnt[2 * ICP_WAVES][ICP_NSLAB];     // source sort: [chunk of 64][slab]
+    __shared__ double s_x0, s_inv;
+    __shared__ int s_axis;
     const int z = blockIdx.y;
 #ifdef CREG_STAMPS
-    const bool stamp_on = true;
     const int stamp_b = (blockIdx.x + gridDim.x * blockIdx.y) % 512;
     unsigned long long stamp_t = clock64();
 #endif
@@ -180,29 +334,28 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
     const int* __restrict__ toff = P.toff[z];         // block-uniform
     // ---- 1. box in float32, exactly as numpy evaluates it on the float32 cluster (min / max: any order) ----
     if (!toff) {
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    if (world) {
-        // the box cloud of cluster k may have another size than its ICP source (match() --mlp_icp: frame-0 clusters
-        // are the source, the trained clouds of the CURRENT segmentation give the boxes, mlp_reg.py:248,325)
-        const int* __restrict__ woff = P.woff[z] ? P.woff[z] : off;
-        const int wb = woff[k], we = woff[k + 1];
-        for (int i = wb + tid; i < we; i += ICP_NT)
-            for (int d = 0; d < 3; ++d) { const float v = world[3 * (size_t)i + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
-    } else {
-        // no world clouds given: the cluster in its current pose, evaluated in float32 exactly as
-        // creg_cluster_transform_f32 does on the float32 casts of `local` and `M` (same fma order)
-        float Tf[12];
-        for (int q = 0; q < 12; ++q) Tf[q] = (float)Min[16 * k + q];
-        for (int i = b + tid; i < e; i += ICP_NT) {
-            const float p0 = (float)local[3 * (size_t)i], p1 = (float)local[3 * (size_t)i + 1], p2 = (float)local[3 * (size_t)i + 2];
-            for (int d = 0; d < 3; ++d) {
-                const float v = fmaf(p2, Tf[4 * d + 2], fmaf(p1, Tf[4 * d + 1], p0 * Tf[4 * d])) + Tf[4 * d + 3];
-                lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v);
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (world) {
+            // the box cloud of cluster k may have another size than its ICP source (match() --mlp_icp: frame-0 clusters
+            // are the source, the trained clouds of the CURRENT segmentation give the boxes, mlp_reg.py:248,325)
+            const int* __restrict__ woff = P.woff[z] ? P.woff[z] : off;
+            const int wb = woff[k], we = woff[k + 1];
+            for (int i = wb + tid; i < we; i += ICP_NT)
+                for (int d = 0; d < 3; ++d) { const float v = world[3 * (size_t)i + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
+        } else {
+            // no world clouds given: the cluster in its current pose, evaluated in float32 exactly as
+            // creg_cluster_transform_f32 does on the float32 casts of `local` and `M` (same fma order)
+            float Tf[12];
+            for (int q = 0; q < 12; ++q) Tf[q] = (float)Min[16 * k + q];
+            for (int i = b + tid; i < e; i += ICP_NT) {
+                const float p0 = (float)local[3 * (size_t)i], p1 = (float)local[3 * (size_t)i + 1], p2 = (float)local[3 * (size_t)i + 2];
+                for (int d = 0; d < 3; ++d) {
+                    const float v = fmaf(p2, Tf[4 * d + 2], fmaf(p1, Tf[4 * d + 1], p0 * Tf[4 * d])) + Tf[4 * d + 3];
+                    lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v);
+                }
             }
         }
-    }
-    {
-        __shared__ float wl[ICP_NT / 64][3], wh[ICP_NT / 64][3];
+        __shared__ float wl[ICP_WAVES][3], wh[ICP_WAVES][3];
         for (int d = 0; d < 3; ++d) {
             for (int o = 32; o >= 1; o >>= 1) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64)); }
             if (lane == 0) { wl[wv][d] = lo[d]; wh[wv][d] = hi[d]; }
@@ -211,78 +364,297 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
         if (tid < 3) {
             const int d = tid;
             float l = wl[0][d], h = wh[0][d];
-            for (int w = 1; w < ICP_NT / 64; ++w) { l = fminf(l, wl[w][d]); h = fmaxf(h, wh[w][d]); }
+            for (int w = 1; w < ICP_WAVES; ++w) { l = fminf(l, wl[w][d]); h = fmaxf(h, wh[w][d]); }
             const float c = (l + h) / 2.0f, sz = h - l;
             s_lo[d] = c - half_scale * sz; s_hi[d] = c + half_scale * sz;
         }
         __syncthreads();
-    }
-    }
-    // ---- ordered compaction of the frame points strictly inside the box ----
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* sT = (double*)smem;                       // [lds_cap][3] masked target coordinates
-    int* sI = (int*)(sT + 3 * (size_t)lds_cap);       // [lds_cap]    their frame indices
-    double* sS = (double*)(sI + lds_cap);             // [ICP_SRC_LDS][3] moving source points
-    int* sN = (int*)(sS + 3 * ICP_SRC_LDS);           // [ICP_SRC_LDS] matched target slot / frame index, -1 = none
-    int run = 0;                                      // points kept so far (block-uniform)
-    if (toff) {                                       // point-to-point mode: the cluster's own target segment, unmasked
-        const int tb = toff[k];
-        run = toff[k + 1] - tb;
-        for (int t = tid; t < run; t += ICP_NT) {
-            const int j = tb + t;
-            tidx[t] = j;
-            if (t < lds_cap) { sT[3 * t] = frame[3 * (size_t)j]; sT[3 * t + 1] = frame[3 * (size_t)j + 1]; sT[3 * t + 2] = frame[3 * (size_t)j + 2]; sI[t] = j; }
+    } else {
+        // point-to-point mode: no mask; the bins need the extent of the cluster's own target segment
+        const int tb = toff[k], te = toff[k + 1];
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int j = tb + tid; j < te; j += ICP_NT)
+            for (int d = 0; d < 3; ++d) { const double v = frame[3 * (size_t)j + d]; lo[d] = fmin(lo[d], v); hi[d] = fmax(hi[d], v); }
+        __shared__ double dl[ICP_WAVES][3], dh[ICP_WAVES][3];
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = wave_min_f64(lo[d]); hi[d] = wave_max_f64(hi[d]);
+            if (lane == 0) { dl[wv][d] = lo[d]; dh[wv][d] = hi[d]; }
         }
+        __syncthreads();
+        if (tid < 3) {
+            const int d = tid;
+            double l = dl[0][d], h = dh[0][d];
+            for (int w = 1; w < ICP_WAVES; ++w) { l = fmin(l, dl[w][d]); h = fmax(h, dh[w][d]); }
+            s_lo[d] = (float)l; s_hi[d] = (float)h;          // only the binning reads them in this mode
+        }
+        __syncthreads();
     }
+    if (tid == 0) {
+        // binning axis: the longest edge of the box.  Any choice is correct; this one prunes best.
+        int ax = 0;
+        float ext = s_hi[0] - s_lo[0];
+        for (int d = 1; d < 3; ++d) if (s_hi[d] - s_lo[d] > ext) { ext = s_hi[d] - s_lo[d]; ax = d; }
+        s_axis = ax; s_x0 = (double)s_lo[ax];
+        s_inv = ext > 0.f && ext < INFINITY ? (double)ICP_NSLAB / (double)ext : 0.0;
+    }
+    if (tid < ICP_NSLAB) { tstart[tid] = 0; tfill[tid] = 0; }          // tstart doubles as the slab counters of the first pass
+    __syncthreads();
+    const int axis = s_axis;
+    const double x0 = s_x0, inv_w = s_inv;
     const double blo0 = (double)s_lo[0], blo1 = (double)s_lo[1], blo2 = (double)s_lo[2];
     const double bhi0 = (double)s_hi[0], bhi1 = (double)s_hi[1], bhi2 = (double)s_hi[2];
-    for (int base = 0; base < (toff ? 0 : nf); base += ICP_NT) {
-        const int j = base + tid;
-        bool in = false;
-        double x = 0, y = 0, zc = 0;
-        if (j < nf && ns > 0) {
-            x = frame[3 * (size_t)j]; y = frame[3 * (size_t)j + 1]; zc = frame[3 * (size_t)j + 2];
-            in = x > blo0 && x < bhi0 && y > blo1 && y < bhi1 && zc > blo2 && zc < bhi2;
-        }
-        const unsigned long long m = __ballot(in);
-        __syncthreads();                              // s_wofs of the previous round has been read
-        if (lane == 0) s_wofs[wv] = __popcll(m);
-        __syncthreads();
-        int before = run, total = 0;
-        for (int w = 0; w < ICP_NT / 64; ++w) { const int c = s_wofs[w]; before += w < wv ? c : 0; total += c; }
-        if (in) {
-            const int slot = before + __popcll(m & ((1ull << lane) - 1ull));
-            tidx[slot] = j;
-            if (slot < lds_cap) { sT[3 * slot] = x; sT[3 * slot + 1] = y; sT[3 * slot + 2] = zc; sI[slot] = j; }
-        }
-        run += total;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sT = (double*)smem;                       // [lds_cap + 64][3] masked target coordinates
+    int* sI = (int*)(sT + 3 * (size_t)(lds_cap + 64));   // [lds_cap + 64] their frame indices (64 entries of padding: see the fast path)
+    double* sS = (double*)(sI + lds_cap + 64);        // [ICP_SRC_LDS][3] moving source points
+    int* sN = (int*)(sS + 3 * ICP_SRC_LDS);           // [ICP_SRC_LDS] matched target position / frame index, -1 = none
+    // ---- 2. the candidate targets: frame points strictly inside the box (masked mode) or the cluster's own segment ----
+    const int cb = toff ? toff[k] : 0, cend = toff ? toff[k + 1] : (ns > 0 ? nf : 0);
+    auto candidate = [&](int j, double& x, double& y, double& zc) -> bool {
+        if (j >= cend) return false;
+        x = frame[3 * (size_t)j]; y = frame[3 * (size_t)j + 1]; zc = frame[3 * (size_t)j + 2];
+        return toff ? true : (x > blo0 && x < bhi0 && y > blo1 && y < bhi1 && zc > blo2 && zc < bhi2);
+    };
+    for (int base = cb; base < cend; base += ICP_NT) {                 // pass 1: how many per slab
+        double x, y, zc;
+        if (candidate(base + tid, x, y, zc)) atomicAdd(&tstart[icp_slab(axis == 0 ? x : (axis == 1 ? y : zc), x0, inv_w)], 1);
     }
-    const int nt = run;
-    const bool in_lds = nt <= lds_cap;
+    __syncthreads();
+    if (wv == 0) {                                    // exclusive prefix over the 64 slabs
+        const int c = tstart[lane];
+        int inc = c;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        __builtin_amdgcn_wave_barrier();
+        tstart[lane] = inc - c;
+        if (lane == 63) tstart[ICP_NSLAB] = inc;
+    }
+    __syncthreads();
+    const int nt = tstart[ICP_NSLAB];
+    const bool fast = nt <= lds_cap && ns <= ICP_SRC_LDS;             // block-uniform
+    bool in_lds = nt <= lds_cap;
     const bool src_lds = ns <= ICP_SRC_LDS;
+    if (fast) {
+        for (int base = cb; base < cend; base += ICP_NT) {             // pass 2: into the slabs (any order inside one)
+            const int j = base + tid;
+            double x, y, zc;
+            if (candidate(j, x, y, zc)) {
+                const int sl = icp_slab(axis == 0 ? x : (axis == 1 ? y : zc), x0, inv_w);
+                const int p = tstart[sl] + atomicAdd(&tfill[sl], 1);
+                sT[3 * p] = x; sT[3 * p + 1] = y; sT[3 * p + 2] = zc; sI[p] = j;
+            }
+        }
+        // padding: the last lanes of a split range read up to 63 entries past it; far-away points that never win
+        // (each farther than the one before: equal distances would look like ties to the scan)
+        if (tid < 64) { sT[3 * (nt + tid)] = 1e150 * (double)(1 + tid); sT[3 * (nt + tid) + 1] = 1e150; sT[3 * (nt + tid) + 2] = 1e150; sI[nt + tid] = 0x7fffffff; }
+    } else {
+        // fallback: ordered compaction (ascending frame index) into the workspace list, and into LDS while it fits
+        int run = 0;
+        for (int base = cb; base < cend; base += ICP_NT) {
+            const int j = base + tid;
+            double x, y, zc;
+            const bool in = candidate(j, x, y, zc);
+            const unsigned long long m = __ballot(in);
+            __syncthreads();                          // s_wofs of the previous round has been read
+            if (lane == 0) s_wofs[wv] = __popcll(m);
+            __syncthreads();
+            int before = run, total = 0;
+            for (int w = 0; w < ICP_WAVES; ++w) { const int c = s_wofs[w]; before += w < wv ? c : 0; total += c; }
+            if (in) {
+                const int slot = before + __popcll(m & ((1ull << lane) - 1ull));
+                tidx[slot] = j;
+                if (slot < lds_cap) { sT[3 * slot] = x; sT[3 * slot + 1] = y; sT[3 * slot + 2] = zc; sI[slot] = j; }
+            }
+            run += total;
+        }
+    }
     double* S = src_lds ? sS : (double*)(wz + o_srcw) + 3 * (size_t)b;      // flat pointer: LDS or workspace
     int* nn = src_lds ? sN : (int*)(wz + o_nn) + b;
 
-    // ---- 2. ICP ----
+    // ---- 3. sources into the world frame with the initial pose (fast path: binned like the targets, stable) ----
     if (tid < 16) { T[tid] = Min[16 * k + tid]; Vp[tid] = (tid % 5 == 0) ? 1.0 : 0.0; }
-    __syncthreads();                                  // T, sT/sI and (not in_lds) tidx visible to the block
-    if (row)
+    for (int i = tid; i < 2 * ICP_WAVES * ICP_NSLAB; i += ICP_NT) (&wcnt[0][0])[i] = 0;
+    __syncthreads();                                  // T, sT/sI and (fallback) tidx visible to the block
+    if (fast) {
+        double pw[2][3];
+        int psl[2], prk[2];
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            const int c = wv + ICP_WAVES * rnd, i = 64 * c + lane;
+            const bool valid = i < ns;
+            int sl = 0;
+            if (valid) {
+                const double* p = local + 3 * (size_t)(b + i);
+                const double p0 = p[0], p1 = p[1], p2 = p[2];
+                for (int a = 0; a < 3; ++a) pw[rnd][a] = fma(T[4 * a + 2], p2, fma(T[4 * a + 1], p1, T[4 * a] * p0)) + T[4 * a + 3];
+                sl = icp_slab(axis == 0 ? pw[rnd][0] : (axis == 1 ? pw[rnd][1] : pw[rnd][2]), x0, inv_w);
+            }
+            // rank among the chunk's lower lanes of the same slab; the chunk's count per slab
+            unsigned long long rem = __ballot(valid);
+            int rank = 0;
+            while (rem) {
+                const int lead = __ffsll((long long)rem) - 1;
+                const int lsl = __builtin_amdgcn_readlane(sl, lead);
+                const unsigned long long m = __ballot(valid && sl == lsl);
+                if (valid && sl == lsl) rank = __popcll(m & ((1ull << lane) - 1ull));
+                if (lane == lead) wcnt[c][lsl] = __popcll(m);
+                rem &= ~m;
+            }
+            psl[rnd] = sl; prk[rnd] = rank;
+        }
+        __syncthreads();
+        if (wv == 0) {                                // slab-major, chunk-minor exclusive prefix
+            int run = 0;
+            for (int c = 0; c < 2 * ICP_WAVES; ++c) { const int t = wcnt[c][lane]; wcnt[c][lane] = run; run += t; }
+            int inc = run;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+            s_sbase[lane] = inc - run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            const int c = wv + ICP_WAVES * rnd, i = 64 * c + lane;
+            if (i < ns) {
+                const int pos = s_sbase[psl[rnd]] + wcnt[c][psl[rnd]] + prk[rnd];
+                S[3 * pos] = pw[rnd][0]; S[3 * pos + 1] = pw[rnd][1]; S[3 * pos + 2] = pw[rnd][2];
+                nn[pos] = -1;
+            }
+        }
+    } else if (row) {
         for (int i = tid; i < ns; i += ICP_ROWS) {
             const double* p = local + 3 * (size_t)(b + i);
             const double p0 = p[0], p1 = p[1], p2 = p[2];
             for (int a = 0; a < 3; ++a) S[3 * i + a] = fma(T[4 * a + 2], p2, fma(T[4 * a + 1], p1, T[4 * a] * p0)) + T[4 * a + 3];
         }
+    }
     const double th2 = th * th;
     double fit = 0, rmse = 0;
     int it = 0;
-    const int part = __builtin_amdgcn_readfirstlane(tid / ICP_ROWS), pi = tid % ICP_ROWS;
-    const int t0 = (int)((long long)nt * part / ICP_PARTS), t1 = (int)((long long)nt * (part + 1) / ICP_PARTS);
-    // matched target of a source point (slot in LDS, or frame index when the targets did not fit)
+    // matched target of a source point (position in LDS, or frame index when the targets did not fit)
     auto tgt = [&](int m, int a) -> double { return in_lds ? sT[3 * m + a] : frame[3 * (size_t)m + a]; };
-    auto correspond = [&](double& fitness, double& rm) {
-        double ce[2] = {0, 0};
-        __syncthreads();                              // the row threads' moves of S are visible
+
+    // reference point of the per-iteration moments (see the loop below)
+    double shc[3] = {0.5 * (blo0 + bhi0), 0.5 * (blo1 + bhi1), 0.5 * (blo2 + bhi2)};
+    // ---- fast path: slab-pruned exact nearest target; leaves the reduced [count, sum d2, sum src - shc (3), sum tgt - shc (3),
+    //      sum (src - shc)(tgt - shc)^T (9)] in cm ----
+    // G = 2^lg lanes share one source point and split the scanned range between them, so a wave owns only 64 / G consecutive
+    // sorted sources: the range a wave must scan is the union of its sources' intervals, and it shrinks with the number of
+    // sources in the wave until the intervals' own width (previous distance + slab granularity) dominates.  Measured on the
+    // reference's frames (ns ~ 200, ~600 targets): 64 sources per wave scan ~190 targets each, 16 sources ~80, split four ways.
+    const int lg = ns >= 128 ? 2 : (ns >= 64 ? 3 : (ns >= 32 ? 4 : (ns >= 16 ? 5 : 6)));     // small clusters: more lanes per source, all waves busy
+    const int G = 1 << lg, spw = 64 >> lg;
+    const int units = (ns + spw - 1) >> (6 - lg);                     // wave-sized work items
+    const int nround = (units + ICP_WAVES - 1) / ICP_WAVES;
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);               // scalar copy: the scan bounds below must stay wave-uniform
+                                                                      // for the compiler (a divergent range costs a branch per target)
+    const int lg_g = lane & (G - 1), lg_s = lane >> lg;               // lane -> (share of the range, source within the wave)
+    const int tsv = tstart[lane];
+    auto correspond_fast = [&](double (&cm)[17], bool have_prev) {
+        for (int a = 0; a < 17; ++a) cm[a] = 0;
+        __syncthreads();                              // the moves of S are visible
         ICP_STAMP(5);
+        for (int rnd = 0; rnd < nround; ++rnd) {
+            const int unit = rnd * ICP_WAVES + wvs;
+            const bool active = unit < units;                         // wave-uniform
+            const int i = unit * spw + lg_s;
+            const bool live = active && i < ns;
+            double s0 = 0, s1 = 0, s2 = 0, lo = INFINITY, hi = -INFINITY;
+            if (live) {
+                s0 = S[3 * i]; s1 = S[3 * i + 1]; s2 = S[3 * i + 2];
+                const int pm = have_prev ? nn[i] : -1;
+                lo = -INFINITY; hi = INFINITY;
+                if (pm >= 0) {
+                    // no target can be nearer than the previous match is now: the same expression the scan evaluates
+                    const double dx = s0 - sT[3 * pm], dy = s1 - sT[3 * pm + 1], dz = s2 - sT[3 * pm + 2];
+                    const double sx = axis == 0 ? s0 : (axis == 1 ? s1 : s2);
+                    // (x rsqrt(x): a few ulp from sqrt(x), far inside the 1e-12 allowance)
+                    const double d2p = (dx * dx + dy * dy) + dz * dz;
+                    const double r = (d2p > 1e-280 ? d2p * fast_rsqrt(d2p) : 1e-140) * (1.0 + 1e-12) + (4e-16 * fabs(sx) + 1e-300);
+                    lo = sx - r; hi = sx + r;
+                }
+            }
+            const double wlo = wave_min_fast(lo), whi = wave_max_fast(hi);
+            // slab -> first target: lane l of tsv holds tstart[l] (one v_readlane each instead of two dependent LDS reads)
+            const int sa = __builtin_amdgcn_readfirstlane(icp_slab(wlo, x0, inv_w)), sb = __builtin_amdgcn_readfirstlane(icp_slab(whi, x0, inv_w)) + 1;
+            const int r0 = active ? __builtin_amdgcn_readlane(tsv, sa) : 0;
+            const int r1 = active ? (sb >= ICP_NSLAB ? nt : __builtin_amdgcn_readlane(tsv, sb & (ICP_NSLAB - 1))) : 0;
+            const int per = (r1 - r0 + G - 1) >> lg;                  // targets per lane; the last lanes run into the following
+                                                                      // targets or the padding behind the list: both harmless
+            const int base = r0 + lg_g * per;
+#ifdef CREG_STAMPS
+            if (lane == 0) atomicAdd(&g_icp_stamps[stamp_b * 16 + 7], (unsigned long long)per);
+            unsigned long long st2 = clock64();
+            if (tid == 0) g_icp_stamps[stamp_b * 16 + 8] += st2 - stamp_t;
+#endif
+            // first minimum in scan order (strict <) and last one (<=): they differ exactly when a second candidate as near
+            // as the best was seen -- then the wave rescans with the frame-index tie-break.  5 VALU ops per target on top
+            // of the 8 of the distance: two compares, one v_min_f64, two selects.
+            double best = INFINITY; int bm = -1, bl = -1;
+            const double* tp = sT + 3 * base;
+            int st = 0;
+            for (; st + 4 <= per; st += 4) {          // unconditional body: the 12 LDS reads of a trip go out together
+                double d2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double dx = s0 - tp[3 * (st + u)], dy = s1 - tp[3 * (st + u) + 1], dz = s2 - tp[3 * (st + u) + 2];
+                    d2[u] = (dx * dx + dy * dy) + dz * dz;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    bm = d2[u] < best ? st + u : bm;
+                    bl = d2[u] <= best ? st + u : bl;
+                    best = vmin_f64(best, d2[u]);
+                }
+            }
+            for (; st < per; ++st) {
+                const double dx = s0 - tp[3 * st], dy = s1 - tp[3 * st + 1], dz = s2 - tp[3 * st + 2];
+                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                bm = d2 < best ? st : bm;
+                bl = d2 <= best ? st : bl;
+                best = vmin_f64(best, d2);
+            }
+            const unsigned long long tie = __ballot(bm != bl);
+            int bj = 0x7fffffff;
+            if (tie) {                                // equidistant candidates somewhere in the wave: the lowest frame index wins
+                best = INFINITY; bm = -1;
+                for (st = 0; st < per; ++st) {
+                    const double dx = s0 - tp[3 * st], dy = s1 - tp[3 * st + 1], dz = s2 - tp[3 * st + 2];
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    const int j = sI[base + st];
+                    if (d2 < best || (d2 == best && j < bj)) { best = d2; bm = st; bj = j; }
+                }
+            } else if (bm >= 0) bj = sI[base + bm];
+            bm = bm >= 0 ? base + bm : -1;
+#ifdef CREG_STAMPS
+            { const unsigned long long now2 = clock64(); if (tid == 0) { g_icp_stamps[stamp_b * 16 + 9] += now2 - st2; g_icp_stamps[stamp_b * 16 + 10] += tie ? 1 : 0; } st2 = now2; }
+#endif
+            // the G lanes of a source: (distance, frame index) lexicographic minimum
+            for (int o = 1; o < G; o <<= 1) {
+                const double od = __shfl_xor(best, o, 64); const int om = __shfl_xor(bm, o, 64), oj = __shfl_xor(bj, o, 64);
+                if (od < best || (od == best && oj < bj)) { best = od; bm = om; bj = oj; }
+            }
+            if (live && lg_g == 0) {
+                const bool ok = bm >= 0 && best <= th2;
+                nn[i] = ok ? bm : -1;
+                if (ok) {
+                    const double sv[3] = {s0 - shc[0], s1 - shc[1], s2 - shc[2]};
+                    const double dv[3] = {sT[3 * bm] - shc[0], sT[3 * bm + 1] - shc[1], sT[3 * bm + 2] - shc[2]};
+                    cm[0] += 1.0; cm[1] += best;
+                    for (int a = 0; a < 3; ++a) { cm[2 + a] += sv[a]; cm[5 + a] += dv[a]; }
+                    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) cm[8 + 3 * a + c] = fma(sv[a], dv[c], cm[8 + 3 * a + c]);
+                }
+            }
+        }
+        ICP_STAMP(1);
+        bsum_n<17>(cm, sc, wvs < units);
+        ICP_STAMP(2);
+    };
+
+    // ---- fallback: unbinned lists (row threads own the sources, the target list is split over ICP_PARTS threads each) ----
+    const int part_s = __builtin_amdgcn_readfirstlane(tid / ICP_ROWS), pi = tid % ICP_ROWS;
+    const int t0 = (int)((long long)nt * part_s / ICP_PARTS), t1 = (int)((long long)nt * (part_s + 1) / ICP_PARTS);
+    auto correspond_slow = [&](double (&cm)[17]) {
+        for (int a = 0; a < 17; ++a) cm[a] = 0;
+        __syncthreads();                              // the row threads' moves of S are visible
         for (int r0 = 0; r0 < ns; r0 += ICP_ROWS) {
             const int i = r0 + pi;
             double best = INFINITY; int bm = -1;
@@ -304,47 +676,50 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
                     }
                 }
             }
-            sB[part][pi] = best; sM[part][pi] = bm;
+            sB[part_s * ICP_ROWS + pi] = best; sM[part_s * ICP_ROWS + pi] = bm;
             __syncthreads();
-            ICP_STAMP(1);
-            if (row && i < ns) {                      // quarters in ascending target order, strict '<': first minimum
-                best = sB[0][pi]; bm = sM[0][pi];
+            if (row && i < ns) {                      // parts in ascending target order, strict '<': first minimum
+                best = sB[pi]; bm = sM[pi];
 #pragma unroll
-                for (int q = 1; q < ICP_PARTS; ++q) { const double d = sB[q][pi]; if (d < best) { best = d; bm = sM[q][pi]; } }
-                if (bm >= 0 && best <= th2) { nn[i] = bm; ce[0] += 1.0; ce[1] += best; } else nn[i] = -1;
+                for (int q = 1; q < ICP_PARTS; ++q) { const double d = sB[q * ICP_ROWS + pi]; if (d < best) { best = d; bm = sM[q * ICP_ROWS + pi]; } }
+                const bool ok = bm >= 0 && best <= th2;
+                nn[i] = ok ? bm : -1;
+                if (ok) {
+                    double sv[3], dv[3];
+                    for (int a = 0; a < 3; ++a) { sv[a] = S[3 * i + a] - shc[a]; dv[a] = tgt(bm, a) - shc[a]; }
+                    cm[0] += 1.0; cm[1] += best;
+                    for (int a = 0; a < 3; ++a) { cm[2 + a] += sv[a]; cm[5 + a] += dv[a]; }
+                    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) cm[8 + 3 * a + c] = fma(sv[a], dv[c], cm[8 + 3 * a + c]);
+                }
             }
             if (r0 + ICP_ROWS < ns) __syncthreads();  // sB / sM are rewritten by the next round
         }
-        bsum_n<2>(ce, sc);
-        ICP_STAMP(2);
-        fitness = ns > 0 ? ce[0] / (double)ns : 0.0;
-        rm = ce[0] > 0 ? sqrt(ce[1] / ce[0]) : 0.0;
-        return ce[0];
+        bsum_n<17>(cm, sc);
+    };
+    auto correspond = [&](double (&cm)[17], bool have_prev) {
+        if (fast) correspond_fast(cm, have_prev); else correspond_slow(cm);
+        fit = ns > 0 ? cm[0] / (double)ns : 0.0;
+        rmse = cm[0] > 0 ? sqrt(cm[1] / cm[0]) : 0.0;
     };
     ICP_STAMP(0);
-    double ncorr = correspond(fit, rmse);
+    // One pass per iteration: a matched pair adds its count, squared distance, coordinates and their outer product, all
+    // taken relative to the point shc -- the centroid of the previous iteration's matched targets (the box centre at the
+    // start).  Horn's update puts the matched sources' centroid exactly there, so shc is within the iteration's small
+    // motion of both centroids of the NEXT correspondences and  C = sum (s - shc)(d - shc)^T - n (ms - shc)(md - shc)^T
+    // loses nothing to cancellation; the separate centred pass over the correspondences (and its block reduction) is gone.
+    double cm[17];
+    correspond(cm, false);
     for (it = 1; it <= max_iter; ++it) {
-        // best rigid update from the current correspondences
-        double mm[6] = {0, 0, 0, 0, 0, 0};            // sums of matched source / target coordinates
-        if (row)
-            for (int i = tid; i < ns; i += ICP_ROWS) {
-                const int m = nn[i];
-                if (m < 0) continue;
-                for (int a = 0; a < 3; ++a) { mm[a] += S[3 * i + a]; mm[3 + a] += tgt(m, a); }
-            }
-        bsum_n<6>(mm, sc);
-        if (ncorr > 0) for (int a = 0; a < 6; ++a) mm[a] /= ncorr;
-        const double* ms = mm; const double* md = mm + 3;
-        double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};            // C[a][c] = sum (src-ms)_a (dst-md)_c
-        if (row)
-            for (int i = tid; i < ns; i += ICP_ROWS) {
-                const int m = nn[i];
-                if (m < 0) continue;
-                double sv[3], dv[3];
-                for (int a = 0; a < 3; ++a) { sv[a] = S[3 * i + a] - ms[a]; dv[a] = tgt(m, a) - md[a]; }
-                for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) C[3 * a + c] = fma(sv[a], dv[c], C[3 * a + c]);
-            }
-        bsum_n<9>(C, sc);
+        // best rigid update from the current correspondences (their count and moments came with them)
+        const double ncorr = cm[0];
+        double ms[3], md[3], msr[3], mdr[3];          // centroids, absolute and relative to shc
+        for (int a = 0; a < 3; ++a) {
+            msr[a] = ncorr > 0 ? cm[2 + a] / ncorr : 0.0; mdr[a] = ncorr > 0 ? cm[5 + a] / ncorr : 0.0;
+            ms[a] = shc[a] + msr[a]; md[a] = shc[a] + mdr[a];
+        }
+        double C[9];                                  // C[a][c] = sum (src-ms)_a (dst-md)_c
+        for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) C[3 * a + c] = fma(-ncorr * msr[a], mdr[c], cm[8 + 3 * a + c]);
+        if (ncorr > 0) for (int a = 0; a < 3; ++a) shc[a] = md[a];
         ICP_STAMP(3);
         if (tid == 0) {
             for (int i = 0; i < 16; ++i) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
@@ -355,7 +730,7 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
                                   {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
                                   {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
                 double q[4], R[9];
-                sym4_max_eigvec(N, q, Vp);
+                horn_max_eigvec(N, q, Vp);
                 quat_to_matrix(q, R);
                 for (int a = 0; a < 3; ++a) {
                     U[4 * a] = R[3 * a]; U[4 * a + 1] = R[3 * a + 1]; U[4 * a + 2] = R[3 * a + 2];
@@ -373,18 +748,17 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
         __syncthreads();
         ICP_STAMP(4);
 #ifdef CREG_STAMPS
-        if (stamp_on && tid == 0) g_icp_stamps[stamp_b * 8 + 6] += 1;
+        if (tid == 0) g_icp_stamps[stamp_b * 16 + 6] += 1;
 #endif
-        if (row)
-            for (int i = tid; i < ns; i += ICP_ROWS) {
-                const double p0 = S[3 * i], p1 = S[3 * i + 1], p2 = S[3 * i + 2];
-                for (int a = 0; a < 3; ++a) S[3 * i + a] = fma(U[4 * a + 2], p2, fma(U[4 * a + 1], p1, U[4 * a] * p0)) + U[4 * a + 3];
-            }
+        for (int i = tid; i < ns; i += ICP_NT) {
+            const double p0 = S[3 * i], p1 = S[3 * i + 1], p2 = S[3 * i + 2];
+            for (int a = 0; a < 3; ++a) S[3 * i + a] = fma(U[4 * a + 2], p2, fma(U[4 * a + 1], p1, U[4 * a] * p0)) + U[4 * a + 3];
+        }
         const double pf = fit, pr = rmse;
-        ncorr = correspond(fit, rmse);
+        correspond(cm, true);
         if (fabs(pf - fit) < 1e-6 && fabs(pr - rmse) < 1e-6) break;
     }
-    // ---- 3. outputs: icp matrix (optionally with the old translation), cluster moved by it ----
+    // ---- 4. outputs: icp matrix (optionally with the old translation), cluster moved by it ----
     __syncthreads();
     if (tid == 0) {
         if (keep_t) { T[3] = Min[16 * k + 3]; T[7] = Min[16 * k + 7]; T[11] = Min[16 * k + 11]; }
@@ -608,7 +982,7 @@ __global__ __launch_bounds__(512) void k_icp_fit(IcpLarge P, int max_iter) {
                               {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
                               {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
             double q[4], R[9];
-            sym4_max_eigvec(N, q, Vp);
+            horn_max_eigvec(N, q, Vp);
             quat_to_matrix(q, R);
             for (int a = 0; a < 3; ++a) {
                 U[4 * a] = R[3 * a]; U[4 * a + 1] = R[3 * a + 1]; U[4 * a + 2] = R[3 * a + 2];
@@ -745,11 +1119,11 @@ static int icp_launch(const creg_icp_problem* pr, int batch, int64_t n, int32_t 
         B.toff[i] = q.tgt_offsets; B.woff[i] = q.world_offsets;
         B.Mout[i] = q.M_out; B.world_out[i] = q.world_out; B.n_iter_out[i] = q.n_iter_out;
     }
-    const int lds_cap = (int)(nf < 4096 ? nf : 4096);             // masked targets kept in LDS (28 B each, <= 112 KB)
-    const int smem = lds_cap * 28 + ICP_SRC_LDS * 28;
+    const int lds_cap = (int)(nf < 4096 ? (nf + 1) & ~1ll : 4096);  // masked targets kept in LDS (28 B each, <= 112 KB); even: the doubles behind the int table stay aligned
+    const int smem = (lds_cap + 64) * 28 + ICP_SRC_LDS * 28;      // 64 targets of padding behind the list
     // per device, not per process: set on every call (a cached flag would leave a second GPU at the 64 KB default)
     CREG_HIP(hipFuncSetAttribute((const void*)k_masked_icp, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 4096 * 28 + ICP_SRC_LDS * 28));
+                                 (4096 + 64) * 28 + ICP_SRC_LDS * 28));
     hipLaunchKernelGGL(k_masked_icp, dim3(k, batch), dim3(ICP_NT), smem, s, B, (int)nf, (float)(0.5 * scale), th,
                        max_iteration, keep_translation, (char*)workspace, one, L.srcw, L.tidx, L.nn, lds_cap);
     CREG_LAUNCH_CHECK();
@@ -796,8 +1170,8 @@ extern "C" int creg_icp_p2p_f64(const double* src, int64_t n_src, const int32_t*
 
 #ifdef CREG_STAMPS
 extern "C" int creg_debug_icp_stamps(unsigned long long* out8, int reset) {
-    if (out8) CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_icp_stamps), sizeof(unsigned long long) * 512 * 8));
-    if (reset) { static unsigned long long z[512 * 8]; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_icp_stamps), z, sizeof(z))); }
+    if (out8) CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_icp_stamps), sizeof(unsigned long long) * 512 * 16));
+    if (reset) { static unsigned long long z[512 * 16]; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_icp_stamps), z, sizeof(z))); }
     return CREG_OK;
 }
 #endif
