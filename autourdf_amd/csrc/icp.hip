@@ -777,29 +777,37 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
 
 // =================================================================================================================
 // Large regime (clusters of more than ICP_SRC_LDS points, or frames whose masked targets do not fit a CU's LDS: the
-// BASELINE configs[4] shape has 2048-point clusters against ~3000 masked targets each): the same ICP as k_masked_icp,
-// iteration by iteration over MANY workgroups instead of one workgroup per cluster running out of global memory:
-//   k_icp_mask   (cluster)            box, ordered compaction of the frame indices inside it
-//   k_icp_init   (cluster)            sources into the world frame with the initial pose
-//   k_icp_nn     (256-source chunk)   nearest masked target of every source point: tiles of the cluster's targets staged in
-//                                     LDS, sequential-equivalent first minimum (strict '<' in ascending target order)
-//   k_icp_fit    (cluster)            fitness / RMSE of the new correspondences, open3d's convergence test against the
-//                                     previous ones, else Horn's closed form from them, pose and source update
+// BASELINE configs[4] shape has 2048-point clusters against ~3000 masked targets each): the same ICP as k_masked_icp's
+// fast path -- slab-binned targets and sources, exact search pruned by the previous match, one-pass shifted moments --
+// iteration by iteration over MANY workgroups instead of one workgroup per cluster:
+//   k_icp_mask   (cluster)            box; frame indices inside it, binned into ICP_NSLAB slabs along the box's longest
+//                                     axis (count pass + scatter pass), or in ascending order for creg_aabb_mask_f64
+//   k_icp_init   (cluster)            sources into the world frame with the initial pose, stable-sorted by slab
+//   k_icp_nn     (256-source chunk)   applies the pending rigid update to its sources, then the nearest masked target of
+//                                     each (a wave = 64 consecutive sorted sources scans the slabs its sources' [x - r, x + r]
+//                                     intervals touch, r = distance to the previous match), and the chunk's moments
+//   k_icp_fit    (cluster, one wave)  chunk moments in chunk order -> fitness / RMSE, open3d's convergence test against the
+//                                     previous ones, else Horn's closed form: new pose, pending update for the sources
 //   k_icp_finish (cluster)            outputs
 // The host enqueues [fit, nn] in batches of 16 and reads one "clusters still running" word between batches.
 struct IcpLarge {                          // per problem
     const double* local; const float* world; const int* off; const int* woff; const double* frame; const double* Min;
     double* Mout; double* world_out; int* n_iter_out;
-    double* srcw; int* tidx; int* tcount; float* box; int* nn; double* d2; double* state; int* running;
+    double* srcw; int* tidx; int* tcount; float* box; int* nn; double* part; double* state; int* running;
     int* chunk0;                               // [k + 1] first source chunk of every cluster (k_icp_nn's block -> cluster map)
+    int* tst;                                  // [k][ICP_NSLAB + 1] first target of every slab (binned mode)
 };
 constexpr int ICP_CH = 256;                // sources per k_icp_nn workgroup
-constexpr int ICP_ST = 48;                 // doubles of per-cluster state: T[16] Vp[16] prev_fit prev_rmse done n_updates ...
+constexpr int ICP_ST = 48;                 // doubles of per-cluster state: T[16] U[16] prev_fit prev_rmse done n_updates x0 inv_w axis shc[3]
+constexpr int ICP_NM = 17;                 // moments per chunk: count, sum d2, sum (s - shc), sum (d - shc), sum (s - shc)(d - shc)^T
 
-__global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float half_scale, int from_pose) {
+// binned = 0: ascending compaction into tidx / tcount (creg_aabb_mask_f64, the G9 golden).
+// binned = 1: tidx holds the same indices grouped by slab (any order inside one), tst the slab starts, state the binning.
+__global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float half_scale, int from_pose, int binned) {
     __shared__ float wl[16][3], wh[16][3];
     __shared__ float s_lo[3], s_hi[3];
     __shared__ int s_wofs[16];
+    __shared__ int cnt[ICP_NSLAB + 1], fill[ICP_NSLAB];
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = P.off[k], e = P.off[k + 1];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -822,6 +830,8 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
         for (int o = 32; o >= 1; o >>= 1) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64)); }
         if (lane == 0) { wl[wv][d] = lo[d]; wh[wv][d] = hi[d]; }
     }
+    if (tid <= ICP_NSLAB) cnt[tid] = 0;
+    if (tid < ICP_NSLAB) fill[tid] = 0;
     __syncthreads();
     if (tid < 3) {
         const int d = tid;
@@ -835,6 +845,42 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
     const double blo0 = (double)s_lo[0], blo1 = (double)s_lo[1], blo2 = (double)s_lo[2];
     const double bhi0 = (double)s_hi[0], bhi1 = (double)s_hi[1], bhi2 = (double)s_hi[2];
     int* tidx = P.tidx + (size_t)k * nf;
+    if (binned) {
+        int ax = 0;
+        float ext = s_hi[0] - s_lo[0];
+        for (int d = 1; d < 3; ++d) if (s_hi[d] - s_lo[d] > ext) { ext = s_hi[d] - s_lo[d]; ax = d; }
+        const double x0 = (double)s_lo[ax], inv_w = ext > 0.f && ext < INFINITY ? (double)ICP_NSLAB / (double)ext : 0.0;
+        const int nfe = e > b ? nf : 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int j = tid; j < nfe; j += 1024) {
+                const double x = P.frame[3 * (size_t)j], y = P.frame[3 * (size_t)j + 1], z = P.frame[3 * (size_t)j + 2];
+                if (x > blo0 && x < bhi0 && y > blo1 && y < bhi1 && z > blo2 && z < bhi2) {
+                    const int sl = icp_slab(ax == 0 ? x : (ax == 1 ? y : z), x0, inv_w);
+                    if (pass == 0) atomicAdd(&cnt[sl], 1);
+                    else tidx[cnt[sl] + atomicAdd(&fill[sl], 1)] = j;
+                }
+            }
+            __syncthreads();
+            if (pass == 0) {
+                if (wv == 0) {                    // exclusive prefix over the slabs
+                    const int c = cnt[lane];
+                    int inc = c;
+                    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+                    cnt[lane] = inc - c;
+                    if (lane == 63) cnt[ICP_NSLAB] = inc;
+                }
+                __syncthreads();
+            }
+        }
+        if (tid <= ICP_NSLAB) P.tst[(size_t)k * (ICP_NSLAB + 1) + tid] = cnt[tid];
+        if (tid == 0) {
+            P.tcount[k] = cnt[ICP_NSLAB];
+            double* st = P.state + ICP_ST * k;
+            st[36] = x0; st[37] = inv_w; st[38] = (double)ax;
+            st[39] = 0.5 * (blo0 + bhi0); st[40] = 0.5 * (blo1 + bhi1); st[41] = 0.5 * (blo2 + bhi2);
+        }
+        return;
+    }
     int run = 0;
     for (int base = 0; base < nf; base += 1024) {
         const int j = base + tid;
@@ -855,18 +901,71 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
     if (tid == 0) P.tcount[k] = run;
 }
 
-__global__ __launch_bounds__(256) void k_icp_init(IcpLarge P, int k_total) {
-    const int k = blockIdx.x, tid = threadIdx.x;
-    const int b = P.off[k], e = P.off[k + 1];
+// one workgroup per cluster: sources with the initial pose, stable counting sort by slab into srcw (k_icp_mask ran before)
+__global__ __launch_bounds__(1024) void k_icp_init(IcpLarge P, int k_total) {
+    __shared__ int base[ICP_NSLAB], run[ICP_NSLAB];
+    __shared__ int wcnt[16][ICP_NSLAB];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = P.off[k], e = P.off[k + 1], ns = e - b;
+    double* st = P.state + ICP_ST * k;
+    const double x0 = st[36], inv_w = st[37];
+    const int axis = (int)st[38];
     double T[12];
     for (int q = 0; q < 12; ++q) T[q] = P.Min[16 * k + q];
-    for (int i = b + tid; i < e; i += 256) {
-        const double p0 = P.local[3 * (size_t)i], p1 = P.local[3 * (size_t)i + 1], p2 = P.local[3 * (size_t)i + 2];
-        for (int a = 0; a < 3; ++a) P.srcw[3 * (size_t)i + a] = fma(T[4 * a + 2], p2, fma(T[4 * a + 1], p1, T[4 * a] * p0)) + T[4 * a + 3];
+    auto world_pt = [&](int i, double (&w)[3]) {
+        const double p0 = P.local[3 * (size_t)(b + i)], p1 = P.local[3 * (size_t)(b + i) + 1], p2 = P.local[3 * (size_t)(b + i) + 2];
+        for (int a = 0; a < 3; ++a) w[a] = fma(T[4 * a + 2], p2, fma(T[4 * a + 1], p1, T[4 * a] * p0)) + T[4 * a + 3];
+    };
+    if (tid < ICP_NSLAB) { base[tid] = 0; run[tid] = 0; }
+    __syncthreads();
+    for (int i = tid; i < ns; i += 1024) {
+        double w[3];
+        world_pt(i, w);
+        atomicAdd(&base[icp_slab(axis == 0 ? w[0] : (axis == 1 ? w[1] : w[2]), x0, inv_w)], 1);
     }
-    if (tid < 16) { P.state[ICP_ST * k + tid] = P.Min[16 * k + tid]; P.state[ICP_ST * k + 16 + tid] = (tid % 5 == 0) ? 1.0 : 0.0; }
+    __syncthreads();
+    if (wv == 0) {
+        const int c = base[lane];
+        int inc = c;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        base[lane] = inc - c;
+    }
+    for (int r0 = 0; r0 < ns; r0 += 1024) {
+        __syncthreads();                              // base / run of the previous round are final; wcnt may be rewritten
+        for (int q = tid; q < 16 * ICP_NSLAB; q += 1024) (&wcnt[0][0])[q] = 0;
+        __syncthreads();
+        const int i = r0 + tid;
+        const bool valid = i < ns;
+        double w[3] = {0, 0, 0};
+        int sl = 0;
+        if (valid) { world_pt(i, w); sl = icp_slab(axis == 0 ? w[0] : (axis == 1 ? w[1] : w[2]), x0, inv_w); }
+        unsigned long long rem = __ballot(valid);
+        int rank = 0;
+        while (rem) {                                 // rank among the wave's lower lanes of the same slab; the wave's count per slab
+            const int lead = __ffsll((long long)rem) - 1;
+            const int lsl = __builtin_amdgcn_readlane(sl, lead);
+            const unsigned long long m = __ballot(valid && sl == lsl);
+            if (valid && sl == lsl) rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == lead) wcnt[wv][lsl] = __popcll(m);
+            rem &= ~m;
+        }
+        __syncthreads();
+        if (tid < ICP_NSLAB) {                        // per slab: exclusive prefix over the waves, then the round's total
+            int acc = 0;
+            for (int w2 = 0; w2 < 16; ++w2) { const int t = wcnt[w2][tid]; wcnt[w2][tid] = acc; acc += t; }
+            const int r = run[tid];
+            run[tid] = r + acc;
+            for (int w2 = 0; w2 < 16; ++w2) wcnt[w2][tid] += r;
+        }
+        __syncthreads();
+        if (valid) {
+            const size_t pos = (size_t)b + base[sl] + wcnt[wv][sl] + rank;
+            P.srcw[3 * pos] = w[0]; P.srcw[3 * pos + 1] = w[1]; P.srcw[3 * pos + 2] = w[2];
+            P.nn[pos] = -1;
+        }
+    }
+    if (tid < 16) { st[tid] = P.Min[16 * k + tid]; st[16 + tid] = (tid % 5 == 0) ? 1.0 : 0.0; }      // pose; pending update = identity
     if (tid == 0) {
-        double* st = P.state + ICP_ST * k;
         st[32] = 0.0; st[33] = 0.0; st[34] = 0.0; st[35] = 0.0;       // prev fitness, prev rmse, done, updates applied
         if (k == 0) {
             *P.running = k_total;
@@ -877,131 +976,184 @@ __global__ __launch_bounds__(256) void k_icp_init(IcpLarge P, int k_total) {
     }
 }
 
-// Block = one chunk of ICP_CH = 256 sources of ONE cluster (chunk0 maps blocks to clusters; blocks past the last chunk
-// exit), one source per thread: every thread of the block scans the same target list, staged tile by tile in LDS.
-// (Measured at N = 262144, K = 128: blocks over the concatenated sources that straddle two clusters 51 ms per frame's ICP,
-//  cluster-aligned chunks 32 ms, two sources per thread -- half the LDS broadcast reads per pair, half the waves -- 41 ms.)
+// Block = one chunk of ICP_CH = 256 sorted sources of ONE cluster (chunk0 maps blocks to clusters; blocks past the last
+// chunk exit); a wave = 64 consecutive sources with its own target range, staged 64 at a time in the wave's own LDS slice
+// (no block barrier in the scan).
 __global__ __launch_bounds__(256) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2) {
-    __shared__ double tx[256], ty[256], tz[256];
-    const int tid = threadIdx.x, blk = blockIdx.x;
+    __shared__ double tx[4][64], ty[4][64], tz[4][64];
+    __shared__ int tj[4][64];
+    __shared__ double sc[5 * ICP_NM];
+    const int tid = threadIdx.x, blk = blockIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (blk >= P.chunk0[k_total]) return;
-    int lo = 0, hi = k_total;                                         // cluster c with chunk0[c] <= blk < chunk0[c + 1]
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P.chunk0[mid] <= blk) lo = mid; else hi = mid; }
-    const int c = lo;
-    if (P.state[ICP_ST * c + 34] != 0.0) return;                      // converged cluster: its correspondences stay
+    int clo = 0, chi = k_total;                                       // cluster c with chunk0[c] <= blk < chunk0[c + 1]
+    while (chi - clo > 1) { const int mid = (clo + chi) >> 1; if (P.chunk0[mid] <= blk) clo = mid; else chi = mid; }
+    const int c = clo;
+    const double* st = P.state + ICP_ST * c;
+    if (st[34] != 0.0) return;                                        // converged cluster: nothing moves any more
     const int i = P.off[c] + (blk - P.chunk0[c]) * ICP_CH + tid;
     const bool live = i < P.off[c + 1];
-    double s0 = 0, s1 = 0, s2 = 0;
-    if (live) { s0 = P.srcw[3 * (size_t)i]; s1 = P.srcw[3 * (size_t)i + 1]; s2 = P.srcw[3 * (size_t)i + 2]; }
-    double best = INFINITY; int bm = -1;
-    const int nt = P.tcount[c];
-    const int* tidx = P.tidx + (size_t)c * nf;
-    for (int t0 = 0; t0 < nt; t0 += 256) {
-        __syncthreads();
-        if (t0 + tid < nt) {
-            const int j = tidx[t0 + tid];
-            tx[tid] = P.frame[3 * (size_t)j]; ty[tid] = P.frame[3 * (size_t)j + 1]; tz[tid] = P.frame[3 * (size_t)j + 2];
-        }
-        __syncthreads();
-        const int cnt = min(256, nt - t0);
-#pragma unroll 8
-        for (int t = 0; t < cnt; ++t) {
-            const double dx = s0 - tx[t], dy = s1 - ty[t], dz = s2 - tz[t];
-            const double d = (dx * dx + dy * dy) + dz * dz;
-            if (d < best) { best = d; bm = t0 + t; }                  // the slot; its frame index is looked up once at the end
+    const double x0 = st[36], inv_w = st[37];
+    const int axis = (int)st[38];
+    const double shc0 = st[39], shc1 = st[40], shc2 = st[41];
+    double s0 = 0, s1 = 0, s2 = 0, lo = INFINITY, hi = -INFINITY;
+    if (live) {
+        // the rigid update the last fit left pending (identity before the first one)
+        const double p0 = P.srcw[3 * (size_t)i], p1 = P.srcw[3 * (size_t)i + 1], p2 = P.srcw[3 * (size_t)i + 2];
+        s0 = fma(st[16 + 2], p2, fma(st[16 + 1], p1, st[16] * p0)) + st[16 + 3];
+        s1 = fma(st[16 + 6], p2, fma(st[16 + 5], p1, st[16 + 4] * p0)) + st[16 + 7];
+        s2 = fma(st[16 + 10], p2, fma(st[16 + 9], p1, st[16 + 8] * p0)) + st[16 + 11];
+        P.srcw[3 * (size_t)i] = s0; P.srcw[3 * (size_t)i + 1] = s1; P.srcw[3 * (size_t)i + 2] = s2;
+        const int pm = P.nn[i];
+        lo = -INFINITY; hi = INFINITY;
+        if (pm >= 0) {
+            const double dx = s0 - P.frame[3 * (size_t)pm], dy = s1 - P.frame[3 * (size_t)pm + 1], dz = s2 - P.frame[3 * (size_t)pm + 2];
+            const double sx = axis == 0 ? s0 : (axis == 1 ? s1 : s2);
+            const double d2p = (dx * dx + dy * dy) + dz * dz;
+            const double r = (d2p > 1e-280 ? d2p * fast_rsqrt(d2p) : 1e-140) * (1.0 + 1e-12) + (4e-16 * fabs(sx) + 1e-300);
+            lo = sx - r; hi = sx + r;
         }
     }
+    const double wlo = wave_min_fast(lo), whi = wave_max_fast(hi);
+    const int* tst = P.tst + (size_t)c * (ICP_NSLAB + 1);
+    const bool any = __ballot(live) != 0;
+    const int r0 = any ? tst[__builtin_amdgcn_readfirstlane(icp_slab(wlo, x0, inv_w))] : 0;
+    const int r1 = any ? tst[__builtin_amdgcn_readfirstlane(icp_slab(whi, x0, inv_w)) + 1] : 0;
+    const int* tidx = P.tidx + (size_t)c * nf;
+#ifdef CREG_STAMPS
+    if (lane == 0 && any) { atomicAdd(&g_icp_stamps[0], (unsigned long long)(r1 - r0)); atomicAdd(&g_icp_stamps[1], 1ull); atomicAdd(&g_icp_stamps[3], (unsigned long long)P.tcount[c]); }
+#endif
+    double best = INFINITY; int bm = -1, bl = -1;
+    bool tief = false;
+    for (int pass = 0; pass < 2; ++pass) {                            // pass 1 only after a tie was seen: frame-index tie-break
+        int bj = 0x7fffffff;
+        for (int t0 = r0; t0 < r1; t0 += 64) {
+            const int cnt = min(64, r1 - t0);
+            if (lane < cnt) {
+                const int j = tidx[t0 + lane];
+                tx[wv][lane] = P.frame[3 * (size_t)j]; ty[wv][lane] = P.frame[3 * (size_t)j + 1]; tz[wv][lane] = P.frame[3 * (size_t)j + 2];
+                tj[wv][lane] = j;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (pass == 0) {
+                int t = 0;
+                for (; t + 4 <= cnt; t += 4) {
+                    double d2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double dx = s0 - tx[wv][t + u], dy = s1 - ty[wv][t + u], dz = s2 - tz[wv][t + u];
+                        d2[u] = (dx * dx + dy * dy) + dz * dz;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        bm = d2[u] < best ? t0 + t + u : bm;
+                        bl = d2[u] <= best ? t0 + t + u : bl;
+                        best = vmin_f64(best, d2[u]);
+                    }
+                }
+                for (; t < cnt; ++t) {
+                    const double dx = s0 - tx[wv][t], dy = s1 - ty[wv][t], dz = s2 - tz[wv][t];
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    bm = d2 < best ? t0 + t : bm;
+                    bl = d2 <= best ? t0 + t : bl;
+                    best = vmin_f64(best, d2);
+                }
+            } else {
+                for (int t = 0; t < cnt; ++t) {
+                    const double dx = s0 - tx[wv][t], dy = s1 - ty[wv][t], dz = s2 - tz[wv][t];
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    const int j = tj[wv][t];
+                    if (d2 < best || (d2 == best && j < bj)) { best = d2; bm = t0 + t; bj = j; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (pass == 0) {
+            tief = __ballot(bm != bl) != 0;
+#ifdef CREG_STAMPS
+            if (lane == 0 && tief) atomicAdd(&g_icp_stamps[2], 1ull);
+#endif
+            if (!tief) break;
+            best = INFINITY; bm = -1;
+        }
+    }
+    double cm[ICP_NM];
+    for (int a = 0; a < ICP_NM; ++a) cm[a] = 0;
     if (live) {
         const bool ok = bm >= 0 && best <= th2;
-        P.nn[i] = ok ? tidx[bm] : -1;
-        P.d2[i] = ok ? best : 0.0;
+        const int j = ok ? tidx[bm] : -1;
+        P.nn[i] = j;
+        if (ok) {
+            const double sv[3] = {s0 - shc0, s1 - shc1, s2 - shc2};
+            const double dv[3] = {P.frame[3 * (size_t)j] - shc0, P.frame[3 * (size_t)j + 1] - shc1, P.frame[3 * (size_t)j + 2] - shc2};
+            cm[0] = 1.0; cm[1] = best;
+            for (int a = 0; a < 3; ++a) { cm[2 + a] = sv[a]; cm[5 + a] = dv[a]; }
+            for (int a = 0; a < 3; ++a) for (int q = 0; q < 3; ++q) cm[8 + 3 * a + q] = sv[a] * dv[q];
+        }
     }
-}
-
-template <int N>
-__device__ __forceinline__ void bsum512(double (&v)[N], double* sc /* [8][N] */) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the chunk's moments: DPP wave sums, then 0 + w0 + w1 + w2 + w3 (fixed association)
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = wave_sum_fast(v[i]);
-    __syncthreads();
+    for (int a = 0; a < ICP_NM; ++a) cm[a] = wave_sum_fast(cm[a]);
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) sc[wv * N + i] = v[i];
+        for (int a = 0; a < ICP_NM; ++a) sc[wv * ICP_NM + a] = cm[a];
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < N; ++i) { double r = 0.0; for (int w = 0; w < 8; ++w) r += sc[w * N + i]; v[i] = r; }
+    if (tid < ICP_NM) {
+        double r = 0.0;
+        for (int w = 0; w < 4; ++w) r += sc[w * ICP_NM + tid];
+        P.part[(size_t)blk * ICP_NM + tid] = r;
+    }
 }
 
-__global__ __launch_bounds__(512) void k_icp_fit(IcpLarge P, int max_iter) {
-    __shared__ double sc[8 * 9];
-    __shared__ double T[16], U[16], Vp[16];
-    const int k = blockIdx.x, tid = threadIdx.x;
+// one wave per cluster: moments of the chunks in chunk order, convergence, Horn
+__global__ __launch_bounds__(64) void k_icp_fit(IcpLarge P, int max_iter) {
+    const int k = blockIdx.x, lane = threadIdx.x;
     double* st = P.state + ICP_ST * k;
     if (st[34] != 0.0) return;                                        // done
-    const int b = P.off[k], e = P.off[k + 1], ns = e - b;
+    const int ns = P.off[k + 1] - P.off[k];
+    double v = 0.0;
+    if (lane < ICP_NM) for (int ch = P.chunk0[k]; ch < P.chunk0[k + 1]; ++ch) v += P.part[(size_t)ch * ICP_NM + lane];
+    double cm[ICP_NM];
+#pragma unroll
+    for (int a = 0; a < ICP_NM; ++a) cm[a] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), a), __builtin_amdgcn_readlane(__double2loint(v), a));
+    if (lane != 0) return;
     // fitness / inlier RMSE of the correspondences the last k_icp_nn produced (registration_icp's GetRegistrationResult)
-    double ce[2] = {0, 0};
-    for (int i = b + tid; i < e; i += 512) if (P.nn[i] >= 0) { ce[0] += 1.0; ce[1] += P.d2[i]; }
-    bsum512<2>(ce, sc);
-    const double ncorr = ce[0];
-    const double fit = ns > 0 ? ce[0] / (double)ns : 0.0, rmse = ce[0] > 0 ? sqrt(ce[1] / ce[0]) : 0.0;
+    const double ncorr = cm[0];
+    const double fit = ns > 0 ? cm[0] / (double)ns : 0.0, rmse = cm[0] > 0 ? sqrt(cm[1] / cm[0]) : 0.0;
     const double pf = st[32], pr = st[33];
     const int updates = (int)st[35];
     const bool converged = updates >= 1 && fabs(pf - fit) < 1e-6 && fabs(pr - rmse) < 1e-6;
-    if (converged || updates >= max_iter) {
-        __syncthreads();
-        if (tid == 0) { st[34] = 1.0; atomicSub(P.running, 1); }
-        return;
-    }
-    if (tid < 16) { T[tid] = st[tid]; Vp[tid] = st[16 + tid]; }
-    double mm[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = b + tid; i < e; i += 512) {
-        const int m = P.nn[i];
-        if (m < 0) continue;
-        for (int a = 0; a < 3; ++a) { mm[a] += P.srcw[3 * (size_t)i + a]; mm[3 + a] += P.frame[3 * (size_t)m + a]; }
-    }
-    bsum512<6>(mm, sc);
-    if (ncorr > 0) for (int a = 0; a < 6; ++a) mm[a] /= ncorr;
-    const double* ms = mm; const double* md = mm + 3;
-    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = b + tid; i < e; i += 512) {
-        const int m = P.nn[i];
-        if (m < 0) continue;
-        double sv[3], dv[3];
-        for (int a = 0; a < 3; ++a) { sv[a] = P.srcw[3 * (size_t)i + a] - ms[a]; dv[a] = P.frame[3 * (size_t)m + a] - md[a]; }
-        for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) C[3 * a + c] = fma(sv[a], dv[c], C[3 * a + c]);
-    }
-    bsum512<9>(C, sc);
-    if (tid == 0) {
-        for (int i = 0; i < 16; ++i) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
-        if (ncorr > 0) {
-            const double Sxx = C[0], Sxy = C[1], Sxz = C[2], Syx = C[3], Syy = C[4], Syz = C[5], Szx = C[6], Szy = C[7], Szz = C[8];
-            double N[4][4] = {{Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx},
-                              {Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz},
-                              {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
-                              {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
-            double q[4], R[9];
-            horn_max_eigvec(N, q, Vp);
-            quat_to_matrix(q, R);
-            for (int a = 0; a < 3; ++a) {
-                U[4 * a] = R[3 * a]; U[4 * a + 1] = R[3 * a + 1]; U[4 * a + 2] = R[3 * a + 2];
-                U[4 * a + 3] = md[a] - (R[3 * a] * ms[0] + R[3 * a + 1] * ms[1] + R[3 * a + 2] * ms[2]);
-            }
+    if (converged || updates >= max_iter) { st[34] = 1.0; atomicSub(P.running, 1); return; }
+    double U[16], T[16], Vp[16];
+    for (int i = 0; i < 16; ++i) { U[i] = (i % 5 == 0) ? 1.0 : 0.0; Vp[i] = U[i]; T[i] = st[i]; }
+    if (ncorr > 0) {
+        const double shc[3] = {st[39], st[40], st[41]};
+        double ms[3], md[3], msr[3], mdr[3];
+        for (int a = 0; a < 3; ++a) { msr[a] = cm[2 + a] / ncorr; mdr[a] = cm[5 + a] / ncorr; ms[a] = shc[a] + msr[a]; md[a] = shc[a] + mdr[a]; }
+        double C[9];
+        for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) C[3 * a + c] = fma(-ncorr * msr[a], mdr[c], cm[8 + 3 * a + c]);
+        const double Sxx = C[0], Sxy = C[1], Sxz = C[2], Syx = C[3], Syy = C[4], Syz = C[5], Szx = C[6], Szy = C[7], Szz = C[8];
+        double N[4][4] = {{Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx},
+                          {Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz},
+                          {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
+                          {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
+        double q[4], R[9];
+        horn_max_eigvec(N, q, Vp);
+        quat_to_matrix(q, R);
+        for (int a = 0; a < 3; ++a) {
+            U[4 * a] = R[3 * a]; U[4 * a + 1] = R[3 * a + 1]; U[4 * a + 2] = R[3 * a + 2];
+            U[4 * a + 3] = md[a] - (R[3 * a] * ms[0] + R[3 * a + 1] * ms[1] + R[3 * a + 2] * ms[2]);
         }
-        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) {
-            double s = 0;
-            for (int m = 0; m < 4; ++m) s = fma(U[4 * r + m], T[4 * m + c], s);
-            st[4 * r + c] = s;
-        }
-        for (int i = 0; i < 16; ++i) st[16 + i] = Vp[i];
-        st[32] = fit; st[33] = rmse; st[35] = (double)(updates + 1);
+        st[39] = md[0]; st[40] = md[1]; st[41] = md[2];              // the matched sources' centroid lands here
     }
-    __syncthreads();
-    for (int i = b + tid; i < e; i += 512) {
-        const double p0 = P.srcw[3 * (size_t)i], p1 = P.srcw[3 * (size_t)i + 1], p2 = P.srcw[3 * (size_t)i + 2];
-        for (int a = 0; a < 3; ++a) P.srcw[3 * (size_t)i + a] = fma(U[4 * a + 2], p2, fma(U[4 * a + 1], p1, U[4 * a] * p0)) + U[4 * a + 3];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) {
+        double s = 0;
+        for (int m = 0; m < 4; ++m) s = fma(U[4 * r + m], T[4 * m + c], s);
+        st[4 * r + c] = s;
     }
+    for (int i = 0; i < 16; ++i) st[16 + i] = U[i];                   // k_icp_nn applies it to the sources
+    st[32] = fit; st[33] = rmse; st[35] = (double)(updates + 1);
 }
 
 __global__ __launch_bounds__(256) void k_icp_finish(IcpLarge P, int keep_t) {
@@ -1022,13 +1174,15 @@ __global__ __launch_bounds__(256) void k_icp_finish(IcpLarge P, int keep_t) {
     }
 }
 
-struct IcpLargeLayout { size_t srcw, tidx, tcount, box, nn, d2, state, running, chunk0, total; };
+struct IcpLargeLayout { size_t srcw, tidx, tcount, box, nn, part, state, running, chunk0, tst, total; };
 static IcpLargeLayout icp_large_layout(int64_t n, int64_t nf, int k) {
     IcpLargeLayout L; size_t o = 0;
     auto take = [&](size_t b) { size_t r = o; o = align_up(o + b, 256); return r; };
     L.srcw = take(sizeof(double) * 3 * n); L.tidx = take(sizeof(int) * (size_t)k * nf); L.tcount = take(sizeof(int) * k);
-    L.box = take(sizeof(float) * 6 * k); L.nn = take(sizeof(int) * n); L.d2 = take(sizeof(double) * n);
-    L.state = take(sizeof(double) * ICP_ST * k); L.running = take(sizeof(int) * 4); L.chunk0 = take(sizeof(int) * (k + 1)); L.total = o;
+    L.box = take(sizeof(float) * 6 * k); L.nn = take(sizeof(int) * n);
+    L.part = take(sizeof(double) * ICP_NM * (size_t)(n / ICP_CH + k + 1));
+    L.state = take(sizeof(double) * ICP_ST * k); L.running = take(sizeof(int) * 4); L.chunk0 = take(sizeof(int) * (k + 1));
+    L.tst = take(sizeof(int) * (size_t)k * (ICP_NSLAB + 1)); L.total = o;
     return L;
 }
 // the regime switch (host-side sizes only): average cluster above the LDS source budget, or a frame too large for the
@@ -1061,13 +1215,14 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
     P.local = q.local; P.world = q.world; P.off = q.seg_offsets; P.woff = q.world_offsets; P.frame = q.frame; P.Min = q.M;
     P.Mout = q.M_out; P.world_out = q.world_out; P.n_iter_out = q.n_iter_out;
     P.srcw = (double*)(ws + L.srcw); P.tidx = (int*)(ws + L.tidx); P.tcount = (int*)(ws + L.tcount); P.box = (float*)(ws + L.box);
-    P.nn = (int*)(ws + L.nn); P.d2 = (double*)(ws + L.d2); P.state = (double*)(ws + L.state); P.running = (int*)(ws + L.running); P.chunk0 = (int*)(ws + L.chunk0);
+    P.nn = (int*)(ws + L.nn); P.part = (double*)(ws + L.part); P.state = (double*)(ws + L.state); P.running = (int*)(ws + L.running);
+    P.chunk0 = (int*)(ws + L.chunk0); P.tst = (int*)(ws + L.tst);
     if (q.tgt_offsets) {
         set_error("creg_masked_icp: point-to-point mode (tgt_offsets) is not available in the large-cluster regime");
         return CREG_EINVAL;
     }
-    hipLaunchKernelGGL(k_icp_mask, dim3(k), dim3(1024), 0, s, P, (int)nf, (float)(0.5 * scale), q.world ? 0 : 1);
-    hipLaunchKernelGGL(k_icp_init, dim3(k), dim3(256), 0, s, P, k);
+    hipLaunchKernelGGL(k_icp_mask, dim3(k), dim3(1024), 0, s, P, (int)nf, (float)(0.5 * scale), q.world ? 0 : 1, 1);
+    hipLaunchKernelGGL(k_icp_init, dim3(k), dim3(1024), 0, s, P, k);
     const int nblk = cdiv(n, ICP_CH) + k;                // an upper bound of sum_c ceil(ns_c / ICP_CH); the surplus blocks exit
     hipLaunchKernelGGL(k_icp_nn, dim3(nblk), dim3(256), 0, s, P, (int)n, k, (int)nf, th * th);
     CREG_LAUNCH_CHECK();
@@ -1076,7 +1231,7 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
     for (int64_t done = 0; running > 0 && done <= (int64_t)max_iteration; ) {
         const int batch = 16;
         for (int b = 0; b < batch; ++b, ++done) {
-            hipLaunchKernelGGL(k_icp_fit, dim3(k), dim3(512), 0, s, P, max_iteration);
+            hipLaunchKernelGGL(k_icp_fit, dim3(k), dim3(64), 0, s, P, max_iteration);
             hipLaunchKernelGGL(k_icp_nn, dim3(nblk), dim3(256), 0, s, P, (int)n, k, (int)nf, th * th);
         }
         CREG_LAUNCH_CHECK();
@@ -1153,7 +1308,7 @@ extern "C" int creg_aabb_mask_f64(const float* world, const int32_t* world_offse
     IcpLarge P{};
     P.world = world; P.off = world_offsets; P.woff = world_offsets; P.frame = frame;
     P.tidx = mask_idx; P.tcount = mask_count; P.box = boxes;
-    hipLaunchKernelGGL(k_icp_mask, dim3(k), dim3(1024), 0, (hipStream_t)stream, P, (int)nf, (float)(0.5 * scale), 0);
+    hipLaunchKernelGGL(k_icp_mask, dim3(k), dim3(1024), 0, (hipStream_t)stream, P, (int)nf, (float)(0.5 * scale), 0, 0);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }

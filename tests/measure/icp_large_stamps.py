@@ -1,0 +1,33 @@
+"""Debug build only (CREG_EXTRA_FLAGS=-DCREG_STAMPS): how many targets a wave of k_icp_nn scans at the configs[4] shape."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from autourdf_amd import _lib, ops                                      # noqa: E402
+from autourdf_amd.synthetic import initial_segmentation, make_sequence  # noqa: E402
+
+L = _lib.load()
+fn = L.creg_debug_icp_stamps
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+dev = torch.device("cuda")
+N, K = 262144, 128
+seq = make_sequence("chain32", 0, 3, N)
+mats0, clusters0, _ = initial_segmentation(seq[0], K, seed=0, iters=8)
+M = torch.as_tensor(mats0, dtype=torch.float64, device=dev).contiguous()
+local, off = ops.pack_clusters(clusters0, dev, torch.float64)
+out = (ctypes.c_ulonglong * (512 * 16))()
+for f in seq[1:]:
+    f64 = torch.as_tensor(f, dtype=torch.float64, device=dev)
+    world32 = ops.cluster_transform(local.to(torch.float32), off, M.to(torch.float32))
+    torch.cuda.synchronize(); fn(None, 1)
+    M_new, _, n_it = ops.masked_icp(local, world32, off, f64, M)
+    torch.cuda.synchronize(); fn(out, 0)
+    v = np.array(list(out)[:8], dtype=np.float64)
+    print(f"waves {v[1]:.0f}, targets scanned per wave {v[0] / max(v[1], 1):.1f} of {v[3] / max(v[1], 1):.0f} masked, tie rescans {v[2]:.0f}, iterations mean {n_it.double().mean():.1f} max {int(n_it.max())}")
+    _, labels, _, _ = ops.kmeans_lloyd(f64, M_new[:, :3, 3].contiguous())
+    local, off = ops.group_to_local(f64, labels, M_new)
+    M = M_new

@@ -23,8 +23,8 @@ def main():
         print(nm[:90])
         print(f"  calls {len(dur)}  duration us: mean {dur.mean():.1f}  p10 {np.percentile(dur, 10):.1f}  p50 {np.percentile(dur, 50):.1f}  "
               f"p90 {np.percentile(dur, 90):.1f}  p99 {np.percentile(dur, 99):.1f}  max {dur.max():.1f}")
-        if len(gap):
-            g = gap[gap < 1000]
+        g = gap[gap < 1000] if len(gap) else gap
+        if len(g):
             print(f"  gap to the next launch of the same kernel (us, gaps < 1 ms): mean {g.mean():.1f}  p50 {np.percentile(g, 50):.1f}  p90 {np.percentile(g, 90):.1f}")
         big = np.argsort(-dur)[:8]
         print("  longest:", ", ".join(f"#{i}: {dur[i]:.0f}" for i in sorted(big)))
