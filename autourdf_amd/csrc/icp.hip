@@ -795,11 +795,20 @@ struct IcpLarge {                          // per problem
     double* Mout; double* world_out; int* n_iter_out;
     double* srcw; int* tidx; int* tcount; float* box; int* nn; double* part; double* state; int* running;
     int* chunk0;                               // [k + 1] first source chunk of every cluster (k_icp_nn's block -> cluster map)
-    int* tst;                                  // [k][ICP_NSLAB + 1] first target of every slab (binned mode)
+    int* tst;                                  // [k][ICP_NCELL + 1] first target of every cell, row-major in (a, b) (binned mode)
+    int* chunk_cl;                             // [chunks] cluster of every chunk (k_icp_nn's block -> cluster map)
+    double* prevt;                             // [n][3] coordinates of every source's current match (the next search's bound)
+    double* tcx; double* tcy; double* tcz;     // pool of the clusters' masked target coordinates in cell order (coalesced staging)
+    int* tbase;                                // [k] a cluster's first pool entry, -1: did not fit (its targets are gathered through tidx)
+    int pool_cap;
 };
-constexpr int ICP_CH = 256;                // sources per k_icp_nn workgroup
-constexpr int ICP_ST = 48;                 // doubles of per-cluster state: T[16] U[16] prev_fit prev_rmse done n_updates x0 inv_w axis shc[3]
+constexpr int ICP_CH = 64;                 // sources per k_icp_nn workgroup (4 waves of 16)
+constexpr int ICP_NNW = ICP_CH / 16;       // waves of a k_icp_nn workgroup
+constexpr int ICP_ST = 48;                 // doubles of per-cluster state: T[16] U[16] prev_fit prev_rmse done n_updates | a: x0 inv_w axis | shc[3] | b: x0 inv_w axis
 constexpr int ICP_NM = 17;                 // moments per chunk: count, sum d2, sum (s - shc), sum (d - shc), sum (s - shc)(d - shc)^T
+constexpr int ICP_GA = 16, ICP_GB = 16;    // cells along the box's longest (a) and second longest (b) edge
+constexpr int ICP_NCELL = ICP_GA * ICP_GB;
+__device__ __forceinline__ int icp_bin(double x, double x0, double inv_w, int nbin) { return (int)fmin(fmax((x - x0) * inv_w, 0.0), (double)(nbin - 1)); }
 
 // binned = 0: ascending compaction into tidx / tcount (creg_aabb_mask_f64, the G9 golden).
 // binned = 1: tidx holds the same indices grouped by slab (any order inside one), tst the slab starts, state the binning.
@@ -807,7 +816,7 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
     __shared__ float wl[16][3], wh[16][3];
     __shared__ float s_lo[3], s_hi[3];
     __shared__ int s_wofs[16];
-    __shared__ int cnt[ICP_NSLAB + 1], fill[ICP_NSLAB];
+    __shared__ int cnt[ICP_NCELL + 1], fill[ICP_NCELL];
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = P.off[k], e = P.off[k + 1];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -830,8 +839,8 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
         for (int o = 32; o >= 1; o >>= 1) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64)); }
         if (lane == 0) { wl[wv][d] = lo[d]; wh[wv][d] = hi[d]; }
     }
-    if (tid <= ICP_NSLAB) cnt[tid] = 0;
-    if (tid < ICP_NSLAB) fill[tid] = 0;
+    if (tid <= ICP_NCELL) cnt[tid] = 0;
+    if (tid < ICP_NCELL) fill[tid] = 0;
     __syncthreads();
     if (tid < 3) {
         const int d = tid;
@@ -846,38 +855,46 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
     const double bhi0 = (double)s_hi[0], bhi1 = (double)s_hi[1], bhi2 = (double)s_hi[2];
     int* tidx = P.tidx + (size_t)k * nf;
     if (binned) {
-        int ax = 0;
-        float ext = s_hi[0] - s_lo[0];
-        for (int d = 1; d < 3; ++d) if (s_hi[d] - s_lo[d] > ext) { ext = s_hi[d] - s_lo[d]; ax = d; }
-        const double x0 = (double)s_lo[ax], inv_w = ext > 0.f && ext < INFINITY ? (double)ICP_NSLAB / (double)ext : 0.0;
+        // cells over the two longest edges of the box (a surface patch is two-dimensional: the third edge prunes nothing)
+        float ext[3] = {s_hi[0] - s_lo[0], s_hi[1] - s_lo[1], s_hi[2] - s_lo[2]};
+        int axa = 0;
+        for (int d = 1; d < 3; ++d) if (ext[d] > ext[axa]) axa = d;
+        int axb = axa == 0 ? 1 : 0;
+        for (int d = 0; d < 3; ++d) if (d != axa && ext[d] > ext[axb]) axb = d;
+        const double x0a = (double)s_lo[axa], inv_a = ext[axa] > 0.f && ext[axa] < INFINITY ? (double)ICP_GA / (double)ext[axa] : 0.0;
+        const double x0b = (double)s_lo[axb], inv_b = ext[axb] > 0.f && ext[axb] < INFINITY ? (double)ICP_GB / (double)ext[axb] : 0.0;
         const int nfe = e > b ? nf : 0;
         for (int pass = 0; pass < 2; ++pass) {
             for (int j = tid; j < nfe; j += 1024) {
-                const double x = P.frame[3 * (size_t)j], y = P.frame[3 * (size_t)j + 1], z = P.frame[3 * (size_t)j + 2];
-                if (x > blo0 && x < bhi0 && y > blo1 && y < bhi1 && z > blo2 && z < bhi2) {
-                    const int sl = icp_slab(ax == 0 ? x : (ax == 1 ? y : z), x0, inv_w);
-                    if (pass == 0) atomicAdd(&cnt[sl], 1);
-                    else tidx[cnt[sl] + atomicAdd(&fill[sl], 1)] = j;
+                const double p[3] = {P.frame[3 * (size_t)j], P.frame[3 * (size_t)j + 1], P.frame[3 * (size_t)j + 2]};
+                if (p[0] > blo0 && p[0] < bhi0 && p[1] > blo1 && p[1] < bhi1 && p[2] > blo2 && p[2] < bhi2) {
+                    const double ca = axa == 0 ? p[0] : (axa == 1 ? p[1] : p[2]), cb = axb == 0 ? p[0] : (axb == 1 ? p[1] : p[2]);
+                    const int cell = icp_bin(ca, x0a, inv_a, ICP_GA) * ICP_GB + icp_bin(cb, x0b, inv_b, ICP_GB);
+                    if (pass == 0) atomicAdd(&cnt[cell], 1);
+                    else tidx[cnt[cell] + atomicAdd(&fill[cell], 1)] = j;
                 }
             }
             __syncthreads();
             if (pass == 0) {
-                if (wv == 0) {                    // exclusive prefix over the slabs
-                    const int c = cnt[lane];
-                    int inc = c;
+                if (wv == 0) {                    // exclusive prefix over the 256 cells: four per lane
+                    int c4[4], run4 = 0;
+                    for (int q = 0; q < 4; ++q) { c4[q] = cnt[4 * lane + q]; run4 += c4[q]; }
+                    int inc = run4;
                     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-                    cnt[lane] = inc - c;
-                    if (lane == 63) cnt[ICP_NSLAB] = inc;
+                    int acc = inc - run4;
+                    for (int q = 0; q < 4; ++q) { cnt[4 * lane + q] = acc; acc += c4[q]; }
+                    if (lane == 63) cnt[ICP_NCELL] = inc;
                 }
                 __syncthreads();
             }
         }
-        if (tid <= ICP_NSLAB) P.tst[(size_t)k * (ICP_NSLAB + 1) + tid] = cnt[tid];
+        if (tid <= ICP_NCELL) P.tst[(size_t)k * (ICP_NCELL + 1) + tid] = cnt[tid];
         if (tid == 0) {
-            P.tcount[k] = cnt[ICP_NSLAB];
+            P.tcount[k] = cnt[ICP_NCELL];
             double* st = P.state + ICP_ST * k;
-            st[36] = x0; st[37] = inv_w; st[38] = (double)ax;
+            st[36] = x0a; st[37] = inv_a; st[38] = (double)axa;
             st[39] = 0.5 * (blo0 + bhi0); st[40] = 0.5 * (blo1 + bhi1); st[41] = 0.5 * (blo2 + bhi2);
+            st[42] = x0b; st[43] = inv_b; st[44] = (double)axb;
         }
         return;
     }
@@ -901,47 +918,50 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
     if (tid == 0) P.tcount[k] = run;
 }
 
-// one workgroup per cluster: sources with the initial pose, stable counting sort by slab into srcw (k_icp_mask ran before)
+// one workgroup per cluster: sources with the initial pose, stable counting sort by cell into srcw (k_icp_mask ran before)
 __global__ __launch_bounds__(1024) void k_icp_init(IcpLarge P, int k_total) {
-    __shared__ int base[ICP_NSLAB], run[ICP_NSLAB];
-    __shared__ int wcnt[16][ICP_NSLAB];
+    __shared__ int base[ICP_NCELL], run[ICP_NCELL];
+    __shared__ int wcnt[16][ICP_NCELL];
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = P.off[k], e = P.off[k + 1], ns = e - b;
     double* st = P.state + ICP_ST * k;
-    const double x0 = st[36], inv_w = st[37];
-    const int axis = (int)st[38];
+    const double x0a = st[36], inv_a = st[37], x0b = st[42], inv_b = st[43];
+    const int axa = (int)st[38], axb = (int)st[44];
     double T[12];
     for (int q = 0; q < 12; ++q) T[q] = P.Min[16 * k + q];
-    auto world_pt = [&](int i, double (&w)[3]) {
+    auto world_pt = [&](int i, double (&w)[3]) -> int {
         const double p0 = P.local[3 * (size_t)(b + i)], p1 = P.local[3 * (size_t)(b + i) + 1], p2 = P.local[3 * (size_t)(b + i) + 2];
         for (int a = 0; a < 3; ++a) w[a] = fma(T[4 * a + 2], p2, fma(T[4 * a + 1], p1, T[4 * a] * p0)) + T[4 * a + 3];
+        const double ca = axa == 0 ? w[0] : (axa == 1 ? w[1] : w[2]), cb = axb == 0 ? w[0] : (axb == 1 ? w[1] : w[2]);
+        return icp_bin(ca, x0a, inv_a, ICP_GA) * ICP_GB + icp_bin(cb, x0b, inv_b, ICP_GB);
     };
-    if (tid < ICP_NSLAB) { base[tid] = 0; run[tid] = 0; }
+    if (tid < ICP_NCELL) { base[tid] = 0; run[tid] = 0; }
     __syncthreads();
     for (int i = tid; i < ns; i += 1024) {
         double w[3];
-        world_pt(i, w);
-        atomicAdd(&base[icp_slab(axis == 0 ? w[0] : (axis == 1 ? w[1] : w[2]), x0, inv_w)], 1);
+        atomicAdd(&base[world_pt(i, w)], 1);
     }
     __syncthreads();
     if (wv == 0) {
-        const int c = base[lane];
-        int inc = c;
+        int c4[4], run4 = 0;
+        for (int q = 0; q < 4; ++q) { c4[q] = base[4 * lane + q]; run4 += c4[q]; }
+        int inc = run4;
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-        base[lane] = inc - c;
+        int acc = inc - run4;
+        for (int q = 0; q < 4; ++q) { base[4 * lane + q] = acc; acc += c4[q]; }
     }
     for (int r0 = 0; r0 < ns; r0 += 1024) {
         __syncthreads();                              // base / run of the previous round are final; wcnt may be rewritten
-        for (int q = tid; q < 16 * ICP_NSLAB; q += 1024) (&wcnt[0][0])[q] = 0;
+        for (int q = tid; q < 16 * ICP_NCELL; q += 1024) (&wcnt[0][0])[q] = 0;
         __syncthreads();
         const int i = r0 + tid;
         const bool valid = i < ns;
         double w[3] = {0, 0, 0};
         int sl = 0;
-        if (valid) { world_pt(i, w); sl = icp_slab(axis == 0 ? w[0] : (axis == 1 ? w[1] : w[2]), x0, inv_w); }
+        if (valid) sl = world_pt(i, w);
         unsigned long long rem = __ballot(valid);
         int rank = 0;
-        while (rem) {                                 // rank among the wave's lower lanes of the same slab; the wave's count per slab
+        while (rem) {                                 // rank among the wave's lower lanes of the same cell; the wave's count per cell
             const int lead = __ffsll((long long)rem) - 1;
             const int lsl = __builtin_amdgcn_readlane(sl, lead);
             const unsigned long long m = __ballot(valid && sl == lsl);
@@ -950,7 +970,7 @@ __global__ __launch_bounds__(1024) void k_icp_init(IcpLarge P, int k_total) {
             rem &= ~m;
         }
         __syncthreads();
-        if (tid < ICP_NSLAB) {                        // per slab: exclusive prefix over the waves, then the round's total
+        if (tid < ICP_NCELL) {                        // per cell: exclusive prefix over the waves, then the round's total
             int acc = 0;
             for (int w2 = 0; w2 < 16; ++w2) { const int t = wcnt[w2][tid]; wcnt[w2][tid] = acc; acc += t; }
             const int r = run[tid];
@@ -972,120 +992,213 @@ __global__ __launch_bounds__(1024) void k_icp_init(IcpLarge P, int k_total) {
             int c = 0;                                                // chunks of ICP_CH sources, never across clusters
             for (int j = 0; j < k_total; ++j) { P.chunk0[j] = c; c += (P.off[j + 1] - P.off[j] + ICP_CH - 1) / ICP_CH; }
             P.chunk0[k_total] = c;
+            int pb = 0;                                               // pool offsets of the clusters' cell-sorted target coordinates
+            for (int j = 0; j < k_total; ++j) {
+                const int ntj = P.tcount[j];
+                if (pb + ntj <= P.pool_cap) { P.tbase[j] = pb; pb += ntj; } else P.tbase[j] = -1;
+            }
         }
+    }
+    // the cluster of each of this cluster's chunks (the same count, recomputed here: no wait for thread 0 of cluster 0)
+    {
+        int c0 = 0;
+        for (int j = tid; j < k; j += 1024) c0 += (P.off[j + 1] - P.off[j] + ICP_CH - 1) / ICP_CH;
+        __shared__ int s_part[16];
+        c0 = wave_sum(c0);
+        __syncthreads();
+        if (lane == 0) s_part[wv] = c0;
+        __syncthreads();
+        int first = 0;
+        for (int w2 = 0; w2 < 16; ++w2) first += s_part[w2];
+        const int mine = (ns + ICP_CH - 1) / ICP_CH;
+        for (int q = tid; q < mine; q += 1024) P.chunk_cl[first + q] = k;
     }
 }
 
-// Block = one chunk of ICP_CH = 256 sorted sources of ONE cluster (chunk0 maps blocks to clusters; blocks past the last
-// chunk exit); a wave = 64 consecutive sources with its own target range, staged 64 at a time in the wave's own LDS slice
-// (no block barrier in the scan).
-__global__ __launch_bounds__(256) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2) {
-    __shared__ double tx[4][64], ty[4][64], tz[4][64];
-    __shared__ int tj[4][64];
-    __shared__ double sc[5 * ICP_NM];
+// grid (cluster, slices): the cluster's masked targets, in cell order, into the coordinate pool (one gather per frame
+// instead of one per search: k_icp_nn stages them with coalesced loads)
+__global__ __launch_bounds__(256) void k_icp_pool(IcpLarge P, int nf) {
+    const int c = blockIdx.x, tb = P.tbase[c];
+    if (tb < 0) return;
+    const int nt = P.tcount[c];
+    const int* tidx = P.tidx + (size_t)c * nf;
+    for (int t = blockIdx.y * 256 + threadIdx.x; t < nt; t += gridDim.y * 256) {
+        const int j = tidx[t];
+        P.tcx[tb + t] = P.frame[3 * (size_t)j]; P.tcy[tb + t] = P.frame[3 * (size_t)j + 1]; P.tcz[tb + t] = P.frame[3 * (size_t)j + 2];
+    }
+}
+
+// Block = one chunk of ICP_CH = 64 sorted sources of ONE cluster (chunk0 maps blocks to clusters; blocks past the last
+// chunk exit), 256 threads: the tail of a frame's ICP is a few clusters iterating on, and small chunks put their work on
+// many CUs (1024-thread chunks of 256 sources: 59 us per search whatever the number of live clusters).  A wave owns 16 consecutive sorted sources -- about two cells' worth -- and four lanes share one
+// source: lane group g scans grid row ra0 + g of the cell rectangle [ra0, ra1] x [cb0, cb1] that the wave's sources'
+// (x - r, x + r) squares touch, r = distance to the previous match.  A row of the rectangle is one contiguous run of the
+// cell-sorted target list; the runs are staged 16 targets per row at a time in the wave's own LDS slice (no block barrier
+// in the scan), entries past a run's end as far-away points.
+__global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2) {
+    constexpr int SB = 64, SR = 66;                                   // staged targets per row and batch (4 rows per wave); row stride
+                                                                      // (66: the four rows' equal slots fall into different LDS banks)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* tx = (double*)smem;                                       // [waves][4 rows][SR] x | y | z, then the frame indices
+    double* ty = tx + ICP_NNW * 4 * SR; double* tz = ty + ICP_NNW * 4 * SR;
+    int* tj = (int*)(tz + ICP_NNW * 4 * SR);
+    __shared__ double sc[ICP_NNW * ICP_NM];
     const int tid = threadIdx.x, blk = blockIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CREG_STAMPS
+    const bool tailonly = *P.running <= 4;                           // stamps of the tail of the frame only: few clusters still iterating
+    unsigned long long nst = clock64();
+#define NN_STAMP(slot) do { const unsigned long long now_ = clock64(); if (tid == 0 && tailonly) atomicAdd(&g_icp_stamps[slot], now_ - nst); nst = now_; } while (0)
+#else
+#define NN_STAMP(slot) do { } while (0)
+#endif
     if (blk >= P.chunk0[k_total]) return;
-    int clo = 0, chi = k_total;                                       // cluster c with chunk0[c] <= blk < chunk0[c + 1]
-    while (chi - clo > 1) { const int mid = (clo + chi) >> 1; if (P.chunk0[mid] <= blk) clo = mid; else chi = mid; }
-    const int c = clo;
+    const int c = P.chunk_cl[blk];
     const double* st = P.state + ICP_ST * c;
     if (st[34] != 0.0) return;                                        // converged cluster: nothing moves any more
-    const int i = P.off[c] + (blk - P.chunk0[c]) * ICP_CH + tid;
+    const int g = lane >> 4, l16 = lane & 15;                         // lane group: the grid row of the rectangle it scans
+    const int i = P.off[c] + (blk - P.chunk0[c]) * ICP_CH + wv * 16 + l16;
     const bool live = i < P.off[c + 1];
-    const double x0 = st[36], inv_w = st[37];
-    const int axis = (int)st[38];
+    const double x0a = st[36], inv_a = st[37], x0b = st[42], inv_b = st[43];
+    const int axa = (int)st[38], axb = (int)st[44];
     const double shc0 = st[39], shc1 = st[40], shc2 = st[41];
-    double s0 = 0, s1 = 0, s2 = 0, lo = INFINITY, hi = -INFINITY;
+    double s0 = 0, s1 = 0, s2 = 0, alo = INFINITY, ahi = -INFINITY, blo = INFINITY, bhi = -INFINITY;
     if (live) {
-        // the rigid update the last fit left pending (identity before the first one)
+        // the rigid update the last fit left pending (identity before the first one); the four lanes of a source agree,
+        // lane group 0 stores
         const double p0 = P.srcw[3 * (size_t)i], p1 = P.srcw[3 * (size_t)i + 1], p2 = P.srcw[3 * (size_t)i + 2];
+        const int pm = P.nn[i];                                       // -1 before the first search (k_icp_init)
+        const double q0 = P.prevt[3 * (size_t)i], q1 = P.prevt[3 * (size_t)i + 1], q2 = P.prevt[3 * (size_t)i + 2];
         s0 = fma(st[16 + 2], p2, fma(st[16 + 1], p1, st[16] * p0)) + st[16 + 3];
         s1 = fma(st[16 + 6], p2, fma(st[16 + 5], p1, st[16 + 4] * p0)) + st[16 + 7];
         s2 = fma(st[16 + 10], p2, fma(st[16 + 9], p1, st[16 + 8] * p0)) + st[16 + 11];
-        P.srcw[3 * (size_t)i] = s0; P.srcw[3 * (size_t)i + 1] = s1; P.srcw[3 * (size_t)i + 2] = s2;
-        const int pm = P.nn[i];
-        lo = -INFINITY; hi = INFINITY;
+        alo = -INFINITY; ahi = INFINITY; blo = -INFINITY; bhi = INFINITY;
         if (pm >= 0) {
-            const double dx = s0 - P.frame[3 * (size_t)pm], dy = s1 - P.frame[3 * (size_t)pm + 1], dz = s2 - P.frame[3 * (size_t)pm + 2];
-            const double sx = axis == 0 ? s0 : (axis == 1 ? s1 : s2);
+            const double dx = s0 - q0, dy = s1 - q1, dz = s2 - q2;
+            const double sa = axa == 0 ? s0 : (axa == 1 ? s1 : s2), sb = axb == 0 ? s0 : (axb == 1 ? s1 : s2);
             const double d2p = (dx * dx + dy * dy) + dz * dz;
-            const double r = (d2p > 1e-280 ? d2p * fast_rsqrt(d2p) : 1e-140) * (1.0 + 1e-12) + (4e-16 * fabs(sx) + 1e-300);
-            lo = sx - r; hi = sx + r;
+            const double r0 = (d2p > 1e-280 ? d2p * fast_rsqrt(d2p) : 1e-140) * (1.0 + 1e-12) + 1e-300;
+            const double ra = r0 + 4e-16 * fabs(sa), rb = r0 + 4e-16 * fabs(sb);
+            alo = sa - ra; ahi = sa + ra; blo = sb - rb; bhi = sb + rb;
         }
     }
-    const double wlo = wave_min_fast(lo), whi = wave_max_fast(hi);
-    const int* tst = P.tst + (size_t)c * (ICP_NSLAB + 1);
+    NN_STAMP(8);
+    if (live && g == 0) { P.srcw[3 * (size_t)i] = s0; P.srcw[3 * (size_t)i + 1] = s1; P.srcw[3 * (size_t)i + 2] = s2; }
     const bool any = __ballot(live) != 0;
-    const int r0 = any ? tst[__builtin_amdgcn_readfirstlane(icp_slab(wlo, x0, inv_w))] : 0;
-    const int r1 = any ? tst[__builtin_amdgcn_readfirstlane(icp_slab(whi, x0, inv_w)) + 1] : 0;
+    const int ra0 = __builtin_amdgcn_readfirstlane(icp_bin(wave_min_fast(alo), x0a, inv_a, ICP_GA));
+    const int ra1 = __builtin_amdgcn_readfirstlane(icp_bin(wave_max_fast(ahi), x0a, inv_a, ICP_GA));
+    const int cb0 = __builtin_amdgcn_readfirstlane(icp_bin(wave_min_fast(blo), x0b, inv_b, ICP_GB));
+    const int cb1 = __builtin_amdgcn_readfirstlane(icp_bin(wave_max_fast(bhi), x0b, inv_b, ICP_GB));
+    const int* tst = P.tst + (size_t)c * (ICP_NCELL + 1);
     const int* tidx = P.tidx + (size_t)c * nf;
+    // lane l < rows: the run of grid row ra0 + l
+    int q0v = 0, q1v = 0;
+    if (any && lane <= ra1 - ra0) { q0v = tst[(ra0 + lane) * ICP_GB + cb0]; q1v = tst[(ra0 + lane) * ICP_GB + cb1 + 1]; }
+    const int nrows = any ? ra1 - ra0 + 1 : 0;
+    NN_STAMP(9);
 #ifdef CREG_STAMPS
-    if (lane == 0 && any) { atomicAdd(&g_icp_stamps[0], (unsigned long long)(r1 - r0)); atomicAdd(&g_icp_stamps[1], 1ull); atomicAdd(&g_icp_stamps[3], (unsigned long long)P.tcount[c]); }
+    if (lane == 0 && any) { atomicAdd(&g_icp_stamps[1], 1ull); atomicAdd(&g_icp_stamps[3], (unsigned long long)P.tcount[c]); atomicAdd(&g_icp_stamps[5], (unsigned long long)nrows); atomicAdd(&g_icp_stamps[6], (unsigned long long)(cb1 - cb0 + 1)); }
+    const unsigned long long stt = clock64();
 #endif
-    double best = INFINITY; int bm = -1, bl = -1;
+    double* px = tx + (wv * 4 + g) * SR; double* py = ty + (wv * 4 + g) * SR; double* pz = tz + (wv * 4 + g) * SR;
+    int* pj = tj + (wv * 4 + g) * SR;
+    const int tb = P.tbase[c];                                        // >= 0: coordinates in the pool, in the order of tidx
+    double best = 1e299; int bslot = -1, bj = 0x7fffffff;  // 1e299: below the staged padding's 3e300, above any real squared distance
+    double bx = 0, by = 0, bz = 0;                                    // the best target's coordinates, picked up from LDS after its batch
     bool tief = false;
     for (int pass = 0; pass < 2; ++pass) {                            // pass 1 only after a tie was seen: frame-index tie-break
-        int bj = 0x7fffffff;
-        for (int t0 = r0; t0 < r1; t0 += 64) {
-            const int cnt = min(64, r1 - t0);
-            if (lane < cnt) {
-                const int j = tidx[t0 + lane];
-                tx[wv][lane] = P.frame[3 * (size_t)j]; ty[wv][lane] = P.frame[3 * (size_t)j + 1]; tz[wv][lane] = P.frame[3 * (size_t)j + 2];
-                tj[wv][lane] = j;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (pass == 0) {
-                int t = 0;
-                for (; t + 4 <= cnt; t += 4) {
-                    double d2[4];
+        for (int rg = 0; rg < nrows; rg += 4) {                       // four rows at a time, one per lane group
+            const int myrow = rg + g;
+            const int q0 = __shfl(q0v, min(myrow, 63), 64), q1 = myrow < nrows ? __shfl(q1v, min(myrow, 63), 64) : q0;
+            int per = q1 - q0;
+            per = max(per, __shfl_xor(per, 16, 64)); per = max(per, __shfl_xor(per, 32, 64));
+            per = __builtin_amdgcn_readfirstlane(per);                // the longest of the four runs
+#ifdef CREG_STAMPS
+            if (lane == 0 && pass == 0) { atomicAdd(&g_icp_stamps[0], (unsigned long long)per); atomicAdd(&g_icp_stamps[4], 1ull); }
+#endif
+            for (int t0 = 0; t0 < per; t0 += SB) {
+                // stage SB targets of each of the four runs: lane (g, l) takes entries t0 + l, t0 + l + 16, ... of row g; all
+                // index loads go out first, then all coordinate loads: two memory round trips per batch
+                int jv[SB / 16];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const double dx = s0 - tx[wv][t + u], dy = s1 - ty[wv][t + u], dz = s2 - tz[wv][t + u];
-                        d2[u] = (dx * dx + dy * dy) + dz * dz;
+                for (int u = 0; u < SB / 16; ++u) { const int t = q0 + t0 + 16 * u + l16; jv[u] = t < q1 ? tidx[t] : -1; }
+                if (tb >= 0) {                        // block-uniform: consecutive lanes read consecutive pool entries
+                    double cx[SB / 16], cy[SB / 16], cz[SB / 16];
+#pragma unroll
+                    for (int u = 0; u < SB / 16; ++u) {
+                        const int t = min(q0 + t0 + 16 * u + l16, max(q1 - 1, 0));
+                        cx[u] = P.tcx[tb + t]; cy[u] = P.tcy[tb + t]; cz[u] = P.tcz[tb + t];
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        bm = d2[u] < best ? t0 + t + u : bm;
-                        bl = d2[u] <= best ? t0 + t + u : bl;
-                        best = vmin_f64(best, d2[u]);
+                    for (int u = 0; u < SB / 16; ++u) {
+                        const int e = 16 * u + l16;
+                        const bool in = jv[u] >= 0;
+                        px[e] = in ? cx[u] : 1e150; py[e] = in ? cy[u] : 1e150; pz[e] = in ? cz[u] : 1e150; pj[e] = in ? jv[u] : 0x7fffffff;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < SB / 16; ++u) {
+                        const int e = 16 * u + l16;
+                        if (jv[u] >= 0) {
+                            px[e] = P.frame[3 * (size_t)jv[u]]; py[e] = P.frame[3 * (size_t)jv[u] + 1]; pz[e] = P.frame[3 * (size_t)jv[u] + 2];
+                            pj[e] = jv[u];
+                        } else { px[e] = 1e150; py[e] = 1e150; pz[e] = 1e150; pj[e] = 0x7fffffff; }   // past the run: farther than `best` ever is
                     }
                 }
-                for (; t < cnt; ++t) {
-                    const double dx = s0 - tx[wv][t], dy = s1 - ty[wv][t], dz = s2 - tz[wv][t];
-                    const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    bm = d2 < best ? t0 + t : bm;
-                    bl = d2 <= best ? t0 + t : bl;
-                    best = vmin_f64(best, d2);
+                __builtin_amdgcn_wave_barrier();
+                NN_STAMP(10);
+                const int cnt = min(SB, per - t0);                    // uniform; rounded up to a multiple of 4 (padding is harmless)
+                int bm = -1, bl = -1;                                 // slots of this batch
+                if (pass == 0) {
+                    for (int t = 0; t < cnt; t += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double dx = s0 - px[t + u], dy = s1 - py[t + u], dz = s2 - pz[t + u];
+                            const double d2 = (dx * dx + dy * dy) + dz * dz;
+                            bm = d2 < best ? t + u : bm;
+                            bl = d2 <= best ? t + u : bl;
+                            best = vmin_f64(best, d2);
+                        }
+                    }
+                    tief |= bl >= 0 && bl != bm;                      // a candidate as near as the best (of this or an earlier batch)
+                } else {
+                    for (int t = 0; t < cnt; ++t) {
+                        const double dx = s0 - px[t], dy = s1 - py[t], dz = s2 - pz[t];
+                        const double d2 = (dx * dx + dy * dy) + dz * dz;
+                        const int j = pj[t];
+                        if (d2 < best || (d2 == best && j < bj)) { best = d2; bm = t; bj = j; }
+                    }
                 }
-            } else {
-                for (int t = 0; t < cnt; ++t) {
-                    const double dx = s0 - tx[wv][t], dy = s1 - ty[wv][t], dz = s2 - tz[wv][t];
-                    const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    const int j = tj[wv][t];
-                    if (d2 < best || (d2 == best && j < bj)) { best = d2; bm = t0 + t; bj = j; }
-                }
+                if (bm >= 0) { bx = px[bm]; by = py[bm]; bz = pz[bm]; bj = pj[bm]; bslot = bm; }
+                NN_STAMP(11);
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
         if (pass == 0) {
-            tief = __ballot(bm != bl) != 0;
-#ifdef CREG_STAMPS
-            if (lane == 0 && tief) atomicAdd(&g_icp_stamps[2], 1ull);
-#endif
-            if (!tief) break;
-            best = INFINITY; bm = -1;
+            if (!__ballot(tief)) break;
+            best = 1e299; bslot = -1; bj = 0x7fffffff;
         }
     }
+    if (bslot < 0) { best = INFINITY; bj = 0x7fffffff; }              // a lane group whose rows were all empty has no candidate
+#ifdef CREG_STAMPS
+    if (lane == 0 && any) { atomicAdd(&g_icp_stamps[7], clock64() - stt); if (tief) atomicAdd(&g_icp_stamps[2], 1ull); }
+#endif
+    // the four lane groups of a source: (distance, frame index) lexicographic minimum, the winner's coordinates along
+    for (int o = 16; o <= 32; o <<= 1) {
+        const double od = __shfl_xor(best, o, 64); const int oj = __shfl_xor(bj, o, 64);
+        const double ox = __shfl_xor(bx, o, 64), oy = __shfl_xor(by, o, 64), oz = __shfl_xor(bz, o, 64);
+        if (od < best || (od == best && oj < bj)) { best = od; bj = oj; bx = ox; by = oy; bz = oz; }
+    }
+    NN_STAMP(12);
     double cm[ICP_NM];
     for (int a = 0; a < ICP_NM; ++a) cm[a] = 0;
-    if (live) {
-        const bool ok = bm >= 0 && best <= th2;
-        const int j = ok ? tidx[bm] : -1;
-        P.nn[i] = j;
+    if (live && g == 0) {
+        const bool ok = bj != 0x7fffffff && best <= th2;
+        P.nn[i] = ok ? bj : -1;
         if (ok) {
+            P.prevt[3 * (size_t)i] = bx; P.prevt[3 * (size_t)i + 1] = by; P.prevt[3 * (size_t)i + 2] = bz;
             const double sv[3] = {s0 - shc0, s1 - shc1, s2 - shc2};
-            const double dv[3] = {P.frame[3 * (size_t)j] - shc0, P.frame[3 * (size_t)j + 1] - shc1, P.frame[3 * (size_t)j + 2] - shc2};
+            const double dv[3] = {bx - shc0, by - shc1, bz - shc2};
             cm[0] = 1.0; cm[1] = best;
             for (int a = 0; a < 3; ++a) { cm[2 + a] = sv[a]; cm[5 + a] = dv[a]; }
             for (int a = 0; a < 3; ++a) for (int q = 0; q < 3; ++q) cm[8 + 3 * a + q] = sv[a] * dv[q];
@@ -1098,12 +1211,17 @@ __global__ __launch_bounds__(256) void k_icp_nn(IcpLarge P, int n, int k_total, 
 #pragma unroll
         for (int a = 0; a < ICP_NM; ++a) sc[wv * ICP_NM + a] = cm[a];
     }
+    NN_STAMP(13);
     __syncthreads();
+    NN_STAMP(14);
     if (tid < ICP_NM) {
         double r = 0.0;
-        for (int w = 0; w < 4; ++w) r += sc[w * ICP_NM + tid];
+        for (int w = 0; w < ICP_NNW; ++w) r += sc[w * ICP_NM + tid];
         P.part[(size_t)blk * ICP_NM + tid] = r;
     }
+#ifdef CREG_STAMPS
+    if (tid == 0 && tailonly) atomicAdd(&g_icp_stamps[15], 1ull);
+#endif
 }
 
 // one wave per cluster: moments of the chunks in chunk order, convergence, Horn
@@ -1113,7 +1231,16 @@ __global__ __launch_bounds__(64) void k_icp_fit(IcpLarge P, int max_iter) {
     if (st[34] != 0.0) return;                                        // done
     const int ns = P.off[k + 1] - P.off[k];
     double v = 0.0;
-    if (lane < ICP_NM) for (int ch = P.chunk0[k]; ch < P.chunk0[k + 1]; ++ch) v += P.part[(size_t)ch * ICP_NM + lane];
+    if (lane < ICP_NM) {
+        const int c0 = P.chunk0[k], c1 = P.chunk0[k + 1];
+        for (int ch = c0; ch < c1; ch += 8) {                         // chunk order; a group's loads are issued together
+            double pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pv[u] = P.part[(size_t)min(ch + u, c1 - 1) * ICP_NM + lane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (ch + u < c1) v += pv[u];
+        }
+    }
     double cm[ICP_NM];
 #pragma unroll
     for (int a = 0; a < ICP_NM; ++a) cm[a] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), a), __builtin_amdgcn_readlane(__double2loint(v), a));
@@ -1174,7 +1301,7 @@ __global__ __launch_bounds__(256) void k_icp_finish(IcpLarge P, int keep_t) {
     }
 }
 
-struct IcpLargeLayout { size_t srcw, tidx, tcount, box, nn, part, state, running, chunk0, tst, total; };
+struct IcpLargeLayout { size_t srcw, tidx, tcount, box, nn, part, state, running, chunk0, tst, chunk_cl, prevt, tcx, tcy, tcz, tbase, total; int pool_cap; };
 static IcpLargeLayout icp_large_layout(int64_t n, int64_t nf, int k) {
     IcpLargeLayout L; size_t o = 0;
     auto take = [&](size_t b) { size_t r = o; o = align_up(o + b, 256); return r; };
@@ -1182,7 +1309,14 @@ static IcpLargeLayout icp_large_layout(int64_t n, int64_t nf, int k) {
     L.box = take(sizeof(float) * 6 * k); L.nn = take(sizeof(int) * n);
     L.part = take(sizeof(double) * ICP_NM * (size_t)(n / ICP_CH + k + 1));
     L.state = take(sizeof(double) * ICP_ST * k); L.running = take(sizeof(int) * 4); L.chunk0 = take(sizeof(int) * (k + 1));
-    L.tst = take(sizeof(int) * (size_t)k * (ICP_NSLAB + 1)); L.total = o;
+    L.tst = take(sizeof(int) * (size_t)k * (ICP_NCELL + 1));
+    L.chunk_cl = take(sizeof(int) * (size_t)(n / ICP_CH + k + 1)); L.prevt = take(sizeof(double) * 3 * n);
+    // coordinate pool: room for 4 nf masked targets over all clusters (they overlap by the box scale: ~1.5 nf in practice);
+    // clusters beyond it fall back to gathering
+    const int64_t cap = 4 * nf < (int64_t)k * nf ? 4 * nf : (int64_t)k * nf;
+    L.pool_cap = (int)(cap < (1ll << 30) ? cap : (1ll << 30));
+    L.tcx = take(sizeof(double) * (size_t)L.pool_cap); L.tcy = take(sizeof(double) * (size_t)L.pool_cap); L.tcz = take(sizeof(double) * (size_t)L.pool_cap);
+    L.tbase = take(sizeof(int) * k); L.total = o;
     return L;
 }
 // the regime switch (host-side sizes only): average cluster above the LDS source budget, or a frame too large for the
@@ -1216,15 +1350,19 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
     P.Mout = q.M_out; P.world_out = q.world_out; P.n_iter_out = q.n_iter_out;
     P.srcw = (double*)(ws + L.srcw); P.tidx = (int*)(ws + L.tidx); P.tcount = (int*)(ws + L.tcount); P.box = (float*)(ws + L.box);
     P.nn = (int*)(ws + L.nn); P.part = (double*)(ws + L.part); P.state = (double*)(ws + L.state); P.running = (int*)(ws + L.running);
-    P.chunk0 = (int*)(ws + L.chunk0); P.tst = (int*)(ws + L.tst);
+    P.chunk0 = (int*)(ws + L.chunk0); P.tst = (int*)(ws + L.tst); P.chunk_cl = (int*)(ws + L.chunk_cl); P.prevt = (double*)(ws + L.prevt);
+    P.tcx = (double*)(ws + L.tcx); P.tcy = (double*)(ws + L.tcy); P.tcz = (double*)(ws + L.tcz); P.tbase = (int*)(ws + L.tbase); P.pool_cap = L.pool_cap;
     if (q.tgt_offsets) {
         set_error("creg_masked_icp: point-to-point mode (tgt_offsets) is not available in the large-cluster regime");
         return CREG_EINVAL;
     }
+    const int nn_smem = ICP_NNW * 4 * 66 * 28;            // k_icp_nn: per wave 4 rows x 64 (+2: bank offset) staged targets (x, y, z, frame index)
+    CREG_HIP(hipFuncSetAttribute((const void*)k_icp_nn, hipFuncAttributeMaxDynamicSharedMemorySize, nn_smem));
     hipLaunchKernelGGL(k_icp_mask, dim3(k), dim3(1024), 0, s, P, (int)nf, (float)(0.5 * scale), q.world ? 0 : 1, 1);
     hipLaunchKernelGGL(k_icp_init, dim3(k), dim3(1024), 0, s, P, k);
+    hipLaunchKernelGGL(k_icp_pool, dim3(k, 8), dim3(256), 0, s, P, (int)nf);
     const int nblk = cdiv(n, ICP_CH) + k;                // an upper bound of sum_c ceil(ns_c / ICP_CH); the surplus blocks exit
-    hipLaunchKernelGGL(k_icp_nn, dim3(nblk), dim3(256), 0, s, P, (int)n, k, (int)nf, th * th);
+    hipLaunchKernelGGL(k_icp_nn, dim3(nblk), dim3(64 * ICP_NNW), nn_smem, s, P, (int)n, k, (int)nf, th * th);
     CREG_LAUNCH_CHECK();
     int running = k;
     // every k_icp_fit call is one convergence test + (unless converged) one update; max_iteration updates need one call more
@@ -1232,7 +1370,7 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
         const int batch = 16;
         for (int b = 0; b < batch; ++b, ++done) {
             hipLaunchKernelGGL(k_icp_fit, dim3(k), dim3(64), 0, s, P, max_iteration);
-            hipLaunchKernelGGL(k_icp_nn, dim3(nblk), dim3(256), 0, s, P, (int)n, k, (int)nf, th * th);
+            hipLaunchKernelGGL(k_icp_nn, dim3(nblk), dim3(64 * ICP_NNW), nn_smem, s, P, (int)n, k, (int)nf, th * th);
         }
         CREG_LAUNCH_CHECK();
         CREG_HIP(hipMemcpyAsync(&running, P.running, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -26,8 +26,12 @@ for f in seq[1:]:
     torch.cuda.synchronize(); fn(None, 1)
     M_new, _, n_it = ops.masked_icp(local, world32, off, f64, M)
     torch.cuda.synchronize(); fn(out, 0)
-    v = np.array(list(out)[:8], dtype=np.float64)
-    print(f"waves {v[1]:.0f}, targets scanned per wave {v[0] / max(v[1], 1):.1f} of {v[3] / max(v[1], 1):.0f} masked, tie rescans {v[2]:.0f}, iterations mean {n_it.double().mean():.1f} max {int(n_it.max())}")
+    v = np.array(list(out)[:16], dtype=np.float64)
+    w = max(v[1], 1)
+    print(f"waves {v[1]:.0f}: scan steps per wave {v[0] / w:.1f} (row groups {v[4] / w:.2f}, rows {v[5] / w:.2f}, columns {v[6] / w:.2f}) of {v[3] / w:.0f} masked targets, "
+          f"scan cycles per wave {v[7] / w:.0f}, waves with a tie rescan {v[2]:.0f}, iterations mean {n_it.double().mean():.1f} max {int(n_it.max())}")
+    nb = max(v[15], 1)
+    print('   wave 0 of a block, cycles per block: load+update %.0f, bounds+rows %.0f, staging %.0f, scan %.0f, combine %.0f, moments %.0f, barrier wait %.0f  (%d blocks)' % (v[8] / nb, v[9] / nb, v[10] / nb, v[11] / nb, v[12] / nb, v[13] / nb, v[14] / nb, nb))
     _, labels, _, _ = ops.kmeans_lloyd(f64, M_new[:, :3, 3].contiguous())
     local, off = ops.group_to_local(f64, labels, M_new)
     M = M_new

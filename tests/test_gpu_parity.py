@@ -861,3 +861,66 @@ def test_full_size_c5_masked_icp_spot_check_vs_oracle(dev):
         T, _, _, it = oicp.registration_icp(src, fr[1][mask], 1.0, M[j].cpu().numpy())
         np.testing.assert_allclose(Mh[j], T, atol=1e-8)
         assert int(n_it[j]) == it
+
+
+def _icp_vs_oracle(dev, clusters, mats, frame, scale=1.2, atol=1e-8):
+    from autourdf_amd import ops
+    from oracle import icp as oicp
+    local, off = ops.pack_clusters(clusters, dev, torch.float64)
+    M = _cuda(np.asarray(mats, np.float64), dev)
+    world32 = ops.cluster_transform(local.to(torch.float32), off, M.to(torch.float32))
+    M_out, w_out, n_it = ops.masked_icp(local, world32, off, _cuda(frame, dev), M, scale=scale)
+    world_h = _split(world32.cpu().numpy(), off.cpu().numpy())
+    ow, om = oicp.masked_icp(clusters, world_h, frame, mats, scale=scale)
+    np.testing.assert_allclose(M_out.cpu().numpy(), om, atol=atol)
+    np.testing.assert_allclose(w_out.cpu().numpy(), np.concatenate(ow), atol=atol)
+    return n_it.cpu().numpy()
+
+
+def test_masked_icp_fallback_paths_of_the_one_workgroup_kernel(dev):
+    """The binned fast path needs <= 1024 source points and <= 4096 masked targets per cluster; a ragged segmentation (one
+    cluster above the LDS source budget while the average stays below it) and a box holding more targets than fit take the
+    unbinned fallback inside the same launch.  Both against the oracle."""
+    from autourdf_amd.synthetic import make_sequence
+    seq = make_sequence("wx200_5", 31, 2, 2600)
+    X = seq[0]
+    order = np.argsort(X[:, 2], kind="stable")                          # three slices along z: 1500 / 700 / 400 points
+    parts = [X[order[:1500]], X[order[1500:2200]], X[order[2200:]]]
+    mats = np.stack([np.eye(4) for _ in parts])
+    for m, p in zip(mats, parts):
+        m[:3, 3] = p.mean(0)
+    clusters = [p - m[:3, 3] for p, m in zip(parts, mats)]
+    assert len(X) // 3 <= 1024 < len(clusters[0])
+    n_it = _icp_vs_oracle(dev, clusters, mats, seq[1])
+    assert (n_it >= 1).all()
+    # more masked targets than the LDS table holds: a 6000-point frame inside one generous box
+    rng = np.random.default_rng(5)
+    src = rng.normal(size=(600, 3)) * [0.05, 0.03, 0.02]
+    frame = np.concatenate([src @ _rot_z(0.05).T + [0.004, -0.002, 0.001] + rng.normal(scale=2e-4, size=src.shape),
+                            rng.normal(size=(5400, 3)) * [0.05, 0.03, 0.02]])
+    assert len(frame) > 4096
+    _icp_vs_oracle(dev, [src], np.eye(4)[None], frame, scale=3.0)
+
+
+def _rot_z(a):
+    return np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
+
+
+def test_masked_icp_large_regime_coordinate_pool_overflow(dev):
+    """Large regime with boxes that all hold the whole frame: the clusters' masked targets exceed the coordinate pool
+    (4 x frame points), so the later clusters stage their targets by gathering; same results as the oracle either way."""
+    rng = np.random.default_rng(9)
+    base = rng.normal(size=(1100, 3)) * [0.06, 0.04, 0.03]
+    k = 6
+    clusters, mats = [], []
+    for c in range(k):
+        m = np.eye(4)
+        m[:3, :3] = _rot_z(0.01 * (c + 1))
+        m[:3, 3] = [0.002 * c, -0.001 * c, 0.0005 * c]
+        clusters.append(base + rng.normal(scale=1e-4, size=base.shape))
+        mats.append(m)
+    frame = base @ _rot_z(0.03).T + [0.003, 0.001, -0.002] + rng.normal(scale=3e-4, size=base.shape)
+    frame = np.concatenate([frame, frame + rng.normal(scale=5e-4, size=frame.shape)])     # 2200 targets, all inside every box
+    assert sum(len(c) for c in clusters) // k > 1024 and k * len(frame) > 4 * len(frame)
+    n_it = _icp_vs_oracle(dev, clusters, np.stack(mats), frame, scale=1.5)
+    assert (n_it >= 1).all()
