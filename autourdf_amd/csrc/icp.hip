@@ -277,7 +277,16 @@ __device__ __forceinline__ int icp_slab(double x, double x0, double inv_w) {
 // debug build only (CREG_EXTRA_FLAGS=-DCREG_STAMPS, tests/measure/icp_stamps.py): shader-clock cycles of the phases of
 // every workgroup, accumulated over its iterations: [0] mask + setup [1] NN scan [2] combine + sums of the means [3]
 // covariance sums [4] Horn on lane 0 [5] move [6] iterations [7] targets scanned per wave and iteration (fast path)
-__device__ unsigned long long g_icp_stamps[512 * 16];     // [workgroup (x + gridDim.x * y) % 512][slot]; 8.. = finer split of the NN scan (wave 0's view): [8] bounds + range [9] scan [10] rescans [11] wait for the other waves
+__device__ unsigned long long g_icp_wall[8];      // tail launches: sums of [0] first live block start - launch start [1] last search end - launch start [2] fit end - launch start (100 MHz ticks) [3] launches
+__device__ unsigned long long g_icp_wmin[4];      // scratch of the running launch: launch start, first live start, last search end, fit end
+__device__ unsigned long long g_icp_stamps[512 * 16];
+__global__ void k_icp_wall_fold() {
+    if (g_icp_wmin[0] != ~0ull && g_icp_wmin[3] != 0ull) {
+        g_icp_wall[0] += g_icp_wmin[1] - g_icp_wmin[0]; g_icp_wall[1] += g_icp_wmin[2] - g_icp_wmin[0]; g_icp_wall[2] += g_icp_wmin[3] - g_icp_wmin[0]; g_icp_wall[3] += 1;
+    }
+    g_icp_wmin[0] = ~0ull; g_icp_wmin[1] = ~0ull; g_icp_wmin[2] = 0ull; g_icp_wmin[3] = 0ull;
+}
+     // [workgroup (x + gridDim.x * y) % 512][slot]; 8.. = finer split of the NN scan (wave 0's view): [8] bounds + range [9] scan [10] rescans [11] wait for the other waves
 #define ICP_STAMP(slot) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_icp_stamps[stamp_b * 16 + slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
 #else
 #define ICP_STAMP(slot) do { } while (0)
@@ -778,18 +787,22 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
 // =================================================================================================================
 // Large regime (clusters of more than ICP_SRC_LDS points, or frames whose masked targets do not fit a CU's LDS: the
 // BASELINE configs[4] shape has 2048-point clusters against ~3000 masked targets each): the same ICP as k_masked_icp's
-// fast path -- slab-binned targets and sources, exact search pruned by the previous match, one-pass shifted moments --
-// iteration by iteration over MANY workgroups instead of one workgroup per cluster:
-//   k_icp_mask   (cluster)            box; frame indices inside it, binned into ICP_NSLAB slabs along the box's longest
-//                                     axis (count pass + scatter pass), or in ascending order for creg_aabb_mask_f64
-//   k_icp_init   (cluster)            sources into the world frame with the initial pose, stable-sorted by slab
-//   k_icp_nn     (256-source chunk)   applies the pending rigid update to its sources, then the nearest masked target of
-//                                     each (a wave = 64 consecutive sorted sources scans the slabs its sources' [x - r, x + r]
-//                                     intervals touch, r = distance to the previous match), and the chunk's moments
-//   k_icp_fit    (cluster, one wave)  chunk moments in chunk order -> fitness / RMSE, open3d's convergence test against the
-//                                     previous ones, else Horn's closed form: new pose, pending update for the sources
-//   k_icp_finish (cluster)            outputs
-// The host enqueues [fit, nn] in batches of 16 and reads one "clusters still running" word between batches.
+// fast path -- binned targets and sources, exact search pruned by the previous match, one-pass shifted moments --
+// iteration by iteration over MANY workgroups instead of one workgroup per cluster.  The bins are a 16 x 16 grid over the
+// box's two longest edges (a cluster is a surface patch: slabs along one axis pruned 2.5x at this size, the grid ~12x).
+//   k_icp_mask    (cluster)           box; frame indices inside it, grouped by grid cell (count pass + scatter pass), or in
+//                                     ascending order for creg_aabb_mask_f64
+//   k_icp_init    (cluster)           sources into the world frame with the initial pose, stable-sorted by cell
+//   k_icp_pool    (cluster, slices)   the masked targets' coordinates, in cell order, into a pool (coalesced staging)
+//   k_icp_nn      (64-source chunk)   applies the pending rigid update to its sources; nearest masked target of each: a wave =
+//                                     16 consecutive sorted sources x 4 lanes, the lanes of a source walking the grid rows of
+//                                     the cell rectangle the wave's (x - r, x + r) squares touch (r = distance to the
+//                                     previous match); the chunk's moments; and, in the cluster's LAST chunk to finish, the
+//                                     fit (one wave): chunk moments in chunk order -> fitness / RMSE, open3d's convergence
+//                                     test against the previous ones, else Horn's closed form: new pose, pending update
+//   k_icp_compact (one workgroup)     between batches: the chunks of the clusters still iterating (the next batch's grid)
+//   k_icp_finish  (cluster)           outputs
+// The host enqueues the search in batches of 16 and reads "clusters / chunks still running" between batches.
 struct IcpLarge {                          // per problem
     const double* local; const float* world; const int* off; const int* woff; const double* frame; const double* Min;
     double* Mout; double* world_out; int* n_iter_out;
@@ -800,6 +813,9 @@ struct IcpLarge {                          // per problem
     double* prevt;                             // [n][3] coordinates of every source's current match (the next search's bound)
     double* tcx; double* tcy; double* tcz;     // pool of the clusters' masked target coordinates in cell order (coalesced staging)
     int* tbase;                                // [k] a cluster's first pool entry, -1: did not fit (its targets are gathered through tidx)
+    int* arrive;                               // [k] chunks of the cluster that have finished the running search
+    int* live;                                 // [chunks] chunks of the clusters still iterating (k_icp_compact), read when `use_live`
+    int use_live;
     int pool_cap;
 };
 constexpr int ICP_CH = 64;                 // sources per k_icp_nn workgroup (4 waves of 16)
@@ -987,8 +1003,13 @@ __global__ __launch_bounds__(1024) void k_icp_init(IcpLarge P, int k_total) {
     if (tid < 16) { st[tid] = P.Min[16 * k + tid]; st[16 + tid] = (tid % 5 == 0) ? 1.0 : 0.0; }      // pose; pending update = identity
     if (tid == 0) {
         st[32] = 0.0; st[33] = 0.0; st[34] = 0.0; st[35] = 0.0;       // prev fitness, prev rmse, done, updates applied
+        P.arrive[k] = 0;
+        // a cluster without points has no chunk to run its fit: what two fits would leave (identity update, then converged)
+        if (ns == 0) { st[34] = 1.0; st[35] = 1.0; }
         if (k == 0) {
-            *P.running = k_total;
+            int live_clusters = 0;
+            for (int j = 0; j < k_total; ++j) live_clusters += P.off[j + 1] > P.off[j];
+            *P.running = live_clusters;
             int c = 0;                                                // chunks of ICP_CH sources, never across clusters
             for (int j = 0; j < k_total; ++j) { P.chunk0[j] = c; c += (P.off[j + 1] - P.off[j] + ICP_CH - 1) / ICP_CH; }
             P.chunk0[k_total] = c;
@@ -1028,207 +1049,47 @@ __global__ __launch_bounds__(256) void k_icp_pool(IcpLarge P, int nf) {
     }
 }
 
-// Block = one chunk of ICP_CH = 64 sorted sources of ONE cluster (chunk0 maps blocks to clusters; blocks past the last
-// chunk exit), 256 threads: the tail of a frame's ICP is a few clusters iterating on, and small chunks put their work on
-// many CUs (1024-thread chunks of 256 sources: 59 us per search whatever the number of live clusters).  A wave owns 16 consecutive sorted sources -- about two cells' worth -- and four lanes share one
-// source: lane group g scans grid row ra0 + g of the cell rectangle [ra0, ra1] x [cb0, cb1] that the wave's sources'
-// (x - r, x + r) squares touch, r = distance to the previous match.  A row of the rectangle is one contiguous run of the
-// cell-sorted target list; the runs are staged 16 targets per row at a time in the wave's own LDS slice (no block barrier
-// in the scan), entries past a run's end as far-away points.
-__global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2) {
-    constexpr int SB = 64, SR = 66;                                   // staged targets per row and batch (4 rows per wave); row stride
-                                                                      // (66: the four rows' equal slots fall into different LDS banks)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* tx = (double*)smem;                                       // [waves][4 rows][SR] x | y | z, then the frame indices
-    double* ty = tx + ICP_NNW * 4 * SR; double* tz = ty + ICP_NNW * 4 * SR;
-    int* tj = (int*)(tz + ICP_NNW * 4 * SR);
-    __shared__ double sc[ICP_NNW * ICP_NM];
-    const int tid = threadIdx.x, blk = blockIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef CREG_STAMPS
-    const bool tailonly = *P.running <= 4;                           // stamps of the tail of the frame only: few clusters still iterating
-    unsigned long long nst = clock64();
-#define NN_STAMP(slot) do { const unsigned long long now_ = clock64(); if (tid == 0 && tailonly) atomicAdd(&g_icp_stamps[slot], now_ - nst); nst = now_; } while (0)
-#else
-#define NN_STAMP(slot) do { } while (0)
-#endif
-    if (blk >= P.chunk0[k_total]) return;
-    const int c = P.chunk_cl[blk];
-    const double* st = P.state + ICP_ST * c;
-    if (st[34] != 0.0) return;                                        // converged cluster: nothing moves any more
-    const int g = lane >> 4, l16 = lane & 15;                         // lane group: the grid row of the rectangle it scans
-    const int i = P.off[c] + (blk - P.chunk0[c]) * ICP_CH + wv * 16 + l16;
-    const bool live = i < P.off[c + 1];
-    const double x0a = st[36], inv_a = st[37], x0b = st[42], inv_b = st[43];
-    const int axa = (int)st[38], axb = (int)st[44];
-    const double shc0 = st[39], shc1 = st[40], shc2 = st[41];
-    double s0 = 0, s1 = 0, s2 = 0, alo = INFINITY, ahi = -INFINITY, blo = INFINITY, bhi = -INFINITY;
-    if (live) {
-        // the rigid update the last fit left pending (identity before the first one); the four lanes of a source agree,
-        // lane group 0 stores
-        const double p0 = P.srcw[3 * (size_t)i], p1 = P.srcw[3 * (size_t)i + 1], p2 = P.srcw[3 * (size_t)i + 2];
-        const int pm = P.nn[i];                                       // -1 before the first search (k_icp_init)
-        const double q0 = P.prevt[3 * (size_t)i], q1 = P.prevt[3 * (size_t)i + 1], q2 = P.prevt[3 * (size_t)i + 2];
-        s0 = fma(st[16 + 2], p2, fma(st[16 + 1], p1, st[16] * p0)) + st[16 + 3];
-        s1 = fma(st[16 + 6], p2, fma(st[16 + 5], p1, st[16 + 4] * p0)) + st[16 + 7];
-        s2 = fma(st[16 + 10], p2, fma(st[16 + 9], p1, st[16 + 8] * p0)) + st[16 + 11];
-        alo = -INFINITY; ahi = INFINITY; blo = -INFINITY; bhi = INFINITY;
-        if (pm >= 0) {
-            const double dx = s0 - q0, dy = s1 - q1, dz = s2 - q2;
-            const double sa = axa == 0 ? s0 : (axa == 1 ? s1 : s2), sb = axb == 0 ? s0 : (axb == 1 ? s1 : s2);
-            const double d2p = (dx * dx + dy * dy) + dz * dz;
-            const double r0 = (d2p > 1e-280 ? d2p * fast_rsqrt(d2p) : 1e-140) * (1.0 + 1e-12) + 1e-300;
-            const double ra = r0 + 4e-16 * fabs(sa), rb = r0 + 4e-16 * fabs(sb);
-            alo = sa - ra; ahi = sa + ra; blo = sb - rb; bhi = sb + rb;
-        }
-    }
-    NN_STAMP(8);
-    if (live && g == 0) { P.srcw[3 * (size_t)i] = s0; P.srcw[3 * (size_t)i + 1] = s1; P.srcw[3 * (size_t)i + 2] = s2; }
-    const bool any = __ballot(live) != 0;
-    const int ra0 = __builtin_amdgcn_readfirstlane(icp_bin(wave_min_fast(alo), x0a, inv_a, ICP_GA));
-    const int ra1 = __builtin_amdgcn_readfirstlane(icp_bin(wave_max_fast(ahi), x0a, inv_a, ICP_GA));
-    const int cb0 = __builtin_amdgcn_readfirstlane(icp_bin(wave_min_fast(blo), x0b, inv_b, ICP_GB));
-    const int cb1 = __builtin_amdgcn_readfirstlane(icp_bin(wave_max_fast(bhi), x0b, inv_b, ICP_GB));
-    const int* tst = P.tst + (size_t)c * (ICP_NCELL + 1);
-    const int* tidx = P.tidx + (size_t)c * nf;
-    // lane l < rows: the run of grid row ra0 + l
-    int q0v = 0, q1v = 0;
-    if (any && lane <= ra1 - ra0) { q0v = tst[(ra0 + lane) * ICP_GB + cb0]; q1v = tst[(ra0 + lane) * ICP_GB + cb1 + 1]; }
-    const int nrows = any ? ra1 - ra0 + 1 : 0;
-    NN_STAMP(9);
-#ifdef CREG_STAMPS
-    if (lane == 0 && any) { atomicAdd(&g_icp_stamps[1], 1ull); atomicAdd(&g_icp_stamps[3], (unsigned long long)P.tcount[c]); atomicAdd(&g_icp_stamps[5], (unsigned long long)nrows); atomicAdd(&g_icp_stamps[6], (unsigned long long)(cb1 - cb0 + 1)); }
-    const unsigned long long stt = clock64();
-#endif
-    double* px = tx + (wv * 4 + g) * SR; double* py = ty + (wv * 4 + g) * SR; double* pz = tz + (wv * 4 + g) * SR;
-    int* pj = tj + (wv * 4 + g) * SR;
-    const int tb = P.tbase[c];                                        // >= 0: coordinates in the pool, in the order of tidx
-    double best = 1e299; int bslot = -1, bj = 0x7fffffff;  // 1e299: below the staged padding's 3e300, above any real squared distance
-    double bx = 0, by = 0, bz = 0;                                    // the best target's coordinates, picked up from LDS after its batch
-    bool tief = false;
-    for (int pass = 0; pass < 2; ++pass) {                            // pass 1 only after a tie was seen: frame-index tie-break
-        for (int rg = 0; rg < nrows; rg += 4) {                       // four rows at a time, one per lane group
-            const int myrow = rg + g;
-            const int q0 = __shfl(q0v, min(myrow, 63), 64), q1 = myrow < nrows ? __shfl(q1v, min(myrow, 63), 64) : q0;
-            int per = q1 - q0;
-            per = max(per, __shfl_xor(per, 16, 64)); per = max(per, __shfl_xor(per, 32, 64));
-            per = __builtin_amdgcn_readfirstlane(per);                // the longest of the four runs
-#ifdef CREG_STAMPS
-            if (lane == 0 && pass == 0) { atomicAdd(&g_icp_stamps[0], (unsigned long long)per); atomicAdd(&g_icp_stamps[4], 1ull); }
-#endif
-            for (int t0 = 0; t0 < per; t0 += SB) {
-                // stage SB targets of each of the four runs: lane (g, l) takes entries t0 + l, t0 + l + 16, ... of row g; all
-                // index loads go out first, then all coordinate loads: two memory round trips per batch
-                int jv[SB / 16];
-#pragma unroll
-                for (int u = 0; u < SB / 16; ++u) { const int t = q0 + t0 + 16 * u + l16; jv[u] = t < q1 ? tidx[t] : -1; }
-                if (tb >= 0) {                        // block-uniform: consecutive lanes read consecutive pool entries
-                    double cx[SB / 16], cy[SB / 16], cz[SB / 16];
-#pragma unroll
-                    for (int u = 0; u < SB / 16; ++u) {
-                        const int t = min(q0 + t0 + 16 * u + l16, max(q1 - 1, 0));
-                        cx[u] = P.tcx[tb + t]; cy[u] = P.tcy[tb + t]; cz[u] = P.tcz[tb + t];
-                    }
-#pragma unroll
-                    for (int u = 0; u < SB / 16; ++u) {
-                        const int e = 16 * u + l16;
-                        const bool in = jv[u] >= 0;
-                        px[e] = in ? cx[u] : 1e150; py[e] = in ? cy[u] : 1e150; pz[e] = in ? cz[u] : 1e150; pj[e] = in ? jv[u] : 0x7fffffff;
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < SB / 16; ++u) {
-                        const int e = 16 * u + l16;
-                        if (jv[u] >= 0) {
-                            px[e] = P.frame[3 * (size_t)jv[u]]; py[e] = P.frame[3 * (size_t)jv[u] + 1]; pz[e] = P.frame[3 * (size_t)jv[u] + 2];
-                            pj[e] = jv[u];
-                        } else { px[e] = 1e150; py[e] = 1e150; pz[e] = 1e150; pj[e] = 0x7fffffff; }   // past the run: farther than `best` ever is
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                NN_STAMP(10);
-                const int cnt = min(SB, per - t0);                    // uniform; rounded up to a multiple of 4 (padding is harmless)
-                int bm = -1, bl = -1;                                 // slots of this batch
-                if (pass == 0) {
-                    for (int t = 0; t < cnt; t += 4) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const double dx = s0 - px[t + u], dy = s1 - py[t + u], dz = s2 - pz[t + u];
-                            const double d2 = (dx * dx + dy * dy) + dz * dz;
-                            bm = d2 < best ? t + u : bm;
-                            bl = d2 <= best ? t + u : bl;
-                            best = vmin_f64(best, d2);
-                        }
-                    }
-                    tief |= bl >= 0 && bl != bm;                      // a candidate as near as the best (of this or an earlier batch)
-                } else {
-                    for (int t = 0; t < cnt; ++t) {
-                        const double dx = s0 - px[t], dy = s1 - py[t], dz = s2 - pz[t];
-                        const double d2 = (dx * dx + dy * dy) + dz * dz;
-                        const int j = pj[t];
-                        if (d2 < best || (d2 == best && j < bj)) { best = d2; bm = t; bj = j; }
-                    }
-                }
-                if (bm >= 0) { bx = px[bm]; by = py[bm]; bz = pz[bm]; bj = pj[bm]; bslot = bm; }
-                NN_STAMP(11);
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (pass == 0) {
-            if (!__ballot(tief)) break;
-            best = 1e299; bslot = -1; bj = 0x7fffffff;
-        }
-    }
-    if (bslot < 0) { best = INFINITY; bj = 0x7fffffff; }              // a lane group whose rows were all empty has no candidate
-#ifdef CREG_STAMPS
-    if (lane == 0 && any) { atomicAdd(&g_icp_stamps[7], clock64() - stt); if (tief) atomicAdd(&g_icp_stamps[2], 1ull); }
-#endif
-    // the four lane groups of a source: (distance, frame index) lexicographic minimum, the winner's coordinates along
-    for (int o = 16; o <= 32; o <<= 1) {
-        const double od = __shfl_xor(best, o, 64); const int oj = __shfl_xor(bj, o, 64);
-        const double ox = __shfl_xor(bx, o, 64), oy = __shfl_xor(by, o, 64), oz = __shfl_xor(bz, o, 64);
-        if (od < best || (od == best && oj < bj)) { best = od; bj = oj; bx = ox; by = oy; bz = oz; }
-    }
-    NN_STAMP(12);
-    double cm[ICP_NM];
-    for (int a = 0; a < ICP_NM; ++a) cm[a] = 0;
-    if (live && g == 0) {
-        const bool ok = bj != 0x7fffffff && best <= th2;
-        P.nn[i] = ok ? bj : -1;
-        if (ok) {
-            P.prevt[3 * (size_t)i] = bx; P.prevt[3 * (size_t)i + 1] = by; P.prevt[3 * (size_t)i + 2] = bz;
-            const double sv[3] = {s0 - shc0, s1 - shc1, s2 - shc2};
-            const double dv[3] = {bx - shc0, by - shc1, bz - shc2};
-            cm[0] = 1.0; cm[1] = best;
-            for (int a = 0; a < 3; ++a) { cm[2 + a] = sv[a]; cm[5 + a] = dv[a]; }
-            for (int a = 0; a < 3; ++a) for (int q = 0; q < 3; ++q) cm[8 + 3 * a + q] = sv[a] * dv[q];
-        }
-    }
-    // the chunk's moments: DPP wave sums, then 0 + w0 + w1 + w2 + w3 (fixed association)
-#pragma unroll
-    for (int a = 0; a < ICP_NM; ++a) cm[a] = wave_sum_fast(cm[a]);
-    if (lane == 0) {
-#pragma unroll
-        for (int a = 0; a < ICP_NM; ++a) sc[wv * ICP_NM + a] = cm[a];
-    }
-    NN_STAMP(13);
+// One workgroup: the chunks of the clusters that have not converged, in order, into P.live; their number behind the
+// "clusters still running" word the host reads between batches (the next batch of searches launches only those chunks:
+// in the tail of a frame a few clusters iterate on, and the thousands of workgroups that would only find "done" and leave
+// delayed the live ones by 10-40 us per search).
+__global__ __launch_bounds__(1024) void k_icp_compact(IcpLarge P, int k_total) {
+    __shared__ int wsum[16];
+    __shared__ int s_run;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_run = 0;
     __syncthreads();
-    NN_STAMP(14);
-    if (tid < ICP_NM) {
-        double r = 0.0;
-        for (int w = 0; w < ICP_NNW; ++w) r += sc[w * ICP_NM + tid];
-        P.part[(size_t)blk * ICP_NM + tid] = r;
+    for (int c0 = 0; c0 < k_total; c0 += 1024) {
+        const int c = c0 + tid;
+        const bool lv = c < k_total && P.state[ICP_ST * c + 34] == 0.0;
+        const int nch = lv ? P.chunk0[c + 1] - P.chunk0[c] : 0;
+        int inc = nch;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int base = s_run + inc - nch, total = 0;
+        for (int w = 0; w < 16; ++w) { const int t = wsum[w]; base += w < wv ? t : 0; total += t; }
+        for (int q = 0; q < nch; ++q) P.live[base + q] = P.chunk0[c] + q;
+        __syncthreads();
+        if (tid == 0) s_run += total;
+        __syncthreads();
     }
-#ifdef CREG_STAMPS
-    if (tid == 0 && tailonly) atomicAdd(&g_icp_stamps[15], 1ull);
-#endif
+    if (tid == 0) P.running[1] = s_run;
 }
 
-// one wave per cluster: moments of the chunks in chunk order, convergence, Horn
-__global__ __launch_bounds__(64) void k_icp_fit(IcpLarge P, int max_iter) {
-    const int k = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ double ld_agent_f64(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent_f64(double* p, double v) {
+    __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave, run by the LAST chunk of cluster k to finish its search (k_icp_nn): moments of the chunks in chunk order ->
+// fitness / RMSE, open3d's convergence test against the previous ones, else Horn's closed form: new pose, pending update.
+// The other chunks' moments were stored with agent-scope stores and are read with agent-scope loads (no fences:
+// MI355X_MICROARCH.md, "sc1 stores and loads both sides"); everything else the wave reads was written by earlier launches.
+__device__ void icp_fit_cluster(const IcpLarge& P, int k, int max_iter, int lane) {
     double* st = P.state + ICP_ST * k;
-    if (st[34] != 0.0) return;                                        // done
     const int ns = P.off[k + 1] - P.off[k];
     double v = 0.0;
     if (lane < ICP_NM) {
@@ -1236,7 +1097,7 @@ __global__ __launch_bounds__(64) void k_icp_fit(IcpLarge P, int max_iter) {
         for (int ch = c0; ch < c1; ch += 8) {                         // chunk order; a group's loads are issued together
             double pv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) pv[u] = P.part[(size_t)min(ch + u, c1 - 1) * ICP_NM + lane];
+            for (int u = 0; u < 8; ++u) pv[u] = ld_agent_f64(P.part + (size_t)min(ch + u, c1 - 1) * ICP_NM + lane);
 #pragma unroll
             for (int u = 0; u < 8; ++u) if (ch + u < c1) v += pv[u];
         }
@@ -1283,6 +1144,241 @@ __global__ __launch_bounds__(64) void k_icp_fit(IcpLarge P, int max_iter) {
     st[32] = fit; st[33] = rmse; st[35] = (double)(updates + 1);
 }
 
+// Block = one chunk of ICP_CH = 64 sorted sources of ONE cluster (chunk0 maps blocks to clusters; blocks past the last
+// chunk exit), 256 threads: the tail of a frame's ICP is a few clusters iterating on, and small chunks put their work on
+// many CUs (1024-thread chunks of 256 sources: 59 us per search whatever the number of live clusters).  A wave owns 16 consecutive sorted sources -- about two cells' worth -- and four lanes share one
+// source: lane group g scans grid row ra0 + g of the cell rectangle [ra0, ra1] x [cb0, cb1] that the wave's sources'
+// (x - r, x + r) squares touch, r = distance to the previous match.  A row of the rectangle is one contiguous run of the
+// cell-sorted target list; the runs are staged 16 targets per row at a time in the wave's own LDS slice (no block barrier
+// in the scan), entries past a run's end as far-away points.
+__global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2, int max_iter) {
+    constexpr int SB = 64, SR = 66;                                   // staged targets per row and batch (4 rows per wave); row stride
+                                                                      // (66: the four rows' equal slots fall into different LDS banks)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* tx = (double*)smem;                                       // [waves][4 rows][SR] x | y | z, then the frame indices
+    double* ty = tx + ICP_NNW * 4 * SR; double* tz = ty + ICP_NNW * 4 * SR;
+    int* tj = (int*)(tz + ICP_NNW * 4 * SR);
+    __shared__ double sc[ICP_NNW * ICP_NM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int blk = P.use_live ? P.live[blockIdx.x] : (int)blockIdx.x;     // the chunk this workgroup takes
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CREG_STAMPS
+    const bool tailonly = *P.running <= 4;                           // stamps of the tail of the frame only: few clusters still iterating
+    if (tid == 0 && tailonly) atomicMin(&g_icp_wmin[0], wall_clock64());
+    unsigned long long nst = clock64();
+#define NN_STAMP(slot) do { const unsigned long long now_ = clock64(); if (tid == 0 && tailonly) atomicAdd(&g_icp_stamps[slot], now_ - nst); nst = now_; } while (0)
+#else
+#define NN_STAMP(slot) do { } while (0)
+#endif
+    if (blk >= P.chunk0[k_total]) return;
+    const int c = P.chunk_cl[blk];
+    const double* st = P.state + ICP_ST * c;
+    if (st[34] != 0.0) return;                                        // converged cluster: nothing moves any more
+    const int g = lane >> 4, l16 = lane & 15;                         // lane group: the grid row of the rectangle it scans
+#ifdef CREG_STAMPS
+    if (tid == 0 && tailonly) atomicMin(&g_icp_wmin[1], wall_clock64());
+#endif
+    const int i = P.off[c] + (blk - P.chunk0[c]) * ICP_CH + wv * 16 + l16;
+    const bool live = i < P.off[c + 1];
+    const double x0a = st[36], inv_a = st[37], x0b = st[42], inv_b = st[43];
+    const int axa = (int)st[38], axb = (int)st[44];
+    const double shc0 = st[39], shc1 = st[40], shc2 = st[41];
+    double s0 = 0, s1 = 0, s2 = 0, alo = INFINITY, ahi = -INFINITY, blo = INFINITY, bhi = -INFINITY;
+    if (live) {
+        // the rigid update the last fit left pending (identity before the first one); the four lanes of a source agree,
+        // lane group 0 stores
+        const double p0 = P.srcw[3 * (size_t)i], p1 = P.srcw[3 * (size_t)i + 1], p2 = P.srcw[3 * (size_t)i + 2];
+        const int pm = P.nn[i];                                       // -1 before the first search (k_icp_init)
+        const double q0 = P.prevt[3 * (size_t)i], q1 = P.prevt[3 * (size_t)i + 1], q2 = P.prevt[3 * (size_t)i + 2];
+        s0 = fma(st[16 + 2], p2, fma(st[16 + 1], p1, st[16] * p0)) + st[16 + 3];
+        s1 = fma(st[16 + 6], p2, fma(st[16 + 5], p1, st[16 + 4] * p0)) + st[16 + 7];
+        s2 = fma(st[16 + 10], p2, fma(st[16 + 9], p1, st[16 + 8] * p0)) + st[16 + 11];
+        alo = -INFINITY; ahi = INFINITY; blo = -INFINITY; bhi = INFINITY;
+        if (pm >= 0) {
+            const double dx = s0 - q0, dy = s1 - q1, dz = s2 - q2;
+            const double sa = axa == 0 ? s0 : (axa == 1 ? s1 : s2), sb = axb == 0 ? s0 : (axb == 1 ? s1 : s2);
+            const double d2p = (dx * dx + dy * dy) + dz * dz;
+            const double r0 = (d2p > 1e-280 ? d2p * fast_rsqrt(d2p) : 1e-140) * (1.0 + 1e-12) + 1e-300;
+            const double ra = r0 + 4e-16 * fabs(sa), rb = r0 + 4e-16 * fabs(sb);
+            alo = sa - ra; ahi = sa + ra; blo = sb - rb; bhi = sb + rb;
+        }
+    }
+    NN_STAMP(8);
+    if (live && g == 0) { P.srcw[3 * (size_t)i] = s0; P.srcw[3 * (size_t)i + 1] = s1; P.srcw[3 * (size_t)i + 2] = s2; }
+    const bool any = __ballot(live) != 0;
+    const int ra0 = __builtin_amdgcn_readfirstlane(icp_bin(wave_min_fast(alo), x0a, inv_a, ICP_GA));
+    const int ra1 = __builtin_amdgcn_readfirstlane(icp_bin(wave_max_fast(ahi), x0a, inv_a, ICP_GA));
+    const int cb0 = __builtin_amdgcn_readfirstlane(icp_bin(wave_min_fast(blo), x0b, inv_b, ICP_GB));
+    const int cb1 = __builtin_amdgcn_readfirstlane(icp_bin(wave_max_fast(bhi), x0b, inv_b, ICP_GB));
+    const int* tst = P.tst + (size_t)c * (ICP_NCELL + 1);
+    const int* tidx = P.tidx + (size_t)c * nf;
+    // lane l < rows: the run of grid row ra0 + l
+    int q0v = 0, q1v = 0;
+    if (any && lane <= ra1 - ra0) { q0v = tst[(ra0 + lane) * ICP_GB + cb0]; q1v = tst[(ra0 + lane) * ICP_GB + cb1 + 1]; }
+    const int nrows = any ? ra1 - ra0 + 1 : 0;
+#ifdef CREG_STAMPS
+    if (lane == 0 && any && tailonly) { atomicAdd(&g_icp_stamps[1], 1ull); atomicAdd(&g_icp_stamps[3], (unsigned long long)P.tcount[c]); atomicAdd(&g_icp_stamps[5], (unsigned long long)nrows); atomicAdd(&g_icp_stamps[6], (unsigned long long)(cb1 - cb0 + 1)); }
+    const unsigned long long stt = clock64();
+#endif
+    double* px = tx + (wv * 4 + g) * SR; double* py = ty + (wv * 4 + g) * SR; double* pz = tz + (wv * 4 + g) * SR;
+    int* pj = tj + (wv * 4 + g) * SR;
+    const int tb = P.tbase[c];                                        // >= 0: coordinates in the pool, in the order of tidx
+    // Lane group g walks the runs of grid rows ra0 + g, + 4, + 8, + 12 as ONE sequence of L entries (entry p -> run and
+    // offset by three compares), so the scan is a flat loop over batches of SB entries and the four groups carry nearly
+    // equal loads whatever the number of rows.
+    int rs0, rs1, rs2, rs3, c1, c2, c3, L;
+    {
+        const int r0 = g, r1 = g + 4, r2 = g + 8, r3 = g + 12;
+        const int a0 = __shfl(q0v, r0, 64), e0 = __shfl(q1v, r0, 64), a1 = __shfl(q0v, r1, 64), e1 = __shfl(q1v, r1, 64);
+        const int a2 = __shfl(q0v, r2, 64), e2 = __shfl(q1v, r2, 64), a3 = __shfl(q0v, r3, 64), e3 = __shfl(q1v, r3, 64);
+        rs0 = a0; rs1 = a1; rs2 = a2; rs3 = a3;
+        c1 = r0 < nrows ? e0 - a0 : 0;
+        c2 = c1 + (r1 < nrows ? e1 - a1 : 0);
+        c3 = c2 + (r2 < nrows ? e2 - a2 : 0);
+        L = c3 + (r3 < nrows ? e3 - a3 : 0);
+    }
+    int per = L;
+    per = max(per, __shfl_xor(per, 16, 64)); per = max(per, __shfl_xor(per, 32, 64));
+    per = __builtin_amdgcn_readfirstlane(per);                        // the longest of the four sequences
+#ifdef CREG_STAMPS
+    if (lane == 0 && tailonly) { atomicAdd(&g_icp_stamps[0], (unsigned long long)per); atomicAdd(&g_icp_stamps[4], 1ull); }
+#endif
+    // staging registers of one batch: the loads of batch b + 1 are in flight while batch b is scanned from LDS
+    int jv[SB / 16];
+    double cx[SB / 16], cy[SB / 16], cz[SB / 16];
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < SB / 16; ++u) {
+            const int pq = t0 + 16 * u + l16;                         // entry of the group's sequence
+            const int t = pq < c1 ? rs0 + pq : (pq < c2 ? rs1 + (pq - c1) : (pq < c3 ? rs2 + (pq - c2) : rs3 + (pq - c3)));
+            const bool in = pq < L;
+            const int j = in ? tidx[t] : -1;
+            jv[u] = j;
+            if (tb >= 0) {                            // block-uniform: consecutive lanes read consecutive pool entries
+                const int tt = in ? t : 0;
+                cx[u] = P.tcx[tb + tt]; cy[u] = P.tcy[tb + tt]; cz[u] = P.tcz[tb + tt];
+            }
+        }
+        if (tb < 0) {                                 // the pool was full: gather through the frame indices
+#pragma unroll
+            for (int u = 0; u < SB / 16; ++u) {
+                const size_t jj = (size_t)max(jv[u], 0);
+                cx[u] = P.frame[3 * jj]; cy[u] = P.frame[3 * jj + 1]; cz[u] = P.frame[3 * jj + 2];
+            }
+        }
+    };
+    auto publish = [&]() {                            // registers -> the lane group's LDS slice; entries past the sequence as far-away points
+#pragma unroll
+        for (int u = 0; u < SB / 16; ++u) {
+            const int e = 16 * u + l16;
+            const bool in = jv[u] >= 0;
+            px[e] = in ? cx[u] : 1e150; py[e] = in ? cy[u] : 1e150; pz[e] = in ? cz[u] : 1e150; pj[e] = in ? jv[u] : 0x7fffffff;
+        }
+    };
+    double best = 1e299; int bslot = -1, bj = 0x7fffffff;             // 1e299: below the staged padding's 3e300, above any real squared distance
+    double bx = 0, by = 0, bz = 0;                                    // the best target's coordinates, picked up from LDS after its batch
+    bool tief = false;
+    NN_STAMP(9);
+    for (int pass = 0; pass < 2; ++pass) {                            // pass 1 only after a tie was seen: frame-index tie-break
+        if (per > 0) fetch(0);
+        for (int t0 = 0; t0 < per; t0 += SB) {
+            publish();
+            __builtin_amdgcn_wave_barrier();
+            if (t0 + SB < per) fetch(t0 + SB);
+            NN_STAMP(10);
+            const int cnt = min(SB, per - t0);                        // uniform; rounded up to a multiple of 4 (padding is harmless)
+            int bm = -1, bl = -1;                                     // slots of this batch
+            if (pass == 0) {
+                for (int t = 0; t < cnt; t += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double dx = s0 - px[t + u], dy = s1 - py[t + u], dz = s2 - pz[t + u];
+                        const double d2 = (dx * dx + dy * dy) + dz * dz;
+                        bm = d2 < best ? t + u : bm;
+                        bl = d2 <= best ? t + u : bl;
+                        best = vmin_f64(best, d2);
+                    }
+                }
+                tief |= bl >= 0 && bl != bm;                          // a candidate as near as the best (of this or an earlier batch)
+            } else {
+                for (int t = 0; t < cnt; ++t) {
+                    const double dx = s0 - px[t], dy = s1 - py[t], dz = s2 - pz[t];
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    const int j = pj[t];
+                    if (d2 < best || (d2 == best && j < bj)) { best = d2; bm = t; bj = j; }
+                }
+            }
+            if (bm >= 0) { bx = px[bm]; by = py[bm]; bz = pz[bm]; bj = pj[bm]; bslot = bm; }
+            NN_STAMP(11);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (pass == 0) {
+            if (!__ballot(tief)) break;
+            best = 1e299; bslot = -1; bj = 0x7fffffff;
+        }
+    }
+    if (bslot < 0) { best = INFINITY; bj = 0x7fffffff; }              // a lane group whose rows were all empty has no candidate
+#ifdef CREG_STAMPS
+    if (lane == 0 && any && tailonly) { atomicAdd(&g_icp_stamps[7], clock64() - stt); if (tief) atomicAdd(&g_icp_stamps[2], 1ull); }
+#endif
+    // the four lane groups of a source: (distance, frame index) lexicographic minimum, the winner's coordinates along
+    for (int o = 16; o <= 32; o <<= 1) {
+        const double od = __shfl_xor(best, o, 64); const int oj = __shfl_xor(bj, o, 64);
+        const double ox = __shfl_xor(bx, o, 64), oy = __shfl_xor(by, o, 64), oz = __shfl_xor(bz, o, 64);
+        if (od < best || (od == best && oj < bj)) { best = od; bj = oj; bx = ox; by = oy; bz = oz; }
+    }
+    NN_STAMP(12);
+    double cm[ICP_NM];
+    for (int a = 0; a < ICP_NM; ++a) cm[a] = 0;
+    if (live && g == 0) {
+        const bool ok = bj != 0x7fffffff && best <= th2;
+        P.nn[i] = ok ? bj : -1;
+        if (ok) {
+            P.prevt[3 * (size_t)i] = bx; P.prevt[3 * (size_t)i + 1] = by; P.prevt[3 * (size_t)i + 2] = bz;
+            const double sv[3] = {s0 - shc0, s1 - shc1, s2 - shc2};
+            const double dv[3] = {bx - shc0, by - shc1, bz - shc2};
+            cm[0] = 1.0; cm[1] = best;
+            for (int a = 0; a < 3; ++a) { cm[2 + a] = sv[a]; cm[5 + a] = dv[a]; }
+            for (int a = 0; a < 3; ++a) for (int q = 0; q < 3; ++q) cm[8 + 3 * a + q] = sv[a] * dv[q];
+        }
+    }
+    // the chunk's moments: DPP wave sums, then 0 + w0 + w1 + w2 + w3 (fixed association)
+#pragma unroll
+    for (int a = 0; a < ICP_NM; ++a) cm[a] = wave_sum_fast(cm[a]);
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < ICP_NM; ++a) sc[wv * ICP_NM + a] = cm[a];
+    }
+    NN_STAMP(13);
+    __syncthreads();
+    NN_STAMP(14);
+    if (tid < ICP_NM) {
+        double r = 0.0;
+        for (int w = 0; w < ICP_NNW; ++w) r += sc[w * ICP_NM + tid];
+        st_agent_f64(P.part + (size_t)blk * ICP_NM + tid, r);
+    }
+    // the cluster's last chunk to get here runs the fit (the barrier has waited for this chunk's stores)
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) {
+        const int nch = P.chunk0[c + 1] - P.chunk0[c];
+        const int last = atomicAdd(&P.arrive[c], 1) == nch - 1;
+        if (last) P.arrive[c] = 0;                                    // for the next launch
+        s_last = last;
+    }
+    __syncthreads();
+#ifdef CREG_STAMPS
+    if (tid == 0 && tailonly) atomicMax(&g_icp_wmin[2], wall_clock64());
+#endif
+    if (s_last && wv == 0) icp_fit_cluster(P, c, max_iter, lane);
+#ifdef CREG_STAMPS
+    if (s_last && tid == 0 && tailonly) atomicMax(&g_icp_wmin[3], wall_clock64());
+#endif
+#ifdef CREG_STAMPS
+    if (tid == 0 && tailonly) atomicAdd(&g_icp_stamps[15], 1ull);
+#endif
+}
+
 __global__ __launch_bounds__(256) void k_icp_finish(IcpLarge P, int keep_t) {
     __shared__ double T[16];
     const int k = blockIdx.x, tid = threadIdx.x;
@@ -1301,7 +1397,7 @@ __global__ __launch_bounds__(256) void k_icp_finish(IcpLarge P, int keep_t) {
     }
 }
 
-struct IcpLargeLayout { size_t srcw, tidx, tcount, box, nn, part, state, running, chunk0, tst, chunk_cl, prevt, tcx, tcy, tcz, tbase, total; int pool_cap; };
+struct IcpLargeLayout { size_t srcw, tidx, tcount, box, nn, part, state, running, chunk0, tst, chunk_cl, prevt, tcx, tcy, tcz, tbase, arrive, live, total; int pool_cap; };
 static IcpLargeLayout icp_large_layout(int64_t n, int64_t nf, int k) {
     IcpLargeLayout L; size_t o = 0;
     auto take = [&](size_t b) { size_t r = o; o = align_up(o + b, 256); return r; };
@@ -1316,7 +1412,7 @@ static IcpLargeLayout icp_large_layout(int64_t n, int64_t nf, int k) {
     const int64_t cap = 4 * nf < (int64_t)k * nf ? 4 * nf : (int64_t)k * nf;
     L.pool_cap = (int)(cap < (1ll << 30) ? cap : (1ll << 30));
     L.tcx = take(sizeof(double) * (size_t)L.pool_cap); L.tcy = take(sizeof(double) * (size_t)L.pool_cap); L.tcz = take(sizeof(double) * (size_t)L.pool_cap);
-    L.tbase = take(sizeof(int) * k); L.total = o;
+    L.tbase = take(sizeof(int) * k); L.arrive = take(sizeof(int) * k); L.live = take(sizeof(int) * (size_t)(n / ICP_CH + k + 1)); L.total = o;
     return L;
 }
 // the regime switch (host-side sizes only): average cluster above the LDS source budget, or a frame too large for the
@@ -1351,7 +1447,7 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
     P.srcw = (double*)(ws + L.srcw); P.tidx = (int*)(ws + L.tidx); P.tcount = (int*)(ws + L.tcount); P.box = (float*)(ws + L.box);
     P.nn = (int*)(ws + L.nn); P.part = (double*)(ws + L.part); P.state = (double*)(ws + L.state); P.running = (int*)(ws + L.running);
     P.chunk0 = (int*)(ws + L.chunk0); P.tst = (int*)(ws + L.tst); P.chunk_cl = (int*)(ws + L.chunk_cl); P.prevt = (double*)(ws + L.prevt);
-    P.tcx = (double*)(ws + L.tcx); P.tcy = (double*)(ws + L.tcy); P.tcz = (double*)(ws + L.tcz); P.tbase = (int*)(ws + L.tbase); P.pool_cap = L.pool_cap;
+    P.tcx = (double*)(ws + L.tcx); P.tcy = (double*)(ws + L.tcy); P.tcz = (double*)(ws + L.tcz); P.tbase = (int*)(ws + L.tbase); P.arrive = (int*)(ws + L.arrive); P.live = (int*)(ws + L.live); P.use_live = 0; P.pool_cap = L.pool_cap;
     if (q.tgt_offsets) {
         set_error("creg_masked_icp: point-to-point mode (tgt_offsets) is not available in the large-cluster regime");
         return CREG_EINVAL;
@@ -1362,19 +1458,23 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
     hipLaunchKernelGGL(k_icp_init, dim3(k), dim3(1024), 0, s, P, k);
     hipLaunchKernelGGL(k_icp_pool, dim3(k, 8), dim3(256), 0, s, P, (int)nf);
     const int nblk = cdiv(n, ICP_CH) + k;                // an upper bound of sum_c ceil(ns_c / ICP_CH); the surplus blocks exit
-    hipLaunchKernelGGL(k_icp_nn, dim3(nblk), dim3(64 * ICP_NNW), nn_smem, s, P, (int)n, k, (int)nf, th * th);
-    CREG_LAUNCH_CHECK();
-    int running = k;
-    // every k_icp_fit call is one convergence test + (unless converged) one update; max_iteration updates need one call more
-    for (int64_t done = 0; running > 0 && done <= (int64_t)max_iteration; ) {
+    int running[2] = {k, nblk};                                      // clusters still iterating, their chunks
+    // every launch is one search + (last chunk of each cluster) one fit = one convergence test and, unless converged, one
+    // update; max_iteration updates need one launch more.  After every batch the live chunks are compacted and the next
+    // batch launches only those.
+    for (int64_t done = 0; running[0] > 0 && done <= (int64_t)max_iteration; ) {
         const int batch = 16;
         for (int b = 0; b < batch; ++b, ++done) {
-            hipLaunchKernelGGL(k_icp_fit, dim3(k), dim3(64), 0, s, P, max_iteration);
-            hipLaunchKernelGGL(k_icp_nn, dim3(nblk), dim3(64 * ICP_NNW), nn_smem, s, P, (int)n, k, (int)nf, th * th);
+            hipLaunchKernelGGL(k_icp_nn, dim3(running[1]), dim3(64 * ICP_NNW), nn_smem, s, P, (int)n, k, (int)nf, th * th, max_iteration);
+#ifdef CREG_STAMPS
+            hipLaunchKernelGGL(k_icp_wall_fold, dim3(1), dim3(1), 0, s);
+#endif
         }
+        hipLaunchKernelGGL(k_icp_compact, dim3(1), dim3(1024), 0, s, P, k);
         CREG_LAUNCH_CHECK();
-        CREG_HIP(hipMemcpyAsync(&running, P.running, sizeof(int), hipMemcpyDeviceToHost, s));
+        CREG_HIP(hipMemcpyAsync(running, P.running, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         CREG_HIP(hipStreamSynchronize(s));
+        P.use_live = 1;
     }
     hipLaunchKernelGGL(k_icp_finish, dim3(k), dim3(256), 0, s, P, keep_translation);
     CREG_LAUNCH_CHECK();
@@ -1462,6 +1562,12 @@ extern "C" int creg_icp_p2p_f64(const double* src, int64_t n_src, const int32_t*
 }
 
 #ifdef CREG_STAMPS
+extern "C" int creg_debug_icp_wall(unsigned long long* out8, int reset) {
+    if (out8) CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_icp_wall), sizeof(unsigned long long) * 8));
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_icp_wall), z, sizeof(z)));
+                 unsigned long long m[4] = {~0ull, ~0ull, 0ull, 0ull}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_icp_wmin), m, sizeof(m))); }
+    return CREG_OK;
+}
 extern "C" int creg_debug_icp_stamps(unsigned long long* out8, int reset) {
     if (out8) CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_icp_stamps), sizeof(unsigned long long) * 512 * 16));
     if (reset) { static unsigned long long z[512 * 16]; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_icp_stamps), z, sizeof(z))); }
