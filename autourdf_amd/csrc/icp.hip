@@ -808,7 +808,7 @@ struct IcpLarge {                          // per problem
     double* Mout; double* world_out; int* n_iter_out;
     double* srcw; int* tidx; int* tcount; float* box; int* nn; double* part; double* state; int* running;
     int* chunk0;                               // [k + 1] first source chunk of every cluster (k_icp_nn's block -> cluster map)
-    int* tst;                                  // [k][ICP_NCELL + 1] first target of every cell, row-major in (a, b) (binned mode)
+    int* tst;                                  // [k][ICP_NCELL + 1] first target of every cell, row-major in (a, b), g x g used (binned mode)
     int* chunk_cl;                             // [chunks] cluster of every chunk (k_icp_nn's block -> cluster map)
     double* prevt;                             // [n][3] coordinates of every source's current match (the next search's bound)
     double* tcx; double* tcy; double* tcz;     // pool of the clusters' masked target coordinates in cell order (coalesced staging)
@@ -820,10 +820,15 @@ struct IcpLarge {                          // per problem
 };
 constexpr int ICP_CH = 64;                 // sources per k_icp_nn workgroup (4 waves of 16)
 constexpr int ICP_NNW = ICP_CH / 16;       // waves of a k_icp_nn workgroup
-constexpr int ICP_ST = 48;                 // doubles of per-cluster state: T[16] U[16] prev_fit prev_rmse done n_updates | a: x0 inv_w axis | shc[3] | b: x0 inv_w axis
+constexpr int ICP_SB = 64;                 // targets a lane group stages per batch (128 measured no better)
+constexpr int ICP_ST = 48;                 // doubles of per-cluster state: T[16] U[16] prev_fit prev_rmse done n_updates | a: x0 inv_w axis | shc[3] | b: x0 inv_w axis | g
 constexpr int ICP_NM = 17;                 // moments per chunk: count, sum d2, sum (s - shc), sum (d - shc), sum (s - shc)(d - shc)^T
-constexpr int ICP_GA = 16, ICP_GB = 16;    // cells along the box's longest (a) and second longest (b) edge
-constexpr int ICP_NCELL = ICP_GA * ICP_GB;
+constexpr int ICP_GMAX = 64;               // the grid over the box's longest (a) and second longest (b) edge has g x g cells, g per
+constexpr int ICP_NCELL = ICP_GMAX * ICP_GMAX;      // cluster by its size: ~8 sources (~12 targets) per cell, 8 <= g <= 64
+__device__ __forceinline__ int icp_grid_dim(int ns) {
+    int g = (int)ceil(sqrt((double)ns / 8.0));
+    return g < 8 ? 8 : (g > ICP_GMAX ? ICP_GMAX : g);
+}
 __device__ __forceinline__ int icp_bin(double x, double x0, double inv_w, int nbin) { return (int)fmin(fmax((x - x0) * inv_w, 0.0), (double)(nbin - 1)); }
 
 // binned = 0: ascending compaction into tidx / tcount (creg_aabb_mask_f64, the G9 golden).
@@ -855,8 +860,8 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
         for (int o = 32; o >= 1; o >>= 1) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64)); }
         if (lane == 0) { wl[wv][d] = lo[d]; wh[wv][d] = hi[d]; }
     }
-    if (tid <= ICP_NCELL) cnt[tid] = 0;
-    if (tid < ICP_NCELL) fill[tid] = 0;
+    for (int q = tid; q <= ICP_NCELL; q += 1024) cnt[q] = 0;
+    for (int q = tid; q < ICP_NCELL; q += 1024) fill[q] = 0;
     __syncthreads();
     if (tid < 3) {
         const int d = tid;
@@ -877,40 +882,43 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
         for (int d = 1; d < 3; ++d) if (ext[d] > ext[axa]) axa = d;
         int axb = axa == 0 ? 1 : 0;
         for (int d = 0; d < 3; ++d) if (d != axa && ext[d] > ext[axb]) axb = d;
-        const double x0a = (double)s_lo[axa], inv_a = ext[axa] > 0.f && ext[axa] < INFINITY ? (double)ICP_GA / (double)ext[axa] : 0.0;
-        const double x0b = (double)s_lo[axb], inv_b = ext[axb] > 0.f && ext[axb] < INFINITY ? (double)ICP_GB / (double)ext[axb] : 0.0;
+        const int gd = icp_grid_dim(e - b), ncell = gd * gd;
+        const double x0a = (double)s_lo[axa], inv_a = ext[axa] > 0.f && ext[axa] < INFINITY ? (double)gd / (double)ext[axa] : 0.0;
+        const double x0b = (double)s_lo[axb], inv_b = ext[axb] > 0.f && ext[axb] < INFINITY ? (double)gd / (double)ext[axb] : 0.0;
         const int nfe = e > b ? nf : 0;
+        __shared__ int wsum[16];
         for (int pass = 0; pass < 2; ++pass) {
             for (int j = tid; j < nfe; j += 1024) {
                 const double p[3] = {P.frame[3 * (size_t)j], P.frame[3 * (size_t)j + 1], P.frame[3 * (size_t)j + 2]};
                 if (p[0] > blo0 && p[0] < bhi0 && p[1] > blo1 && p[1] < bhi1 && p[2] > blo2 && p[2] < bhi2) {
                     const double ca = axa == 0 ? p[0] : (axa == 1 ? p[1] : p[2]), cb = axb == 0 ? p[0] : (axb == 1 ? p[1] : p[2]);
-                    const int cell = icp_bin(ca, x0a, inv_a, ICP_GA) * ICP_GB + icp_bin(cb, x0b, inv_b, ICP_GB);
+                    const int cell = icp_bin(ca, x0a, inv_a, gd) * gd + icp_bin(cb, x0b, inv_b, gd);
                     if (pass == 0) atomicAdd(&cnt[cell], 1);
                     else tidx[cnt[cell] + atomicAdd(&fill[cell], 1)] = j;
                 }
             }
             __syncthreads();
-            if (pass == 0) {
-                if (wv == 0) {                    // exclusive prefix over the 256 cells: four per lane
-                    int c4[4], run4 = 0;
-                    for (int q = 0; q < 4; ++q) { c4[q] = cnt[4 * lane + q]; run4 += c4[q]; }
-                    int inc = run4;
-                    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-                    int acc = inc - run4;
-                    for (int q = 0; q < 4; ++q) { cnt[4 * lane + q] = acc; acc += c4[q]; }
-                    if (lane == 63) cnt[ICP_NCELL] = inc;
-                }
+            if (pass == 0) {                          // exclusive prefix over the cells: four per thread, wave scans, wave totals
+                int c4[4], run4 = 0;
+                for (int q = 0; q < 4; ++q) { c4[q] = 4 * tid + q < ncell ? cnt[4 * tid + q] : 0; run4 += c4[q]; }
+                int inc = run4;
+                for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+                if (lane == 63) wsum[wv] = inc;
+                __syncthreads();
+                int acc = inc - run4, total = 0;
+                for (int w = 0; w < 16; ++w) { const int t = wsum[w]; acc += w < wv ? t : 0; total += t; }
+                for (int q = 0; q < 4; ++q) { if (4 * tid + q < ncell) cnt[4 * tid + q] = acc; acc += c4[q]; }
+                if (tid == 0) cnt[ncell] = total;
                 __syncthreads();
             }
         }
-        if (tid <= ICP_NCELL) P.tst[(size_t)k * (ICP_NCELL + 1) + tid] = cnt[tid];
+        for (int q = tid; q <= ncell; q += 1024) P.tst[(size_t)k * (ICP_NCELL + 1) + q] = cnt[q];
         if (tid == 0) {
-            P.tcount[k] = cnt[ICP_NCELL];
+            P.tcount[k] = cnt[ncell];
             double* st = P.state + ICP_ST * k;
             st[36] = x0a; st[37] = inv_a; st[38] = (double)axa;
             st[39] = 0.5 * (blo0 + bhi0); st[40] = 0.5 * (blo1 + bhi1); st[41] = 0.5 * (blo2 + bhi2);
-            st[42] = x0b; st[43] = inv_b; st[44] = (double)axb;
+            st[42] = x0b; st[43] = inv_b; st[44] = (double)axb; st[45] = (double)gd;
         }
         return;
     }
@@ -934,70 +942,78 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
     if (tid == 0) P.tcount[k] = run;
 }
 
-// one workgroup per cluster: sources with the initial pose, stable counting sort by cell into srcw (k_icp_mask ran before)
+// one workgroup per cluster: sources with the initial pose, stable-sorted by grid cell into srcw (k_icp_mask ran before).
+// Two stable counting sorts of <= 64 bins each -- by column into the (still unused) match-coordinate buffer, then by row
+// into srcw: least-significant-digit radix, so the final order is row-major by cell with the original order inside a cell.
 __global__ __launch_bounds__(1024) void k_icp_init(IcpLarge P, int k_total) {
-    __shared__ int base[ICP_NCELL], run[ICP_NCELL];
-    __shared__ int wcnt[16][ICP_NCELL];
+    __shared__ int base[ICP_GMAX], run[ICP_GMAX];
+    __shared__ int wcnt[16][ICP_GMAX];
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = P.off[k], e = P.off[k + 1], ns = e - b;
     double* st = P.state + ICP_ST * k;
     const double x0a = st[36], inv_a = st[37], x0b = st[42], inv_b = st[43];
-    const int axa = (int)st[38], axb = (int)st[44];
+    const int axa = (int)st[38], axb = (int)st[44], gd = (int)st[45];
     double T[12];
     for (int q = 0; q < 12; ++q) T[q] = P.Min[16 * k + q];
-    auto world_pt = [&](int i, double (&w)[3]) -> int {
-        const double p0 = P.local[3 * (size_t)(b + i)], p1 = P.local[3 * (size_t)(b + i) + 1], p2 = P.local[3 * (size_t)(b + i) + 2];
-        for (int a = 0; a < 3; ++a) w[a] = fma(T[4 * a + 2], p2, fma(T[4 * a + 1], p1, T[4 * a] * p0)) + T[4 * a + 3];
-        const double ca = axa == 0 ? w[0] : (axa == 1 ? w[1] : w[2]), cb = axb == 0 ? w[0] : (axb == 1 ? w[1] : w[2]);
-        return icp_bin(ca, x0a, inv_a, ICP_GA) * ICP_GB + icp_bin(cb, x0b, inv_b, ICP_GB);
-    };
-    if (tid < ICP_NCELL) { base[tid] = 0; run[tid] = 0; }
-    __syncthreads();
-    for (int i = tid; i < ns; i += 1024) {
-        double w[3];
-        atomicAdd(&base[world_pt(i, w)], 1);
-    }
-    __syncthreads();
-    if (wv == 0) {
-        int c4[4], run4 = 0;
-        for (int q = 0; q < 4; ++q) { c4[q] = base[4 * lane + q]; run4 += c4[q]; }
-        int inc = run4;
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-        int acc = inc - run4;
-        for (int q = 0; q < 4; ++q) { base[4 * lane + q] = acc; acc += c4[q]; }
-    }
-    for (int r0 = 0; r0 < ns; r0 += 1024) {
-        __syncthreads();                              // base / run of the previous round are final; wcnt may be rewritten
-        for (int q = tid; q < 16 * ICP_NCELL; q += 1024) (&wcnt[0][0])[q] = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        // pass 0: local -> world, key = column (b axis), into prevt; pass 1: prevt -> srcw, key = row (a axis)
+        const double* src = pass == 0 ? P.local : P.prevt;
+        double* dst = pass == 0 ? P.prevt : P.srcw;
+        auto point = [&](int i, double (&w)[3]) -> int {
+            const double p0 = src[3 * (size_t)(b + i)], p1 = src[3 * (size_t)(b + i) + 1], p2 = src[3 * (size_t)(b + i) + 2];
+            if (pass == 0) { for (int a = 0; a < 3; ++a) w[a] = fma(T[4 * a + 2], p2, fma(T[4 * a + 1], p1, T[4 * a] * p0)) + T[4 * a + 3]; }
+            else { w[0] = p0; w[1] = p1; w[2] = p2; }
+            const int ax = pass == 0 ? axb : axa;
+            const double cc = ax == 0 ? w[0] : (ax == 1 ? w[1] : w[2]);
+            return pass == 0 ? icp_bin(cc, x0b, inv_b, gd) : icp_bin(cc, x0a, inv_a, gd);
+        };
+        __syncthreads();                              // the previous pass has written its output
+        if (tid < ICP_GMAX) { base[tid] = 0; run[tid] = 0; }
         __syncthreads();
-        const int i = r0 + tid;
-        const bool valid = i < ns;
-        double w[3] = {0, 0, 0};
-        int sl = 0;
-        if (valid) sl = world_pt(i, w);
-        unsigned long long rem = __ballot(valid);
-        int rank = 0;
-        while (rem) {                                 // rank among the wave's lower lanes of the same cell; the wave's count per cell
-            const int lead = __ffsll((long long)rem) - 1;
-            const int lsl = __builtin_amdgcn_readlane(sl, lead);
-            const unsigned long long m = __ballot(valid && sl == lsl);
-            if (valid && sl == lsl) rank = __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == lead) wcnt[wv][lsl] = __popcll(m);
-            rem &= ~m;
+        for (int i = tid; i < ns; i += 1024) {
+            double w[3];
+            atomicAdd(&base[point(i, w)], 1);
         }
         __syncthreads();
-        if (tid < ICP_NCELL) {                        // per cell: exclusive prefix over the waves, then the round's total
-            int acc = 0;
-            for (int w2 = 0; w2 < 16; ++w2) { const int t = wcnt[w2][tid]; wcnt[w2][tid] = acc; acc += t; }
-            const int r = run[tid];
-            run[tid] = r + acc;
-            for (int w2 = 0; w2 < 16; ++w2) wcnt[w2][tid] += r;
+        if (wv == 0) {
+            const int c = base[lane];
+            int inc = c;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+            base[lane] = inc - c;
         }
-        __syncthreads();
-        if (valid) {
-            const size_t pos = (size_t)b + base[sl] + wcnt[wv][sl] + rank;
-            P.srcw[3 * pos] = w[0]; P.srcw[3 * pos + 1] = w[1]; P.srcw[3 * pos + 2] = w[2];
-            P.nn[pos] = -1;
+        for (int r0 = 0; r0 < ns; r0 += 1024) {
+            __syncthreads();                          // base / run of the previous round are final; wcnt may be rewritten
+            for (int q = tid; q < 16 * ICP_GMAX; q += 1024) (&wcnt[0][0])[q] = 0;
+            __syncthreads();
+            const int i = r0 + tid;
+            const bool valid = i < ns;
+            double w[3] = {0, 0, 0};
+            int sl = 0;
+            if (valid) sl = point(i, w);
+            unsigned long long rem = __ballot(valid);
+            int rank = 0;
+            while (rem) {                             // rank among the wave's lower lanes of the same bin; the wave's count per bin
+                const int lead = __ffsll((long long)rem) - 1;
+                const int lsl = __builtin_amdgcn_readlane(sl, lead);
+                const unsigned long long m = __ballot(valid && sl == lsl);
+                if (valid && sl == lsl) rank = __popcll(m & ((1ull << lane) - 1ull));
+                if (lane == lead) wcnt[wv][lsl] = __popcll(m);
+                rem &= ~m;
+            }
+            __syncthreads();
+            if (tid < ICP_GMAX) {                     // per bin: exclusive prefix over the waves, then the round's total
+                int acc = 0;
+                for (int w2 = 0; w2 < 16; ++w2) { const int t = wcnt[w2][tid]; wcnt[w2][tid] = acc; acc += t; }
+                const int r = run[tid];
+                run[tid] = r + acc;
+                for (int w2 = 0; w2 < 16; ++w2) wcnt[w2][tid] += r;
+            }
+            __syncthreads();
+            if (valid) {
+                const size_t pos = (size_t)b + base[sl] + wcnt[wv][sl] + rank;
+                dst[3 * pos] = w[0]; dst[3 * pos + 1] = w[1]; dst[3 * pos + 2] = w[2];
+                if (pass == 1) P.nn[pos] = -1;
+            }
         }
     }
     if (tid < 16) { st[tid] = P.Min[16 * k + tid]; st[16 + tid] = (tid % 5 == 0) ? 1.0 : 0.0; }      // pose; pending update = identity
@@ -1152,8 +1168,8 @@ __device__ void icp_fit_cluster(const IcpLarge& P, int k, int max_iter, int lane
 // cell-sorted target list; the runs are staged 16 targets per row at a time in the wave's own LDS slice (no block barrier
 // in the scan), entries past a run's end as far-away points.
 __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2, int max_iter) {
-    constexpr int SB = 64, SR = 66;                                   // staged targets per row and batch (4 rows per wave); row stride
-                                                                      // (66: the four rows' equal slots fall into different LDS banks)
+    constexpr int SB = ICP_SB, SR = ICP_SB + 2;                       // staged targets per lane group and batch; slice stride
+                                                                      // (+2: the four groups' equal slots fall into different LDS banks)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tx = (double*)smem;                                       // [waves][4 rows][SR] x | y | z, then the frame indices
     double* ty = tx + ICP_NNW * 4 * SR; double* tz = ty + ICP_NNW * 4 * SR;
@@ -1181,7 +1197,7 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
     const int i = P.off[c] + (blk - P.chunk0[c]) * ICP_CH + wv * 16 + l16;
     const bool live = i < P.off[c + 1];
     const double x0a = st[36], inv_a = st[37], x0b = st[42], inv_b = st[43];
-    const int axa = (int)st[38], axb = (int)st[44];
+    const int axa = (int)st[38], axb = (int)st[44], gd = (int)st[45];
     const double shc0 = st[39], shc1 = st[40], shc2 = st[41];
     double s0 = 0, s1 = 0, s2 = 0, alo = INFINITY, ahi = -INFINITY, blo = INFINITY, bhi = -INFINITY;
     if (live) {
@@ -1206,28 +1222,30 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
     NN_STAMP(8);
     if (live && g == 0) { P.srcw[3 * (size_t)i] = s0; P.srcw[3 * (size_t)i + 1] = s1; P.srcw[3 * (size_t)i + 2] = s2; }
     const bool any = __ballot(live) != 0;
-    const int ra0 = __builtin_amdgcn_readfirstlane(icp_bin(wave_min_fast(alo), x0a, inv_a, ICP_GA));
-    const int ra1 = __builtin_amdgcn_readfirstlane(icp_bin(wave_max_fast(ahi), x0a, inv_a, ICP_GA));
-    const int cb0 = __builtin_amdgcn_readfirstlane(icp_bin(wave_min_fast(blo), x0b, inv_b, ICP_GB));
-    const int cb1 = __builtin_amdgcn_readfirstlane(icp_bin(wave_max_fast(bhi), x0b, inv_b, ICP_GB));
+    const int ra0 = __builtin_amdgcn_readfirstlane(icp_bin(wave_min_fast(alo), x0a, inv_a, gd));
+    const int ra1 = __builtin_amdgcn_readfirstlane(icp_bin(wave_max_fast(ahi), x0a, inv_a, gd));
+    const int cb0 = __builtin_amdgcn_readfirstlane(icp_bin(wave_min_fast(blo), x0b, inv_b, gd));
+    const int cb1 = __builtin_amdgcn_readfirstlane(icp_bin(wave_max_fast(bhi), x0b, inv_b, gd));
     const int* tst = P.tst + (size_t)c * (ICP_NCELL + 1);
     const int* tidx = P.tidx + (size_t)c * nf;
-    // lane l < rows: the run of grid row ra0 + l
-    int q0v = 0, q1v = 0;
-    if (any && lane <= ra1 - ra0) { q0v = tst[(ra0 + lane) * ICP_GB + cb0]; q1v = tst[(ra0 + lane) * ICP_GB + cb1 + 1]; }
-    const int nrows = any ? ra1 - ra0 + 1 : 0;
+    const int nrows_all = any ? ra1 - ra0 + 1 : 0;
 #ifdef CREG_STAMPS
+    const int nrows = nrows_all;
     if (lane == 0 && any && tailonly) { atomicAdd(&g_icp_stamps[1], 1ull); atomicAdd(&g_icp_stamps[3], (unsigned long long)P.tcount[c]); atomicAdd(&g_icp_stamps[5], (unsigned long long)nrows); atomicAdd(&g_icp_stamps[6], (unsigned long long)(cb1 - cb0 + 1)); }
     const unsigned long long stt = clock64();
 #endif
     double* px = tx + (wv * 4 + g) * SR; double* py = ty + (wv * 4 + g) * SR; double* pz = tz + (wv * 4 + g) * SR;
     int* pj = tj + (wv * 4 + g) * SR;
     const int tb = P.tbase[c];                                        // >= 0: coordinates in the pool, in the order of tidx
-    // Lane group g walks the runs of grid rows ra0 + g, + 4, + 8, + 12 as ONE sequence of L entries (entry p -> run and
-    // offset by three compares), so the scan is a flat loop over batches of SB entries and the four groups carry nearly
-    // equal loads whatever the number of rows.
-    int rs0, rs1, rs2, rs3, c1, c2, c3, L;
-    {
+    // Lane group g walks the runs of grid rows rb + g, + 4, + 8, + 12 of a band of <= 16 rows as ONE sequence of L entries
+    // (entry p -> run and offset by three compares), so the scan is a flat loop over batches of SB entries and the four groups
+    // carry nearly equal loads whatever the number of rows.  A rectangle of more than 16 rows (the first search of a large
+    // cluster: the whole grid) takes several bands.
+    int rs0 = 0, rs1 = 0, rs2 = 0, rs3 = 0, c1 = 0, c2 = 0, c3 = 0, L = 0, per = 0;
+    auto band = [&](int rb) {
+        const int nrows = min(16, ra1 - rb + 1);
+        int q0v = 0, q1v = 0;                         // lane l < rows: the run of grid row rb + l
+        if (lane < nrows) { q0v = tst[(rb + lane) * gd + cb0]; q1v = tst[(rb + lane) * gd + cb1 + 1]; }
         const int r0 = g, r1 = g + 4, r2 = g + 8, r3 = g + 12;
         const int a0 = __shfl(q0v, r0, 64), e0 = __shfl(q1v, r0, 64), a1 = __shfl(q0v, r1, 64), e1 = __shfl(q1v, r1, 64);
         const int a2 = __shfl(q0v, r2, 64), e2 = __shfl(q1v, r2, 64), a3 = __shfl(q0v, r3, 64), e3 = __shfl(q1v, r3, 64);
@@ -1236,13 +1254,13 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
         c2 = c1 + (r1 < nrows ? e1 - a1 : 0);
         c3 = c2 + (r2 < nrows ? e2 - a2 : 0);
         L = c3 + (r3 < nrows ? e3 - a3 : 0);
-    }
-    int per = L;
-    per = max(per, __shfl_xor(per, 16, 64)); per = max(per, __shfl_xor(per, 32, 64));
-    per = __builtin_amdgcn_readfirstlane(per);                        // the longest of the four sequences
+        int pr = L;
+        pr = max(pr, __shfl_xor(pr, 16, 64)); pr = max(pr, __shfl_xor(pr, 32, 64));
+        per = __builtin_amdgcn_readfirstlane(pr);                     // the longest of the four sequences
 #ifdef CREG_STAMPS
-    if (lane == 0 && tailonly) { atomicAdd(&g_icp_stamps[0], (unsigned long long)per); atomicAdd(&g_icp_stamps[4], 1ull); }
+        if (lane == 0 && tailonly) { atomicAdd(&g_icp_stamps[0], (unsigned long long)per); atomicAdd(&g_icp_stamps[4], 1ull); }
 #endif
+    };
     // staging registers of one batch: the loads of batch b + 1 are in flight while batch b is scanned from LDS
     int jv[SB / 16];
     double cx[SB / 16], cy[SB / 16], cz[SB / 16];
@@ -1280,6 +1298,8 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
     bool tief = false;
     NN_STAMP(9);
     for (int pass = 0; pass < 2; ++pass) {                            // pass 1 only after a tie was seen: frame-index tie-break
+      for (int rb = ra0; rb < ra0 + nrows_all; rb += 16) {
+        band(rb);
         if (per > 0) fetch(0);
         for (int t0 = 0; t0 < per; t0 += SB) {
             publish();
@@ -1312,6 +1332,7 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
             NN_STAMP(11);
             __builtin_amdgcn_wave_barrier();
         }
+      }
         if (pass == 0) {
             if (!__ballot(tief)) break;
             best = 1e299; bslot = -1; bj = 0x7fffffff;
@@ -1452,7 +1473,7 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
         set_error("creg_masked_icp: point-to-point mode (tgt_offsets) is not available in the large-cluster regime");
         return CREG_EINVAL;
     }
-    const int nn_smem = ICP_NNW * 4 * 66 * 28;            // k_icp_nn: per wave 4 rows x 64 (+2: bank offset) staged targets (x, y, z, frame index)
+    const int nn_smem = ICP_NNW * 4 * (ICP_SB + 2) * 28;  // k_icp_nn: per wave 4 lane groups x ICP_SB (+2: bank offset) staged targets (x, y, z, frame index)
     CREG_HIP(hipFuncSetAttribute((const void*)k_icp_nn, hipFuncAttributeMaxDynamicSharedMemorySize, nn_smem));
     hipLaunchKernelGGL(k_icp_mask, dim3(k), dim3(1024), 0, s, P, (int)nf, (float)(0.5 * scale), q.world ? 0 : 1, 1);
     hipLaunchKernelGGL(k_icp_init, dim3(k), dim3(1024), 0, s, P, k);

@@ -18,7 +18,7 @@ fw.argtypes = [ctypes.c_void_p, ctypes.c_int]
 wout = (ctypes.c_ulonglong * 8)()
 dev = torch.device("cuda")
 N, K = 262144, 128
-seq = make_sequence("chain32", 0, 3, N)
+seq = make_sequence("chain32", 0, 14, N)
 mats0, clusters0, _ = initial_segmentation(seq[0], K, seed=0, iters=8)
 M = torch.as_tensor(mats0, dtype=torch.float64, device=dev).contiguous()
 local, off = ops.pack_clusters(clusters0, dev, torch.float64)

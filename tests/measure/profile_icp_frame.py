@@ -40,7 +40,8 @@ def c5(n_frames=6):
         (local, off), t_grp = timed(lambda: ops.group_to_local(f64, labels, M_new))
         M = M_new
         it = n_it.cpu().numpy()
-        print(f"frame {t}: K3 {t_k3:6.2f}  K4 {t_k4:7.2f} (iterations mean {it.mean():5.1f} max {it.max():3d}, clusters over 40: {(it > 40).sum()})  "
+        sizes = np.diff(off.cpu().numpy())
+        print(f"frame {t}: clusters of {sizes.min()}..{int(np.median(sizes))}..{sizes.max()} points (min / median / max); K3 {t_k3:6.2f}  K4 {t_k4:7.2f} (iterations mean {it.mean():5.1f} max {it.max():3d}, clusters over 40: {(it > 40).sum()})  "
               f"K5 {t_k5:5.2f}  K2 {t_k2:6.2f} ({int(n_km)} Lloyd iterations)  change of frame {t_grp:5.2f}  "
               f"sum {t_k3 + t_k4 + t_k5 + t_k2 + t_grp:7.2f}")
 

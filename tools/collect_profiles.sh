@@ -16,6 +16,7 @@ python $R/bench.py --workload allegro --steps 20 --warmup 5 --no-cpu-baseline --
 python $R/bench.py --mode replay --workload allegro --steps 50 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_replay_allegro.log 2>/dev/null
 python $R/bench.py --workload c5 --steps 12 --warmup 2 > $O/bench_c5.log 2>/dev/null
 python $R/tests/measure/bench_c5_resegment.py > $O/c5_resegment.log 2>/dev/null
+python $R/tests/measure/profile_icp_frame.py both 2>/dev/null | grep -v amdgpu.ids > $O/icp_frame_phases.log
 CMD="python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o r02 -- $CMD > $O/prof_run.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o c5 -- python $R/bench.py --workload c5 --steps 4 --warmup 1 > $O/prof_c5.log 2>&1

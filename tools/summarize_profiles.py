@@ -66,6 +66,7 @@ def main(src, tag):
     open(f"profiles/{tag}_final_bench_other_workloads.log", "w").write(open(f"{src}/bench_franka.log").read() + open(f"{src}/bench_allegro.log").read())
     open(f"profiles/{tag}_final_bench_replay_and_c5.log", "w").write(open(f"{src}/bench_replay_allegro.log").read() + open(f"{src}/bench_c5.log").read())
     shutil.copy(f"{src}/c5_resegment.log", f"profiles/{tag}_c5_resegment_bench.log")
+    shutil.copy(f"{src}/icp_frame_phases.log", f"profiles/{tag}_icp_frame_phases.log")
     print("\n".join(lines))
     for r in list(csv.DictReader(open(f"{src}/{tag}_kernel_stats.csv")))[:8]:
         print(r["Name"][:50], r["Calls"], round(float(r["AverageNs"]) / 1e3, 2), r["Percentage"])
