@@ -924,3 +924,23 @@ def test_masked_icp_large_regime_coordinate_pool_overflow(dev):
     assert sum(len(c) for c in clusters) // k > 1024 and k * len(frame) > 4 * len(frame)
     n_it = _icp_vs_oracle(dev, clusters, np.stack(mats), frame, scale=1.5)
     assert (n_it >= 1).all()
+
+
+@pytest.mark.parametrize("mfma", [False, True])
+def test_kmeans_many_empty_clusters_deferred_relocation_large_frame(dev, mfma):
+    """A frame large enough for the many-workgroup Lloyd path (two points per thread, hundreds of workgroups) seeded so that
+    a third of the centres own no point at first: the M-step tail defers, the next launch relocates over all workgroups
+    (segment maxima, rescans of the winners' segments).  Labels, iteration count and centres against the C oracle."""
+    from autourdf_amd import ops
+    from oracle import kmeans
+    rng = np.random.default_rng(11)
+    X = np.concatenate([rng.normal(size=(30000, 3)) * 0.3, rng.normal(size=(10000, 3)) * 0.1 + [2.0, 0.0, 0.0]])
+    k = 24
+    init = np.concatenate([X[rng.choice(len(X), k - 8, replace=False)] + 1e-4,
+                           rng.normal(size=(8, 3)) * 0.01 + [40.0, 40.0, -40.0]])     # eight seeds far from every point
+    c, lab, inertia, n_iter = ops.kmeans_lloyd(_cuda(X, dev), _cuda(init, dev), use_mfma=mfma)
+    oc, olab, oin, oit = kmeans.k_means(X, init)
+    np.testing.assert_array_equal(lab.cpu().numpy(), olab)
+    assert n_iter.item() == oit and len(np.unique(olab)) == k
+    np.testing.assert_allclose(c.cpu().numpy(), oc, atol=1e-11)
+    np.testing.assert_allclose(inertia.item(), oin, rtol=1e-11)
