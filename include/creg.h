@@ -87,7 +87,9 @@ int creg_cluster_transform_bwd_f32(const float* pts, const int32_t* seg_offsets,
  * X (n,3) fp64 is read only (centring happens on an internal copy), init (k,3) fp64.
  * Outputs: centers (k,3) fp64, labels (n) int32, inertia (1) fp64, n_iter (1) int32 -- device.
  * use_mfma != 0 selects the v_mfma_f64_16x16x4_f64 assignment kernel (bit-identical results).
- * This call synchronises the stream periodically to read the convergence flag. */
+ * One launch per Lloyd iteration (E-step, exact incremental M-step sums, M-step tail; the convergence test runs on the
+ * device and later launches return at once); the host enqueues 32 launches at a time and synchronises the stream in
+ * between to read the `done` word. */
 size_t creg_kmeans_workspace_bytes(int64_t n, int32_t k);
 int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* init, int32_t k,
                           int32_t max_iter, double tol_rel, int32_t use_mfma,
@@ -162,10 +164,13 @@ int creg_quat_to_matrix_f32(const float* q, int32_t k, float* R, creg_stream_t s
  * whole sequence (mlp_reg.py:248, never reassigned), `clusters_world` the trained clouds of the current, re-sampled
  * one (mlp_reg.py:301-306,325), so cluster i has another point count in the two lists from frame 2 on.
  * M_out (k,4,4) fp64, world_out (n,3) fp64 = M_out applied to local.  keep_translation mirrors `ori`.
- * Two regimes, same arithmetic: clusters a CU can hold (<= 1024 points on average, frames <= 65536 points) run the whole
+ * The nearest target of a source point is found exactly (the exhaustive scan's result, lowest frame index among equidistant
+ * candidates) over binned lists pruned by the distance to the previous iteration's match.
+ * Two regimes, same algorithm: clusters a CU can hold (<= 1024 points on average, frames <= 65536 points) run the whole
  * loop in ONE asynchronous launch; larger ones (BASELINE configs[4]: 2048-point clusters, 262144-point frames) run it
- * iteration by iteration over many workgroups and synchronise the stream every 16 iterations to read the number of
- * clusters still iterating.
+ * one launch per iteration over many workgroups and synchronise the stream every 16 iterations to read the number of
+ * clusters (and source chunks) still iterating.  The results of the two regimes agree to rounding (different summation
+ * trees), not bit for bit.
  * workspace: creg_icp_workspace_bytes(n, nf, k). */
 size_t creg_icp_workspace_bytes(int64_t n, int64_t nf, int32_t k);
 int creg_masked_icp_f64(const double* local, const float* world, const int32_t* world_offsets, int64_t n,
