@@ -820,10 +820,27 @@ __device__ __forceinline__ DwRow dw_row(const Dims& D, int bkind, int row) {
 // One wave owns DW_RPW parameter rows; the block's DW_RPB rows are of one kind (hidden / output / encoder)
 // and share ONE LDS copy of that kind's input activation matrix, fetched by LDS-DMA.  Parameter and
 // Adam-state loads of all rows, the gradient columns and the DMA are requested before the first wait.
+#ifdef CREG_STAMPS
+// debug build only: where k_dw's launches spend their time, by block kind (0 hidden rows, 1 output rows, 3 encoder rows), in
+// 10 ns ticks of the wall clock: [kind][0] blocks [1] sum of (block start - launch start) [2] sum of (block end - launch
+// start) [3] max (block end - launch start) summed over launches is not kept: [3] = sum of block durations; g_dw_launch:
+// scratch (launch start, end) folded per launch into g_dw_tot = [launches, sum of launch spans]
+__device__ unsigned long long g_dw_stamps[4][4];
+__device__ unsigned long long g_dw_launch[2];
+__device__ unsigned long long g_dw_tot[2];
+__global__ void k_dw_fold() {
+    if (g_dw_launch[1] != 0ull) { g_dw_tot[0] += 1; g_dw_tot[1] += g_dw_launch[1] - g_dw_launch[0]; }
+    g_dw_launch[0] = ~0ull; g_dw_launch[1] = 0ull;
+}
+#endif
 template <int NC>
 __global__ __launch_bounds__(DW_BLOCK, 2) void k_dw(Dims D, Ws W0, int epoch, size_t bstride) {
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef CREG_STAMPS
+    const unsigned long long dw_t0 = wall_clock64();
+    if (threadIdx.x == 0) atomicMin(&g_dw_launch[0], dw_t0);
+#endif
     const TrainState S = W.state[(epoch + 1) & 1];
     const bool live = !S.stopped;                   // gates every store (no early exit: see k_bwd2)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -939,6 +956,15 @@ __global__ __launch_bounds__(DW_BLOCK, 2) void k_dw(Dims D, Ws W0, int epoch, si
             }
         }
     }
+#ifdef CREG_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t1 = wall_clock64(), l0 = g_dw_launch[0];
+        atomicAdd(&g_dw_stamps[bkind][0], 1ull); atomicAdd(&g_dw_stamps[bkind][1], dw_t0 - l0); atomicAdd(&g_dw_stamps[bkind][2], t1 - l0);
+        atomicAdd(&g_dw_stamps[bkind][3], t1 - dw_t0);
+        atomicMax(&g_dw_launch[1], t1);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -1048,6 +1074,9 @@ static void launch_dw(Plan* P, int epoch, hipStream_t s) {
     by_nc(D.H, [&](auto nc) {
         hipLaunchKernelGGL((k_dw<decltype(nc)::value>), dim3(D.H2 / DW_RPB + cdiv(D.OA + D.OB, DW_RPB) + cdiv(D.H, DW_RPB), 1, P->nz),
                            dim3(DW_BLOCK), P->smem_dw, s, D, W, epoch, P->bstride); });
+#ifdef CREG_STAMPS
+    hipLaunchKernelGGL(k_dw_fold, dim3(1), dim3(1), 0, s);
+#endif
 }
 static void launch_nn(const Dims& D, const Ws& W, size_t bstride, int nz, hipStream_t s) {
     const EngineEpi epi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, bstride};
@@ -1410,3 +1439,18 @@ extern "C" int creg_train_plan_destroy(creg_train_plan* plan) {
     delete P;
     return CREG_OK;
 }
+
+#ifdef CREG_STAMPS
+extern "C" int creg_debug_dw_stamps(unsigned long long* out18, int reset) {
+    if (out18) {
+        CREG_HIP(hipMemcpyFromSymbol(out18, HIP_SYMBOL(creg::g_dw_stamps), sizeof(unsigned long long) * 16));
+        CREG_HIP(hipMemcpyFromSymbol(out18 + 16, HIP_SYMBOL(creg::g_dw_tot), sizeof(unsigned long long) * 2));
+    }
+    if (reset) {
+        unsigned long long z[16] = {0}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_dw_stamps), z, sizeof(z)));
+        unsigned long long t[2] = {0, 0}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_dw_tot), t, sizeof(t)));
+        unsigned long long l[2] = {~0ull, 0ull}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_dw_launch), l, sizeof(l)));
+    }
+    return CREG_OK;
+}
+#endif
