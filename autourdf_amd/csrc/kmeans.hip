@@ -301,6 +301,16 @@ __device__ __forceinline__ void km_move(unsigned long long* sA, int lab, int pv,
 // Lloyd launches only: the M-step tail's operands (B = the rows `B` points at, writable), the relocation scratch (far: n
 // doubles, segv / segi: one entry per workgroup) and the label buffers.  A launch works on iteration t = f->n_iter: it
 // writes lab[t & 1] and compares with lab[(t - 1) & 1] (prev0 = "no label" at t = 0).
+#ifdef CREG_STAMPS
+// debug build only: 10 ns wall-clock ticks, per E-step launch relative to its first block's start: [0] launches [1] sum of mean-ish block start [2] sum of
+// last block end (arrival) [3] sum of tail end [4] blocks; scratch: g_km_w = {launch start (min), last arrival (max), tail end}
+__device__ unsigned long long g_km_stamps[8];
+__device__ unsigned long long g_km_w[4];
+__global__ void k_km_fold() {
+    if (g_km_w[2] != 0ull) { g_km_stamps[0] += 1; g_km_stamps[2] += g_km_w[1] - g_km_w[0]; g_km_stamps[3] += g_km_w[2] - g_km_w[0]; g_km_stamps[5] += g_km_w[3] - g_km_w[0]; }
+    g_km_w[0] = ~0ull; g_km_w[1] = 0ull; g_km_w[2] = 0ull; g_km_w[3] = 0ull;
+}
+#endif
 struct KmTail { double* B; double* C2; double* Cw; double* far_d; double* segv; int* segi; int* lab[2]; const int* prev0; int max_iter; };
 
 // The workgroup's table of sums goes to the global accumulators; the last workgroup of the launch to have done so runs
@@ -313,7 +323,14 @@ __device__ __forceinline__ void km_flush_and_tail(const unsigned long long* sA, 
     __syncthreads();
     for (int i = threadIdx.x; i < 4 * k; i += NT) { const unsigned long long v = sA[i]; if (v) atomicAdd(&acc[i], v); }
     if (!km_arrive_last(f, S)) return;
+#ifdef CREG_STAMPS
+    if (threadIdx.x == 0) g_km_w[1] = wall_clock64();
+#endif
     km_mstep_tail<NT>(X, n, nullptr, k, acc, T.C2, T.B, T.Cw, T.far_d, T.segv, T.segi, 0, 0, f, S, lds_scratch, false);
+#ifdef CREG_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0) g_km_w[2] = wall_clock64();
+#endif
 }
 
 // Entry of a Lloyd launch: done / budget spent -> nothing; a deferred M-step tail pending -> this launch does the
@@ -358,6 +375,9 @@ __global__ __launch_bounds__(256) void k_km_assign(const double* __restrict__ X,
     // entry point then needs no device scratch (the library never allocates)
     // acc (Lloyd only): global [k][4] int64 sums of the M-step (fixed-point x, y, z and the count) of the labels in `prev`
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef CREG_STAMPS
+    if (threadIdx.x == 0 && f) atomicMin(&g_km_w[0], wall_clock64());
+#endif
     double* sB = (double*)smem;
     unsigned long long* sA = (unsigned long long*)(sB + 4 * k);
     int* labels = labels_in;
@@ -398,6 +418,9 @@ __global__ __launch_bounds__(256) void k_km_assign(const double* __restrict__ X,
             }
         }
     }
+#ifdef CREG_STAMPS
+    if (threadIdx.x == 0 && f) atomicMax(&g_km_w[3], wall_clock64());      // last block's end of the E-step proper
+#endif
     if (prev && f) {
         diff = wave_sum(diff);
         if ((threadIdx.x & 63) == 0 && diff) atomicAdd(&f->changed, diff);
@@ -1029,8 +1052,13 @@ extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* i
         // its last workgroup the M-step tail; launches after convergence (or after max_iter iterations) return at once, and a
         // launch that follows the discovery of an empty cluster runs the deferred tail instead (see km_lloyd_entry).
         for (int b = 0; b < 32; ++b)
+        {
             CREG_REQUIRE(launch_assign(Xc, ni, B, k, nullptr, nullptr, f, use_mfma, s, 0, acc, T) == 0,
                          "creg_kmeans_lloyd_f64: cannot raise the dynamic LDS limit of the E-step");
+#ifdef CREG_STAMPS
+            hipLaunchKernelGGL(k_km_fold, dim3(1), dim3(1), 0, s);
+#endif
+        }
         CREG_LAUNCH_CHECK();
         CREG_HIP(hipMemcpyAsync(&host, f, sizeof(KmFlags), hipMemcpyDeviceToHost, s));
         CREG_HIP(hipStreamSynchronize(s));
@@ -1127,3 +1155,12 @@ extern "C" int creg_kmeans_lloyd_batch_f64(const double* const* X, int64_t n, co
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }
+
+#ifdef CREG_STAMPS
+extern "C" int creg_debug_km_stamps(unsigned long long* out8, int reset) {
+    if (out8) CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_km_stamps), sizeof(unsigned long long) * 8));
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_km_stamps), z, sizeof(z)));
+                 unsigned long long m[4] = {~0ull, 0ull, 0ull, 0ull}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_km_w), m, sizeof(m))); }
+    return CREG_OK;
+}
+#endif
