@@ -328,11 +328,14 @@ def run_c5(args, robot, n_points, k_clusters, wl_tag):
         torch.cuda.synchronize()
     poses = torch.zeros(max(len(mine), 1), k_clusters, 4, 4, dtype=torch.float64, device=dev)
     iters = []
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(mine) + 1)]     # per-frame times without a sync in the loop
     t0 = time.perf_counter()
+    marks[0].record()
     for i, it in enumerate(mine):
         M_new, _, n_it = register(it)
         poses[i].copy_(M_new)
         iters.append(n_it)
+        marks[i + 1].record()
     counts = [len(job[r::world]) for r in range(world)]
     gathered = gather_poses(poses[:len(mine)], counts=counts if dist is not None else None)
     torch.cuda.synchronize()
@@ -378,6 +381,9 @@ def run_c5(args, robot, n_points, k_clusters, wl_tag):
                           "k_clusters": k_clusters,
                           "mode": "replay / independent-frame mode: --steps work items in TOTAL from a sequential pass, dealt round-robin to the ranks",
                           "mean_icp_iterations_per_cluster": round(float(torch.stack(iters).double().mean()), 1),
+                          "max_icp_iterations_per_frame": [int(x.max()) for x in iters],
+                          "largest_cluster_points_per_frame": [int((it[2][1:] - it[2][:-1]).max()) for it in mine],
+                          "frame_ms_rank0": [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(len(mine))],
                           "host_generation_s": round(t_gen, 1)},
                "roofline": {"bound": "hbm", "kernel": "k_km_assign (K2 E-step, VALU form)", "achieved": round(alg_bytes / (us * 1e-6) / 1e9, 1),
                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg_bytes / (us * 1e-6) / (HBM_PEAK_GBPS * 1e9), 4),
