@@ -819,7 +819,13 @@ struct IcpLarge {                          // per problem
     int pool_cap;
 };
 constexpr int ICP_CH = 64;                 // sources per k_icp_nn workgroup (4 waves of 16)
-constexpr int ICP_NNW = ICP_CH / 16;       // waves of a k_icp_nn workgroup
+#ifndef ICP_LG
+#define ICP_LG 2                           // log2 of the lanes that share one source point in k_icp_nn (measured at configs[4], 12 frames:
+                                           // 4 lanes 38.5 ms per frame, 8 lanes (-DICP_LG=3) 43.6)
+#endif
+constexpr int ICP_G = 1 << ICP_LG;         // lane groups of a wave = lanes per source
+constexpr int ICP_SPW = 64 >> ICP_LG;      // sources per wave
+constexpr int ICP_NNW = ICP_CH / ICP_SPW;  // waves of a k_icp_nn workgroup
 constexpr int ICP_SB = 64;                 // targets a lane group stages per batch (128 measured no better)
 constexpr int ICP_ST = 48;                 // doubles of per-cluster state: T[16] U[16] prev_fit prev_rmse done n_updates | a: x0 inv_w axis | shc[3] | b: x0 inv_w axis | g
 constexpr int ICP_NM = 17;                 // moments per chunk: count, sum d2, sum (s - shc), sum (d - shc), sum (s - shc)(d - shc)^T
@@ -1172,8 +1178,8 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
                                                                       // (+2: the four groups' equal slots fall into different LDS banks)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tx = (double*)smem;                                       // [waves][4 rows][SR] x | y | z, then the frame indices
-    double* ty = tx + ICP_NNW * 4 * SR; double* tz = ty + ICP_NNW * 4 * SR;
-    int* tj = (int*)(tz + ICP_NNW * 4 * SR);
+    double* ty = tx + ICP_NNW * ICP_G * SR; double* tz = ty + ICP_NNW * ICP_G * SR;
+    int* tj = (int*)(tz + ICP_NNW * ICP_G * SR);
     __shared__ double sc[ICP_NNW * ICP_NM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int blk = P.use_live ? P.live[blockIdx.x] : (int)blockIdx.x;     // the chunk this workgroup takes
@@ -1190,11 +1196,11 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
     const int c = P.chunk_cl[blk];
     const double* st = P.state + ICP_ST * c;
     if (st[34] != 0.0) return;                                        // converged cluster: nothing moves any more
-    const int g = lane >> 4, l16 = lane & 15;                         // lane group: the grid row of the rectangle it scans
+    const int g = lane / ICP_SPW, l16 = lane % ICP_SPW;               // lane group (the grid rows of the rectangle it scans), source in the wave
 #ifdef CREG_STAMPS
     if (tid == 0 && tailonly) atomicMin(&g_icp_wmin[1], wall_clock64());
 #endif
-    const int i = P.off[c] + (blk - P.chunk0[c]) * ICP_CH + wv * 16 + l16;
+    const int i = P.off[c] + (blk - P.chunk0[c]) * ICP_CH + wv * ICP_SPW + l16;
     const bool live = i < P.off[c + 1];
     const double x0a = st[36], inv_a = st[37], x0b = st[42], inv_b = st[43];
     const int axa = (int)st[38], axb = (int)st[44], gd = (int)st[45];
@@ -1234,8 +1240,8 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
     if (lane == 0 && any && tailonly) { atomicAdd(&g_icp_stamps[1], 1ull); atomicAdd(&g_icp_stamps[3], (unsigned long long)P.tcount[c]); atomicAdd(&g_icp_stamps[5], (unsigned long long)nrows); atomicAdd(&g_icp_stamps[6], (unsigned long long)(cb1 - cb0 + 1)); }
     const unsigned long long stt = clock64();
 #endif
-    double* px = tx + (wv * 4 + g) * SR; double* py = ty + (wv * 4 + g) * SR; double* pz = tz + (wv * 4 + g) * SR;
-    int* pj = tj + (wv * 4 + g) * SR;
+    double* px = tx + (wv * ICP_G + g) * SR; double* py = ty + (wv * ICP_G + g) * SR; double* pz = tz + (wv * ICP_G + g) * SR;
+    int* pj = tj + (wv * ICP_G + g) * SR;
     const int tb = P.tbase[c];                                        // >= 0: coordinates in the pool, in the order of tidx
     // Lane group g walks the runs of grid rows rb + g, + 4, + 8, + 12 of a band of <= 16 rows as ONE sequence of L entries
     // (entry p -> run and offset by three compares), so the scan is a flat loop over batches of SB entries and the four groups
@@ -1246,28 +1252,29 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
         const int nrows = min(16, ra1 - rb + 1);
         int q0v = 0, q1v = 0;                         // lane l < rows: the run of grid row rb + l
         if (lane < nrows) { q0v = tst[(rb + lane) * gd + cb0]; q1v = tst[(rb + lane) * gd + cb1 + 1]; }
-        const int r0 = g, r1 = g + 4, r2 = g + 8, r3 = g + 12;
-        const int a0 = __shfl(q0v, r0, 64), e0 = __shfl(q1v, r0, 64), a1 = __shfl(q0v, r1, 64), e1 = __shfl(q1v, r1, 64);
-        const int a2 = __shfl(q0v, r2, 64), e2 = __shfl(q1v, r2, 64), a3 = __shfl(q0v, r3, 64), e3 = __shfl(q1v, r3, 64);
+        const int r0 = g, r1 = g + ICP_G, r2 = g + 2 * ICP_G, r3 = g + 3 * ICP_G;   // this group's rows of the band (those < 16)
+        const int a0 = __shfl(q0v, r0 & 63, 64), e0 = __shfl(q1v, r0 & 63, 64), a1 = __shfl(q0v, r1 & 63, 64), e1 = __shfl(q1v, r1 & 63, 64);
+        const int a2 = __shfl(q0v, r2 & 63, 64), e2 = __shfl(q1v, r2 & 63, 64), a3 = __shfl(q0v, r3 & 63, 64), e3 = __shfl(q1v, r3 & 63, 64);
         rs0 = a0; rs1 = a1; rs2 = a2; rs3 = a3;
         c1 = r0 < nrows ? e0 - a0 : 0;
         c2 = c1 + (r1 < nrows ? e1 - a1 : 0);
         c3 = c2 + (r2 < nrows ? e2 - a2 : 0);
         L = c3 + (r3 < nrows ? e3 - a3 : 0);
         int pr = L;
-        pr = max(pr, __shfl_xor(pr, 16, 64)); pr = max(pr, __shfl_xor(pr, 32, 64));
+        for (int o = ICP_SPW; o < 64; o <<= 1) pr = max(pr, __shfl_xor(pr, o, 64));
         per = __builtin_amdgcn_readfirstlane(pr);                     // the longest of the four sequences
 #ifdef CREG_STAMPS
         if (lane == 0 && tailonly) { atomicAdd(&g_icp_stamps[0], (unsigned long long)per); atomicAdd(&g_icp_stamps[4], 1ull); }
 #endif
     };
     // staging registers of one batch: the loads of batch b + 1 are in flight while batch b is scanned from LDS
-    int jv[SB / 16];
-    double cx[SB / 16], cy[SB / 16], cz[SB / 16];
+    constexpr int EPL = SB / ICP_SPW;                                 // staged entries per lane and batch
+    int jv[EPL];
+    double cx[EPL], cy[EPL], cz[EPL];
     auto fetch = [&](int t0) {
 #pragma unroll
-        for (int u = 0; u < SB / 16; ++u) {
-            const int pq = t0 + 16 * u + l16;                         // entry of the group's sequence
+        for (int u = 0; u < EPL; ++u) {
+            const int pq = t0 + ICP_SPW * u + l16;                         // entry of the group's sequence
             const int t = pq < c1 ? rs0 + pq : (pq < c2 ? rs1 + (pq - c1) : (pq < c3 ? rs2 + (pq - c2) : rs3 + (pq - c3)));
             const bool in = pq < L;
             const int j = in ? tidx[t] : -1;
@@ -1279,7 +1286,7 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
         }
         if (tb < 0) {                                 // the pool was full: gather through the frame indices
 #pragma unroll
-            for (int u = 0; u < SB / 16; ++u) {
+            for (int u = 0; u < EPL; ++u) {
                 const size_t jj = (size_t)max(jv[u], 0);
                 cx[u] = P.frame[3 * jj]; cy[u] = P.frame[3 * jj + 1]; cz[u] = P.frame[3 * jj + 2];
             }
@@ -1287,8 +1294,8 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
     };
     auto publish = [&]() {                            // registers -> the lane group's LDS slice; entries past the sequence as far-away points
 #pragma unroll
-        for (int u = 0; u < SB / 16; ++u) {
-            const int e = 16 * u + l16;
+        for (int u = 0; u < EPL; ++u) {
+            const int e = ICP_SPW * u + l16;
             const bool in = jv[u] >= 0;
             px[e] = in ? cx[u] : 1e150; py[e] = in ? cy[u] : 1e150; pz[e] = in ? cz[u] : 1e150; pj[e] = in ? jv[u] : 0x7fffffff;
         }
@@ -1343,7 +1350,7 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
     if (lane == 0 && any && tailonly) { atomicAdd(&g_icp_stamps[7], clock64() - stt); if (tief) atomicAdd(&g_icp_stamps[2], 1ull); }
 #endif
     // the four lane groups of a source: (distance, frame index) lexicographic minimum, the winner's coordinates along
-    for (int o = 16; o <= 32; o <<= 1) {
+    for (int o = ICP_SPW; o < 64; o <<= 1) {
         const double od = __shfl_xor(best, o, 64); const int oj = __shfl_xor(bj, o, 64);
         const double ox = __shfl_xor(bx, o, 64), oy = __shfl_xor(by, o, 64), oz = __shfl_xor(bz, o, 64);
         if (od < best || (od == best && oj < bj)) { best = od; bj = oj; bx = ox; by = oy; bz = oz; }
@@ -1473,7 +1480,7 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
         set_error("creg_masked_icp: point-to-point mode (tgt_offsets) is not available in the large-cluster regime");
         return CREG_EINVAL;
     }
-    const int nn_smem = ICP_NNW * 4 * (ICP_SB + 2) * 28;  // k_icp_nn: per wave 4 lane groups x ICP_SB (+2: bank offset) staged targets (x, y, z, frame index)
+    const int nn_smem = ICP_NNW * ICP_G * (ICP_SB + 2) * 28;  // k_icp_nn: per wave 4 lane groups x ICP_SB (+2: bank offset) staged targets (x, y, z, frame index)
     CREG_HIP(hipFuncSetAttribute((const void*)k_icp_nn, hipFuncAttributeMaxDynamicSharedMemorySize, nn_smem));
     hipLaunchKernelGGL(k_icp_mask, dim3(k), dim3(1024), 0, s, P, (int)nf, (float)(0.5 * scale), q.world ? 0 : 1, 1);
     hipLaunchKernelGGL(k_icp_init, dim3(k), dim3(1024), 0, s, P, k);
