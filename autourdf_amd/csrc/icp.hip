@@ -316,7 +316,7 @@ struct IcpBatch {
 __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float half_scale, double th, int max_iter,
                                                        int keep_t, char* __restrict__ ws, size_t ws_stride, size_t o_srcw,
                                                        size_t o_tidx, size_t o_nn, int lds_cap) {
-    __shared__ double sc[(ICP_WAVES + 1) * 17];
+    __shared__ double sc[(ICP_WAVES + 1) * 20];
     __shared__ float s_lo[3], s_hi[3];
     __shared__ int s_wofs[ICP_WAVES];
     __shared__ double T[16], U[16], Vp[16];
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
     const int lg_g = lane & (G - 1), lg_s = lane >> lg;               // lane -> (share of the range, source within the wave)
     const int tsv = tstart[lane];
     auto correspond_fast = [&](double (&cm)[17], bool have_prev) {
-        for (int a = 0; a < 17; ++a) cm[a] = 0;
+        double cq[5] = {0, 0, 0, 0, 0};                // this lane's share of the moments (by lane & 3 within its source)
         __syncthreads();                              // the moves of S are visible
         ICP_STAMP(5);
         for (int rnd = 0; rnd < nround; ++rnd) {
@@ -637,24 +637,63 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
             { const unsigned long long now2 = clock64(); if (tid == 0) { g_icp_stamps[stamp_b * 16 + 9] += now2 - st2; g_icp_stamps[stamp_b * 16 + 10] += tie ? 1 : 0; } st2 = now2; }
 #endif
             // the G lanes of a source: (distance, frame index) lexicographic minimum
-            for (int o = 1; o < G; o <<= 1) {
-                const double od = __shfl_xor(best, o, 64); const int om = __shfl_xor(bm, o, 64), oj = __shfl_xor(bj, o, 64);
-                if (od < best || (od == best && oj < bj)) { best = od; bm = om; bj = oj; }
+            // (lanes of a source are adjacent: the first two steps are quad permutes on the DPP path, no LDS-crossbar trip)
+            {
+                auto take = [&](double od, int om, int oj) { if (od < best || (od == best && oj < bj)) { best = od; bm = om; bj = oj; } };
+#define CREG_QUAD_XCHG(ctrl)                                                                                                       \
+                take(__hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(best), ctrl, 0xF, 0xF, false),                  \
+                                      __builtin_amdgcn_update_dpp(0, __double2loint(best), ctrl, 0xF, 0xF, false)),                  \
+                     __builtin_amdgcn_update_dpp(0, bm, ctrl, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, bj, ctrl, 0xF, 0xF, false))
+                CREG_QUAD_XCHG(0xB1);                 // quad_perm [1,0,3,2]: lane ^ 1
+                CREG_QUAD_XCHG(0x4E);                 // quad_perm [2,3,0,1]: lane ^ 2   (G >= 4 always)
+#undef CREG_QUAD_XCHG
+                for (int o = 4; o < G; o <<= 1) take(__shfl_xor(best, o, 64), __shfl_xor(bm, o, 64), __shfl_xor(bj, o, 64));
             }
-            if (live && lg_g == 0) {
-                const bool ok = bm >= 0 && best <= th2;
-                nn[i] = ok ? bm : -1;
-                if (ok) {
-                    const double sv[3] = {s0 - shc[0], s1 - shc[1], s2 - shc[2]};
-                    const double dv[3] = {sT[3 * bm] - shc[0], sT[3 * bm + 1] - shc[1], sT[3 * bm + 2] - shc[2]};
-                    cm[0] += 1.0; cm[1] += best;
-                    for (int a = 0; a < 3; ++a) { cm[2 + a] += sv[a]; cm[5 + a] += dv[a]; }
-                    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) cm[8 + 3 * a + c] = fma(sv[a], dv[c], cm[8 + 3 * a + c]);
-                }
+            // every lane of the source knows the winner; lane 0 records it, lanes 0..3 share the 17 moments between them
+            // (5 + 5 + 5 + 2: a quarter of the wave reductions below for each)
+            const bool ok = live && bm >= 0 && best <= th2;
+            if (live && lg_g == 0) nn[i] = ok ? bm : -1;
+            if (ok && lg_g < 4) {
+                const double sv[3] = {s0 - shc[0], s1 - shc[1], s2 - shc[2]};
+                const double dv[3] = {sT[3 * bm] - shc[0], sT[3 * bm + 1] - shc[1], sT[3 * bm + 2] - shc[2]};
+                if (lg_g == 0) { cq[0] += 1.0; cq[1] += best; cq[2] += sv[0]; cq[3] += sv[1]; cq[4] += sv[2]; }
+                else if (lg_g == 1) { cq[0] += dv[0]; cq[1] += dv[1]; cq[2] += dv[2]; cq[3] = fma(sv[0], dv[0], cq[3]); cq[4] = fma(sv[0], dv[1], cq[4]); }
+                else if (lg_g == 2) { cq[0] = fma(sv[0], dv[2], cq[0]); cq[1] = fma(sv[1], dv[0], cq[1]); cq[2] = fma(sv[1], dv[1], cq[2]);
+                                      cq[3] = fma(sv[1], dv[2], cq[3]); cq[4] = fma(sv[2], dv[0], cq[4]); }
+                else { cq[0] = fma(sv[2], dv[1], cq[0]); cq[1] = fma(sv[2], dv[2], cq[1]); }
             }
         }
         ICP_STAMP(1);
-        bsum_n<17>(cm, sc, wvs < units);
+        // sums over the lanes of equal (lane & 3): two row rotations on the DPP path, two cross-row exchanges; fixed association
+        const bool mine = wvs < units;
+        if (mine) {
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {
+                double v = cq[a];
+#define CREG_ROR_ADD(ctrl) v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xF, 0xF, false), \
+                                                 __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xF, 0xF, false))
+                CREG_ROR_ADD(0x124);                  // row_ror:4
+                CREG_ROR_ADD(0x128);                  // row_ror:8 -> every lane holds its residue's sum over its row of 16
+#undef CREG_ROR_ADD
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                cq[a] = v;
+            }
+        }
+        __syncthreads();                              // previous readers of sc are done
+        if (lane < 4) {
+#pragma unroll
+            for (int a = 0; a < 5; ++a) sc[wvs * 20 + lane * 5 + a] = mine ? cq[a] : 0.0;
+        }
+        __syncthreads();
+        if (tid < 20) { double r = 0.0; for (int w = 0; w < ICP_WAVES; ++w) r += sc[w * 20 + tid]; sc[ICP_WAVES * 20 + tid] = r; }
+        __syncthreads();
+        // slot (residue, a) -> moment: residue 0: count, sum d2, s0..2; 1: d0..2, C00, C01; 2: C02, C10, C11, C12, C20; 3: C21, C22
+        const double* so = sc + ICP_WAVES * 20;
+        cm[0] = so[0]; cm[1] = so[1]; cm[2] = so[2]; cm[3] = so[3]; cm[4] = so[4];
+        cm[5] = so[5]; cm[6] = so[6]; cm[7] = so[7]; cm[8] = so[8]; cm[9] = so[9];
+        cm[10] = so[10]; cm[11] = so[11]; cm[12] = so[12]; cm[13] = so[13]; cm[14] = so[14];
+        cm[15] = so[15]; cm[16] = so[16];
         ICP_STAMP(2);
     };
 
