@@ -206,6 +206,7 @@ constexpr int ICP_ROWS = 256;                         // fallback path: threads 
 constexpr int ICP_PARTS = ICP_NT / ICP_ROWS;          // fallback path: the target list is split this many ways per source point
 constexpr int ICP_BATCH_MAX = 16;
 constexpr int ICP_SRC_LDS = 1024;                     // source points of a cluster kept in LDS (28 B each)
+constexpr int ICP_PAD = 72;                           // far-away entries behind the LDS target list (the split scan overshoots by < 64 + 4)
 constexpr int ICP_NSLAB = 64;                         // slabs along the cluster's longest axis (targets and sources are binned by them)
 
 // Sum N values held by the threads over the block, result in every thread.  `mine` (wave-uniform): this wave holds
@@ -413,9 +414,9 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
     const double blo0 = (double)s_lo[0], blo1 = (double)s_lo[1], blo2 = (double)s_lo[2];
     const double bhi0 = (double)s_hi[0], bhi1 = (double)s_hi[1], bhi2 = (double)s_hi[2];
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* sT = (double*)smem;                       // [lds_cap + 64][3] masked target coordinates
-    int* sI = (int*)(sT + 3 * (size_t)(lds_cap + 64));   // [lds_cap + 64] their frame indices (64 entries of padding: see the fast path)
-    double* sS = (double*)(sI + lds_cap + 64);        // [ICP_SRC_LDS][3] moving source points
+    double* sT = (double*)smem;                       // [lds_cap + ICP_PAD][3] masked target coordinates
+    int* sI = (int*)(sT + 3 * (size_t)(lds_cap + ICP_PAD));   // [lds_cap + ICP_PAD] their frame indices (padding: see the fast path)
+    double* sS = (double*)(sI + lds_cap + ICP_PAD);   // [ICP_SRC_LDS][3] moving source points
     int* sN = (int*)(sS + 3 * ICP_SRC_LDS);           // [ICP_SRC_LDS] matched target position / frame index, -1 = none
     // ---- 2. the candidate targets: frame points strictly inside the box (masked mode) or the cluster's own segment ----
     const int cb = toff ? toff[k] : 0, cend = toff ? toff[k + 1] : (ns > 0 ? nf : 0);
@@ -452,9 +453,9 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
                 sT[3 * p] = x; sT[3 * p + 1] = y; sT[3 * p + 2] = zc; sI[p] = j;
             }
         }
-        // padding: the last lanes of a split range read up to 63 entries past it; far-away points that never win
+        // padding: the last lanes of a split range read up to 66 entries past it; far-away points that never win
         // (each farther than the one before: equal distances would look like ties to the scan)
-        if (tid < 64) { sT[3 * (nt + tid)] = 1e150 * (double)(1 + tid); sT[3 * (nt + tid) + 1] = 1e150; sT[3 * (nt + tid) + 2] = 1e150; sI[nt + tid] = 0x7fffffff; }
+        if (tid < ICP_PAD) { sT[3 * (nt + tid)] = 1e150 * (double)(1 + tid); sT[3 * (nt + tid) + 1] = 1e150; sT[3 * (nt + tid) + 2] = 1e150; sI[nt + tid] = 0x7fffffff; }
     } else {
         // fallback: ordered compaction (ascending frame index) into the workspace list, and into LDS while it fits
         int run = 0;
@@ -599,8 +600,9 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
             // of the 8 of the distance: two compares, one v_min_f64, two selects.
             double best = INFINITY; int bm = -1, bl = -1;
             const double* tp = sT + 3 * base;
-            int st = 0;
-            for (; st + 4 <= per; st += 4) {          // unconditional body: the 12 LDS reads of a trip go out together
+            // whole trips of four: the last one may run up to three entries past the lane's share -- the next lane's targets
+            // (scanned twice: harmless) or the padding behind the list
+            for (int st = 0; st < per; st += 4) {     // unconditional body: the 12 LDS reads of a trip go out together
                 double d2[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -614,18 +616,11 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
                     best = vmin_f64(best, d2[u]);
                 }
             }
-            for (; st < per; ++st) {
-                const double dx = s0 - tp[3 * st], dy = s1 - tp[3 * st + 1], dz = s2 - tp[3 * st + 2];
-                const double d2 = (dx * dx + dy * dy) + dz * dz;
-                bm = d2 < best ? st : bm;
-                bl = d2 <= best ? st : bl;
-                best = vmin_f64(best, d2);
-            }
             const unsigned long long tie = __ballot(bm != bl);
             int bj = 0x7fffffff;
             if (tie) {                                // equidistant candidates somewhere in the wave: the lowest frame index wins
                 best = INFINITY; bm = -1;
-                for (st = 0; st < per; ++st) {
+                for (int st = 0; st < ((per + 3) & ~3); ++st) {
                     const double dx = s0 - tp[3 * st], dy = s1 - tp[3 * st + 1], dz = s2 - tp[3 * st + 2];
                     const double d2 = (dx * dx + dy * dy) + dz * dz;
                     const int j = sI[base + st];
@@ -1580,10 +1575,10 @@ static int icp_launch(const creg_icp_problem* pr, int batch, int64_t n, int32_t 
         B.Mout[i] = q.M_out; B.world_out[i] = q.world_out; B.n_iter_out[i] = q.n_iter_out;
     }
     const int lds_cap = (int)(nf < 4096 ? (nf + 1) & ~1ll : 4096);  // masked targets kept in LDS (28 B each, <= 112 KB); even: the doubles behind the int table stay aligned
-    const int smem = (lds_cap + 64) * 28 + ICP_SRC_LDS * 28;      // 64 targets of padding behind the list
+    const int smem = (lds_cap + ICP_PAD) * 28 + ICP_SRC_LDS * 28;   // padding behind the target list
     // per device, not per process: set on every call (a cached flag would leave a second GPU at the 64 KB default)
     CREG_HIP(hipFuncSetAttribute((const void*)k_masked_icp, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (4096 + 64) * 28 + ICP_SRC_LDS * 28));
+                                 (4096 + ICP_PAD) * 28 + ICP_SRC_LDS * 28));
     hipLaunchKernelGGL(k_masked_icp, dim3(k, batch), dim3(ICP_NT), smem, s, B, (int)nf, (float)(0.5 * scale), th,
                        max_iteration, keep_translation, (char*)workspace, one, L.srcw, L.tidx, L.nn, lds_cap);
     CREG_LAUNCH_CHECK();
