@@ -944,3 +944,29 @@ def test_kmeans_many_empty_clusters_deferred_relocation_large_frame(dev, mfma):
     assert n_iter.item() == oit and len(np.unique(olab)) == k
     np.testing.assert_allclose(c.cpu().numpy(), oc, atol=1e-11)
     np.testing.assert_allclose(inertia.item(), oin, rtol=1e-11)
+
+
+def test_masked_icp_large_regime_with_an_empty_cluster(dev):
+    """A cluster without points in the many-workgroup regime has no source chunk (hence no fit): it keeps its pose, reports
+    one iteration, does not hold the loop open, and leaves the other clusters' results untouched."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    seq = make_sequence("wx200_5", 21, 2, 4600)
+    mats, clusters, _ = initial_segmentation(seq[0], 4, seed=1)
+    frame = _cuda(seq[1], dev)
+
+    def run(cl, mt):
+        local, off = ops.pack_clusters(cl, dev, torch.float64)
+        M = _cuda(np.asarray(mt, np.float64), dev)
+        return ops.masked_icp_batch([(local, None, off, frame, M)])[0]
+
+    cl3 = [np.concatenate([clusters[0], clusters[1]]), np.zeros((0, 3)), np.concatenate([clusters[2], clusters[3]])]
+    assert sum(len(c) for c in cl3) // 3 > 1024                        # the average stays above the regime switch
+    mt3 = np.stack([mats[0], np.eye(4), mats[2]])
+    M3, w3, it3 = run(cl3, mt3)
+    M3b, w3b, it3b = run([cl3[0], cl3[2]], np.stack([mats[0], mats[2]]))
+    np.testing.assert_allclose(M3.cpu().numpy()[[0, 2]], M3b.cpu().numpy(), atol=1e-12)
+    np.testing.assert_array_equal(M3.cpu().numpy()[1], np.eye(4))
+    np.testing.assert_array_equal(it3.cpu().numpy()[[0, 2]], it3b.cpu().numpy())
+    assert it3.cpu().numpy()[1] == 1
+    np.testing.assert_allclose(w3.cpu().numpy(), w3b.cpu().numpy(), atol=1e-12)
