@@ -970,3 +970,44 @@ def test_masked_icp_large_regime_with_an_empty_cluster(dev):
     np.testing.assert_array_equal(it3.cpu().numpy()[[0, 2]], it3b.cpu().numpy())
     assert it3.cpu().numpy()[1] == 1
     np.testing.assert_allclose(w3.cpu().numpy(), w3b.cpu().numpy(), atol=1e-12)
+
+
+def test_masked_icp_tiny_clusters_many_lanes_per_source(dev):
+    """Clusters of 3 to 40 points: the one-workgroup kernel gives each source 64 / 32 / 16 / 8 lanes (all waves busy, the scanned
+    range split that many ways, overshoot into the padding behind the target list).  Against the oracle."""
+    rng = np.random.default_rng(17)
+    sizes = [3, 7, 12, 20, 40, 90]
+    clusters, mats, targets = [], [], []
+    for c, ns in enumerate(sizes):
+        ctr = np.array([0.3 * c, 0.1 * (c % 3), 0.05 * c])
+        src = rng.normal(size=(ns, 3)) * [0.03, 0.02, 0.01]
+        m = np.eye(4)
+        m[:3, :3] = _rot_z(0.02 * (c + 1))
+        m[:3, 3] = ctr
+        clusters.append(src)
+        mats.append(m)
+        world = src @ _rot_z(0.02 * (c + 1) + 0.04).T + ctr + [0.002, -0.001, 0.001]
+        targets.append(np.concatenate([world + rng.normal(scale=2e-4, size=world.shape), world[: ns // 2] + rng.normal(scale=5e-4, size=(ns // 2, 3))]))
+    frame = np.concatenate(targets)[rng.permutation(sum(len(t) for t in targets))]
+    n_it = _icp_vs_oracle(dev, clusters, np.stack(mats), frame, scale=1.6)
+    assert (n_it >= 1).all()
+
+
+def test_group_to_local_large_frame_stable_partition(dev):
+    """The workgroup-per-cluster grouping of large frames (n > 16384): offsets, stable order inside a cluster and the change of
+    frame against numpy."""
+    from autourdf_amd import ops
+    rng = np.random.default_rng(23)
+    n, k = 50000, 37
+    X = rng.normal(size=(n, 3))
+    lab = rng.integers(0, k, size=n).astype(np.int32)
+    lab[lab == 5] = 6                                                 # an empty cluster in the middle
+    M = np.stack([np.eye(4) for _ in range(k)])
+    for j in range(k):
+        M[j, :3, :3] = _rot_z(0.1 * j)
+        M[j, :3, 3] = rng.normal(size=3)
+    local, off = ops.group_to_local(_cuda(X, dev), torch.as_tensor(lab, device=dev), _cuda(M, dev))
+    counts = np.bincount(lab, minlength=k)
+    np.testing.assert_array_equal(off.cpu().numpy(), np.concatenate([[0], np.cumsum(counts)]))
+    ref = np.concatenate([(X[lab == j] - M[j, :3, 3]) @ M[j, :3, :3] for j in range(k)])      # inv(M) p for a rigid M
+    np.testing.assert_allclose(local.cpu().numpy(), ref, atol=1e-12)
