@@ -77,6 +77,7 @@ SIGNATURES = {
     "creg_train_plan_run_batch": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), i32, vp]),
     "creg_train_plan_probe": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), vp, vp, vp, vp, vp]),
     "creg_train_plan_profile": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), i32, ctypes.POINTER(f32), vp]),
+    "creg_train_plan_info": (ctypes.c_int, [vp, vp]),
     "creg_train_plan_destroy": (ctypes.c_int, [vp]),
 }
 

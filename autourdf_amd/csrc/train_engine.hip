@@ -1432,6 +1432,18 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
     return CREG_OK;
 }
 
+extern "C" int creg_train_plan_info(const creg_train_plan* plan, creg_train_plan_info_t* info) {
+    CREG_REQUIRE(plan && info, "creg_train_plan_info: null pointer");
+    const Plan* P = (const Plan*)plan;
+    info->pruned_target_search = P->D.nyb > 0;
+    info->pruned_predicted_search = P->D.npb > 0;
+    info->graph_branches = P->branches;
+    info->batch = P->B;
+    info->epochs_per_graph = P->shape.use_graph ? P->graph_epochs : 0;
+    info->reserved[0] = info->reserved[1] = info->reserved[2] = 0;
+    return CREG_OK;
+}
+
 extern "C" int creg_train_plan_destroy(creg_train_plan* plan) {
     Plan* P = (Plan*)plan;
     if (!P) return CREG_OK;

@@ -479,6 +479,18 @@ class TrainPlan:
         _lib.check(self.L.creg_train_plan_create(ctypes.byref(self.shape), ctypes.c_void_p(base), need,
                                                  ctypes.byref(self.plan)), "creg_train_plan_create")
         self.k, self.n_pred, self.n_tgt, self.epochs, self.hidden = k, n_pred, n_tgt, epochs, hidden
+        info = (ctypes.c_int32 * 8)()
+        _lib.check(self.L.creg_train_plan_info(self.plan, info), "creg_train_plan_info")
+        #: what the plan chose from its shape (never a result): searches, graph branches, problems per launch, epochs per graph
+        self.info = {"pruned_target_search": bool(info[0]), "pruned_predicted_search": bool(info[1]), "graph_branches": int(info[2]),
+                     "batch": int(info[3]), "epochs_per_graph": int(info[4])}
+        if nn_search == 0 and not (self.info["pruned_target_search"] and self.info["pruned_predicted_search"]):
+            import warnings
+            which = [d for d, on in (("predicted -> target", self.info["pruned_target_search"]),
+                                     ("target -> predicted", self.info["pruned_predicted_search"])) if not on]
+            warnings.warn(f"creg train plan (k={k}, n_pred={n_pred}, n_tgt={n_tgt}): exhaustive nearest-neighbour search in the "
+                          f"{' and '.join(which)} direction(s) -- the shape is beyond the block-pruned search's limits "
+                          "(n_tgt <= 16384, predicted blocks + k <= 128); same results, several times the launch time", RuntimeWarning, stacklevel=2)
 
     def __del__(self):
         plan = getattr(self, "plan", None)

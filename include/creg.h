@@ -307,6 +307,18 @@ typedef struct creg_train_args {
 
 typedef struct creg_train_plan creg_train_plan;
 
+/* What a plan decided from its shape (nothing here changes a result): which nearest-neighbour search each direction runs,
+ * how many graph branches and problems per launch it uses.  A caller that sized its clouds beyond the pruned search's
+ * limits sees it here instead of only in the timing. */
+typedef struct creg_train_plan_info_t {
+    int32_t pruned_target_search;     /* 1: predicted -> target search over k-d leaf blocks; 0: exhaustive (n_tgt > 16384 or nn_search = 1) */
+    int32_t pruned_predicted_search;  /* 1: target -> predicted search over blocks; 0: exhaustive (more than 128 predicted blocks, ...) */
+    int32_t graph_branches;           /* parallel chains in the captured graph */
+    int32_t batch;                    /* problems the plan advances per run_batch call */
+    int32_t epochs_per_graph;         /* 0: eager launches */
+    int32_t reserved[3];
+} creg_train_plan_info_t;
+
 size_t creg_train_workspace_bytes(const creg_train_shape* shape);   /* covers shape.batch problems */
 /* `workspace` (device, 256-byte aligned) must stay valid until creg_train_plan_destroy. */
 int creg_train_plan_create(const creg_train_shape* shape, void* workspace, size_t workspace_bytes,
@@ -318,6 +330,7 @@ int creg_train_plan_run(creg_train_plan* plan, const creg_train_args* args, creg
  * overlap those of the others (sequences of a run are independent; frames of ONE sequence are not).
  * args[b] describes problem b; results are bit-identical to n separate creg_train_plan_run calls. */
 int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train_args* args, int32_t n, creg_stream_t stream);
+int creg_train_plan_info(const creg_train_plan* plan, creg_train_plan_info_t* info);
 int creg_train_plan_destroy(creg_train_plan* plan);
 
 /* Test / profiling hook: run exactly one epoch's forward and return intermediates.

@@ -1011,3 +1011,18 @@ def test_group_to_local_large_frame_stable_partition(dev):
     np.testing.assert_array_equal(off.cpu().numpy(), np.concatenate([[0], np.cumsum(counts)]))
     ref = np.concatenate([(X[lab == j] - M[j, :3, 3]) @ M[j, :3, :3] for j in range(k)])      # inv(M) p for a rigid M
     np.testing.assert_allclose(local.cpu().numpy(), ref, atol=1e-12)
+
+
+def test_train_plan_reports_its_search_form(dev):
+    """creg_train_plan_info: a shape inside the block-pruned search's limits runs it in both directions; one beyond them
+    (70 clusters of one 64-point block each + 70 > 128 predicted blocks) says so -- and ops.TrainPlan warns -- instead of
+    only being slower."""
+    import warnings
+    from autourdf_amd import ops
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        p = ops.TrainPlan("q", 20, 64, 4096, 4096, epochs=4, device=dev)
+    assert p.info["pruned_target_search"] and p.info["pruned_predicted_search"] and p.info["batch"] == 1
+    with pytest.warns(RuntimeWarning, match="exhaustive nearest-neighbour search"):
+        q = ops.TrainPlan("q", 70, 64, 70 * 60, 4096, epochs=4, device=dev)
+    assert q.info["pruned_target_search"] and not q.info["pruned_predicted_search"]
