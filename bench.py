@@ -568,7 +568,7 @@ def main(argv=None):
                "pose_checksum": round(float(gathered.double().abs().sum()), 6)}
         if not STUB and not args.no_roofline:
             out["roofline"] = roofline_block(reg, frames32, n_points, args.workload)
-        if not STUB and not args.no_icp_variant and not replay:
+        if not STUB and world == 1 and not args.no_icp_variant and not replay:      # a one-GPU secondary line: not while other ranks wait
             out["icp_variant"] = icp_variant(frames64, mats0, clusters0, dev, warm_rounds, timed_rounds)
         if not STUB and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters)
