@@ -1419,8 +1419,12 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
         for (int w = 0; w < ICP_NNW; ++w) r += sc[w * ICP_NM + tid];
         st_agent_f64(P.part + (size_t)blk * ICP_NM + tid, r);
     }
-    // the cluster's last chunk to get here runs the fit (the barrier has waited for this chunk's stores)
+    // the cluster's last chunk to get here runs the fit.  A bare s_barrier does not wait for the st_agent_f64 stores
+    // above: the storing wave drains its vmcnt explicitly before the barrier, so the partial moments are acknowledged by
+    // the memory side before thread 0 bumps the arrival counter (P.part is reused by every iteration launch: without the
+    // drain the last chunk could read the previous iteration's moments).
     __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         const int nch = P.chunk0[c + 1] - P.chunk0[c];

@@ -12,8 +12,8 @@
 //                    cluster's sum to the new one's (no drift: integers).  After the first few Lloyd iterations a handful of
 //                    points change, so the M-step costs next to nothing; per-workgroup tables in LDS, non-zero entries
 //                    flushed to the global accumulators with integer atomics.
-//                    The LAST workgroup to arrive (release fence -> counter -> acquire) runs the M-step tail in the same
-//                    launch: sums -> centres (x 1/w), relocation of empty clusters, centre shift, convergence (strict
+//                    The LAST workgroup to arrive (agent-scope atomics on both sides of the hand-off, every wave drains
+//                    vmcnt(0) before the arrival counter: km_arrive_last) runs the M-step tail in the same launch: sums -> centres (x 1/w), relocation of empty clusters, centre shift, convergence (strict
 //                    label equality first, then tol), next b / |c|^2 rows.
 // The host enqueues iterations in batches of 32 and reads the `done` word between batches; launches of
 // iterations after convergence return immediately.
@@ -151,10 +151,15 @@ __device__ __forceinline__ void km_block_argmax(double& bv, int& bi, KmTailSh& S
     bv = S.bv; bi = S.bi;
 }
 
-// Every workgroup of a launch calls this once after its global atomics / agent-scope stores (they have completed: the barrier
-// waits for vmcnt(0)); true in the last workgroup to arrive.  Two levels -- 8 shard counters, then one -- so that a few
-// hundred workgroups finishing together do not queue on one word (MI355X_MICROARCH.md: ~12 ns per arrival on one counter).
+// Every workgroup of a launch calls this once after its global atomics / agent-scope stores; true in the last workgroup to
+// arrive.  ORDERING: a bare s_barrier does not wait for a wave's outstanding memory operations on gfx950 (hipcc emits no
+// s_waitcnt vmcnt(0) in front of it when the wave only has stores / non-returning atomics in flight), so EVERY wave drains
+// its own vmcnt explicitly before the barrier -- only then are all of the workgroup's sums and flags acknowledged by the
+// memory side when thread 0 bumps the counter (cdna_hip_programming.md, Guideline 16 R1: "EVERY storing wave" drains).
+// Two levels -- 8 shard counters, then one -- so that a few hundred workgroups finishing together do not queue on one
+// word (MI355X_MICROARCH.md: ~12 ns per arrival on one counter).
 __device__ __forceinline__ bool km_arrive_last(KmFlags* __restrict__ f, KmTailSh& S) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const int sh = blockIdx.x & 7, in_shard = ((int)gridDim.x - sh + 7) >> 3, shards = min(8, (int)gridDim.x);

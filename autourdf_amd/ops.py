@@ -577,13 +577,18 @@ class TrainPlan:
     KERNELS = ("l2", "head", "nn_l1", "gradc", "bwd2", "dw")
 
     def profile(self, m, y, pts, offsets, params, n_epochs=50):
-        """Average event-bracketed microseconds of each of the 6 epoch kernels (synchronises)."""
-        out = (ctypes.c_float * 10)()
+        """Average event-bracketed microseconds of each of the 5 epoch kernels, and the back-to-back launch time of each
+        (synchronises; the plan's copy of the parameters moves on, the caller's tensors are not written)."""
+        out = (ctypes.c_float * 16)()
         a = self._args(m, y, pts, offsets, params, 2e-4, 0.7, 5, 200, (None, None, None, None, None))
         _lib.check(self.L.creg_train_plan_profile(self.plan, ctypes.byref(a), n_epochs, out, _stream()),
                    "creg_train_plan_profile")
         d = dict(zip(self.KERNELS, [float(v) for v in out]))
+        d.pop("l2")                                     # no launch of its own since round 3 (k_dw computes the next hidden activation)
         d["nn_l1_back_to_back"] = float(out[6])
         d["nn_l1_problems_per_launch"] = int(out[7])
         d["dw_back_to_back"] = float(out[8])
+        d["bwd2_back_to_back"] = float(out[9])
+        d["head_back_to_back"] = float(out[10])
+        d["gradc_back_to_back"] = float(out[11])
         return d

@@ -234,9 +234,10 @@ def roofline_block(reg, frames32, n_points, workload):
     summary and say so in `source`."""
     r = reg.seqs[0]
     prof = reg.plan.profile(r.m, frames32[0][0], r.pts_init, r.off_init, r.p_anchor, n_epochs=100)
-    nn_us = prof.pop("nn_l1_back_to_back")
+    b2b = {k[:-13]: prof.pop(k) for k in [k for k in prof if k.endswith("_back_to_back")]}
+    nn_us = b2b["nn_l1"]
     nz = prof.pop("nn_l1_problems_per_launch")
-    dw_us = prof.pop("dw_back_to_back")
+    dw_us = b2b["dw"]
     here = os.path.dirname(os.path.abspath(__file__))
     pmc, pmc_src = {}, None
     for name in ("r02_pmc.json", "r01_nn_l1_pmc.json"):
