@@ -55,6 +55,8 @@ struct TrainState {
     int epochs_run, best_epoch;
     float step_size, bc2_sqrt;   // Adam scalars for the update of the epoch that produced this state
     float last_loss;
+    float next_bc2s;             // bias corrections of step `step + 1` (k_prep's tables), fetched by the epoch that produced
+    double next_bc1;             //   this state: the next epoch reads them WITH the state instead of in a round trip after it
 };
 
 struct Ws {         // device pointers into the caller's workspace
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(256) void k_prep(Dims D, Ws W0, size_t bstride, Pre
             s.lr = (double)hy.lr; s.sched_best = INFINITY; s.sched_bad = 0; s.count = 0; s.stopped = 0;
             s.step = 0; s.min_loss = 1000.f; s.epochs_run = 0; s.best_epoch = -1; s.step_size = 0.f;
             s.bc2_sqrt = 1.f; s.last_loss = NAN;
+            s.next_bc1 = 1.0 - 0.9; s.next_bc2s = (float)sqrt(1.0 - 0.999);         // step 1 (the tables are filled by this launch)
             W.state[0] = s; W.state[1] = s;
         }
     }
@@ -607,24 +610,15 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
     __shared__ float red[4][14];
     __shared__ float s_loss;
     __shared__ float s_go[16];
-    const TrainState S = W.state[epoch & 1];
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (S.stopped) {
-        if (k == 0 && tid == 0) W.state[(epoch + 1) & 1] = S;
-        return;
-    }
-    // independent loads first (cluster bounds, this thread's first point, hyper-parameters, and the operands of the
-    // last phase: this thread's hidden units of pose row k and their output-layer weights) so they overlap the loss
-    // reduction instead of forming a chain of dependent round trips
+    // ONE round trip for everything that does not depend on another load: the state (with the bias corrections of the
+    // coming step), the cluster bounds, the hyper-parameters, the NN launch's loss partials, the pose row, and the
+    // operands of the last phase (this thread's hidden units of pose row k and their output-layer weights) -- round 2
+    // waited for the state first (the early exit of a stopped train) and then for the table entries it indexes
+    const TrainState S = W.state[epoch & 1];
     const int b0 = W.off[k], e0 = W.off[k + 1];
     const Hyper hy = *W.hyper;
-    const double bc1_next = W.bc1[min(S.step + 1, D.epochs)];
-    const float bc2s_next = W.bc2s[min(S.step + 1, D.epochs)];
-    const int n_first = min(b0 + tid, D.NP - 1);
-    const float4 p_first = W.pts4[n_first];
-    const int4 c_first = W.cnt4[n_first];
-    const int s_first = W.sgn_x[n_first];
-    const float4 pr_first = W.pred4[n_first];
+    float a = tid < nbx ? W.lossp_x[tid] : 0.f, b = tid < nby ? W.lossp_y[tid] : 0.f;
     const float m2v = W.m2[16 * k + (tid & 15)];
     float sv[16];
 #pragma unroll
@@ -641,10 +635,19 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
         for (int j = 0; j < 8; ++j) w3v[q][j] = wb[(size_t)min(j, nj - 1) * stride];
         h2v[q] = h2cur[(size_t)k * D.H2 + o];
     }
+    if (S.stopped) {
+        if (k == 0 && tid == 0) W.state[(epoch + 1) & 1] = S;
+        return;
+    }
+    // second round trip: this thread's first point of the cluster (the loss reduction runs in its shadow)
+    const int n_first = min(b0 + tid, D.NP - 1);
+    const float4 p_first = W.pts4[n_first];
+    const int4 c_first = W.cnt4[n_first];
+    const int s_first = W.sgn_x[n_first];
+    const float4 pr_first = W.pred4[n_first];
     // ---- loss = sum_x / NP + sum_y / NT from the NN launch's per-block partials (fixed order)
-    float a = 0.f, b = 0.f;
-    for (int i = tid; i < nbx; i += 256) a += W.lossp_x[i];
-    for (int i = tid; i < nby; i += 256) b += W.lossp_y[i];
+    for (int i = tid + 256; i < nbx; i += 256) a += W.lossp_x[i];
+    for (int i = tid + 256; i < nby; i += 256) b += W.lossp_y[i];
     a = wave_sum_fast(a); b = wave_sum_fast(b);
     if (lane == 0) { red[wv][0] = a; red[wv][1] = b; }
     __syncthreads();
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
     }
     __syncthreads();
     const float loss = s_loss;
-    const TrainState N = advance_state(S, loss, hy, bc1_next, bc2s_next);
+    TrainState N = advance_state(S, loss, hy, S.next_bc1, S.next_bc2s);
     const bool improved = loss < S.min_loss;
     if (improved) {                                     // best_pcd / best_m  (mlp_reg.py:102-106)
         for (int n = b0 + tid; n < e0; n += 256) {
@@ -665,6 +668,8 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
         if (tid < 16) W.best_m[16 * k + tid] = m2v;
     }
     if (k == 0 && tid == 0) {
+        N.next_bc1 = W.bc1[min(N.step + 1, D.epochs)];          // for the next epoch (another launch): off this one's critical path
+        N.next_bc2s = W.bc2s[min(N.step + 1, D.epochs)];
         W.state[(epoch + 1) & 1] = N;
         W.loss_hist[S.epochs_run] = loss;
         W.lr_hist[S.epochs_run] = (float)S.lr;
@@ -754,18 +759,22 @@ __device__ __forceinline__ float adam_value(float p, float& mm, float& vv, float
 // four workgroups on different XCDs: the 1.6x read amplification of that kernel).  The same workgroup then owns the 16
 // encoder rows W1[c0 .. c0+16): weight gradients, Adam, and the NEXT epoch's encoder activation of its 16 units from the
 // registers that hold the updated rows (the MLP input is the same every epoch: m.clone() of the same m, mlp_reg.py:62).
-// Threads: 8 column pairs x 32 row slices of W2; a thread keeps its OPS = H2 / 32 rows of its two columns in registers
-// (all loads in flight at once, 64-byte row segments), g_h2 comes from LDS (LDS-DMA, RB pose rows per pass, broadcast
-// reads), the 32 slice partials of a (pose row, column) are summed in slice order through LDS: fixed association.
-constexpr int B2_THREADS = 256;
+// Threads: 8 column pairs x (8 AW) row slices of W2; a thread keeps its OPS rows of its two columns in registers (all
+// loads in flight at once, 64-byte row segments), g_h2 comes from LDS (LDS-DMA, RB pose rows per pass, broadcast reads);
+// the slice partials of a (pose row, column) are summed in a fixed tree: the 8 slices of a wave (row_ror DPP, two lane
+// permutes), then the waves in order through LDS.  The rows of a pass are straight-line code (rows past the end repeat the
+// last one and are not stored): per-row branches kept hipcc from overlapping the rows' LDS reads and lane permutes.
+constexpr int B2_THREADS = 512;
+constexpr int B2_WAVES = B2_THREADS / 64;
 constexpr int B2_CB = 16;
-constexpr int B2_NSL = 32;
 constexpr int B2_RB = 20;             // pose rows per pass (K = 20: one pass)
+constexpr int B2_MAXP = (160 + B2_RB - 1) / B2_RB;
 __host__ __device__ inline int b2_rows(int K) { return K < B2_RB ? K : B2_RB; }
-__host__ __device__ inline int b2_sls(int rb) { return rb * B2_CB + 16; }   // slice stride of the partial sums (+16 floats: the two slices of a ds_write_b64 lane group use different banks)
+__host__ __device__ inline int b2_area(int K, int H2) { const int a = b2_rows(K) * H2, b = K * 2 * B2_CB; return a > b ? a : b; }
 __host__ __device__ inline int b2_smem_floats(int K, int H2, int IN) {
-    const int rb = b2_rows(K);
-    return rb * H2 + B2_NSL * b2_sls(rb) + K * B2_CB + K * IN;
+    // [RB][H2] g_h2 rows of a pass (after the last pass the same region holds g_x1 [K][16] and the next-activation tile
+    // [K][16]), the per-wave partial sums [8][RB][16], the features [K][IN]
+    return b2_area(K, H2) + B2_WAVES * b2_rows(K) * B2_CB + K * IN;
 }
 // sum over the 16 lanes of a DPP row; every lane of the row receives it
 __device__ __forceinline__ float row_sum16(float v) {
@@ -775,25 +784,35 @@ __device__ __forceinline__ float row_sum16(float v) {
     CREG_DPP_STEP(v, 0x140, 0xF);   // row_mirror
     return v;
 }
+// sum over the 8 lanes of a wave that share (lane & 7): lanes l, l^8 (row_ror:8), then l^16, l^32; every lane receives it
+__device__ __forceinline__ float slice_sum8(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
 __device__ __forceinline__ nn_f2 fma2(float g, nn_f2 w, nn_f2 a) {        // one v_pk_fma_f32: both columns of the pair
     const nn_f2 gg = {g, g};
     return __builtin_elementwise_fma(gg, w, a);
 }
 
-template <int OPS>
+template <int AW, int OPS>            // AW waves of the workgroup take part in the W2 product: H2 = 8 AW OPS
 __global__ __launch_bounds__(B2_THREADS) void k_bwd2(Dims D, Ws W0, int epoch, size_t bstride) {
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int RB = b2_rows(D.K), SLS = b2_sls(RB);
-    float* gh = (float*)smem;                  // [RB][H2]   g_h2 rows of the pass
-    float* red = gh + RB * D.H2;               // [NSL][SLS] slice partials of the pass
-    float* gxs = red + B2_NSL * SLS;           // [K][16]    g_x1 of this block's columns
-    float* encs = gxs + D.K * B2_CB;           // [K][IN]    MLP input features
+    float* sh = (float*)smem;
+    const int RB = b2_rows(D.K);
+    float* gh = sh;                            // [RB][H2]   g_h2 rows of the pass
+    float* red = sh + b2_area(D.K, D.H2);      // [8][RB][16] per-wave partial sums of the pass
+    float* encs = red + B2_WAVES * RB * B2_CB; // [K][IN] MLP input features
+    float* gxs = sh;                           // after the passes: [K][16] g_x1 of this block's columns,
+    float* xt = gxs + D.K * B2_CB;             //   [K][16] next encoder activation of this block's units
     // (no early exit on `stopped`: every store below is gated; an exit branch here would let hipcc sink the
     //  loads below it and serialise them)
     const TrainState S = W.state[(epoch + 1) & 1];
     const bool live = !S.stopped;
-    const int tid = threadIdx.x, cp = tid & 7, sl = tid >> 3;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, cp = tid & 7, sl = tid >> 3;
+    const bool fma_wave = wv < AW;             // wave-uniform
     const int c0 = blockIdx.x * B2_CB, par = epoch & 1;
     const float* x1cur = par ? W.x1[1] : W.x1[0];     // (a runtime index into the shifted struct would go to scratch)
     float* x1next = par ? W.x1[0] : W.x1[1];
@@ -801,36 +820,39 @@ __global__ __launch_bounds__(B2_THREADS) void k_bwd2(Dims D, Ws W0, int epoch, s
     stage_issue<B2_THREADS>((float4*)gh, (const float4*)W.g_h2, RB * D.H2 / 4);
     stage_issue<B2_THREADS>((float4*)encs, (const float4*)W.enc, D.K * D.IN / 4);
     nn_f2 w[OPS];
-    const float* wbase = W.P + D.oW2 + (size_t)(sl * OPS) * D.H + c0 + 2 * cp;
+    {
+        const float* wbase = W.P + D.oW2 + (size_t)(min(sl, 8 * AW - 1) * OPS) * D.H + c0 + 2 * cp;
 #pragma unroll
-    for (int j = 0; j < OPS; ++j) w[j] = *(const nn_f2*)(wbase + (size_t)j * D.H);
-    // encoder rows: thread = (row of the block, float4 of its IN inputs)
-    const int row = tid >> 4, i4 = tid & 15, hu = c0 + row;
+        for (int j = 0; j < OPS; ++j) w[j] = *(const nn_f2*)(wbase + (size_t)j * D.H);
+    }
+    // encoder rows: thread = (half, row of the block, float4 of its IN inputs); both halves hold the row (same operands,
+    // same Adam result) and share the pose rows of the next-activation loop
+    const int half = tid >> 8, t2 = tid & 255, row = t2 >> 4, i4 = t2 & 15, hu = c0 + row;
     const bool ain = 4 * i4 < D.IN;
     const int ei = min(4 * i4, D.IN - 4);
     const size_t wi = (size_t)D.oW1 + (size_t)hu * D.IN + ei;
     float4 pw = *(const float4*)(W.P + wi), pm = *(const float4*)(W.AM + wi), pv = *(const float4*)(W.AV + wi);
     float pb = W.P[D.ob1 + hu], mb = W.AM[D.ob1 + hu], vb = W.AV[D.ob1 + hu];
-    for (int r0 = 0; r0 < D.K; r0 += RB) {
+    float xv0 = 0.f;                            // post-activation of this thread's (pose row, column) output of pass 0
+    if (tid < RB * B2_CB) xv0 = x1cur[(size_t)(tid >> 4) * D.H + c0 + (tid & 15)];
+    float gxv[B2_MAXP];                         // this thread's g_x1 outputs, one per pass (K <= 160, 20 rows x 16 columns per pass)
+    int np = 0;
+    for (int r0 = 0; r0 < D.K; r0 += RB, ++np) {
         const int nr = min(RB, D.K - r0);
+        float xv = xv0;
         if (r0) {
             __syncthreads();                       // the previous pass has read gh and red
             stage_issue<B2_THREADS>((float4*)gh, (const float4*)(W.g_h2 + (size_t)r0 * D.H2), nr * D.H2 / 4);
-        }
-        float xv[2];                               // post-activations of this thread's (pose row, column) outputs of the pass
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = tid + B2_THREADS * u;
-            xv[u] = x1cur[(size_t)min(r0 + (idx >> 4), D.K - 1) * D.H + c0 + (idx & 15)];
+            if (tid < nr * B2_CB) xv = x1cur[(size_t)(r0 + (tid >> 4)) * D.H + c0 + (tid & 15)];
         }
         stage_wait();
         __syncthreads();
-        nn_f2 acc[B2_RB];
+        if (fma_wave) {
+            nn_f2 acc[B2_RB];
 #pragma unroll
-        for (int q = 0; q < B2_RB; ++q) {
-            acc[q] = nn_f2{0.f, 0.f};
-            if (q < nr) {                          // block-uniform
-                const float* g = gh + q * D.H2 + sl * OPS;
+            for (int q = 0; q < B2_RB; ++q) {
+                acc[q] = nn_f2{0.f, 0.f};
+                const float* g = gh + min(q, nr - 1) * D.H2 + sl * OPS;
                 if constexpr (OPS % 4 == 0) {
 #pragma unroll
                     for (int j = 0; j < OPS; j += 4) {
@@ -848,20 +870,32 @@ __global__ __launch_bounds__(B2_THREADS) void k_bwd2(Dims D, Ws W0, int epoch, s
 #pragma unroll
                     for (int j = 0; j < OPS; ++j) acc[q] = fma2(g[j], w[j], acc[q]);
                 }
-                *(nn_f2*)(red + sl * SLS + q * B2_CB + 2 * cp) = acc[q];
             }
+#pragma unroll
+            for (int q = 0; q < B2_RB; ++q) { acc[q].x = slice_sum8(acc[q].x); acc[q].y = slice_sum8(acc[q].y); }
+#pragma unroll
+            for (int q = 0; q < B2_RB; ++q)
+                if (lane < 8 && q < nr) *(nn_f2*)(red + (wv * RB + q) * B2_CB + 2 * cp) = acc[q];
         }
         __syncthreads();
+        float out = 0.f;
+        if (tid < nr * B2_CB) {                        // tid = (pose row of the pass) * 16 + column
+            float sum = red[tid];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = tid + B2_THREADS * u;          // = (pose row of the pass) * 16 + column
-            if (idx < nr * B2_CB) {
-                float sum = 0.f;
-#pragma unroll 8
-                for (int s2 = 0; s2 < B2_NSL; ++s2) sum += red[s2 * SLS + idx];
-                gxs[r0 * B2_CB + idx] = sum * act_grad(xv[u], D.slope);
-            }
+            for (int w2 = 1; w2 < AW; ++w2) sum += red[w2 * RB * B2_CB + tid];
+            out = sum * act_grad(xv, D.slope);
         }
+#pragma unroll
+        for (int u = 0; u < B2_MAXP; ++u) if (u == np) gxv[u] = out;
+    }
+    __syncthreads();                                   // gh is free: g_x1 moves in
+    np = 0;
+    for (int r0 = 0; r0 < D.K; r0 += RB, ++np) {
+        const int nr = min(RB, D.K - r0);
+        float out = 0.f;
+#pragma unroll
+        for (int u = 0; u < B2_MAXP; ++u) if (u == np) out = gxv[u];
+        if (tid < nr * B2_CB) gxs[r0 * B2_CB + tid] = out;
     }
     __syncthreads();
     // ---- encoder rows: dW1 = g_x1^T enc, Adam, next x1
@@ -879,16 +913,22 @@ __global__ __launch_bounds__(B2_THREADS) void k_bwd2(Dims D, Ws W0, int epoch, s
     nw.z = adam_value(pw.z, pm.z, pv.z, ag.z, S.step_size, S.bc2_sqrt);
     nw.w = adam_value(pw.w, pm.w, pv.w, ag.w, S.step_size, S.bc2_sqrt);
     pb = adam_value(pb, mb, vb, gsum, S.step_size, S.bc2_sqrt);        // every lane of the row (same operands, same result)
-    if (live) {
+    if (live && half == 0) {
         if (ain) { *(float4*)(W.P + wi) = nw; *(float4*)(W.AM + wi) = pm; *(float4*)(W.AV + wi) = pv; }
         if (i4 == 0) { W.P[D.ob1 + hu] = pb; W.AM[D.ob1 + hu] = mb; W.AV[D.ob1 + hu] = vb; }
     }
-    for (int r = 0; r < D.K; ++r) {
+    for (int r = half; r < D.K; r += 2) {
         const float4 e = *(const float4*)(encs + r * D.IN + ei);
         float v = ain ? fmaf(nw.w, e.w, fmaf(nw.z, e.z, fmaf(nw.y, e.y, nw.x * e.x))) : 0.f;
         v = row_sum16(v) + pb;
-        if (i4 == 0 && live) x1next[(size_t)r * D.H + hu] = act_f(v, D.slope);
+        if (i4 == 0) xt[r * B2_CB + row] = act_f(v, D.slope);
     }
+    __syncthreads();
+    if (live)                                   // the tile goes out as 64-byte row segments, 8 bytes per lane
+        for (int t = tid; t < D.K * (B2_CB / 2); t += B2_THREADS) {
+            const int r = t >> 3, c2 = 2 * (t & 7);
+            *(nn_f2*)(x1next + (size_t)r * D.H + c0 + c2) = nn_f2{xt[r * B2_CB + c2], xt[r * B2_CB + c2 + 1]};
+        }
 }
 
 // ------------------------------------------------------------------------------------------ dW + Adam (+ next h2)
@@ -1112,7 +1152,7 @@ static bool make_dims(const creg_train_shape* s, Dims* D) {
     D->oW3A = o; o += D->OA * D->HA; D->ob3A = o; o += D->OA;
     D->oW3B = o; o += D->OB * D->HB; D->ob3B = o; o += D->OB;
     D->NPAR = o;
-    if (D->H2 % B2_NSL || D->H % B2_CB || D->H2 > 256 * GC_QMAX) return false;
+    if (D->H2 % 32 || D->H % B2_CB || D->H2 > 256 * GC_QMAX) return false;
     const NnGrid g = nn_grid(D->NP, D->NT, true, true);
     D->nbx = g.blocksA; D->nby = g.blocksB;
     // block-pruned search of the (static) target cloud: one box per lane, 4 queries per wave
@@ -1171,14 +1211,20 @@ static void launch_head(Plan* P, int par, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
     by_nc(D.H, [&](auto nc) { hipLaunchKernelGGL((k_head<decltype(nc)::value>), dim3(D.K, 1, P->nz), dim3(512), 0, s, D, W, par, P->bstride); });
 }
+// the k_bwd2 instance of a shape: AW waves x 8 slices x OPS rows = H2 ('q': H2 = 96 NC, 'dq': 64 NC; NC = H / 64)
+template <typename F>
+static void by_bwd2(const Dims& D, F f) {
+    by_nc(D.H, [&](auto nc) {
+        constexpr int NC = decltype(nc)::value;
+        if (D.rot == 0) {
+            if constexpr (NC == 1) f(k_bwd2<4, 3>);                    // H2 = 96: 32 slices of 3 rows
+            else f(k_bwd2<8, (3 * NC) / 2>);                           // H2 = 96 NC: 64 slices
+        } else f(k_bwd2<8, NC>);                                       // H2 = 64 NC
+    });
+}
 static void launch_bwd2(Plan* P, int epoch, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
-    by_nc(D.H, [&](auto nc) {
-        constexpr int NC = decltype(nc)::value;              // H2 / 32 rows of W2 per slice: 3 NC ('q': H2 = 96 NC) or 2 NC ('dq')
-        const dim3 grid(D.H / B2_CB, 1, P->nz);
-        if (D.rot == 0) hipLaunchKernelGGL((k_bwd2<3 * NC>), grid, dim3(B2_THREADS), P->smem_bwd2, s, D, W, epoch, P->bstride);
-        else hipLaunchKernelGGL((k_bwd2<2 * NC>), grid, dim3(B2_THREADS), P->smem_bwd2, s, D, W, epoch, P->bstride);
-    });
+    by_bwd2(D, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(D.H / B2_CB, 1, P->nz), dim3(B2_THREADS), P->smem_bwd2, s, D, W, epoch, P->bstride); });
 }
 static void launch_dw(Plan* P, int epoch, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
@@ -1415,11 +1461,9 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     if (D.npb) CREG_HIP(hipFuncSetAttribute((const void*)k_sort_p, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
     if (D.nyb) CREG_HIP(hipFuncSetAttribute((const void*)k_sort_y, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8 + 6 * 4 * 256));
     CREG_REQUIRE(P->smem_bwd2 <= 160 * 1024, "creg_train_plan_create: k_bwd2 needs %d B of LDS (K too large)", P->smem_bwd2);
-    {   // per kernel and per device, like k_dw's: the most any plan can ask for (K = 160, 'q' model of hidden 512)
-        const int B2_LDS_MAX = (int)(sizeof(float) * b2_smem_floats(160, 768, 64));
+    {   // per kernel and per device, like k_dw's
         hipError_t e2 = hipSuccess;
-        auto raise = [&](auto kern) { if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_MAX); };
-        raise(k_bwd2<2>); raise(k_bwd2<3>); raise(k_bwd2<4>); raise(k_bwd2<6>); raise(k_bwd2<8>); raise(k_bwd2<12>); raise(k_bwd2<16>); raise(k_bwd2<24>);
+        by_bwd2(D, [&](auto kern) { e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         CREG_REQUIRE(e2 == hipSuccess, "creg_train_plan_create: cannot raise the dynamic LDS limit of k_bwd2");
     }
     *plan = (creg_train_plan*)P;
