@@ -304,6 +304,30 @@ def match_all(data_dirs):
             np.savetxt(sd + "loss.txt", l)
 
 
+def _shard_for_rank(dirs):
+    """One process per GPU (python -m torch.distributed.run ... -m autourdf_amd.mlp_reg): the sequences are dealt
+    round-robin to the ranks, nothing is exchanged on the data path; only the frame-0 state every sequence starts from
+    is shared -- through the file system, as the reference shares it between its sequential match() calls
+    (mlp_reg.py:242-253): rank 0 writes it, a barrier, everybody reads it.  Backend: RCCL ("nccl"); the CPU
+    plumbing test of tests/test_distributed_cpu.py sets CREG_DIST_BACKEND=gloo."""
+    global DEVICE
+    import torch.distributed as dist
+    from .distributed import shard_sequences
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    backend = os.environ.get("CREG_DIST_BACKEND", "nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        DEVICE = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=DEVICE)
+    else:
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if rank == 0:
+        _ensure_frame0(dirs[0])
+    dist.barrier()
+    return [dirs[i] for i in shard_sequences(len(dirs), rank, world)]
+
+
 def main(argv=None):
     global DEVICE, ROBOT, NUM_SEG, DOF, STEP_SZIE, NUM_CAMERAS, MLP_ICP, VIS, ROT, LOSS, NORMAL, RAW_PATH_LIST
     if not torch.cuda.is_available():
@@ -335,27 +359,16 @@ def main(argv=None):
         RAW_PATH_LIST = sorted(glob.glob(f"data/raw/{ROBOT}/*/"))
     print(f"Found {len(RAW_PATH_LIST)} raw data directories")
     dirs = RAW_PATH_LIST[: args.num_video]
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     distributed = "RANK" in os.environ and bool(dirs)          # launched by torch.distributed.run (any world size)
     if distributed:
-        # one process per GPU (python -m torch.distributed.run ... -m autourdf_amd.mlp_reg): sequences are sharded
-        # round-robin, nothing is exchanged but the shared frame-0 state, which rank 0 writes first
-        import torch.distributed as dist
-        from .distributed import shard_sequences
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        DEVICE = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=DEVICE)
-        if rank == 0:
-            _ensure_frame0(dirs[0])
-        dist.barrier()
-        dirs = [dirs[i] for i in shard_sequences(len(dirs), rank, world)]
+        dirs = _shard_for_rank(dirs)
     if args.sequential:
         for i, data_dir in enumerate(dirs):
             match(data_dir, i)
     elif dirs:
         match_all(dirs)
     if distributed:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

@@ -7,7 +7,7 @@ per-cluster ICP, optional keep-translation) and open3d==0.18.0
 nearest neighbour within ``th`` (brute force here instead of a KD-tree: same answer), fitness =
 inliers/|source|, inlier_rmse, Umeyama/Kabsch without scaling (``Eigen::umeyama``: R = U S V^T,
 S = diag(1,1,sign det(U)det(V))), update composed on the left.  open3d is not vendored: parity
-UNPINNED; cross-checked on known rigid motions in tests/test_oracle_icp.py.
+UNPINNED; cross-checked on known rigid motions in tests/test_oracle_golden.py (test_kabsch_known_motion_reflection_and_planar, test_masked_icp_matches_reference).
 """
 import numpy as np
 

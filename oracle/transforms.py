@@ -5,7 +5,7 @@ conventions: real-first quaternions (w,x,y,z); ``quaternion_to_matrix`` scales b
 assumption); ``matrix_to_quaternion`` evaluates the four sqrt candidates, picks the
 best-conditioned one (largest |component|, denominators floored at 0.1) and returns w >= 0;
 ``quaternion_invert`` is the conjugate.  Parity UNPINNED by the reference; cross-checked against
-scipy.spatial.transform.Rotation in tests/test_oracle_transforms.py.
+scipy.spatial.transform.Rotation in tests/test_oracle_golden.py (test_transforms_against_scipy).
 """
 import torch
 

@@ -7,6 +7,7 @@ Sources of truth, per fixture:
   models_reference.npz    reference model_utils.QRegMLP / DQRegMLP forward, pinned small state_dicts
   calculate_pc.npz        reference mlp_reg.calculate_pc
   train_reference.npz     reference mlp_reg.train (full 300-epoch loop, tiny problem, ROT q and dq)
+  train_reference_h64.npz reference mlp_reg.train at hidden 64 (6 epochs with the loss of each, and 300), ROT q and dq
   resample_reference.npz  reference mlp_reg.resample_cluster with LIVE scikit-learn k_means
   masked_icp_reference.npz reference cluster_icp.masked_icp (mask + bookkeeping; ICP via oracle stub)
   kmeans_sklearn.npz      live sklearn.cluster.k_means (labels, centres, inertia)
@@ -147,6 +148,50 @@ def g_train():
     save("train_reference.npz", **out)
 
 
+def g_train_h64():
+    """The reference's own train() at hidden 64 -- a width the HIP plan tiles (64 | hidden), so the GPU test compares the
+    plan with the reference DIRECTLY (A1 was pinned two hops away, through the oracle at hidden 32).  Two
+    runs per rotation: the first six epochs with every epoch's loss (the reference function, its `range` shadowed in its
+    module so the loop stops after 6, chamfer_distance wrapped to record what it returns), and the full 300 epochs."""
+    import builtins
+    out = {}
+    for rot, ctor, seed in (("q", lambda: ref_models.QRegMLP(True, hidden_dim=64), 31),
+                            ("dq", lambda: ref_models.DQRegMLP(hidden_dim=64), 32)):
+        seq, mats, clusters = tiny_problem(2, n=512, k=5)
+        y = torch.from_numpy(seq[1].astype(np.float32))
+        ref_reg.ROT = rot
+        sd0 = None
+        for tag, n_ep in (("e6", 6), ("e300", 300)):
+            model = ctor()
+            sd = _small_state(model, seed)
+            sd = {k: (v * 0.1).astype(np.float32) for k, v in sd.items()}
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            sd0 = sd
+            losses = []
+            orig_cd = ref_reg.chamfer_distance
+
+            def spy(*a, **k):
+                r = orig_cd(*a, **k)
+                losses.append(float(r[0].item()))
+                return r
+
+            ref_reg.chamfer_distance = spy
+            ref_reg.range = lambda n, _n=n_ep: builtins.range(min(n, _n))
+            try:
+                pred_np, _, best_m, min_loss = ref_reg.train(
+                    torch.from_numpy(mats), y, model, [torch.from_numpy(c) for c in clusters])
+            finally:
+                ref_reg.chamfer_distance = orig_cd
+                del ref_reg.range
+            out.update({f"{rot}_{tag}_best_m": best_m.detach().numpy(), f"{rot}_{tag}_min_loss": np.float64(min_loss),
+                        f"{rot}_{tag}_best_pred": np.concatenate(pred_np), f"{rot}_{tag}_loss_hist": np.array(losses, np.float64)})
+            out.update({f"{rot}_{tag}.final." + k: v.detach().numpy() for k, v in model.state_dict().items()})
+        out.update({f"{rot}.sd." + k: v for k, v in sd0.items()})
+        out.update({f"{rot}_m": mats, f"{rot}_y": y.numpy(), f"{rot}_local": np.concatenate(clusters),
+                    f"{rot}_offsets": np.cumsum([0] + [len(c) for c in clusters])})
+    save("train_reference_h64.npz", **out)
+
+
 class _Seg:
     def __init__(self, frames):
         self.pc_list = [ref_shims._PointCloud(f) for f in frames]
@@ -253,4 +298,4 @@ def g_chamfer():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    g_dq(); g_models(); g_calc_pc(); g_train(); g_resample(); g_segments(); g_masked_icp(); g_kmeans(); g_chamfer()
+    g_dq(); g_models(); g_calc_pc(); g_train(); g_train_h64(); g_resample(); g_segments(); g_masked_icp(); g_kmeans(); g_chamfer()

@@ -67,3 +67,45 @@ def test_gather_is_identity_without_process_group():
     from autourdf_amd.distributed import gather_poses
     x = torch.randn(3, 2, 4, 4)
     assert gather_poses(x) is x
+
+
+def _main_worker(rank, world, port, root, q):
+    """autourdf_amd.mlp_reg.main()'s torchrun prologue (_shard_for_rank) at world size 2 on gloo: the registration itself
+    is stubbed (no GPU here) -- what runs is the drop-in's own code for: who writes the frame-0 state, the barrier before
+    anybody reads it, which sequences a rank takes."""
+    os.chdir(root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      CREG_DIST_BACKEND="gloo")
+    from autourdf_amd import mlp_reg
+    calls = []
+
+    def fake_frame0(first_dir):
+        assert rank == 0
+        os.makedirs("data/part/frame0_written", exist_ok=True)
+        open("data/part/frame0_written/by_rank_%d" % rank, "w").write(first_dir)
+
+    mlp_reg._ensure_frame0 = fake_frame0
+    dirs = ["data/raw/toy/4_deg_20_cams/V%04d/" % i for i in range(5)]
+    mine = mlp_reg._shard_for_rank(dirs)
+    saw_frame0 = os.path.exists("data/part/frame0_written/by_rank_0")      # after the barrier every rank must see it
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, mine, saw_frame0))
+
+
+def test_mlp_reg_main_sharding_prologue_two_ranks_gloo(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_main_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d = ["data/raw/toy/4_deg_20_cams/V%04d/" % i for i in range(5)]
+    assert res[0][1] == [d[0], d[2], d[4]] and res[1][1] == [d[1], d[3]]
+    assert res[0][2] and res[1][2]
+    assert os.listdir(tmp_path / "data/part/frame0_written") == ["by_rank_0"]

@@ -60,6 +60,30 @@ def test_match_writes_the_reference_file_layout(workdir, flags, monkeypatch):
     assert np.abs(np.sort(world, 0) - np.sort(frame, 0)).max() < 1e-6
 
 
+def test_torchrun_world_size_one_of_the_dropin_module(workdir):
+    """`python -m torch.distributed.run --nproc-per-node 1 -m autourdf_amd.mlp_reg ...`: the one-process-per-GPU launch of
+    the drop-in (RCCL process group, frame-0 state by rank 0, barrier, this rank's shard) writes the reference's files."""
+    import subprocess
+    import sys
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "autourdf_amd.mlp_reg", "--robot", "wx200_5", "--num_video", "2", "--loss"],
+                       cwd=str(workdir), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    base = workdir / "data/part/wx200_5_8_seg/4_deg_20_cams"
+    for v in range(2):
+        for t in range(3):
+            m = np.load(base / f"V{v:04}/matrix/{t:04}.npy")
+            assert m.shape == (8, 4, 4) and np.isfinite(m).all()
+            with np.load(base / f"V{v:04}/cluster/{t:04}.npz") as z:
+                assert list(z.keys()) == [str(i) for i in range(8)] and sum(len(z[k]) for k in z.keys()) == 1024
+        assert np.loadtxt(base / f"V{v:04}/loss.txt").shape == (2,)
+    np.testing.assert_array_equal(np.load(base / "V0000/matrix/0000.npy"), np.load(base / "V0001/matrix/0000.npy"))
+
+
 @pytest.mark.parametrize("rot,extra", [("q", []), ("dq", []), ("q", ["--mlp_icp"])])
 def test_lock_step_run_equals_one_match_per_sequence(workdir, rot, extra, monkeypatch):
     """main() registers all sequences in lock-step (match_all); --sequential is the reference's loop of match()
@@ -114,9 +138,10 @@ def test_train_signature_drop_in_returns(workdir):
     np.testing.assert_allclose(torch.cat(pcs).cpu().numpy(), np.concatenate(pred_np), atol=1e-6)
 
 
-@pytest.mark.parametrize("robot,n,k", [("franka", 16384, 40), ("allegro", 4096, 30), ("chain32", 32768, 128)])
+@pytest.mark.parametrize("robot,n,k", [("wx200_5", 4096, 20), ("franka", 16384, 40), ("allegro", 4096, 30), ("chain32", 32768, 128)])
 def test_larger_configs_two_epochs_vs_oracle(robot, n, k):
-    """BASELINE configs 3-5 shapes (hidden 512), K up to 128, multi-chunk NN.  With identical weights the
+    """BASELINE configs[0] / [1] (the headline shape: wx200_5, N=4096, K=20) and configs 3-5 shapes (hidden 512), K up to 128,
+    multi-chunk NN.  With identical weights the
     poses agree to 1e-5 (checked on the forward of epoch 0 and on the loss of both epochs).  After an Adam
     step they can differ more: Adam's first update is lr * g / (|g| + eps), so a weight whose gradient is
     rounding noise (|g| ~ 1e-10; a few dozen of 426k here) moves by +-lr depending on the summation
@@ -137,7 +162,11 @@ def test_larger_configs_two_epochs_vs_oracle(robot, n, k):
     plan = ops.TrainPlan("q", k, 512, n, n, epochs=2, use_graph=True, device=dev)
     best_m, _, res, lh, _ = plan.run(m.to(dev), y.to(dev), pts, off, params)
     _, o_best, o_min, hist = registration.train(m, y, model, cl, rot="q", epochs=2)
-    np.testing.assert_allclose(lh.cpu().numpy(), np.array(hist["loss"], np.float32), rtol=2e-5)
+    # epoch 0 (identical weights): 2e-6; epoch 1 follows the first Adam step, whose +-lr kicks on noise-gradient weights (above)
+    # show in the loss at the 2e-5 level (measured 2.0e-5 on the headline shape, 0.157265 vs 0.157261)
+    lh_h, o_l = lh.cpu().numpy(), np.array(hist["loss"], np.float32)
+    assert abs(lh_h[0] - o_l[0]) <= 2e-6 * o_l[0]
+    np.testing.assert_allclose(lh_h, o_l, rtol=5e-5)
     np.testing.assert_allclose(best_m.cpu().numpy(), o_best.detach().numpy(), atol=2e-4)
     torch.manual_seed(1)
     model0 = models.QRegMLP(True, 512)                                     # pristine weights: forward parity at 1e-5

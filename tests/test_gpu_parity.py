@@ -239,6 +239,34 @@ def test_dq_rows_vs_reference_golden(dev, golden):
     np.testing.assert_allclose(ops.matrix_to_quat(R).cpu().numpy(), g["f32_dq"][:, :4], atol=2e-6)
 
 
+def test_dq_func_dropin_all_eleven_functions_vs_reference_golden(dev, golden):
+    """Every function of the drop-in module autourdf_amd.dq_func (same 11 names as PointCloud/dq_func.py:4-257) against
+    EVERY key of dq_reference.npz (minted by the reference module itself): SURVEY 8 rows D1-D10 on the GPU, not only
+    through the oracle."""
+    from autourdf_amd import dq_func as D
+    g = golden("dq_reference.npz")
+    t = lambda k: _cuda(g[f"f32_{k}"], dev)
+    close = lambda a, k, tol=2e-6: np.testing.assert_allclose(a.detach().cpu().numpy(), g[f"f32_{k}"], rtol=0, atol=tol)
+    M, dq, dq_b, noisy = t("M"), t("dq"), t("dq_b"), t("noisy")
+    R, tr = M[:, :3, :3], M[:, :3, 3]                                       # non-contiguous views, as callers hand them
+    close(D.transform_from_rot_trans(R, tr), "assemble", 0)                  # D1: exact (assembly only)
+    close(D.quaternion_conjugate(dq[:, :4]), "conj", 0)                      # D2: sign flips only
+    close(D.quat_trans_to_dualquat(dq[:, :4], tr), "from_qt")                # D3
+    close(D.rot_trans_to_dualquat(R, tr), "from_rt")                         # D4
+    close(D.transform_to_dualquat(M), "dq")                                  # D5
+    q, t2 = D.dualquat_to_quat_trans(noisy)                                  # D6 (incl. the reference's "returns the product" quirk)
+    close(q, "qt_q"); close(t2, "qt_t")
+    Rr, tt = D.dualquat_to_rot_trans(noisy)                                  # D7
+    close(Rr, "rt_R"); close(tt, "rt_t")
+    close(D.dualquat_to_transform(noisy), "to_transform")                    # D8
+    close(D.dualquat_multiply(dq, dq_b), "mul")                              # D9
+    close(D.dualquat_invert(noisy), "inv")
+    close(D.point_to_dualquat(tr), "point", 0)                               # D10
+    # leading batch dimensions are kept (the reference functions broadcast over them)
+    assert D.transform_to_dualquat(M.reshape(8, 8, 4, 4)).shape == (8, 8, 8)
+    assert D.dualquat_to_transform(noisy.reshape(4, 16, 8)).shape == (4, 16, 4, 4)
+
+
 def test_dq_to_se3_backward_vs_autograd(dev):
     from autourdf_amd import ops
     from oracle import dq as odq
@@ -253,6 +281,67 @@ def test_dq_to_se3_backward_vs_autograd(dev):
 
 
 # ------------------------------------------------------------------------------------------ K4
+def _deg_cases():
+    """Correspondence sets on which a quaternion (Horn) fit and an SVD (Umeyama) fit could part ways:
+    name -> (source (n,3), target (m,3), threshold, compare poses?)."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(5)
+    R = Rotation.from_rotvec([0.2, -0.15, 0.25]).as_matrix()
+    t = np.array([0.03, -0.02, 0.04])
+    move = lambda p: p @ R.T + t
+    plane = np.c_[rng.uniform(-1, 1, (60, 2)), np.zeros(60)]                  # rank-2 covariance
+    line = np.outer(np.linspace(-1, 1, 40) + rng.normal(scale=0.01, size=40), [0.6, 0.64, 0.48])   # rank 1: the spin about the line is free
+    two = np.array([[0.0, 0.0, 0.0], [0.5, 0.1, -0.2]])
+    blob = rng.normal(scale=0.5, size=(80, 3))
+    return {"planar": (plane, move(plane), 1.0, True),
+            "collinear": (line, move(line), 1.0, False),
+            "two_pairs": (two, move(two), 1.0, False),
+            "no_pairs": (blob, blob + 10.0, 0.05, True),                      # nothing within the threshold: the pose stays
+            "one_pair": (blob[:1], move(blob[:1]), 1.0, False),
+            "mirrored": (blob, blob * np.array([1.0, 1.0, -1.0]) + t, 5.0, True)}   # det < 0 optimum: the best PROPER rotation
+
+
+@pytest.mark.parametrize("name", ["planar", "collinear", "two_pairs", "no_pairs", "one_pair", "mirrored"])
+def test_icp_fit_degenerate_correspondences_vs_oracle(dev, name):
+    """K4's closed-form fit is Horn's quaternion (Newton on the characteristic polynomial + adjugate, Jacobi fallback),
+    the oracle's is open3d's Umeyama / SVD with the reflection fix.  On degenerate correspondence sets both must land on a
+    minimiser: the MOVED sources always agree; the pose itself where it is unique."""
+    from autourdf_amd import ops
+    from oracle import icp as oicp
+    src, tgt, th, unique = _deg_cases()[name]
+    init = np.eye(4)[None]
+    T, moved, n_it = ops.icp_p2p(torch.tensor(src, device=dev), torch.tensor([0, len(src)], dtype=torch.int32, device=dev),
+                                 torch.tensor(tgt, device=dev), torch.tensor([0, len(tgt)], dtype=torch.int32, device=dev),
+                                 torch.tensor(init, device=dev), th=th, max_iteration=200)
+    oT, fit, rmse, o_it = oicp.registration_icp(src, tgt, th, init[0], max_iteration=200)
+    T, moved = T.cpu().numpy()[0], moved.cpu().numpy()
+    assert np.isfinite(T).all() and abs(np.linalg.det(T[:3, :3]) - 1.0) < 1e-9
+    np.testing.assert_allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-9)
+    np.testing.assert_allclose(moved, src @ oT[:3, :3].T + oT[:3, 3], atol=1e-7)
+    if unique:
+        np.testing.assert_allclose(T, oT, atol=1e-7)
+        assert int(n_it.cpu()[0]) == o_it
+
+
+def test_masked_icp_ori_keeps_translation_vs_oracle(dev, golden):
+    """ori=True (cluster_icp.py:161-163): the ICP rotation with the INPUT translation, on the inputs of the reference-minted
+    masked_icp golden (every box there holds enough targets for a unique fit: a box with two targets makes the rotation
+    about their line arbitrary, and Horn's and Umeyama's arbitrary choices differ -- test_icp_fit_degenerate_... covers those)."""
+    from autourdf_amd.cluster_icp import masked_icp
+    from oracle import icp as oicp
+    g = golden("masked_icp_reference.npz")
+    local, world = _split(g["local"], g["offsets"]), _split(g["world_pred"], g["offsets"])
+    counts = [int(oicp.aabb_mask(wc, g["frame"], 1.2).sum()) for wc in world]
+    assert all(c == 0 or c >= 10 for c in counts), counts          # (an empty box leaves the pose alone: unique too)
+    w, m = masked_icp(local, world, g["frame"], g["mats"], ori=True)
+    ow, om = oicp.masked_icp(local, world, g["frame"], g["mats"], ori=True)
+    np.testing.assert_allclose(m[:, :3, 3], g["mats"][:, :3, 3].astype(np.float64), atol=0)     # translations untouched
+    np.testing.assert_allclose(m, om, atol=1e-8)
+    np.testing.assert_allclose(np.concatenate(w), np.concatenate(ow), atol=1e-8)
+    np.testing.assert_allclose(m[:, :3, :3], g["new_mats"][:, :3, :3], atol=1e-8)               # the reference's rotations (ori=False golden)
+    assert np.abs(m[:, :3, :3] - g["mats"][:, :3, :3]).max() > 1e-4                             # ... and they did move
+
+
 def test_masked_icp_vs_reference_golden(dev, golden):
     from autourdf_amd.cluster_icp import masked_icp
     g = golden("masked_icp_reference.npz")
@@ -390,6 +479,37 @@ def test_train_probe_forward_and_pose_gradient_vs_oracle(dev, golden, rot):
     np.testing.assert_allclose(gpred.cpu().numpy(), pred.detach().numpy(), atol=2e-6)
     assert abs(gloss.item() - loss.item()) <= 2e-6 * abs(loss.item())
     np.testing.assert_allclose(ggrad.cpu().numpy()[:, :3, :], m2.grad.numpy()[:, :3, :], rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("rot", ["q", "dq"])
+def test_train_vs_reference_train_directly_hidden64(dev, golden, rot):
+    """A1 against the REFERENCE, no oracle in between: tests/golden/train_reference_h64.npz was minted by the reference's own
+    train() (PointCloud/mlp_reg.py:17-152, run under ref_shims in the build container) at hidden 64 -- a width the plan tiles.
+    Six epochs are pinned per step: every epoch's loss to 1e-5 relative, the best pose to 1e-5 (the north star's bound), the
+    parameters after six Adam steps to 2e-5 (six updates of lr = 2e-4 each: a parameter whose gradient is rounding noise moves
+    by +-lr whatever the implementation, see test_larger_configs_two_epochs_vs_oracle).  The 300-epoch run is compared loosely:
+    argmin switches amplify 1 ulp, min_loss 1e-3 relative, poses 2e-3."""
+    from autourdf_amd import ops
+    g = golden("train_reference_h64.npz")
+    order = ops.Q_PARAM_ORDER if rot == "q" else ops.DQ_PARAM_ORDER
+    m, y = torch.from_numpy(g[f"{rot}_m"]).to(dev), torch.from_numpy(g[f"{rot}_y"]).to(dev)
+    clusters = [torch.from_numpy(c) for c in _split(g[f"{rot}_local"], g[f"{rot}_offsets"])]
+    pts, off = ops.pack_clusters(clusters, dev)
+    for tag, epochs in (("e6", 6), ("e300", 300)):
+        params = [torch.from_numpy(g[f"{rot}.sd.{k}"]).clone().to(dev) for k in order]
+        plan = ops.TrainPlan(rot, len(clusters), 64, pts.shape[0], y.shape[0], epochs=epochs, use_graph=True, device=dev)
+        bm, bp, res, lh, _ = plan.run(m, y, pts, off, params)
+        res = res.cpu().numpy()
+        if epochs == 6:
+            np.testing.assert_allclose(lh.cpu().numpy().astype(np.float64), g[f"{rot}_e6_loss_hist"], rtol=1e-5)
+            np.testing.assert_allclose(bm.cpu().numpy(), g[f"{rot}_e6_best_m"], atol=1e-5)
+            np.testing.assert_allclose(bp.cpu().numpy(), g[f"{rot}_e6_best_pred"], atol=1e-5)
+            for k, p in zip(order, params):
+                np.testing.assert_allclose(p.cpu().numpy(), g[f"{rot}_e6.final.{k}"], atol=2e-5, err_msg=k)
+        else:
+            assert int(res[1]) == 300
+            assert abs(res[0] - float(g[f"{rot}_e300_min_loss"])) <= 1e-3 * float(g[f"{rot}_e300_min_loss"])
+            np.testing.assert_allclose(bm.cpu().numpy(), g[f"{rot}_e300_best_m"], atol=2e-3)
 
 
 @pytest.mark.parametrize("rot,hidden,k", [("q", 64, 7), ("q", 128, 5), ("dq", 64, 3), ("dq", 128, 9), ("q", 256, 21), ("dq", 512, 33)])

@@ -108,6 +108,27 @@ def test_train_matches_reference_full_300_epochs(golden, rot, ctor):
     assert len(hist["loss"]) == 300
 
 
+@pytest.mark.parametrize("rot,ctor", [("q", lambda: models.QRegMLP(True, 64)), ("dq", lambda: models.DQRegMLP(64))])
+def test_train_hidden64_matches_reference_six_epochs_and_300(golden, rot, ctor):
+    """train_reference_h64.npz (the reference's own train() at a width the HIP plan tiles): per-epoch losses of the first six
+    epochs, the best pose, the parameters after them, and the full 300-epoch run."""
+    g = golden("train_reference_h64.npz")
+    clusters = [torch.from_numpy(c) for c in _split(g[f"{rot}_local"], g[f"{rot}_offsets"])]
+    m, y = torch.from_numpy(g[f"{rot}_m"]), torch.from_numpy(g[f"{rot}_y"])
+    model = ctor()
+    model.load_state_dict(_load_sd(g, f"{rot}.sd."))
+    _, best_m, min_loss, hist = registration.train(m, y, model, clusters, rot=rot, epochs=6)
+    np.testing.assert_allclose(np.array(hist["loss"]), g[f"{rot}_e6_loss_hist"], rtol=1e-6)
+    np.testing.assert_allclose(best_m.detach().numpy(), g[f"{rot}_e6_best_m"], atol=1e-6)
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), g[f"{rot}_e6.final.{k}"], atol=2e-6)
+    model = ctor()
+    model.load_state_dict(_load_sd(g, f"{rot}.sd."))
+    _, best_m, min_loss, hist = registration.train(m, y, model, clusters, rot=rot)
+    assert abs(min_loss - float(g[f"{rot}_e300_min_loss"])) < 1e-6
+    np.testing.assert_allclose(best_m.detach().numpy(), g[f"{rot}_e300_best_m"], atol=2e-5)
+
+
 def test_resample_matches_reference_and_live_sklearn(golden):
     g = golden("resample_reference.npz")
     local, labels = registration.resample_cluster(g["frame"], len(g["mats"]), g["mats"])
