@@ -37,7 +37,6 @@ WORKLOADS = {"wx200_5": ("wx200_5", 4096, 20, "BASELINE configs[1]"),
              "franka": ("franka", 16384, 40, "BASELINE configs[2] shape"),
              "allegro": ("allegro_hand", 4096, 30, "BASELINE configs[3] shape"),
              "c5": ("chain32", 262144, 128, "BASELINE configs[4] shape (ICP-style frame: assign + fit kernels)")}
-FP32_VECTOR_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32 vector peak (FMA = 2 flops, packed)
 HBM_PEAK_GBPS = 8000.0
 STUB = os.environ.get("CREG_BENCH_STUB") == "1"      # CPU plumbing test: gloo + a stand-in registrar (tests/test_bench_cpu.py)
 
@@ -227,54 +226,88 @@ def clone_item(it):
 
 
 # ------------------------------------------------------------------------------------------ roofline block
-def roofline_block(reg, frames32, n_points, workload):
-    """Per kernel, measured live with HIP events on the plan's own launches (back-to-back, kernel + launch gap):
-    algorithmic figure / launch time against the GUIDE's peaks.  SQ-counter utilisation and HBM-side traffic cannot be
-    read inside this process (rocprofv3 --pmc needs its own passes): they are replayed from the committed profile
-    summary and say so in `source`."""
+CHIP_SIMDS, CHIP_CLOCK_HZ = 256 * 4, 2.4e9              # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock
+
+
+def epoch_kernel_model(k_clusters, n_points, info):
+    """Algorithmic HBM bytes per PROBLEM and launch of the five kernels of an epoch (DESIGN.md section 4 has the derivation),
+    QRegMLP(True, hidden 512): H = 512, H2 = 768, IN = 56."""
+    H, H2, IN, K, N = HIDDEN, HIDDEN + HIDDEN // 2, 56, k_clusters, n_points
+    w1 = H * IN + H                                     # encoder rows (k_bwd2 updates them)
+    w23 = N_PARAMS - w1                                 # hidden + output rows (k_dw updates them)
+    pruned = info["pruned_target_search"] and info["pruned_predicted_search"]
+    nn_name = (f"k_nn_plan<{'true' if info['pruned_predicted_search'] else 'false'}, {info['nn_points_per_lane']}>"
+               if info["pruned_target_search"] else "k_nn_l1<4>")
+    return {
+        # parameters + both Adam moments read and written (24 B each), current / next activations, gradients
+        "dw": {"name": "k_dw<8>", "bound": "hbm", "bytes": 24 * w23 + 4 * (2 * K * H + 3 * K * H2 + 16 * K)},
+        # W2 read once (its columns), the encoder rows + moments read and written, g_h2, current / next encoder activation
+        "bwd2": {"name": "k_bwd2<8, 12>", "bound": "hbm", "bytes": 4 * H2 * H + 24 * w1 + 4 * (K * H2 + 2 * K * H + K * IN)},
+        # both clouds (16 B points, block-sorted copies) read once, sign bits + integer scatter counters written
+        "nn_l1": {"name": nn_name, "bound": "valu", "bytes": 2 * 16 * N + 4 * N + 16 * N, "pruned": pruned},
+        # points, counters, signs and predictions of the clusters read, best cloud written when the loss improved, g_h2 rows
+        "gradc": {"name": "k_gradc", "bound": "latency", "bytes": (16 + 16 + 4 + 16 + 12) * N + 4 * K * H2 + 4 * 8 * H2},
+        # hidden activation + output rows read, predicted cloud (16 B), sorted copy (16 B) and zeroed counters (16 B) written
+        "head": {"name": "k_head<8>", "bound": "latency", "bytes": 4 * K * H2 + 4 * 7 * H2 + (16 + 16 + 16 + 16) * N},
+    }
+
+
+def roofline_block(reg, frames32, n_points, k_clusters, workload):
+    """Per kernel, measured live with HIP events on the plan's own launches (200 back-to-back launches on the plan's stream,
+    kernel + ~1 us launch gap): algorithmic bytes / launch time against the GUIDE's HBM peak.  The top-level block is the
+    kernel with the LONGEST launch in THIS run (it was hard-wired to k_dw, wrong for the franka shape).  What
+    cannot be read inside this process -- HBM-side traffic and SQ counters need rocprofv3's own --pmc passes -- is replayed
+    from the committed summary of this workload (profiles/r03_pmc.json) and tagged with its source; `frac` of a VALU-bound
+    kernel is a measured utilisation (wave-cycles the VALUs were issuing / SIMD-cycles of the launch), never an
+    exhaustive-search-equivalent rate."""
     r = reg.seqs[0]
     prof = reg.plan.profile(r.m, frames32[0][0], r.pts_init, r.off_init, r.p_anchor, n_epochs=100)
     b2b = {k[:-13]: prof.pop(k) for k in [k for k in prof if k.endswith("_back_to_back")]}
-    nn_us = b2b["nn_l1"]
     nz = prof.pop("nn_l1_problems_per_launch")
-    dw_us = b2b["dw"]
+    model = epoch_kernel_model(k_clusters, n_points, reg.plan.info)
     here = os.path.dirname(os.path.abspath(__file__))
     pmc, pmc_src = {}, None
-    for name in ("r02_pmc.json", "r01_nn_l1_pmc.json"):
-        path = os.path.join(here, "profiles", name)
-        if os.path.exists(path) and workload == "wx200_5":
-            pmc, pmc_src = json.load(open(path)), "profiles/" + name
-            break
-    dw_bytes = 24 * N_PARAMS * nz                       # P, Adam m, Adam v: read + written, 4 B each, per problem
-    nn_ops = 9.0 * n_points * n_points * nz             # SURVEY 8(d): the exhaustive bidirectional search the reference runs
-    nn_bytes = nz * (2 * 12 * n_points + 2 * (4 + 8) * n_points)
-    dw_traffic = pmc.get("k_dw_hbm_bytes_per_problem")
-    nn_traffic = pmc.get("k_nn_hbm_bytes_per_problem", pmc.get("hbm_bytes_per_problem"))
-    roof = {
-        # the dominant kernel of an epoch by rocprofv3 time (profiles/): dW fused with Adam, a stream over parameters + state
-        "bound": "hbm", "kernel": "k_dw<8>", "achieved": round(dw_bytes / (dw_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBPS,
-        "unit": "GB/s", "frac": round(dw_bytes / (dw_us * 1e-6) / (HBM_PEAK_GBPS * 1e9), 4),
-        "traffic": dw_traffic * nz if dw_traffic else None, "traffic_source": pmc_src if dw_traffic else None,
-        "avg_launch_us": round(dw_us, 3), "problems_per_launch": nz,
-        "timing_source": "HIP events around 200 back-to-back launches of the kernel on the plan's stream, in this run (kernel + ~1 us "
-                         "launch gap); the launch carries the problems of the larger graph branch, as in the timed region",
-        "algorithmic_bytes": dw_bytes,
-        "wasted_traffic_ratio": round(dw_traffic * nz / dw_bytes, 2) if dw_traffic else None,
-        "kernels": {
-            "k_nn_plan<true,1>": {
-                "bound": "valu", "avg_launch_us": round(nn_us, 3), "problems_per_launch": nz,
-                "algorithmic_ops": nn_ops, "achieved_TFLOPs": round(nn_ops / (nn_us * 1e-6) / 1e12, 3),
-                "peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS, "frac": round(nn_ops / (nn_us * 1e-6) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
-                "executed_valu_utilisation": pmc.get("k_nn_valu_active_frac"), "utilisation_source": pmc_src,
-                "algorithmic_bytes": nn_bytes, "traffic": nn_traffic * nz if nn_traffic else None, "traffic_source": pmc_src if nn_traffic else None,
-                "wasted_traffic_ratio": round(nn_traffic * nz / nn_bytes, 2) if nn_traffic else None,
-                "note": "algorithmic = 9 lane-ops x N^2 of the exhaustive search the reference runs (SURVEY 8d) against the fp32 vector "
-                        "peak of the guide; the kernel returns that search's result bit for bit while executing a few percent of the pair "
-                        "evaluations (exact k-d block pruning), so `frac` is distance from a perfect exhaustive kernel, "
-                        "`executed_valu_utilisation` (SQ_ACTIVE_INST_VALU / wave cycles) is how busy the VALUs really are"}},
-        "epoch_kernels_event_bracketed_us": {k: round(v, 2) if isinstance(v, float) else v for k, v in prof.items()},
-        "note": "event-bracketed per-kernel times carry ~7 us of event overhead each (upper bounds); rocprofv3 stats of the same "
-                "command are under profiles/"}
+    path = os.path.join(here, "profiles", "r03_pmc.json")
+    if os.path.exists(path):
+        allp = json.load(open(path))
+        if workload in allp:
+            pmc, pmc_src = allp[workload], f"profiles/r03_pmc.json[{workload!r}]"
+    kernels = {}
+    for key, m in model.items():
+        us = b2b[key]
+        pk = pmc.get("kernels", {}).get(key, {})
+        per = pmc.get("problems_per_launch_avg", 1.0)
+        e = {"kernel": m["name"], "bound": m["bound"], "avg_launch_us": round(us, 3), "problems_per_launch": nz,
+             "algorithmic_bytes": m["bytes"] * nz, "achieved_GBps": round(m["bytes"] * nz / (us * 1e-6) / 1e9, 1),
+             "hbm_frac": round(m["bytes"] * nz / (us * 1e-6) / (HBM_PEAK_GBPS * 1e9), 4)}
+        if pk:
+            traffic = (2 * pk["FETCH_SIZE_KB"] + pk["WRITE_SIZE_KB"]) * 1024 / per * nz
+            e.update({"traffic": round(traffic), "traffic_source": pmc_src,
+                      "wasted_traffic_ratio": round(traffic / (m["bytes"] * nz), 2),
+                      # VALU issue cycles of all waves of a launch / SIMD-cycles the chip offers in the launch's duration
+                      "valu_utilisation": round(pk["waves"] / per * nz * pk["active_valu_cycles_per_wave"] / (us * 1e-6 * CHIP_SIMDS * CHIP_CLOCK_HZ), 4),
+                      "valu_insts_per_wave": round(pk["valu_insts_per_wave"]), "utilisation_source": pmc_src})
+        kernels[key] = e
+    top_key = max(kernels, key=lambda k: kernels[k]["avg_launch_us"])
+    top = kernels[top_key]
+    if top["bound"] == "valu" and "valu_utilisation" in top:
+        peak_ginst = CHIP_SIMDS * CHIP_CLOCK_HZ / 4 / 1e9          # one wave64 VALU instruction per SIMD every 4 cycles (measured: DESIGN 4)
+        roof = {"bound": "valu", "kernel": top["kernel"], "achieved": round(top["valu_utilisation"] * peak_ginst, 1), "peak": round(peak_ginst, 1),
+                "unit": "G wave-instructions/s", "frac": top["valu_utilisation"], "traffic": top.get("traffic"),
+                "frac_note": "measured VALU utilisation of the launch: SQ_ACTIVE_INST_VALU of all its waves (rocprofv3 pass, " + str(pmc_src) +
+                             ") / (launch time of this run x 1024 SIMDs x 2.4 GHz); achieved / peak restate it as wave-instructions per second"}
+    else:
+        roof = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": top["hbm_frac"], "traffic": top.get("traffic")}
+    roof.update({"traffic_source": top.get("traffic_source"), "avg_launch_us": top["avg_launch_us"], "problems_per_launch": nz,
+                 "algorithmic_bytes": top["algorithmic_bytes"], "wasted_traffic_ratio": top.get("wasted_traffic_ratio"),
+                 "dominant_by": "longest back-to-back launch of the five epoch kernels in this run",
+                 "timing_source": "HIP events around 200 back-to-back launches of each kernel on the plan's stream, in this run (kernel + ~1 us "
+                                  "launch gap); launches carry the problems of the larger graph branch, as in the timed region",
+                 "kernels": kernels,
+                 "epoch_kernels_event_bracketed_us": {k: round(v, 2) if isinstance(v, float) else v for k, v in prof.items()},
+                 "note": "event-bracketed per-kernel times carry ~7 us of event overhead each (upper bounds); rocprofv3 stats of the same "
+                         "command are under profiles/"})
     return roof
 
 
@@ -568,7 +601,7 @@ def main(argv=None):
                                       if world > 1 else "single GPU"},
                "pose_checksum": round(float(gathered.double().abs().sum()), 6)}
         if not STUB and not args.no_roofline:
-            out["roofline"] = roofline_block(reg, frames32, n_points, args.workload)
+            out["roofline"] = roofline_block(reg, frames32, n_points, k_clusters, args.workload)
         if not STUB and world == 1 and not args.no_icp_variant and not replay:      # a one-GPU secondary line: not while other ranks wait
             out["icp_variant"] = icp_variant(frames64, mats0, clusters0, dev, warm_rounds, timed_rounds)
         if not STUB and world == 1 and not args.no_cpu_baseline:

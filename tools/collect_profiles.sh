@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repository root: bench lines + rocprofv3 evidence into gpurun_out/final/.
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
-# then here:  python tools/summarize_profiles.py gpurun_out/final r02
+# then here:  python tools/summarize_profiles.py gpurun_out/final r03
 set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
@@ -18,12 +18,17 @@ python $R/bench.py --workload c5 --steps 12 --warmup 2 > $O/bench_c5.log 2>/dev/
 python $R/tests/measure/bench_c5_resegment.py > $O/c5_resegment.log 2>/dev/null
 python $R/tests/measure/profile_icp_frame.py both 2>/dev/null | grep -v amdgpu.ids > $O/icp_frame_phases.log
 CMD="python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -o r02 -- $CMD > $O/prof_run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats -- $CMD > $O/prof_run.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o c5 -- python $R/bench.py --workload c5 --steps 4 --warmup 1 > $O/prof_c5.log 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O -o pmc_$c -- python $R/bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline > $O/pmc_$c.log 2>&1
+# counters: one set per pass (FETCH_SIZE | WRITE_SIZE | the SQ set), per workload, never together with a trace domain other than --kernel-trace
+for wl in wx200_5 franka allegro; do
+  steps=5; [ $wl = franka ] && steps=5
+  W="python $R/bench.py --workload $wl --steps $steps --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O -o pmc_${wl}_$c -- $W > $O/pmc_${wl}_$c.log 2>&1
+  done
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O -o pmc_${wl}_sq -- $W > $O/pmc_${wl}_sq.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O -o pmc_sq -- python $R/bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline > $O/pmc_sq.log 2>&1
 rm -f $O/*_kernel_trace.csv $O/*_agent_info.csv $O/*_domain_stats.csv
-ls -la $O | head -40
+ls -la $O | head -60
 tail -c 600 $O/bench.log
