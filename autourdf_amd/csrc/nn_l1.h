@@ -169,9 +169,13 @@ __device__ __forceinline__ void nn_l1_block(
 // clouds 2-3 of the 64-80 blocks are visited.
 struct NnBlocks { const float4* ts4; const float* tbox; int nblk; const int* nblk_dev; };
 
+// stop_flag (optional, wave-uniform address): non-zero = the caller's train has stopped early -- the block returns before
+// its search (the flag is requested with the first loads and tested after the box bounds, so a live search pays nothing).
 template <int NB, int PPL, typename Epi>
-__device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int sq, NnBlocks tb, int dir, Epi& epi, int blk) {
+__device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int sq, NnBlocks tb, int dir, Epi& epi, int blk,
+                                                   const int* stop_flag = nullptr) {
     constexpr int QW = 4;
+    const int stop = stop_flag ? *stop_flag : 0;
     __shared__ float s_partp[NN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,6 +221,7 @@ __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int s
         if (!found) pend[u][0] = 1ull;                          // NaN bound: any block, nothing will be taken
         bd[u] = INFINITY; bi[u] = 0x7fffffff; tx[u] = ty[u] = tz[u] = 0.f; wb[u] = INFINITY;
     }
+    if (stop) return;                                           // workgroup-uniform
     bool more = true;
     while (more) {
         int b[QW];

@@ -239,6 +239,8 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bst
     __shared__ float m2s[12];
     const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NO = D.OA + D.OB;
+    const int stopped = W.state[par].stopped;      // early stop (mlp_reg.py:107-111): the remaining epochs of a captured graph
+                                                   // return at their first barrier (requested with the first loads: no extra wait)
     // loads that do not depend on the dot products go first so they share its round trip
     float pin[8];
 #pragma unroll
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bst
         if (lane == 0) outs[o] = s;
     }
     __syncthreads();
+    if (stopped) return;
     if (threadIdx.x == 0) {
         const float* in = pin;
         float R[9], t[3], save[16];
@@ -526,10 +529,12 @@ __global__ __launch_bounds__(512) void k_sort_p(Dims D, Ws W0, size_t bstride) {
 struct EngineEpi {
     int* sgn_x; int4* cnt4; float* lossp_x; float* lossp_y;
     size_t bstride;
+    const int* stopped;            // &state[epoch & 1].stopped of problem 0 (nullptr: no early exit)
     __device__ __forceinline__ void shift(int z) {
         const size_t b = (size_t)z * bstride;
         sgn_x = (int*)((char*)sgn_x + b); cnt4 = (int4*)((char*)cnt4 + b);
         lossp_x = (float*)((char*)lossp_x + b); lossp_y = (float*)((char*)lossp_y + b);
+        if (stopped) stopped = (const int*)((const char*)stopped + b);
     }
     __device__ __forceinline__ void operator()(int dir, int q, int idx, float d, float qx, float qy, float qz,
                                                float tx, float ty, float tz, float& acc) const {
@@ -565,12 +570,12 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_plan(const float* A, int na, co
     yb.ts4 = (const float4*)((const char*)yb.ts4 + zb);
     yb.tbox = (const float*)((const char*)yb.tbox + zb);
     epi.shift(z);
-    if (bx < blocksA) nn_l1_block_pruned<1, PPL, EngineEpi>(A, na, 4, yb, 0, epi, bx);
+    if (bx < blocksA) nn_l1_block_pruned<1, PPL, EngineEpi>(A, na, 4, yb, 0, epi, bx, epi.stopped);
     else if constexpr (P1) {
         pb.ts4 = (const float4*)((const char*)pb.ts4 + zb);
         pb.tbox = (const float*)((const char*)pb.tbox + zb);
         pb.nblk_dev = (const int*)((const char*)pb.nblk_dev + zb);
-        nn_l1_block_pruned<2, PPL, EngineEpi>(B, nb, 4, pb, 1, epi, bx - blocksA);
+        nn_l1_block_pruned<2, PPL, EngineEpi>(B, nb, 4, pb, 1, epi, bx - blocksA, epi.stopped);
     } else nn_l1_block<4, int, EngineEpi>(A, na, 4, B, nb, 4, nullptr, nullptr, nullptr, nullptr, blocksA, epi, bx);
 }
 
@@ -847,6 +852,7 @@ __global__ __launch_bounds__(B2_THREADS) void k_bwd2(Dims D, Ws W0, int epoch, s
         }
         stage_wait();
         __syncthreads();
+        if (!live) return;                             // a stopped train: nothing below may be stored (workgroup-uniform)
         if (fma_wave) {
             nn_f2 acc[B2_RB];
 #pragma unroll
@@ -1032,6 +1038,7 @@ __global__ __launch_bounds__(DW_BLOCK, 2) void k_dw(Dims D, Ws W0, int epoch, si
         }
         stage_wait();
         __syncthreads();
+        if (!live) return;                             // a stopped train: nothing below may be stored (workgroup-uniform)
 #pragma unroll 2
         for (int r = 0; r < nr; ++r) {
             const float* a = as + r * awidth;
@@ -1235,8 +1242,8 @@ static void launch_dw(Plan* P, int epoch, hipStream_t s) {
     hipLaunchKernelGGL(k_dw_fold, dim3(1), dim3(1), 0, s);
 #endif
 }
-static void launch_nn(const Dims& D, const Ws& W, size_t bstride, int nz, hipStream_t s) {
-    const EngineEpi epi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, bstride};
+static void launch_nn(const Dims& D, const Ws& W, size_t bstride, int nz, hipStream_t s, int par = 0) {
+    const EngineEpi epi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, bstride, &W.state[par].stopped};
     if (D.nyb) {
         const NnGrid g = nn_grid(D.NP, D.NT, true, true);
         const NnBlocks yb{W.ys4, W.ybox, D.nyb, nullptr}, pb{W.ps4, W.pbox, 0, W.sb + D.K};
@@ -1262,7 +1269,7 @@ static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nu
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], s); };
     mark(0);
     launch_head(P, par, s); mark(1);
-    launch_nn(D, W, P->bstride, P->nz, s); mark(2);
+    launch_nn(D, W, P->bstride, P->nz, s, par); mark(2);
     hipLaunchKernelGGL(k_gradc, dim3(D.K, 1, P->nz), dim3(256), 0, s, D, W, epoch, D.nbx, D.nby, P->bstride); mark(3);
     launch_bwd2(P, epoch, s); mark(4);
     launch_dw(P, epoch, s); mark(5);

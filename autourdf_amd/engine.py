@@ -102,7 +102,7 @@ class BatchRegistrar:
         """One batched `train` (mlp_reg.py:17-152) of the S problems (m, y, pts, offsets, params); a seam so the
         match-level golden test can replay the reference's loop with the deterministic stub the golden was minted
         with (tests/_match_stub.py).  Returns per problem (best_m, best_pred, result, ...)."""
-        return self.plan.run_batch(problems, lr=lr)
+        return self.plan.run_batch(problems, lr=lr, stop=getattr(self, "stop", 200))
 
     def step(self, frames64, frames32=None):
         """frames64: list of S (N,3) fp64 device tensors (the next frame of every sequence)."""

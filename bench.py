@@ -447,6 +447,9 @@ def main(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="eager launches instead of the captured epoch graph")
     ap.add_argument("--graph-branches", type=int, default=0, help="parallel chains in the captured graph (0 = the library's default)")
+    ap.add_argument("--stop", type=int, default=200,
+                    help="early-stopping patience of train() (mlp_reg.py:17: stop=200, the default and the headline's); a small value "
+                         "forces early stops to show what a stopped train costs")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="wx200_5",
                     help="default = the configuration BASELINE.json's metric is quoted on")
     args = ap.parse_args(argv)
@@ -513,6 +516,7 @@ def main(argv=None):
     frames32 = [[f.to(torch.float32) for f in s] for s in frames64]
     reg = Registrar(mats0, clusters0, n_points, S, "q", HIDDEN, EPOCHS, not args.eager, dev,
                     seeds=seq_ids, graph_branches=args.graph_branches)
+    reg.stop = args.stop
     epochs_log = []
 
     def note_epochs():
@@ -582,8 +586,10 @@ def main(argv=None):
             ep = {"epochs_run_step": {"min": int(e[:, 0].min()), "mean": round(float(e[:, 0].mean()), 1)},
                   "epochs_run_anchor": {"min": int(e[:, 1].min()), "mean": round(float(e[:, 1].mean()), 1)},
                   "early_stop": bool((e < EPOCHS).any()),
-                  "early_stop_note": "early stopping is live (stop=200, mlp_reg.py:107-111); after a stop the remaining launches of the "
-                                     "300-epoch graph still run as no-ops, so a stopped train costs the same time as a full one"}
+                  "stop_patience": args.stop,
+                  "early_stop_note": "early stopping is live (mlp_reg.py:107-111; stop=200 unless --stop says otherwise); the epochs of a "
+                                     "captured graph that follow a stop return at their first barrier (each kernel reads the stop flag with "
+                                     "its first loads), so a stopped train costs its launch floors only"}
         out = {"metric": f"registered frames/sec (N={n_points} pts, K={k_clusters} clusters)", "value": round(n_counted / elapsed, 4),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
