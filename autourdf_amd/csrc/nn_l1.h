@@ -181,21 +181,19 @@ __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int s
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q0 = (blk * (NN_BLOCK / 64) + wave) * QW;
     const int nblk = tb.nblk_dev ? *tb.nblk_dev : tb.nblk;
-    unsigned long long valid[NB];
     float lox[NB], loy[NB], loz[NB], hix[NB], hiy[NB], hiz[NB];
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
-        const int ng = min(max(nblk - 64 * g, 0), 64);
-        valid[g] = ng == 64 ? ~0ull : ((1ull << ng) - 1ull);
         // (the box table is allocated for 64 * NB entries: no dependence of these loads on nblk_dev's round trip;
-        //  entries past nblk are masked by `valid`)
+        //  entries past nblk get an infinite bound below)
         const float* bx = tb.tbox + (tb.nblk_dev ? 64 * g + lane : min(64 * g + lane, nblk - 1));
         constexpr int BP = 64 * NB;                             // plane stride
         lox[g] = bx[0]; loy[g] = bx[BP]; loz[g] = bx[2 * BP]; hix[g] = bx[3 * BP]; hiy[g] = bx[4 * BP]; hiz[g] = bx[5 * BP];
     }
     float qx[QW], qy[QW], qz[QW], lb[QW][NB], bd[QW], tx[QW], ty[QW], tz[QW], wb[QW];
     int bi[QW];
-    unsigned long long pend[QW][NB], vis[QW][NB];
+    unsigned long long pend[QW][NB];          // (wave-uniform masks: SGPR pairs.  A visited block's bound is set to +inf
+                                              //  instead of keeping a second mask array: QW x NB x 2 masks ran out of SGPRs at NB > 2)
 #pragma unroll
     for (int u = 0; u < QW; ++u) {
         const int qi = min(q0 + u, nq - 1);
@@ -206,17 +204,17 @@ __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int s
             const float ex = fmaxf(fmaxf(lox[g] - qx[u], qx[u] - hix[g]), 0.f);
             const float ey = fmaxf(fmaxf(loy[g] - qy[u], qy[u] - hiy[g]), 0.f);
             const float ez = fmaxf(fmaxf(loz[g] - qz[u], qz[u] - hiz[g]), 0.f);
-            lb[u][g] = (ex + ey) + ez;                          // same association as l1_dist
-            lm = __builtin_fminf(lm, 64 * g + lane < nblk ? lb[u][g] : INFINITY);
+            const float bound = (ex + ey) + ez;                 // same association as l1_dist
+            lb[u][g] = 64 * g + lane < nblk ? bound : INFINITY; // (slots past the last block: never visited)
+            lm = __builtin_fminf(lm, lb[u][g]);
         }
         const float m = wave_min_fast(lm);                      // start from the block with the smallest bound
         bool found = false;
 #pragma unroll
         for (int g = 0; g < NB; ++g) {
-            const unsigned long long f = __ballot(lb[u][g] == m) & valid[g];
+            const unsigned long long f = __ballot(lb[u][g] == m && 64 * g + lane < nblk);
             pend[u][g] = (!found && f) ? (f & (~f + 1ull)) : 0ull;       // lowest set bit
             found = found || f != 0ull;
-            vis[u][g] = 0ull;
         }
         if (!found) pend[u][0] = 1ull;                          // NaN bound: any block, nothing will be taken
         bd[u] = INFINITY; bi[u] = 0x7fffffff; tx[u] = ty[u] = tz[u] = 0.f; wb[u] = INFINITY;
@@ -250,7 +248,7 @@ __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int s
                 }
 #pragma unroll
                 for (int g = 0; g < NB; ++g)
-                    if ((b[u] >> 6) == g) vis[u][g] |= 1ull << (b[u] & 63);
+                    if ((b[u] >> 6) == g && lane == (b[u] & 63)) lb[u][g] = INFINITY;     // visited: never again
 #pragma unroll
                 for (int k = 0; k < PPL; ++k) {
                     const float d = l1_dist(qx[u], qy[u], qz[u], v[k].x, v[k].y, v[k].z);
@@ -262,7 +260,7 @@ __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int s
                 wb[u] = wave_min_fast(bd[u]);
 #pragma unroll
                 for (int g = 0; g < NB; ++g) {
-                    pend[u][g] = __ballot(lb[u][g] <= wb[u]) & valid[g] & ~vis[u][g];
+                    pend[u][g] = __ballot(lb[u][g] <= wb[u] && lb[u][g] < INFINITY);
                     more |= pend[u][g] != 0ull;
                 }
             }
@@ -306,11 +304,12 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_l1(
 }
 
 struct NnGrid { int qw, blocksA, blocksB, smem; };
-inline NnGrid nn_grid(int na, int nb, bool doA, bool doB) {
-    // queries per wave: 4 fills all 256 CUs at N=4096; larger clouds amortise LDS reads with 8
+inline NnGrid nn_grid(int na, int nb, bool doA, bool doB, int force_qw = 0) {
+    // queries per wave: 4 fills all 256 CUs at N=4096; larger clouds amortise LDS reads with 8 (force_qw: the train plan
+    // always cuts its queries in fours, so that its loss partials do not depend on the search it runs)
     const long total = (long)(doA ? na : 0) + (long)(doB ? nb : 0);
     NnGrid g;
-    g.qw = (total / (8 * 8) >= 2048) ? 8 : 4;
+    g.qw = force_qw ? force_qw : ((total / (8 * 8) >= 2048) ? 8 : 4);
     const int per = (NN_BLOCK / 64) * g.qw;
     g.blocksA = doA ? (na + per - 1) / per : 0;
     g.blocksB = doB ? (nb + per - 1) / per : 0;
@@ -323,8 +322,8 @@ inline NnGrid nn_grid(int na, int nb, bool doA, bool doB) {
 template <typename IdxT, typename Epi>
 inline void launch_nn_l1(const float* A, int na, int sa, const float* B, int nb, int sb, float* dA, IdxT* iA,
                          float* dB, IdxT* iB, bool doA, bool doB, Epi epi, hipStream_t s, int nz = 1,
-                         size_t zstride = 0) {
-    const NnGrid g = nn_grid(na, nb, doA, doB);
+                         size_t zstride = 0, int force_qw = 0) {
+    const NnGrid g = nn_grid(na, nb, doA, doB, force_qw);
     if (g.blocksA + g.blocksB == 0) return;
     if (g.qw == 8)
         hipLaunchKernelGGL((k_nn_l1<8, IdxT, Epi>), dim3(g.blocksA + g.blocksB, 1, nz), dim3(NN_BLOCK), g.smem, s, A, na, sa,

@@ -38,10 +38,11 @@ struct Dims {
     int nbx, nby;  // NN blocks per direction (= loss partial counts)
     int nyb;       // 64-point blocks of the sorted target frame (0: exhaustive search only)
     int npb;       // upper bound of the blocks of the predicted cloud, clusters padded (0: that direction exhaustive)
-    int ppl;       // points per lane and block visit: blocks hold 64 * ppl points (1 up to 4096 targets, 4 up to 16384)
+    int ppl;       // points per lane and block visit: blocks hold 64 * ppl points
+    int nbt, nbp;  // boxes per lane of the search over the target frame / the predicted cloud (their box tables hold 64 nbt / 64 nbp)
 };
 
-constexpr int PS_MAXB = 128;                   // blocks of the predicted cloud: two boxes per lane in the search
+constexpr int PS_MAXB = 512;                   // most blocks of the predicted cloud (clusters padded): eight boxes per lane in the search
 
 struct Hyper {      // uploaded per run
     float lr, factor;
@@ -320,9 +321,9 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bst
             }
             if (D.ppl == 1) {
                 if (lane == 0 && in) {
-                    float* pb = W.pbox + (sl >> 6);            // six planes of PS_MAXB boxes
+                    float* pb = W.pbox + (sl >> 6);            // six planes of 64 nbp boxes
 #pragma unroll
-                    for (int a = 0; a < 6; ++a) pb[a * PS_MAXB] = bx[a];
+                    for (int a = 0; a < 6; ++a) pb[a * 64 * D.nbp] = bx[a];
                 }
             } else {                                             // 4 waves per block, 2 blocks per trip
                 if (lane == 0) {
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bst
                     if (base + 256 * hb < s1) {
                         float v = wbox[4 * hb][a];
                         for (int w = 1; w < 4; ++w) v = a < 3 ? fminf(v, wbox[4 * hb + w][a]) : fmaxf(v, wbox[4 * hb + w][a]);
-                        W.pbox[a * PS_MAXB + (base >> 8) + hb] = v;
+                        W.pbox[a * 64 * D.nbp + (base >> 8) + hb] = v;
                     }
                 }
                 __syncthreads();
@@ -392,13 +393,20 @@ __device__ __forceinline__ void bitonic_segments(unsigned long long* key, int np
 }
 static int pow2_at_least(int n) { int p = 64; while (p < n) p <<= 1; return p; }
 
+// Frames above YS_CHUNK = 16384 points (the keys of one workgroup's LDS) are cut in index order into chunks of that size,
+// one workgroup (grid.x) and one set of 64 leaves of 256 points each: every chunk is a sample of the whole frame, so a
+// query has to look into at least one block per chunk -- a few times the work of a single tree, still a small fraction of
+// the exhaustive sweep (round 2 fell back to it above 16384 targets).
+constexpr int YS_CHUNK = 16384;
 __global__ __launch_bounds__(1024) void k_sort_y(Dims D, Ws W0, size_t bstride, int npow) {
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned long long* key = (unsigned long long*)smem_raw;               // npow keys
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int BS = 64 * D.ppl;
-    for (int j = tid; j < npow; j += 1024) key[j] = j < D.NT ? (unsigned long long)j : ~0ull;
+    const int base = blockIdx.x * YS_CHUNK, nc = min(YS_CHUNK, D.NT - base);        // this chunk's targets [base, base + nc)
+    const int blk0 = base / BS, nblk = (nc + BS - 1) / BS;                            // its blocks [blk0, blk0 + nblk)
+    for (int j = tid; j < npow; j += 1024) key[j] = j < nc ? (unsigned long long)j : ~0ull;
     __syncthreads();
     int level = 0;
     for (int seg = npow; seg > BS; seg >>= 1, ++level) {
@@ -407,7 +415,7 @@ __global__ __launch_bounds__(1024) void k_sort_y(Dims D, Ws W0, size_t bstride, 
             const unsigned long long k = key[j];
             if (k != ~0ull) {
                 const int idx = (int)(k & 0xFFFFull);
-                const float4 p = W.y4[idx];
+                const float4 p = W.y4[base + idx];
                 key[j] = ((unsigned long long)ordered_bits(axis == 0 ? p.x : axis == 1 ? p.y : p.z) << 32) | (unsigned)idx;
             }
         }
@@ -416,18 +424,18 @@ __global__ __launch_bounds__(1024) void k_sort_y(Dims D, Ws W0, size_t bstride, 
     }
     // sorted slots + per-block boxes: wave w handles the 64-slot groups w, w + 16, ...; a block is D.ppl groups
     float* boxes = (float*)(key + npow);                                   // [group][6] scratch behind the keys
-    const int groups = D.nyb * D.ppl;
+    const int groups = nblk * D.ppl;
     for (int gq = wv; gq < groups; gq += 16) {
         const unsigned long long k = key[gq * 64 + lane];
         float4 p = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0x7fffffff));
         float l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
         if (k != ~0ull) {
-            const int j = (int)(k & 0xFFFFull);
+            const int j = base + (int)(k & 0xFFFFull);
             const float4 y = W.y4[j];
             p = make_float4(y.x, y.y, y.z, __int_as_float(j));
             l[0] = h[0] = y.x; l[1] = h[1] = y.y; l[2] = h[2] = y.z;
         }
-        W.ys4[gq * 64 + lane] = p;
+        W.ys4[(size_t)blk0 * BS + gq * 64 + lane] = p;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             for (int off = 32; off >= 1; off >>= 1) {
@@ -440,14 +448,14 @@ __global__ __launch_bounds__(1024) void k_sort_y(Dims D, Ws W0, size_t bstride, 
         }
     }
     __syncthreads();
-    for (int b = tid; b < D.nyb; b += 1024) {
+    for (int b = tid; b < nblk; b += 1024) {
         float o[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
         for (int g = 0; g < D.ppl; ++g)
             for (int c = 0; c < 3; ++c) {
                 o[c] = fminf(o[c], boxes[6 * (b * D.ppl + g) + c]);
                 o[3 + c] = fmaxf(o[3 + c], boxes[6 * (b * D.ppl + g) + 3 + c]);
             }
-        for (int c = 0; c < 6; ++c) W.ybox[c * 64 + b] = o[c];             // six planes of 64 boxes
+        for (int c = 0; c < 6; ++c) W.ybox[c * 64 * D.nbt + blk0 + b] = o[c];     // six planes of 64 nbt boxes
     }
 }
 
@@ -464,7 +472,7 @@ __global__ __launch_bounds__(512) void k_sort_p(Dims D, Ws W0, size_t bstride) {
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned long long* key = (unsigned long long*)smem_raw;
-    __shared__ unsigned char sf[PS_MAXB], sm[PS_MAXB];                  // per block of this cluster: its segment's first block, block count
+    __shared__ unsigned short sf[PS_MAXB], sm[PS_MAXB];                 // per block of this cluster: its segment's first block, block count
     __shared__ int s_more;
     const int tid = threadIdx.x, c = blockIdx.x;
     const int BS = 64 * D.ppl, bshift = D.ppl == 1 ? 6 : 8;
@@ -479,10 +487,20 @@ __global__ __launch_bounds__(512) void k_sort_p(Dims D, Ws W0, size_t bstride) {
     const int ns = m * BS;
     int npow = 64;
     while (npow < ns) npow <<= 1;
+    if (npow > YS_CHUNK) {
+        // a cluster above 16384 slots does not fit one workgroup's LDS: its blocks keep the points' given order (any
+        // permutation gives the same search result -- the boxes are reduced from whatever a block holds -- it only prunes less)
+        for (int sl = tid; sl < ns; sl += 512) {
+            float4 o = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
+            if (sl < n) { const float4 p = W.pts4[p0 + sl]; o = make_float4(p.x, p.y, p.z, __int_as_float(p0 + sl)); }
+            W.psl4[(size_t)first * BS + sl] = o;
+        }
+        return;
+    }
     for (int sl = tid; sl < npow; sl += 512) key[sl] = sl >= ns ? ~0ull : sl < n ? (unsigned long long)(p0 + sl) : 0xFFFFull;
-    for (int b = tid; b < m; b += 512) { sf[b] = 0; sm[b] = (unsigned char)m; }
+    for (int b = tid; b < m; b += 512) { sf[b] = 0; sm[b] = (unsigned short)m; }
     __syncthreads();
-    for (int level = 0; level < 8; ++level) {
+    for (int level = 0; level < 9; ++level) {
         if (tid == 0) s_more = 0;
         __syncthreads();
         for (int b = tid; b < m; b += 512) if (sm[b] > 1) s_more = 1;
@@ -500,15 +518,15 @@ __global__ __launch_bounds__(512) void k_sort_p(Dims D, Ws W0, size_t bstride) {
         }
         __syncthreads();
         bitonic_segments(key, npow, npow, tid, 512);
-        unsigned char nf = 0, nm = 0;
+        unsigned short nf = 0, nm = 0;
         const bool mine = tid < m;
         if (mine) {
             const int f = sf[tid], mm = sm[tid];
-            nf = (unsigned char)f; nm = (unsigned char)mm;
+            nf = (unsigned short)f; nm = (unsigned short)mm;
             if (mm >= 2) {
                 const int ml = mm >> 1;
-                if (tid < f + ml) nm = (unsigned char)ml;
-                else { nf = (unsigned char)(f + ml); nm = (unsigned char)(mm - ml); }
+                if (tid < f + ml) nm = (unsigned short)ml;
+                else { nf = (unsigned short)(f + ml); nm = (unsigned short)(mm - ml); }
             }
         }
         __syncthreads();
@@ -554,7 +572,7 @@ struct EngineEpi {
 // points (pruned, exact); direction 1 searches the predicted cloud for the target points -- over k_head's
 // block-sorted copy of it (P1) or exhaustively.  Same epilogue, same per-block loss partials as k_nn_l1: the
 // launches are interchangeable bit for bit.
-template <bool P1, int PPL>
+template <bool P1, int PPL, int NBT, int NBP>
 __global__ __launch_bounds__(NN_BLOCK) void k_nn_plan(const float* A, int na, const float* B, int nb, int blocksA,
                                                       int blocksB, EngineEpi epi, NnBlocks yb, NnBlocks pb, size_t zstride) {
     // grid.x = (blocksA + blocksB) * problems, direction 1 (the long blocks when it is exhaustive) of ALL problems
@@ -570,12 +588,12 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_plan(const float* A, int na, co
     yb.ts4 = (const float4*)((const char*)yb.ts4 + zb);
     yb.tbox = (const float*)((const char*)yb.tbox + zb);
     epi.shift(z);
-    if (bx < blocksA) nn_l1_block_pruned<1, PPL, EngineEpi>(A, na, 4, yb, 0, epi, bx, epi.stopped);
+    if (bx < blocksA) nn_l1_block_pruned<NBT, PPL, EngineEpi>(A, na, 4, yb, 0, epi, bx, epi.stopped);
     else if constexpr (P1) {
         pb.ts4 = (const float4*)((const char*)pb.ts4 + zb);
         pb.tbox = (const float*)((const char*)pb.tbox + zb);
         pb.nblk_dev = (const int*)((const char*)pb.nblk_dev + zb);
-        nn_l1_block_pruned<2, PPL, EngineEpi>(B, nb, 4, pb, 1, epi, bx - blocksA, epi.stopped);
+        nn_l1_block_pruned<NBP, PPL, EngineEpi>(B, nb, 4, pb, 1, epi, bx - blocksA, epi.stopped);
     } else nn_l1_block<4, int, EngineEpi>(A, na, 4, B, nb, 4, nullptr, nullptr, nullptr, nullptr, blocksA, epi, bx);
 }
 
@@ -1160,14 +1178,23 @@ static bool make_dims(const creg_train_shape* s, Dims* D) {
     D->oW3B = o; o += D->OB * D->HB; D->ob3B = o; o += D->OB;
     D->NPAR = o;
     if (D->H2 % 32 || D->H % B2_CB || D->H2 > 256 * GC_QMAX) return false;
-    const NnGrid g = nn_grid(D->NP, D->NT, true, true);
+    const NnGrid g = nn_grid(D->NP, D->NT, true, true, 4);
     D->nbx = g.blocksA; D->nby = g.blocksB;
-    // block-pruned search of the (static) target cloud: one box per lane, 4 queries per wave
+    // block-pruned search: 4 queries per wave, a lane holds nbt boxes of the (static) target frame / nbp of the predicted cloud
+    // (clusters padded to whole blocks: up to 8 x 64 of them; round 2 stopped at 128 and sent K > 64 at N = 4096 to the
+    // exhaustive kernel).  Blocks of 64 points (one per lane and visit) up to 4096 targets, of 256 points (four per lane and
+    // visit) beyond: measured at the franka shape (N = 16384, K = 40), 64-point blocks with 4 + 5 boxes per lane take 67.6 us
+    // per NN launch against 46 for 64 + 104 blocks of 256 -- evaluating nine boxes per query and lane costs more than the
+    // finer blocks save.  The target frame is cut into k-d leaves in LDS, 16384 points per workgroup (k_sort_y; up to four
+    // chunks), a cluster by one workgroup (k_sort_p): n_tgt <= 65536, n_pred < 65535 (16-bit indices in the sort keys) and
+    // clusters of at most 16384 points are this form's limits; outside them the plan runs the exhaustive kernel per direction.
     D->ppl = D->NT <= 64 * 64 ? 1 : 4;
     const int BS = 64 * D->ppl;
-    D->nyb = (s->nn_search == 0 && D->NT <= 64 * BS && g.qw == 4) ? (D->NT + BS - 1) / BS : 0;
-    // the other direction: clusters padded to whole blocks, two boxes per lane -> at most 128 blocks
+    D->nyb = (s->nn_search == 0 && D->NT <= 4 * YS_CHUNK && g.qw == 4) ? (D->NT + BS - 1) / BS : 0;      // (chunks of 16384: k_sort_y)
     D->npb = (D->nyb && D->NP < 65535 && (D->NP + BS - 1) / BS + D->K <= PS_MAXB) ? (D->NP + BS - 1) / BS + D->K : 0;
+    const int nt = (D->nyb + 63) / 64, np = (D->npb + 63) / 64;
+    D->nbt = nt <= 1 ? 1 : (nt <= 2 ? 2 : 4);
+    D->nbp = np <= 2 ? 2 : (np <= 3 ? 3 : (np <= 4 ? 4 : (np <= 5 ? 5 : (np <= 6 ? 6 : 8))));
     return true;
 }
 
@@ -1184,9 +1211,9 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     w.pts4 = (float4*)take(sizeof(float4) * D.NP); w.y4 = (float4*)take(sizeof(float4) * D.NT);
     w.pred4 = (float4*)take(sizeof(float4) * D.NP);
     const size_t bs = 64 * (size_t)D.ppl;
-    w.ys4 = (float4*)take(sizeof(float4) * bs * (D.nyb ? D.nyb : 1)); w.ybox = (float*)take(f * 6 * 64);
+    w.ys4 = (float4*)take(sizeof(float4) * bs * (D.nyb ? D.nyb : 1)); w.ybox = (float*)take(f * 6 * 64 * D.nbt);
     w.psl4 = (float4*)take(sizeof(float4) * bs * (D.npb ? D.npb : 1)); w.ps4 = (float4*)take(sizeof(float4) * bs * (D.npb ? D.npb : 1));
-    w.pbox = (float*)take(f * 6 * 128); w.sb = (int*)take(sizeof(int) * (D.K + 1));
+    w.pbox = (float*)take(f * 6 * 64 * D.nbp); w.sb = (int*)take(sizeof(int) * (D.K + 1));
     w.sgn_x = (int*)take(sizeof(int) * D.NP);
     w.cnt4 = (int4*)take(sizeof(int4) * D.NP);
     w.lossp_x = (float*)take(f * D.nbx); w.lossp_y = (float*)take(f * D.nby);
@@ -1245,18 +1272,37 @@ static void launch_dw(Plan* P, int epoch, hipStream_t s) {
 static void launch_nn(const Dims& D, const Ws& W, size_t bstride, int nz, hipStream_t s, int par = 0) {
     const EngineEpi epi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, bstride, &W.state[par].stopped};
     if (D.nyb) {
-        const NnGrid g = nn_grid(D.NP, D.NT, true, true);
+        const NnGrid g = nn_grid(D.NP, D.NT, true, true, 4);
         const NnBlocks yb{W.ys4, W.ybox, D.nyb, nullptr}, pb{W.ps4, W.pbox, 0, W.sb + D.K};
         const dim3 grid((g.blocksA + g.blocksB) * nz);
         auto go = [&](auto kern, int smem) {
             hipLaunchKernelGGL(kern, grid, dim3(NN_BLOCK), smem, s, (const float*)W.pred4, D.NP, (const float*)W.y4, D.NT,
                                g.blocksA, g.blocksB, epi, yb, pb, bstride);
         };
-        if (D.npb) { if (D.ppl == 1) go(k_nn_plan<true, 1>, 0); else go(k_nn_plan<true, 4>, 0); }
-        else { if (D.ppl == 1) go(k_nn_plan<false, 1>, g.smem); else go(k_nn_plan<false, 4>, g.smem); }
+        // the instance of this shape: boxes per lane are template arguments (register arrays)
+        auto pick_p = [&](auto ppl, auto nbt) {
+            constexpr int PPL = decltype(ppl)::value, NBT = decltype(nbt)::value;
+            if (!D.npb) { go(k_nn_plan<false, PPL, NBT, 2>, g.smem); return; }
+            switch (D.nbp) {
+                case 2: go(k_nn_plan<true, PPL, NBT, 2>, 0); break;
+                case 3: go(k_nn_plan<true, PPL, NBT, 3>, 0); break;
+                case 4: go(k_nn_plan<true, PPL, NBT, 4>, 0); break;
+                case 5: go(k_nn_plan<true, PPL, NBT, 5>, 0); break;
+                case 6: go(k_nn_plan<true, PPL, NBT, 6>, 0); break;
+                default: go(k_nn_plan<true, PPL, NBT, 8>, 0); break;
+            }
+        };
+        auto pick_t = [&](auto ppl) {
+            switch (D.nbt) {
+                case 1: pick_p(ppl, std::integral_constant<int, 1>{}); break;
+                case 2: pick_p(ppl, std::integral_constant<int, 2>{}); break;
+                default: pick_p(ppl, std::integral_constant<int, 4>{}); break;
+            }
+        };
+        if (D.ppl == 1) pick_t(std::integral_constant<int, 1>{}); else pick_t(std::integral_constant<int, 4>{});
     } else {
         launch_nn_l1<int>((const float*)W.pred4, D.NP, 4, (const float*)W.y4, D.NT, 4, nullptr, nullptr, nullptr, nullptr,
-                          true, true, epi, s, nz, bstride);
+                          true, true, epi, s, nz, bstride, 4);
     }
 }
 constexpr int NKERN = 5;
@@ -1308,15 +1354,19 @@ static int param_map(const Dims& D, ParamMap* pm) {
 }
 
 // After the problems' inputs are staged: the once-per-train block layouts of the two clouds, all problems in one launch each.
-static int ys_sort_npow(const Dims& D) { return pow2_at_least(D.NT); }
-static int ys_sort_smem(const Dims& D) { return ys_sort_npow(D) * 8 + 6 * 4 * D.nyb * D.ppl; }
+static int ys_sort_npow(const Dims& D) { return pow2_at_least(D.NT < YS_CHUNK ? D.NT : YS_CHUNK); }
+static int ys_sort_smem(const Dims& D) {       // keys + [group][6] box scratch of ONE chunk's blocks
+    const int per_chunk = YS_CHUNK / (64 * D.ppl);
+    return ys_sort_npow(D) * 8 + 6 * 4 * (D.nyb < per_chunk ? D.nyb : per_chunk) * D.ppl;
+}
 static int ps_sort_smem(const Dims& D) {       // a cluster can hold every point
     const int BS = 64 * D.ppl;
-    return pow2_at_least((D.NP + BS - 1) / BS * BS) * 8;
+    const int np = pow2_at_least((D.NP + BS - 1) / BS * BS);
+    return (np < YS_CHUNK ? np : YS_CHUNK) * 8;
 }
 static void launch_sorts(Plan* P, hipStream_t s, int nz) {
     const Dims& D = P->D;
-    if (D.nyb) hipLaunchKernelGGL(k_sort_y, dim3(1, 1, nz), dim3(1024), ys_sort_smem(D), s, D, P->W, P->bstride, ys_sort_npow(D));
+    if (D.nyb) hipLaunchKernelGGL(k_sort_y, dim3(cdiv(D.NT, YS_CHUNK), 1, nz), dim3(1024), ys_sort_smem(D), s, D, P->W, P->bstride, ys_sort_npow(D));
     if (D.npb) hipLaunchKernelGGL(k_sort_p, dim3(D.K, 1, nz), dim3(512), ps_sort_smem(D), s, D, P->W, P->bstride);
 }
 

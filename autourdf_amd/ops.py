@@ -490,7 +490,8 @@ class TrainPlan:
                                      ("target -> predicted", self.info["pruned_predicted_search"])) if not on]
             warnings.warn(f"creg train plan (k={k}, n_pred={n_pred}, n_tgt={n_tgt}): exhaustive nearest-neighbour search in the "
                           f"{' and '.join(which)} direction(s) -- the shape is beyond the block-pruned search's limits "
-                          "(n_tgt <= 16384, predicted blocks + k <= 128); same results, several times the launch time", RuntimeWarning, stacklevel=2)
+                          "(n_tgt <= 65536: four chunks of k-d leaves built in LDS; n_pred < 65535 and at most 512 blocks of the padded "
+                          "predicted cloud); same results, several times the launch time", RuntimeWarning, stacklevel=2)
 
     def __del__(self):
         plan = getattr(self, "plan", None)

@@ -748,13 +748,17 @@ def test_graph_branches_bench_shape_bit_identical_to_single_runs(dev):
     ("q", 6, 64, 2048, 4096, True),         # lattice clouds: exact distance ties everywhere
     ("dq", 3, 128, 513, 4033, False),
     ("q", 4, 64, 700, 1, False),            # a single target
-    ("q", 70, 64, 4096, 4096, False),       # 64 + 70 blocks > 128: the target -> predicted direction stays exhaustive
+    ("q", 70, 64, 4096, 4096, False),       # 64 + 70 = 134 predicted blocks: three boxes per lane (round 2: exhaustive above 128)
+    ("q", 150, 64, 9600, 4000, False),      # 150 + 150 = 300 predicted blocks: five boxes per lane
+    ("q", 12, 64, 20000, 20000, False),     # > 16384 targets: two chunks of k-d leaves (the second one ragged), NBT = 2
+    ("dq", 128, 64, 32768, 32768, False),   # the chain32 shape (BASELINE configs[4] scaled down): 2 chunks, 128 + 128 predicted blocks
     ("dq", 1, 64, 4096, 3000, False),       # one cluster of 64 blocks: six k-d levels
     ("q", 9, 64, 640, 900, False),          # cluster sizes forced to multiples of 64 below + an empty cluster
     ("q", 10, 64, 9000, 6000, False),       # > 4096 targets: 256-point blocks, four points per lane and visit
     ("dq", 40, 64, 16384, 16384, False),    # the franka-shaped config (BASELINE configs[2])
     ("q", 3, 64, 500, 5000, False),         # big frame, tiny clusters (one padded 256-block each)
     ("q", 2, 64, 16000, 4097, True),        # lattice ties with 256-point blocks; one cluster of 32 blocks
+    ("q", 4, 64, 3000, 40000, True),        # lattice ties across three chunks of the frame
 ])
 def test_train_pruned_search_bit_identical_to_exhaustive(dev, rot, k, hidden, n_pred, n_tgt, lattice):
     """nn_search 0 (predicted -> target direction over the Morton-sorted, boxed target frame) against nn_search 1
@@ -1134,15 +1138,20 @@ def test_group_to_local_large_frame_stable_partition(dev):
 
 
 def test_train_plan_reports_its_search_form(dev):
-    """creg_train_plan_info: a shape inside the block-pruned search's limits runs it in both directions; one beyond them
-    (70 clusters of one 64-point block each + 70 > 128 predicted blocks) says so -- and ops.TrainPlan warns -- instead of
-    only being slower."""
+    """creg_train_plan_info: a shape inside the block-pruned search's limits runs it in both directions -- since round 3 also
+    70 clusters of one 64-point block each (70 + 70 = 140 predicted blocks: three boxes per lane; round 2 stopped at 128);
+    a 20000-point frame (two chunks of k-d leaves; round 2 stopped at 16384); one beyond the limits (a frame above 65536
+    points) says so -- and ops.TrainPlan warns -- instead of only being slower."""
     import warnings
     from autourdf_amd import ops
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         p = ops.TrainPlan("q", 20, 64, 4096, 4096, epochs=4, device=dev)
-    assert p.info["pruned_target_search"] and p.info["pruned_predicted_search"] and p.info["batch"] == 1
-    with pytest.warns(RuntimeWarning, match="exhaustive nearest-neighbour search"):
         q = ops.TrainPlan("q", 70, 64, 70 * 60, 4096, epochs=4, device=dev)
-    assert q.info["pruned_target_search"] and not q.info["pruned_predicted_search"]
+        c = ops.TrainPlan("q", 8, 64, 2048, 20000, epochs=4, device=dev)
+    assert p.info["pruned_target_search"] and p.info["pruned_predicted_search"] and p.info["batch"] == 1
+    assert q.info["pruned_target_search"] and q.info["pruned_predicted_search"]
+    assert c.info["pruned_target_search"] and c.info["pruned_predicted_search"]
+    with pytest.warns(RuntimeWarning, match="exhaustive nearest-neighbour search"):
+        r = ops.TrainPlan("q", 8, 64, 2048, 70000, epochs=4, device=dev)
+    assert not r.info["pruned_target_search"] and not r.info["pruned_predicted_search"]
