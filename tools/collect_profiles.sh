@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repository root: bench lines + rocprofv3 evidence into gpurun_out/final/.
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
-# then here:  python tools/summarize_profiles.py gpurun_out/final r03
+# then here:  cp gpurun_out/r03_profiles/* profiles/
 set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
@@ -30,5 +30,8 @@ for wl in wx200_5 franka allegro; do
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O -o pmc_${wl}_sq -- $W > $O/pmc_${wl}_sq.log 2>&1
 done
 rm -f $O/*_kernel_trace.csv $O/*_agent_info.csv $O/*_domain_stats.csv
-ls -la $O | head -60
+# summaries on the box (gpurun brings back at most 64 MiB; the raw counter CSVs are ~18 MB each), raw files dropped
+cd $R && python tools/summarize_profiles.py $O r03 $R/gpurun_out/r03_profiles > $R/gpurun_out/r03_profiles_summary.log 2>&1
+rm -f $O/*_counter_collection.csv
+ls -la $R/gpurun_out/r03_profiles | head -40
 tail -c 600 $O/bench.log

@@ -1,6 +1,9 @@
 """Turn the rocprofv3 outputs of a gpurun (gpurun_out/final/) into the tracked summaries under profiles/.
 
-    python tools/summarize_profiles.py gpurun_out/final r03
+    python tools/summarize_profiles.py gpurun_out/final r03 [output directory, default profiles/]
+
+tools/collect_profiles.sh runs it ON THE GPU BOX into gpurun_out/r03_profiles/ (the raw counter CSVs are tens of MB each and
+stay there); copy that directory's files into profiles/ afterwards.
 """
 import collections
 import csv
@@ -33,7 +36,8 @@ def mean(v):
     return sum(v) / len(v) if v else float("nan")
 
 
-def main(src, tag):
+def main(src, tag, dst="profiles"):
+    os.makedirs(dst, exist_ok=True)
     lines, out = [], {}
     for wl, per in (("wx200_5", 2.5), ("franka", 2.5), ("allegro", 2.5)):
         f, _ = agg(f"{src}/pmc_{wl}_FETCH_SIZE_counter_collection.csv")
@@ -64,15 +68,16 @@ def main(src, tag):
               "on average); per-wave values are cycles (quad-cycle counters x4); FETCH_SIZE / WRITE_SIZE are the raw rocprofv3 values in KB.  "
               "MI355X_MICROARCH.md: FETCH_SIZE counts 128-B requests of wide (16 B/lane) coalesced reads as 64 B -> bench.py doubles it "
               "before comparing with a byte count; narrower reads are uncalibrated, so `traffic` of the latency-bound kernels is an upper bound.\n")
-    open(f"profiles/{tag}_pmc_summary.txt", "w").write(header + "\n".join(lines) + "\n")
+    open(f"{dst}/{tag}_pmc_summary.txt", "w").write(header + "\n".join(lines) + "\n")
     out["source"] = ("rocprofv3 --kernel-trace --pmc, separate passes for FETCH_SIZE / WRITE_SIZE / the SQ set per workload, `bench.py --workload W "
                      "--steps 5 --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline` (tools/collect_profiles.sh)")
-    json.dump(out, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
-    cp = lambda a, b: os.path.exists(f"{src}/{a}") and shutil.copy(f"{src}/{a}", f"profiles/{b}")
+    json.dump(out, open(f"{dst}/{tag}_pmc.json", "w"), indent=1)
+    cp = lambda a, b: os.path.exists(f"{src}/{a}") and shutil.copy(f"{src}/{a}", f"{dst}/{b}")
     cp("stats_kernel_stats.csv", f"{tag}_final_kernel_stats.csv")
     cp("c5_kernel_stats.csv", f"{tag}_c5_kernel_stats.csv")
     cp("bench.log", f"{tag}_final_bench.log")
-    cat = lambda names, dst: open(f"profiles/{dst}", "w").write("".join(open(f"{src}/{n}").read() for n in names if os.path.exists(f"{src}/{n}")))
+    dst_dir = dst
+    cat = lambda names, dst: open(f"{dst_dir}/{dst}", "w").write("".join(open(f"{src}/{n}").read() for n in names if os.path.exists(f"{src}/{n}")))
     cat(["bench_b1.log", "bench_b8.log"], f"{tag}_final_bench_b1_b8.log")
     cat(["bench_franka.log", "bench_allegro.log"], f"{tag}_final_bench_other_workloads.log")
     cat(["bench_replay_allegro.log", "bench_c5.log"], f"{tag}_final_bench_replay_and_c5.log")
@@ -85,4 +90,4 @@ def main(src, tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
