@@ -33,9 +33,8 @@ def kmeans_plusplus_sklearn(X, k, random_state):
         d = -2.0 * (Xc[rows] @ Xc.T)
         d += xx[rows][:, None]
         d += xx[None, :]
-        np.maximum(d, 0, out=d)
-        d[np.arange(len(rows)), rows] = 0.0
-        return d
+        np.maximum(d, 0, out=d)                       # (no zeroing of a candidate's own entry: sklearn 1.5-1.7 fills the diagonal only when X is Y,
+        return d                                      #  which X[cand] is not -- the rounding residue stays in the potentials, as there)
 
     trials = 2 + int(np.log(k))
     w = np.ones(n)

@@ -1617,6 +1617,84 @@ extern "C" int creg_aabb_mask_f64(const float* world, const int32_t* world_offse
     return CREG_OK;
 }
 
+// ------------------------------------------------------------------------------------------ closed-form fit alone
+// creg_kabsch_f64: the (weighted) least-squares rigid fit of paired points, per segment -- the fit every ICP iteration of K4
+// runs on its correspondences (open3d TransformationEstimationPointToPoint = Eigen::umeyama without scaling), callable on its
+// own: Horn's unit quaternion of the centred cross-covariance (horn_max_eigvec: Newton + adjugate, Jacobi fallback), which is
+// the proper rotation Umeyama's reflection fix selects.  One workgroup per segment; two passes (weighted centroids, then the
+// centred covariance: no cancellation), every reduction in a fixed order (DPP wave sums, waves in sequence).
+constexpr int KB_NT = 256;
+__device__ __forceinline__ double kb_block_sum(double v, double* sh, int tid) {
+    v = wave_sum_fast(v);
+    __syncthreads();                                   // previous readers of sh are done
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    double r = sh[0];
+#pragma unroll
+    for (int w = 1; w < KB_NT / 64; ++w) r += sh[w];
+    return r;
+}
+__global__ __launch_bounds__(KB_NT) void k_kabsch(const double* __restrict__ src, const double* __restrict__ dst,
+                                                  const double* __restrict__ wgt, const int* __restrict__ off, double* __restrict__ T_out) {
+    __shared__ double sh[KB_NT / 64];
+    const int k = blockIdx.x, tid = threadIdx.x, b = off[k], e = off[k + 1];
+    double sw = 0, s[3] = {0, 0, 0}, d[3] = {0, 0, 0};
+    for (int i = b + tid; i < e; i += KB_NT) {
+        const double w = wgt ? wgt[i] : 1.0;
+        sw += w;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s[a] = fma(w, src[3 * (size_t)i + a], s[a]); d[a] = fma(w, dst[3 * (size_t)i + a], d[a]); }
+    }
+    sw = kb_block_sum(sw, sh, tid);
+    double ms[3], md[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { s[a] = kb_block_sum(s[a], sh, tid); d[a] = kb_block_sum(d[a], sh, tid); }
+    const bool any = sw > 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { ms[a] = any ? s[a] / sw : 0.0; md[a] = any ? d[a] / sw : 0.0; }
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                       // C[a][c] = sum w (s - ms)_a (d - md)_c
+    for (int i = b + tid; i < e; i += KB_NT) {
+        const double w = wgt ? wgt[i] : 1.0;
+        double sc[3], dc[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { sc[a] = src[3 * (size_t)i + a] - ms[a]; dc[a] = dst[3 * (size_t)i + a] - md[a]; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) C[3 * a + c] = fma(w * sc[a], dc[c], C[3 * a + c]);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) C[i] = kb_block_sum(C[i], sh, tid);
+    if (tid != 0) return;
+    double T[16];
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    if (any) {
+        const double Sxx = C[0], Sxy = C[1], Sxz = C[2], Syx = C[3], Syy = C[4], Syz = C[5], Szx = C[6], Szy = C[7], Szz = C[8];
+        double N[4][4] = {{Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx},
+                          {Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz},
+                          {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
+                          {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
+        double q[4], R[9], Vp[16];
+        for (int i = 0; i < 16; ++i) Vp[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        horn_max_eigvec(N, q, Vp);
+        quat_to_matrix(q, R);
+        for (int a = 0; a < 3; ++a) {
+            T[4 * a] = R[3 * a]; T[4 * a + 1] = R[3 * a + 1]; T[4 * a + 2] = R[3 * a + 2];
+            T[4 * a + 3] = md[a] - (R[3 * a] * ms[0] + R[3 * a + 1] * ms[1] + R[3 * a + 2] * ms[2]);
+        }
+    }
+    for (int i = 0; i < 16; ++i) T_out[16 * (size_t)k + i] = T[i];
+}
+
+extern "C" int creg_kabsch_f64(const double* src, const double* dst, const double* weights, int64_t n, const int32_t* offsets,
+                               int32_t k, double* T_out, creg_stream_t stream) {
+    CREG_REQUIRE(src && dst && offsets && T_out, "creg_kabsch_f64: null pointer");
+    CREG_REQUIRE(k >= 1 && n >= 0 && n < (1ll << 31), "creg_kabsch_f64: bad size");
+    hipLaunchKernelGGL(k_kabsch, dim3(k), dim3(KB_NT), 0, (hipStream_t)stream, src, dst, weights, offsets, T_out);
+    CREG_LAUNCH_CHECK();
+    return CREG_OK;
+}
+
 extern "C" int creg_icp_p2p_f64(const double* src, int64_t n_src, const int32_t* src_offsets, const double* tgt,
                                 int64_t n_tgt, const int32_t* tgt_offsets, int32_t k, const double* init, double th,
                                 int32_t max_iteration, double* T_out, double* src_out, int32_t* n_iter_out,

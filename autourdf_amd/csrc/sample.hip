@@ -15,7 +15,7 @@ namespace creg {
 
 __global__ __launch_bounds__(256) void k_sample_mesh(const double* __restrict__ tri, const double* __restrict__ cum_area,
                                                      const int* __restrict__ tri_link, const double* __restrict__ link_T,
-                                                     const double* __restrict__ u, int64_t n, int F,
+                                                     const double* __restrict__ u, int64_t n, int F, int n_links,
                                                      double* __restrict__ out, int* __restrict__ link_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_sample_mesh(const double* __restrict__ 
     double p[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) p[d] = (b0 * t[d] + b1 * t[3 + d]) + b2 * t[6 + d];
-    const int l = tri_link[lo];
+    const int l = min(max(tri_link[lo], 0), n_links - 1);   // a link index outside [0, n_links) would read past link_T: clamped (bad input stays bounded)
     const double* T = link_T + 16 * (size_t)l;
 #pragma unroll
     for (int d = 0; d < 3; ++d) out[3 * i + d] = ((T[4 * d] * p[0] + T[4 * d + 1] * p[1]) + T[4 * d + 2] * p[2]) + T[4 * d + 3];
@@ -68,13 +68,13 @@ __global__ __launch_bounds__(256) void k_depth_clear(unsigned long long* __restr
 }
 
 // grid (ceil(F / 256), C): thread = (triangle, camera)
-__global__ __launch_bounds__(256) void k_raster_depth(const double* __restrict__ tri, const int* __restrict__ tri_link, int F,
+__global__ __launch_bounds__(256) void k_raster_depth(const double* __restrict__ tri, const int* __restrict__ tri_link, int F, int n_links,
                                                       const double* __restrict__ link_T, const double* __restrict__ cams,
                                                       CamParams c, unsigned long long* __restrict__ zbuf) {
     const int f = blockIdx.x * 256 + threadIdx.x, cam_id = blockIdx.y;
     if (f >= F) return;
     const double* cam = cams + 12 * cam_id;
-    const double* T = link_T + 16 * (size_t)tri_link[f];
+    const double* T = link_T + 16 * (size_t)min(max(tri_link[f], 0), n_links - 1);
     double X[3], Y[3], D[3];
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
@@ -84,15 +84,19 @@ __global__ __launch_bounds__(256) void k_raster_depth(const double* __restrict__
         for (int a = 0; a < 3; ++a) w[a] = ((T[4 * a] * q[0] + T[4 * a + 1] * q[1]) + T[4 * a + 2] * q[2]) + T[4 * a + 3];
         double xc, yc;
         cam_project(cam, w, xc, yc, D[v]);
-        if (!(D[v] >= c.near_v)) return;                // a vertex at or behind the near plane: the facet is not drawn
+        if (!(D[v] >= c.near_v)) return;                // a vertex at or behind the near plane: the facet is not drawn (NO clipping
+                                                        // against the near plane: a large facet that reaches behind it stops occluding;
+                                                        // the camera ring stands 10+ near distances off the robot, so none does)
         cam_pixel(c, xc, yc, D[v], X[v], Y[v]);
     }
     const double area = (X[1] - X[0]) * (Y[2] - Y[0]) - (X[2] - X[0]) * (Y[1] - Y[0]);
     if (area == 0.0) return;
     const double xmin = fmin(X[0], fmin(X[1], X[2])), xmax = fmax(X[0], fmax(X[1], X[2]));
     const double ymin = fmin(Y[0], fmin(Y[1], Y[2])), ymax = fmax(Y[0], fmax(Y[1], Y[2]));
-    const int x0 = max(0, (int)floor(xmin - 0.5)), x1 = min(c.W - 1, (int)ceil(xmax - 0.5));
-    const int y0 = max(0, (int)floor(ymin - 0.5)), y1 = min(c.H - 1, (int)ceil(ymax - 0.5));
+    // pixel bounds clamped BEFORE the integer conversion (a huge projected coordinate would overflow the cast)
+    const int x0 = (int)fmax(0.0, floor(xmin - 0.5)), x1 = (int)fmin((double)(c.W - 1), ceil(xmax - 0.5));
+    const int y0 = (int)fmax(0.0, floor(ymin - 0.5)), y1 = (int)fmin((double)(c.H - 1), ceil(ymax - 0.5));
+    if (!(xmin - 0.5 <= (double)c.W) || !(ymin - 0.5 <= (double)c.H) || !(xmax >= -1.0) || !(ymax >= -1.0)) return;   // off screen / NaN
     const double ia = 1.0 / area, i0 = 1.0 / D[0], i1 = 1.0 / D[1], i2 = 1.0 / D[2];
     unsigned long long* z = zbuf + (size_t)cam_id * c.W * c.H;
     for (int y = y0; y <= y1; ++y)
@@ -148,7 +152,7 @@ extern "C" int creg_visibility_f64(const double* tri, const int32_t* tri_link, i
     const size_t npx = (size_t)n_cams * width * height;
     CamParams c{tan(fov_deg * 3.14159265358979323846 / 360.0), aspect, near_val, far_val, width, height};
     hipLaunchKernelGGL(k_depth_clear, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, (unsigned long long*)workspace, npx);
-    hipLaunchKernelGGL(k_raster_depth, dim3(cdiv(n_tri, 256), n_cams), dim3(256), 0, s, tri, tri_link, (int)n_tri, link_T, cams, c,
+    hipLaunchKernelGGL(k_raster_depth, dim3(cdiv(n_tri, 256), n_cams), dim3(256), 0, s, tri, tri_link, (int)n_tri, (int)n_links, link_T, cams, c,
                        (unsigned long long*)workspace);
     hipLaunchKernelGGL(k_visible, dim3((unsigned)cdiv(n, (int64_t)256)), dim3(256), 0, s, pts, n, cams, (int)n_cams, c,
                        (const unsigned long long*)workspace, eps, visible);
@@ -162,7 +166,7 @@ extern "C" int creg_sample_mesh_f64(const double* tri, const double* cum_area, c
     CREG_REQUIRE(tri && cum_area && tri_link && link_T && u && out, "creg_sample_mesh_f64: null pointer");
     CREG_REQUIRE(n_tri >= 1 && n_links >= 1 && n >= 1, "creg_sample_mesh_f64: bad size");
     hipLaunchKernelGGL(k_sample_mesh, dim3((unsigned)cdiv(n, (int64_t)256)), dim3(256), 0, (hipStream_t)stream, tri, cum_area,
-                       tri_link, link_T, u, n, (int)n_tri, out, link_out);
+                       tri_link, link_T, u, n, (int)n_tri, (int)n_links, out, link_out);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }

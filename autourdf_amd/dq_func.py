@@ -2,13 +2,14 @@
 function names and argument meaning, dq_func.py:4,29,47,72,100,126,148,170,188,213,238).
 
 Tensors are (...,8) = [real (w,x,y,z) | dual]; every function takes fp32 CUDA tensors and runs a
-HIP row kernel from libcreg.so (K5).  ``dualquat_to_transform`` is differentiable (it sits inside
-the reference's autograd graph at mlp_reg.py:83-84); ``transform_to_dualquat`` only ever sees the
-detached pose there (mlp_reg.py:80) and refuses inputs that require grad rather than silently
-dropping the gradient.
+HIP row kernel from libcreg.so (K5).  Like the reference's plain-torch functions, all of them are
+transparent to autograd: ``dualquat_to_transform`` (inside the reference's graph at mlp_reg.py:83-84)
+has its adjoint kernel; for the others the forward is the kernel and the backward differentiates the
+same formula in PyTorch-ROCm tensor ops on the device (``_dq_autograd``).
 """
 import torch
 
+from . import _dq_autograd as _ag
 from . import ops
 
 
@@ -20,12 +21,6 @@ def _rows(t: torch.Tensor, width):
     lead = t.shape[:-len(width)] if isinstance(width, tuple) else t.shape[:-1]
     w = width if isinstance(width, tuple) else (width,)
     return t.reshape((-1,) + w).contiguous(), lead
-
-
-def _no_grad(*ts):
-    for t in ts:
-        if t.requires_grad:
-            raise NotImplementedError("this dq_func kernel has no backward; detach the input")
 
 
 def transform_from_rot_trans(R: torch.Tensor, t: torch.Tensor):
@@ -42,10 +37,9 @@ def quaternion_conjugate(q: torch.Tensor) -> torch.Tensor:
 
 def quat_trans_to_dualquat(q: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
     assert q.shape[-1] == 4 and t.shape[-1] == 3
-    _no_grad(q, t)
     qr, lead = _rows(q, 4)
     tr, _ = _rows(t, 3)
-    return ops.quat_trans_to_dq(qr, tr).reshape(lead + (8,))
+    return _ag.with_torch_backward(ops.quat_trans_to_dq, _ag.quat_trans_to_dualquat, qr, tr).reshape(lead + (8,))
 
 
 def rot_trans_to_dualquat(R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
@@ -55,16 +49,14 @@ def rot_trans_to_dualquat(R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
 
 def transform_to_dualquat(T: torch.Tensor) -> torch.Tensor:
     assert T.shape[-2:] == (4, 4)
-    _no_grad(T)
     Tr, lead = _rows(T, (4, 4))
-    return ops.se3_to_dq(Tr).reshape(lead + (8,))
+    return _ag.with_torch_backward(ops.se3_to_dq, _ag.transform_to_dualquat, Tr).reshape(lead + (8,))
 
 
 def dualquat_to_quat_trans(dq: torch.Tensor):
     assert dq.shape[-1] == 8
-    _no_grad(dq)
     d, lead = _rows(dq, 8)
-    q, t = ops.dq_to_quat_trans(d)
+    q, t = _ag.with_torch_backward(ops.dq_to_quat_trans, _ag.dualquat_to_quat_trans, d)
     return q.reshape(lead + (4,)), t.reshape(lead + (3,))
 
 
@@ -93,17 +85,15 @@ def dualquat_to_rot_trans(dq: torch.Tensor):
 
 def dualquat_multiply(dq1: torch.Tensor, dq2: torch.Tensor) -> torch.Tensor:
     assert dq1.shape[-1] == 8 and dq2.shape[-1] == 8
-    _no_grad(dq1, dq2)
     a, lead = _rows(dq1, 8)
     b, _ = _rows(dq2, 8)
-    return ops.dq_multiply(a, b).reshape(lead + (8,))
+    return _ag.with_torch_backward(ops.dq_multiply, _ag.dualquat_multiply, a, b).reshape(lead + (8,))
 
 
 def dualquat_invert(dq: torch.Tensor) -> torch.Tensor:
     assert dq.shape[-1] == 8
-    _no_grad(dq)
     d, lead = _rows(dq, 8)
-    return ops.dq_invert(d).reshape(lead + (8,))
+    return _ag.with_torch_backward(ops.dq_invert, _ag.dualquat_invert, d).reshape(lead + (8,))
 
 
 def point_to_dualquat(p: torch.Tensor) -> torch.Tensor:

@@ -239,6 +239,26 @@ def icp_p2p_batch(problems, th: float = 1.0, max_iteration: int = 100000):
     return outs
 
 
+def kabsch(src, dst, offsets, weights=None):
+    """Closed-form (weighted) rigid fit of paired points per segment (creg_kabsch_f64): src, dst (n,3) f64, offsets (k+1)
+    i32, weights (n) f64 or None -> T (k,4,4) f64 with T src ~ dst in the least-squares sense (open3d point-to-point
+    estimation / Umeyama without scaling); identity for a segment without pairs."""
+    L = _lib.load()
+    src, dst = _need(src, torch.float64, "src"), _need(dst, torch.float64, "dst")
+    offsets = _need(offsets, torch.int32, "offsets")
+    if src.shape != dst.shape or src.dim() != 2 or src.shape[1] != 3:
+        raise ValueError("kabsch: src and dst must both be (n,3)")
+    if weights is not None:
+        weights = _need(weights, torch.float64, "weights")
+        if weights.shape[0] != src.shape[0]:
+            raise ValueError("kabsch: one weight per pair")
+    k = offsets.shape[0] - 1
+    T = torch.empty(k, 4, 4, dtype=torch.float64, device=src.device)
+    _lib.check(L.creg_kabsch_f64(_p(src), _p(dst), _p(weights) if weights is not None else None, src.shape[0], _p(offsets), k, _p(T),
+                                 _stream()), "creg_kabsch_f64")
+    return T
+
+
 def icp_p2p(src, src_offsets, tgt, tgt_offsets, init, th: float = 1.0, max_iteration: int = 100000):
     """`icp_p2p_batch` for one problem, through creg_icp_p2p_f64."""
     L = _lib.load()
@@ -332,7 +352,10 @@ def masked_icp(local: torch.Tensor, world: torch.Tensor, offsets: torch.Tensor, 
     segment offsets `world_offsets` (None: the same segmentation as `local`; match()'s --mlp_icp branch passes the
     frame-0 clusters as `local` and the trained clouds of the current segmentation as `world`, mlp_reg.py:325),
     frame (nf,3) f64, M (k,4,4) f64 initial poses.  Returns (M_out (k,4,4) f64, world_out (n,3) f64,
-    iterations (k) int32); stream-ordered, no host sync."""
+    iterations (k) int32).  Stream-ordered with no host sync in the one-launch regime (clusters of at most 1024 points on
+    average and frames of at most 65536 points: `masked_icp_regime(n, nf, k) == "one_launch"`); in the many-workgroup regime
+    (configs[4]-sized clusters) the call synchronises the stream every 16 ICP iterations to read two words (creg.h) -- it
+    blocks the host and cannot be captured in a graph."""
     L = _lib.load()
     local, world = _need(local, torch.float64, "local"), _need(world, torch.float32, "world")
     frame, M = _need(frame, torch.float64, "frame"), _need(M, torch.float64, "M")
@@ -374,6 +397,13 @@ def aabb_mask(world: torch.Tensor, world_offsets: torch.Tensor, frame: torch.Ten
     _lib.check(L.creg_aabb_mask_f64(_p(world), _p(world_offsets), k, _p(frame), nf, float(scale), _p(idx), _p(cnt), _p(boxes),
                                     _stream()), "creg_aabb_mask_f64")
     return idx, cnt, boxes
+
+
+def masked_icp_regime(n: int, nf: int, k: int) -> str:
+    """Which form creg_masked_icp_f64 runs for n source points in k clusters against a frame of nf points: "one_launch"
+    (everything in one launch, no host sync) or "many_workgroups" (one launch per ICP iteration, a stream synchronisation every
+    16 iterations).  Mirrors the choice in csrc/icp.hip (ICP_SRC_LDS = 1024 source points per cluster on average, 65536 frame points)."""
+    return "many_workgroups" if n // max(k, 1) > 1024 or nf > 65536 else "one_launch"
 
 
 def masked_icp_batch(problems, scale: float = 1.2, th: float = 1.0, max_iteration: int = 10000, ori: bool = False):

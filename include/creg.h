@@ -206,6 +206,16 @@ int creg_masked_icp_batch_f64(const creg_icp_problem* problems, int32_t batch, i
 int creg_aabb_mask_f64(const float* world, const int32_t* world_offsets, int32_t k, const double* frame, int64_t nf,
                        double scale, int32_t* mask_idx, int32_t* mask_count, float* boxes, creg_stream_t stream);
 
+/* The closed-form fit alone (SURVEY 8(b) / north star "per-cluster weighted SVD / least-squares SE(3) pose fits"): for every
+ * segment [offsets[c], offsets[c+1]) of the PAIRED points src[i] <-> dst[i] ((n,3) fp64 each) the rigid T_out[c] (4x4 fp64)
+ * minimising sum_i w_i |T src_i - dst_i|^2 (weights (n) fp64 >= 0, or NULL for 1) -- what open3d's
+ * TransformationEstimationPointToPoint::ComputeTransformation (Eigen::umeyama without scaling, reflection fix) returns for
+ * the correspondences of one ICP iteration (cluster_icp.py:157 through registration_icp).  A segment with no weight at all
+ * gets the identity.  Horn's quaternion form: always a proper rotation; where the optimum is not unique (collinear or fewer
+ * than three distinct pairs) it returns one of the minimisers. */
+int creg_kabsch_f64(const double* src, const double* dst, const double* weights, int64_t n, const int32_t* offsets,
+                    int32_t k, double* T_out, creg_stream_t stream);
+
 /* N3  plain point-to-point ICP of k independent (source, target) cloud pairs in one launch: the
  * registration_icp(source, target, threshold, init, TransformationEstimationPointToPoint,
  * ICPConvergenceCriteria(max_iteration)) calls of link.refine_links_clusters (link.py:85-127, th = 1,

@@ -12,13 +12,14 @@ UNPINNED; cross-checked on known rigid motions in tests/test_oracle_golden.py (t
 import numpy as np
 
 
-def kabsch(src: np.ndarray, dst: np.ndarray) -> np.ndarray:
-    """4x4 rigid T minimising |T src - dst|; identity when there are no pairs."""
+def kabsch(src: np.ndarray, dst: np.ndarray, w: np.ndarray = None) -> np.ndarray:
+    """4x4 rigid T minimising sum w |T src - dst|^2 (w = 1 by default); identity when there are no pairs."""
     T = np.eye(4)
-    if len(src) == 0:
+    if len(src) == 0 or (w is not None and not np.sum(w) > 0):
         return T
-    ms, md = src.mean(0), dst.mean(0)
-    sigma = (dst - md).T @ (src - ms) / len(src)
+    w = np.ones(len(src)) if w is None else np.asarray(w, np.float64)
+    ms, md = (w[:, None] * src).sum(0) / w.sum(), (w[:, None] * dst).sum(0) / w.sum()
+    sigma = ((dst - md) * w[:, None]).T @ (src - ms) / w.sum()
     U, _, Vt = np.linalg.svd(sigma)
     S = np.eye(3)
     if np.linalg.det(U) * np.linalg.det(Vt) < 0:

@@ -267,6 +267,37 @@ def test_dq_func_dropin_all_eleven_functions_vs_reference_golden(dev, golden):
     assert D.dualquat_to_transform(noisy.reshape(4, 16, 8)).shape == (4, 16, 4, 4)
 
 
+def test_dq_func_dropins_are_transparent_to_autograd(dev):
+    """Like the reference's plain-torch functions (dq_func.py:47-257), every drop-in passes gradients: forward = HIP kernel,
+    backward vs autograd through the oracle (fp64) on the same inputs."""
+    from autourdf_amd import dq_func as D
+    from oracle import dq as odq
+    from scipy.spatial.transform import Rotation
+    g = torch.Generator().manual_seed(8)
+    M = torch.eye(4).repeat(32, 1, 1)
+    M[:, :3, :3] = torch.from_numpy(Rotation.random(32, random_state=5).as_matrix()).float()
+    M[:, :3, 3] = torch.randn(32, 3, generator=g)
+    d1 = odq.transform_to_dualquat(M) + 0.05 * torch.randn(32, 8, generator=g)
+    d2 = odq.transform_to_dualquat(M.flip(0)) + 0.05 * torch.randn(32, 8, generator=g)
+    cases = [(D.transform_to_dualquat, odq.transform_to_dualquat, (M,)),
+             (D.rot_trans_to_dualquat, odq.rot_trans_to_dualquat, (M[:, :3, :3].clone(), M[:, :3, 3].clone())),
+             (D.quat_trans_to_dualquat, odq.quat_trans_to_dualquat, (d1[:, :4].clone(), M[:, :3, 3].clone())),
+             (D.dualquat_to_quat_trans, odq.dualquat_to_quat_trans, (d1,)),
+             (D.dualquat_to_rot_trans, odq.dualquat_to_rot_trans, (d1,)),
+             (D.dualquat_multiply, odq.dualquat_multiply, (d1, d2)),
+             (D.dualquat_invert, odq.dualquat_invert, (d1,))]
+    for mine, ref, ins in cases:
+        a = [x.clone().to(dev).requires_grad_(True) for x in ins]
+        b = [x.clone().double().requires_grad_(True) for x in ins]
+        oa, ob = mine(*a), ref(*b)
+        oa, ob = (oa if isinstance(oa, tuple) else (oa,)), (ob if isinstance(ob, tuple) else (ob,))
+        w = [torch.randn(y.shape, generator=g) for y in ob]
+        sum((x * ww.to(dev)).sum() for x, ww in zip(oa, w)).backward()
+        sum((y * ww.double()).sum() for y, ww in zip(ob, w)).backward()
+        for x, y in zip(a, b):
+            np.testing.assert_allclose(x.grad.cpu().numpy(), y.grad.numpy(), rtol=2e-4, atol=2e-5, err_msg=mine.__name__)
+
+
 def test_dq_to_se3_backward_vs_autograd(dev):
     from autourdf_amd import ops
     from oracle import dq as odq
@@ -321,6 +352,44 @@ def test_icp_fit_degenerate_correspondences_vs_oracle(dev, name):
     if unique:
         np.testing.assert_allclose(T, oT, atol=1e-7)
         assert int(n_it.cpu()[0]) == o_it
+
+
+def test_kabsch_standalone_g5_cases_vs_oracle(dev):
+    """creg_kabsch_f64 (golden class G5): known motion, weights, a mirrored target (reflection fix), a planar
+    set, a segment without pairs, and the non-unique cases (collinear, two pairs) through the residual they must reach."""
+    from scipy.spatial.transform import Rotation
+    from autourdf_amd import ops
+    from oracle import icp as oicp
+    rng = np.random.default_rng(11)
+    R, t = Rotation.from_rotvec([0.7, -0.4, 1.1]).as_matrix(), np.array([0.3, -0.2, 0.5])
+    blob = rng.normal(size=(300, 3))
+    plane = np.c_[rng.uniform(-1, 1, (80, 2)), np.zeros(80)]
+    line = np.outer(np.linspace(-1, 1, 50), [0.6, 0.64, 0.48])
+    segs = [(blob, blob @ R.T + t, None),                                             # exact motion
+            (blob, blob @ R.T + t + 0.05 * rng.normal(size=blob.shape), rng.uniform(0, 2, 300)),   # noisy + weights
+            (blob, blob * np.array([1, 1, -1.0]), None),                              # mirrored target: det < 0 optimum
+            (plane, plane @ R.T + t, None),                                           # rank-2 covariance
+            (np.zeros((0, 3)), np.zeros((0, 3)), None),                               # no pairs
+            (line, line @ R.T + t, None),                                             # rank 1: a minimiser, not THE minimiser
+            (blob[:2], blob[:2] @ R.T + t, None)]
+    src = np.concatenate([a for a, _, _ in segs]); dst = np.concatenate([b for _, b, _ in segs])
+    w = np.concatenate([np.ones(len(a)) if ww is None else ww for a, _, ww in segs])
+    off = np.cumsum([0] + [len(a) for a, _, _ in segs]).astype(np.int32)
+    T = ops.kabsch(torch.tensor(src, device=dev), torch.tensor(dst, device=dev), torch.tensor(off, device=dev),
+                   torch.tensor(w, device=dev)).cpu().numpy()
+    T1 = ops.kabsch(torch.tensor(src, device=dev), torch.tensor(dst, device=dev), torch.tensor(off, device=dev)).cpu().numpy()
+    for i, (a, b, ww) in enumerate(segs):
+        o = oicp.kabsch(a, b, ww)
+        assert abs(np.linalg.det(T[i][:3, :3]) - 1) < 1e-12
+        np.testing.assert_allclose(T[i][:3, :3] @ T[i][:3, :3].T, np.eye(3), atol=1e-12)
+        res = lambda M: float((((a @ M[:3, :3].T + M[:3, 3]) - b) ** 2 * (1.0 if ww is None else ww[:, None])).sum())
+        assert res(T[i]) <= res(o) * (1 + 1e-9) + 1e-20                               # never worse than the SVD fit
+        if i < 5:
+            np.testing.assert_allclose(T[i], o, atol=1e-10)
+        if ww is None:
+            np.testing.assert_array_equal(T1[i], T[i])                                 # weights of one == no weights
+    np.testing.assert_allclose(T[0][:3, :3], R, atol=1e-12); np.testing.assert_allclose(T[0][:3, 3], t, atol=1e-12)
+    np.testing.assert_array_equal(T[4], np.eye(4))
 
 
 def test_masked_icp_ori_keeps_translation_vs_oracle(dev, golden):

@@ -174,3 +174,35 @@ def test_kmeans_plusplus_follows_sklearns_draw_sequence(golden):
     np.testing.assert_array_equal(np.cumsum([0] + list(np.bincount(olab, minlength=8))), g["offsets"])
     for i in range(8):
         np.testing.assert_allclose(X[olab == i].mean(0), g["matrices"][i][:3, 3], atol=1e-14)
+
+
+def test_dq_autograd_formulas_match_the_oracle_values_and_gradients():
+    """autourdf_amd._dq_autograd (the torch restatements the drop-in differentiates in its backward) against oracle.dq, which
+    is pinned to the reference module's goldens: values and input gradients, fp64 on the CPU."""
+    import torch
+    from autourdf_amd import _dq_autograd as ag
+    from oracle import dq as odq
+    from scipy.spatial.transform import Rotation
+    g = torch.Generator().manual_seed(4)
+    M = torch.eye(4, dtype=torch.float64).repeat(24, 1, 1)
+    M[:, :3, :3] = torch.from_numpy(Rotation.random(24, random_state=2).as_matrix())
+    M[:, :3, 3] = torch.randn(24, 3, generator=g, dtype=torch.float64)
+    d1 = odq.transform_to_dualquat(M) + 0.05 * torch.randn(24, 8, generator=g, dtype=torch.float64)
+    d2 = odq.transform_to_dualquat(M.flip(0)) + 0.05 * torch.randn(24, 8, generator=g, dtype=torch.float64)
+    cases = [(ag.transform_to_dualquat, odq.transform_to_dualquat, (M,)),
+             (ag.quat_trans_to_dualquat, odq.quat_trans_to_dualquat, (d1[:, :4].clone(), M[:, :3, 3].clone())),
+             (ag.dualquat_to_quat_trans, odq.dualquat_to_quat_trans, (d1,)),
+             (ag.dualquat_multiply, odq.dualquat_multiply, (d1, d2)),
+             (ag.dualquat_invert, odq.dualquat_invert, (d1,))]
+    for mine, ref, ins in cases:
+        a = [x.clone().requires_grad_(True) for x in ins]
+        b = [x.clone().requires_grad_(True) for x in ins]
+        oa, ob = mine(*a), ref(*b)
+        oa, ob = (oa if isinstance(oa, tuple) else (oa,)), (ob if isinstance(ob, tuple) else (ob,))
+        for x, y in zip(oa, ob):
+            assert torch.allclose(x, y, atol=1e-13)
+        w = [torch.randn(x.shape, generator=g, dtype=torch.float64) for x in oa]
+        sum((x * ww).sum() for x, ww in zip(oa, w)).backward()
+        sum((y * ww).sum() for y, ww in zip(ob, w)).backward()
+        for x, y in zip(a, b):
+            assert torch.allclose(x.grad, y.grad, atol=1e-12)
