@@ -61,7 +61,8 @@ struct TrainState {
 };
 
 struct Ws {         // device pointers into the caller's workspace
-    float *P, *AM, *AV;
+    float *P, *P1, *AM, *AV;     // parameters double-buffered by optimizer-step parity: epoch e reads P[e & 1] (P / P1) and writes the
+                                 //   other one, so no kernel of an epoch can see a row another workgroup has already updated
     float *pose_in, *enc, *x1[2], *h2[2], *head_save, *m2, *gm2;      // x1 / h2: double-buffered by epoch parity
     float4 *pts4, *y4, *pred4, *ys4, *psl4, *ps4;
     float *ybox, *pbox;
@@ -189,6 +190,8 @@ constexpr int MLP_BLOCK = 1024;      // 16 waves = 16 parameter rows share one L
 template <int NC>
 __global__ __launch_bounds__(MLP_BLOCK) void k_l2(Dims D, Ws W0, int par, size_t bstride) {
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
+    const float* Pc = par ? W.P1 : W.P;
+    const int stopped = W.state[par].stopped;        // (the state the epoch that ENDS with this launch has produced; tested at the barrier)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = (float*)smem;                      // [rc][H]
     constexpr int H = NC * 64;
@@ -203,9 +206,9 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_l2(Dims D, Ws W0, int par, size_t
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int i = v * 256 + lane * 4;
-        wr[v] = i < H ? *(const float4*)(W.P + D.oW2 + (size_t)o * H + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wr[v] = i < H ? *(const float4*)(Pc + D.oW2 + (size_t)o * H + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float b = W.P[D.ob2 + o];
+    const float b = Pc[D.ob2 + o];
     for (int r0 = 0; r0 < D.K; r0 += rc) {
         const int nr = min(rc, D.K - r0);
         if (r0) {
@@ -214,6 +217,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_l2(Dims D, Ws W0, int par, size_t
         }
         stage_wait();
         __syncthreads();
+        if (stopped) return;                            // a stopped train keeps its activations (workgroup-uniform)
         for (int r = 0; r < nr; ++r) {
             float s = 0.f;
 #pragma unroll
@@ -236,6 +240,7 @@ template <int NC>
 __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bstride) {
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
     const float* h2cur = par ? W.h2[1] : W.h2[0];
+    const float* Pc = par ? W.P1 : W.P;
     __shared__ float outs[8];
     __shared__ float m2s[12];
     const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -254,8 +259,8 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bst
     if (wave < NO) {
         const int o = wave;
         const float *w, *a; int n; float bias;
-        if (o < D.OA) { w = W.P + D.oW3A + (size_t)o * D.HA; a = h2cur + (size_t)r * D.H2; n = D.HA; bias = W.P[D.ob3A + o]; }
-        else { w = W.P + D.oW3B + (size_t)(o - D.OA) * D.HB; a = h2cur + (size_t)r * D.H2 + D.HA; n = D.HB; bias = W.P[D.ob3B + o - D.OA]; }
+        if (o < D.OA) { w = Pc + D.oW3A + (size_t)o * D.HA; a = h2cur + (size_t)r * D.H2; n = D.HA; bias = Pc[D.ob3A + o]; }
+        else { w = Pc + D.oW3B + (size_t)(o - D.OA) * D.HB; a = h2cur + (size_t)r * D.H2 + D.HA; n = D.HB; bias = Pc[D.ob3B + o - D.OA]; }
         float wv[NC], av[NC];                      // n <= 64 NC: every load of the dot in flight at once
 #pragma unroll
         for (int c = 0; c < NC; ++c) { const int i = min(c * 64 + lane, n - 1); wv[c] = w[i]; av[c] = a[i]; }
@@ -652,7 +657,8 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
     for (int q = 0; q < GC_QMAX; ++q) {
         const int o = min(q * 256 + tid, D.H2 - 1);
         const bool isA = o < D.HA;
-        const float* wb = isA ? W.P + D.oW3A + o : W.P + D.oW3B + (o - D.HA);
+        const float* Pc = (epoch & 1) ? W.P1 : W.P;
+        const float* wb = isA ? Pc + D.oW3A + o : Pc + D.oW3B + (o - D.HA);
         const int stride = isA ? D.HA : D.HB, nj = isA ? D.OA : D.OB;
 #pragma unroll
         for (int j = 0; j < 8; ++j) w3v[q][j] = wb[(size_t)min(j, nj - 1) * stride];
@@ -787,10 +793,12 @@ __device__ __forceinline__ float adam_value(float p, float& mm, float& vv, float
 // the slice partials of a (pose row, column) are summed in a fixed tree: the 8 slices of a wave (row_ror DPP, two lane
 // permutes), then the waves in order through LDS.  The rows of a pass are straight-line code (rows past the end repeat the
 // last one and are not stored): per-row branches kept hipcc from overlapping the rows' LDS reads and lane permutes.
-constexpr int B2_THREADS = 512;
+constexpr int BD_THREADS = 512;       // workgroups of the backward launch k_bd (both roles)
+constexpr int B2_THREADS = BD_THREADS;
 constexpr int B2_WAVES = B2_THREADS / 64;
 constexpr int B2_CB = 16;
 constexpr int B2_RB = 20;             // pose rows per pass (K = 20: one pass)
+constexpr int B2_HB = 5;              // rows of a pass whose accumulators are live together
 constexpr int B2_MAXP = (160 + B2_RB - 1) / B2_RB;
 __host__ __device__ inline int b2_rows(int K) { return K < B2_RB ? K : B2_RB; }
 __host__ __device__ inline int b2_area(int K, int H2) { const int a = b2_rows(K) * H2, b = K * 2 * B2_CB; return a > b ? a : b; }
@@ -820,10 +828,7 @@ __device__ __forceinline__ nn_f2 fma2(float g, nn_f2 w, nn_f2 a) {        // one
 }
 
 template <int AW, int OPS>            // AW waves of the workgroup take part in the W2 product: H2 = 8 AW OPS
-__global__ __launch_bounds__(B2_THREADS) void k_bwd2(Dims D, Ws W0, int epoch, size_t bstride) {
-    const Ws W = ws_shift(W0, blockIdx.z * bstride);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sh = (float*)smem;
+__device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch, int blk, float* sh) {
     const int RB = b2_rows(D.K);
     float* gh = sh;                            // [RB][H2]   g_h2 rows of the pass
     float* red = sh + b2_area(D.K, D.H2);      // [8][RB][16] per-wave partial sums of the pass
@@ -836,15 +841,17 @@ __global__ __launch_bounds__(B2_THREADS) void k_bwd2(Dims D, Ws W0, int epoch, s
     const bool live = !S.stopped;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, cp = tid & 7, sl = tid >> 3;
     const bool fma_wave = wv < AW;             // wave-uniform
-    const int c0 = blockIdx.x * B2_CB, par = epoch & 1;
+    const int c0 = blk * B2_CB, par = epoch & 1;
     const float* x1cur = par ? W.x1[1] : W.x1[0];     // (a runtime index into the shifted struct would go to scratch)
     float* x1next = par ? W.x1[0] : W.x1[1];
+    const float* Pc = par ? W.P1 : W.P;               // this epoch's parameters; the updated rows go to the other buffer
+    float* Pn = par ? W.P : W.P1;
     // every load of the first pass is requested before the first wait
     stage_issue<B2_THREADS>((float4*)gh, (const float4*)W.g_h2, RB * D.H2 / 4);
     stage_issue<B2_THREADS>((float4*)encs, (const float4*)W.enc, D.K * D.IN / 4);
     nn_f2 w[OPS];
     {
-        const float* wbase = W.P + D.oW2 + (size_t)(min(sl, 8 * AW - 1) * OPS) * D.H + c0 + 2 * cp;
+        const float* wbase = Pc + D.oW2 + (size_t)(min(sl, 8 * AW - 1) * OPS) * D.H + c0 + 2 * cp;
 #pragma unroll
         for (int j = 0; j < OPS; ++j) w[j] = *(const nn_f2*)(wbase + (size_t)j * D.H);
     }
@@ -854,8 +861,8 @@ __global__ __launch_bounds__(B2_THREADS) void k_bwd2(Dims D, Ws W0, int epoch, s
     const bool ain = 4 * i4 < D.IN;
     const int ei = min(4 * i4, D.IN - 4);
     const size_t wi = (size_t)D.oW1 + (size_t)hu * D.IN + ei;
-    float4 pw = *(const float4*)(W.P + wi), pm = *(const float4*)(W.AM + wi), pv = *(const float4*)(W.AV + wi);
-    float pb = W.P[D.ob1 + hu], mb = W.AM[D.ob1 + hu], vb = W.AV[D.ob1 + hu];
+    float4 pw = *(const float4*)(Pc + wi), pm = *(const float4*)(W.AM + wi), pv = *(const float4*)(W.AV + wi);
+    float pb = Pc[D.ob1 + hu], mb = W.AM[D.ob1 + hu], vb = W.AV[D.ob1 + hu];
     float xv0 = 0.f;                            // post-activation of this thread's (pose row, column) output of pass 0
     if (tid < RB * B2_CB) xv0 = x1cur[(size_t)(tid >> 4) * D.H + c0 + (tid & 15)];
     float gxv[B2_MAXP];                         // this thread's g_x1 outputs, one per pass (K <= 160, 20 rows x 16 columns per pass)
@@ -872,34 +879,42 @@ __global__ __launch_bounds__(B2_THREADS) void k_bwd2(Dims D, Ws W0, int epoch, s
         __syncthreads();
         if (!live) return;                             // a stopped train: nothing below may be stored (workgroup-uniform)
         if (fma_wave) {
-            nn_f2 acc[B2_RB];
+            // B2_HB rows at a time, straight-line (rows past nr repeat the last one and are not stored): per-row branches
+            // kept hipcc from overlapping the rows' LDS reads and lane permutes; all 20 rows' accumulators beside the W2
+            // registers spill at the 128 VGPRs two workgroups per CU leave a wave
 #pragma unroll
-            for (int q = 0; q < B2_RB; ++q) {
-                acc[q] = nn_f2{0.f, 0.f};
-                const float* g = gh + min(q, nr - 1) * D.H2 + sl * OPS;
-                if constexpr (OPS % 4 == 0) {
+            for (int qb = 0; qb < B2_RB; qb += B2_HB) {
+                if (qb < nr) {                        // block-uniform
+                    nn_f2 acc[B2_HB];
 #pragma unroll
-                    for (int j = 0; j < OPS; j += 4) {
-                        const float4 v = *(const float4*)(g + j);
-                        acc[q] = fma2(v.x, w[j], acc[q]); acc[q] = fma2(v.y, w[j + 1], acc[q]);
-                        acc[q] = fma2(v.z, w[j + 2], acc[q]); acc[q] = fma2(v.w, w[j + 3], acc[q]);
+                    for (int q = 0; q < B2_HB; ++q) {
+                        acc[q] = nn_f2{0.f, 0.f};
+                        const float* g = gh + min(qb + q, nr - 1) * D.H2 + sl * OPS;
+                        if constexpr (OPS % 4 == 0) {
+#pragma unroll
+                            for (int j = 0; j < OPS; j += 4) {
+                                const float4 v = *(const float4*)(g + j);
+                                acc[q] = fma2(v.x, w[j], acc[q]); acc[q] = fma2(v.y, w[j + 1], acc[q]);
+                                acc[q] = fma2(v.z, w[j + 2], acc[q]); acc[q] = fma2(v.w, w[j + 3], acc[q]);
+                            }
+                        } else if constexpr (OPS % 2 == 0) {
+#pragma unroll
+                            for (int j = 0; j < OPS; j += 2) {
+                                const nn_f2 v = *(const nn_f2*)(g + j);
+                                acc[q] = fma2(v.x, w[j], acc[q]); acc[q] = fma2(v.y, w[j + 1], acc[q]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < OPS; ++j) acc[q] = fma2(g[j], w[j], acc[q]);
+                        }
                     }
-                } else if constexpr (OPS % 2 == 0) {
 #pragma unroll
-                    for (int j = 0; j < OPS; j += 2) {
-                        const nn_f2 v = *(const nn_f2*)(g + j);
-                        acc[q] = fma2(v.x, w[j], acc[q]); acc[q] = fma2(v.y, w[j + 1], acc[q]);
-                    }
-                } else {
+                    for (int q = 0; q < B2_HB; ++q) { acc[q].x = slice_sum8(acc[q].x); acc[q].y = slice_sum8(acc[q].y); }
 #pragma unroll
-                    for (int j = 0; j < OPS; ++j) acc[q] = fma2(g[j], w[j], acc[q]);
+                    for (int q = 0; q < B2_HB; ++q)
+                        if (lane < 8 && qb + q < nr) *(nn_f2*)(red + (wv * RB + qb + q) * B2_CB + 2 * cp) = acc[q];
                 }
             }
-#pragma unroll
-            for (int q = 0; q < B2_RB; ++q) { acc[q].x = slice_sum8(acc[q].x); acc[q].y = slice_sum8(acc[q].y); }
-#pragma unroll
-            for (int q = 0; q < B2_RB; ++q)
-                if (lane < 8 && q < nr) *(nn_f2*)(red + (wv * RB + q) * B2_CB + 2 * cp) = acc[q];
         }
         __syncthreads();
         float out = 0.f;
@@ -938,8 +953,8 @@ __global__ __launch_bounds__(B2_THREADS) void k_bwd2(Dims D, Ws W0, int epoch, s
     nw.w = adam_value(pw.w, pm.w, pv.w, ag.w, S.step_size, S.bc2_sqrt);
     pb = adam_value(pb, mb, vb, gsum, S.step_size, S.bc2_sqrt);        // every lane of the row (same operands, same result)
     if (live && half == 0) {
-        if (ain) { *(float4*)(W.P + wi) = nw; *(float4*)(W.AM + wi) = pm; *(float4*)(W.AV + wi) = pv; }
-        if (i4 == 0) { W.P[D.ob1 + hu] = pb; W.AM[D.ob1 + hu] = mb; W.AV[D.ob1 + hu] = vb; }
+        if (ain) { *(float4*)(Pn + wi) = nw; *(float4*)(W.AM + wi) = pm; *(float4*)(W.AV + wi) = pv; }
+        if (i4 == 0) { Pn[D.ob1 + hu] = pb; W.AM[D.ob1 + hu] = mb; W.AV[D.ob1 + hu] = vb; }
     }
     for (int r = half; r < D.K; r += 2) {
         const float4 e = *(const float4*)(encs + r * D.IN + ei);
@@ -955,15 +970,13 @@ __global__ __launch_bounds__(B2_THREADS) void k_bwd2(Dims D, Ws W0, int epoch, s
         }
 }
 
-// ------------------------------------------------------------------------------------------ dW + Adam (+ next h2)
+// ------------------------------------------------------------------------------------------ dW + Adam of the hidden / output rows
 // One wave per parameter row, 8 rows per block.  The block stages its rows' input activation matrix
 // ([K][H] encoder activation for hidden rows, [K][H2] hidden activation for output rows) in LDS by LDS-DMA; a
 // row's parameter / Adam-state loads are all issued together.  No loop over K contains a global load.
-constexpr int DW_BLOCK = 512;         // 8 waves
-constexpr int DW_WAVES = DW_BLOCK / 64;
-constexpr int DW_RPW = 1;             // parameter rows per wave (1 measured best: 27 us vs 30 (2) vs 42 (4) at B=5;
-                                      // fewer, fatter waves cost more than the staging traffic they save)
-constexpr int DW_RPB = DW_WAVES * DW_RPW;    // rows per block sharing one LDS copy of the activations
+constexpr int DW_WAVES = BD_THREADS / 64;
+constexpr int DW_RPB = DW_WAVES;      // rows per block sharing one LDS copy of the activations (one row per wave: measured best in
+                                      // round 1 -- 27 us vs 30 (2 rows) vs 42 (4): fewer, fatter waves cost more than the staging they save)
 struct DwRow { int oW, ob, o, n_in, aoff, kind; bool active; };
 
 __device__ __forceinline__ DwRow dw_row(const Dims& D, int bkind, int row) {
@@ -976,83 +989,51 @@ __device__ __forceinline__ DwRow dw_row(const Dims& D, int bkind, int row) {
     return R;
 }
 
-// One wave owns DW_RPW parameter rows; the block's DW_RPB rows are of one kind (hidden / output) and share ONE LDS copy
-// of that kind's input activation matrix, fetched by LDS-DMA.  Parameter and Adam-state loads of all rows, the gradient
-// columns and the DMA are requested before the first wait.  A hidden-row wave then holds its UPDATED row in registers:
-// it stages the next encoder activation (k_bwd2 of this epoch has finished it) into the same LDS buffer and computes the
-// row's next hidden activation with k_l2's arithmetic -- the forward of the hidden layer costs one more LDS round trip
-// here instead of a launch that re-reads W2 (round 2: k_l2, 6.6 us + its boundary per epoch).
-#ifdef CREG_STAMPS
-// debug build only: where k_dw's launches spend their time, by block kind (0 hidden rows, 1 output rows), in
-// 10 ns ticks of the wall clock: [kind][0] blocks [1] sum of (block start - launch start) [2] sum of (block end - launch
-// start) [3] sum of block durations; g_dw_launch: scratch (launch start, end) folded per launch into
-// g_dw_tot = [launches, sum of launch spans]
-__device__ unsigned long long g_dw_stamps[4][4];
-__device__ unsigned long long g_dw_launch[2];
-__device__ unsigned long long g_dw_tot[2];
-__global__ void k_dw_fold() {
-    if (g_dw_launch[1] != 0ull) { g_dw_tot[0] += 1; g_dw_tot[1] += g_dw_launch[1] - g_dw_launch[0]; }
-    g_dw_launch[0] = ~0ull; g_dw_launch[1] = 0ull;
-}
-#endif
 template <int NC>
-__global__ __launch_bounds__(DW_BLOCK, 2) void k_dw(Dims D, Ws W0, int epoch, size_t bstride) {
-    const Ws W = ws_shift(W0, blockIdx.z * bstride);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef CREG_STAMPS
-    const unsigned long long dw_t0 = wall_clock64();
-    if (threadIdx.x == 0) atomicMin(&g_dw_launch[0], dw_t0);
-#endif
+__device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, int blk, float* sh) {
     const TrainState S = W.state[(epoch + 1) & 1];
-    const bool live = !S.stopped;                   // gates every store (no early exit: see k_bwd2)
+    const bool live = !S.stopped;                   // gates every store (no early exit before the loads: see bwd2_role)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int gsz = (DW_WAVES * DW_RPW * D.K + 3) & ~3;
-    float* gall = (float*)smem;                     // [8 waves][DW_RPW][K] gradient columns
-    float* as = (float*)smem + gsz;                 // staged activations [rc][width]
+    const int gsz = (DW_WAVES * D.K + 3) & ~3;
+    float* gall = sh;                               // [8 waves][K] gradient columns
+    float* as = sh + gsz;                           // staged activations [rc][width]
     const int par = epoch & 1;
+    const float* Pc = par ? W.P1 : W.P;             // this epoch's parameters; the updated rows go to the other buffer
+    float* Pn = par ? W.P : W.P1;
     // block -> row kind.  Blocks: [hidden rows / RPB][output rows / RPB]
     const int nb2 = D.H2 / DW_RPB;
-    const int bkind = (int)blockIdx.x < nb2 ? 0 : 1;                                         // block-uniform
-    const int row0 = (bkind == 0 ? blockIdx.x : blockIdx.x - nb2) * DW_RPB + wib * DW_RPW;
-    const float* x1cur = par ? W.x1[1] : W.x1[0];     // (a runtime index into the shifted struct would go to scratch)
-    const float* x1next = par ? W.x1[0] : W.x1[1];
+    const int bkind = blk < nb2 ? 0 : 1;                                          // block-uniform
+    const int row0 = (bkind == 0 ? blk : blk - nb2) * DW_RPB + wib;
+    // (two selects of values, kept apart: hipcc folds a nested select over the four neighbouring members of the shifted
+    //  struct into ONE load with a computed offset -- which puts the whole struct, 40 pointers, into scratch memory)
+    const float* x1cur = par ? W.x1[1] : W.x1[0];
     const float* h2cur = par ? W.h2[1] : W.h2[0];
-    float* h2next = par ? W.h2[0] : W.h2[1];
+    asm volatile("" : "+s"(x1cur), "+s"(h2cur));
     const float* amat = bkind == 0 ? x1cur : h2cur;
     const int awidth = bkind == 0 ? D.H : D.H2;
     const int rc = rows_per_chunk(D.K, awidth);
-    stage_issue<DW_BLOCK>((float4*)as, (const float4*)amat, min(rc, D.K) * awidth / 4);
+    stage_issue<BD_THREADS>((float4*)as, (const float4*)amat, min(rc, D.K) * awidth / 4);
     // a lane owns 4 consecutive inputs per 256-wide slab: parameters / Adam state move as dwordx4, the
     // staged activations are read as ds_read_b128
     constexpr int NV = (NC + 3) / 4;
-    DwRow R[DW_RPW];
-    float4 pw[DW_RPW][NV], pm[DW_RPW][NV], pv[DW_RPW][NV], acc[DW_RPW][NV];
-    float pb[DW_RPW], mb[DW_RPW], vb[DW_RPW];
+    const DwRow R = dw_row(D, bkind, row0);
+    float4 pw[NV], pm[NV], pv[NV], acc[NV];
 #pragma unroll
-    for (int q = 0; q < DW_RPW; ++q) {
-        R[q] = dw_row(D, bkind, row0 + q);
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int i = min(v * 256 + lane * 4, R[q].n_in - 4);
-            pw[q][v] = *(const float4*)(W.P + R[q].oW + i); pm[q][v] = *(const float4*)(W.AM + R[q].oW + i);
-            pv[q][v] = *(const float4*)(W.AV + R[q].oW + i); acc[q][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        pb[q] = W.P[R[q].ob]; mb[q] = W.AM[R[q].ob]; vb[q] = W.AV[R[q].ob];
+    for (int v = 0; v < NV; ++v) {
+        const int i = min(v * 256 + lane * 4, R.n_in - 4);
+        pw[v] = *(const float4*)(Pc + R.oW + i); pm[v] = *(const float4*)(W.AM + R.oW + i);
+        pv[v] = *(const float4*)(W.AV + R.oW + i); acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    auto grad_col = [&](const DwRow& r_, int r) -> float {       // dL/d(pre-activation of unit o) for pose row r
-        if (r_.kind == 0) return W.g_h2[(size_t)r * D.H2 + r_.o];
-        if (r_.kind == 1) return W.g_out[16 * r + r_.o];
-        return W.g_out[16 * r + 4 + r_.o];
-    };
-#pragma unroll
-    for (int q = 0; q < DW_RPW; ++q)
-        for (int r = lane; r < D.K; r += 64) gall[(wib * DW_RPW + q) * D.K + r] = grad_col(R[q], r);
+    float pb = Pc[R.ob], mb = W.AM[R.ob], vb = W.AV[R.ob];
+    // dL/d(pre-activation of this wave's unit) for every pose row
+    for (int r = lane; r < D.K; r += 64)
+        gall[wib * D.K + r] = R.kind == 0 ? W.g_h2[(size_t)r * D.H2 + R.o] : W.g_out[16 * r + (R.kind == 1 ? R.o : 4 + R.o)];
     // accumulate g[r] * act[r][i] over the pose rows from the LDS-staged activation matrix
     for (int r0 = 0; r0 < D.K; r0 += rc) {
         const int nr = min(rc, D.K - r0);
         if (r0) {
             __syncthreads();
-            stage_issue<DW_BLOCK>((float4*)as, (const float4*)(amat + (size_t)r0 * awidth), nr * awidth / 4);
+            stage_issue<BD_THREADS>((float4*)as, (const float4*)(amat + (size_t)r0 * awidth), nr * awidth / 4);
         }
         stage_wait();
         __syncthreads();
@@ -1060,89 +1041,61 @@ __global__ __launch_bounds__(DW_BLOCK, 2) void k_dw(Dims D, Ws W0, int epoch, si
 #pragma unroll 2
         for (int r = 0; r < nr; ++r) {
             const float* a = as + r * awidth;
-#pragma unroll
-            for (int q = 0; q < DW_RPW; ++q) {
-                const float gr = gall[(wib * DW_RPW + q) * D.K + r0 + r];
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const float4 av = *(const float4*)(a + R[q].aoff + min(v * 256 + lane * 4, R[q].n_in - 4));
-                    acc[q][v].x = fmaf(gr, av.x, acc[q][v].x); acc[q][v].y = fmaf(gr, av.y, acc[q][v].y);
-                    acc[q][v].z = fmaf(gr, av.z, acc[q][v].z); acc[q][v].w = fmaf(gr, av.w, acc[q][v].w);
-                }
-            }
-        }
-    }
-    if (bkind == 0) {
-        // the next encoder activation into the same LDS buffer: requested now, so that the DMA flies under the Adam
-        // arithmetic below (K * H floats; more than one chunk only for K > rows_per_chunk: re-staged in the loop)
-        __syncthreads();                              // every wave has finished reading the current activations
-        stage_issue<DW_BLOCK>((float4*)as, (const float4*)x1next, min(rc, D.K) * D.H / 4);
-    }
-    // Adam in registers; the stores go last, behind the next-activation phase: a wave that stored first would sit in
-    // that phase's vmcnt(0) (it waits for the LDS-DMA) until its stores were acknowledged too
-#pragma unroll
-    for (int q = 0; q < DW_RPW; ++q) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            pw[q][v].x = adam_value(pw[q][v].x, pm[q][v].x, pv[q][v].x, acc[q][v].x, S.step_size, S.bc2_sqrt);
-            pw[q][v].y = adam_value(pw[q][v].y, pm[q][v].y, pv[q][v].y, acc[q][v].y, S.step_size, S.bc2_sqrt);
-            pw[q][v].z = adam_value(pw[q][v].z, pm[q][v].z, pv[q][v].z, acc[q][v].z, S.step_size, S.bc2_sqrt);
-            pw[q][v].w = adam_value(pw[q][v].w, pm[q][v].w, pv[q][v].w, acc[q][v].w, S.step_size, S.bc2_sqrt);
-        }
-        float sum = 0.f;
-        for (int r = 0; r < D.K; ++r) sum += gall[(wib * DW_RPW + q) * D.K + r];
-        pb[q] = adam_value(pb[q], mb[q], vb[q], sum, S.step_size, S.bc2_sqrt);
-    }
-    if (bkind == 0) {
-        // next epoch's hidden activation of this wave's unit(s) from the updated row held in registers and the
-        // LDS-staged next encoder activation: k_l2's arithmetic (lane-owned float4 slabs, DPP wave sum, + bias)
-        for (int r0 = 0; r0 < D.K; r0 += rc) {
-            const int nr = min(rc, D.K - r0);
-            if (r0) {
-                __syncthreads();
-                stage_issue<DW_BLOCK>((float4*)as, (const float4*)(x1next + (size_t)r0 * D.H), nr * D.H / 4);
-            }
-            stage_wait();
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < DW_RPW; ++q) {
-                for (int r = 0; r < nr; ++r) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int v = 0; v < NV; ++v) {
-                        const int i = v * 256 + lane * 4;
-                        const float4 a = *(const float4*)(as + r * D.H + min(i, D.H - 4));
-                        const float4 wv = i < D.H ? pw[q][v] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        s = fmaf(wv.x, a.x, s); s = fmaf(wv.y, a.y, s); s = fmaf(wv.z, a.z, s); s = fmaf(wv.w, a.w, s);
-                    }
-                    s = wave_sum_fast(s) + pb[q];
-                    if (lane == 0 && live) h2next[(size_t)(r0 + r) * D.H2 + R[q].o] = act_f(s, D.slope);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < DW_RPW; ++q) {
-        if (R[q].active && live) {
+            const float gr = gall[wib * D.K + r0 + r];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const int i = v * 256 + lane * 4;
-                if (i < R[q].n_in) {
-                    *(float4*)(W.P + R[q].oW + i) = pw[q][v]; *(float4*)(W.AM + R[q].oW + i) = pm[q][v]; *(float4*)(W.AV + R[q].oW + i) = pv[q][v];
-                }
+                const float4 av = *(const float4*)(a + R.aoff + min(v * 256 + lane * 4, R.n_in - 4));
+                acc[v].x = fmaf(gr, av.x, acc[v].x); acc[v].y = fmaf(gr, av.y, acc[v].y);
+                acc[v].z = fmaf(gr, av.z, acc[v].z); acc[v].w = fmaf(gr, av.w, acc[v].w);
             }
-            if (lane == 0) { W.P[R[q].ob] = pb[q]; W.AM[R[q].ob] = mb[q]; W.AV[R[q].ob] = vb[q]; }
         }
     }
-#ifdef CREG_STAMPS
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long t1 = wall_clock64(), l0 = g_dw_launch[0];
-        atomicAdd(&g_dw_stamps[bkind][0], 1ull); atomicAdd(&g_dw_stamps[bkind][1], dw_t0 - l0); atomicAdd(&g_dw_stamps[bkind][2], t1 - l0);
-        atomicAdd(&g_dw_stamps[bkind][3], t1 - dw_t0);
-        atomicMax(&g_dw_launch[1], t1);
+    if (!R.active) return;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int i = v * 256 + lane * 4;
+        float4 nw;
+        nw.x = adam_value(pw[v].x, pm[v].x, pv[v].x, acc[v].x, S.step_size, S.bc2_sqrt);
+        nw.y = adam_value(pw[v].y, pm[v].y, pv[v].y, acc[v].y, S.step_size, S.bc2_sqrt);
+        nw.z = adam_value(pw[v].z, pm[v].z, pv[v].z, acc[v].z, S.step_size, S.bc2_sqrt);
+        nw.w = adam_value(pw[v].w, pm[v].w, pv[v].w, acc[v].w, S.step_size, S.bc2_sqrt);
+        if (i < R.n_in) {
+            *(float4*)(Pn + R.oW + i) = nw; *(float4*)(W.AM + R.oW + i) = pm[v]; *(float4*)(W.AV + R.oW + i) = pv[v];
+        }
     }
-#endif
+    float sum = 0.f;
+    for (int r = 0; r < D.K; ++r) sum += gall[wib * D.K + r];
+    pb = adam_value(pb, mb, vb, sum, S.step_size, S.bc2_sqrt);
+    if (lane == 0) { Pn[R.ob] = pb; W.AM[R.ob] = mb; W.AV[R.ob] = vb; }
+}
+
+// ------------------------------------------------------------------------------------------ the backward launch: k_bd
+// The backward to the encoder (B, H / 16 blocks per problem) and the weight gradients + Adam of the hidden / output rows (D,
+// H2 / 8 + 1 blocks per problem) both need only what k_gradc leaves (g_out, g_h2, the advanced state) and this epoch's
+// parameters, which nobody overwrites (the updates go to the other parameter buffer): two INDEPENDENT roles, so they are one
+// launch of 512-thread workgroups told apart by their block index -- nothing is handed over inside it.  Round 3 first ran them
+// as k_bwd2 (11.7 us) -> k_dw (14.9 us, which also computed the next hidden activation from the rows in its registers); side by
+// side the launch takes what the longer role takes, and the next hidden activation, the one thing that needs BOTH results (the
+// next encoder activation from B, the updated hidden rows from D), is k_l2 again, a launch boundary later.
+// grid.x = (H / 16 + H2 / 8 + 1) * problems: the B blocks of ALL problems first (the longer chain of dependent phases).
+template <int NC, int AW, int OPS>
+__global__ __launch_bounds__(BD_THREADS, 4) void k_bd(Dims D, Ws W0, int epoch, size_t bstride, int nz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nB = D.H / B2_CB, nD = D.H2 / DW_RPB + (D.OA + D.OB + DW_RPB - 1) / DW_RPB;
+    int i = blockIdx.x;
+    const bool roleB = i < nB * nz;
+    if (!roleB) i -= nB * nz;
+    const int n = roleB ? nB : nD, z = i / n, blk = i - z * n;
+    const Ws W = ws_shift(W0, (size_t)z * bstride);
+    if (roleB) bwd2_role<AW, OPS>(D, W, epoch, blk, (float*)smem);
+    else dw_role<NC>(D, W, epoch, blk, (float*)smem);
+}
+
+// after the last epoch: the parameters of an odd number of optimizer steps sit in the second buffer; the copy-out reads the first
+__global__ __launch_bounds__(256) void k_params_home(Dims D, Ws W0, size_t bstride) {
+    const Ws W = ws_shift(W0, blockIdx.z * bstride);
+    if ((W.state[D.epochs & 1].step & 1) == 0) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < D.NPAR; i += gridDim.x * 256) W.P[i] = W.P1[i];
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -1158,7 +1111,7 @@ struct Plan {
     int B;                    // problems the workspace holds
     int nz;                   // problems per launch right now (grid.z): B for run, 1 for probe / profile
     size_t bstride;           // bytes between consecutive problems' workspaces
-    int smem_l2, smem_bwd2, smem_dw;
+    int smem_l2, smem_bd;
     int branches;             // parallel chains in the captured graph (groups of problems)
 };
 
@@ -1203,7 +1156,7 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     auto take = [&](size_t bytes) -> char* { char* r = base ? base + o : nullptr; o = align_up(o + bytes, 256); return r; };
     const size_t f = sizeof(float);
     Ws w;
-    w.P = (float*)take(f * D.NPAR); w.AM = (float*)take(f * D.NPAR); w.AV = (float*)take(f * D.NPAR);
+    w.P = (float*)take(f * D.NPAR); w.P1 = (float*)take(f * D.NPAR); w.AM = (float*)take(f * D.NPAR); w.AV = (float*)take(f * D.NPAR);
     w.pose_in = (float*)take(f * 8 * D.K); w.enc = (float*)take(f * D.K * D.IN);
     w.x1[0] = (float*)take(f * D.K * D.H); w.x1[1] = (float*)take(f * D.K * D.H);
     w.h2[0] = (float*)take(f * D.K * D.H2); w.h2[1] = (float*)take(f * D.K * D.H2); w.head_save = (float*)take(f * 16 * D.K);
@@ -1245,29 +1198,21 @@ static void launch_head(Plan* P, int par, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
     by_nc(D.H, [&](auto nc) { hipLaunchKernelGGL((k_head<decltype(nc)::value>), dim3(D.K, 1, P->nz), dim3(512), 0, s, D, W, par, P->bstride); });
 }
-// the k_bwd2 instance of a shape: AW waves x 8 slices x OPS rows = H2 ('q': H2 = 96 NC, 'dq': 64 NC; NC = H / 64)
+// the k_bd instance of a shape: NC = H / 64; AW waves x 8 slices x OPS rows = H2 ('q': H2 = 96 NC, 'dq': 64 NC)
 template <typename F>
-static void by_bwd2(const Dims& D, F f) {
+static void by_bd(const Dims& D, F f) {
     by_nc(D.H, [&](auto nc) {
         constexpr int NC = decltype(nc)::value;
         if (D.rot == 0) {
-            if constexpr (NC == 1) f(k_bwd2<4, 3>);                    // H2 = 96: 32 slices of 3 rows
-            else f(k_bwd2<8, (3 * NC) / 2>);                           // H2 = 96 NC: 64 slices
-        } else f(k_bwd2<8, NC>);                                       // H2 = 64 NC
+            if constexpr (NC == 1) f(k_bd<1, 4, 3>);                   // H2 = 96: 32 slices of 3 rows
+            else f(k_bd<NC, 8, (3 * NC) / 2>);                         // H2 = 96 NC: 64 slices
+        } else f(k_bd<NC, 8, NC>);                                     // H2 = 64 NC
     });
 }
-static void launch_bwd2(Plan* P, int epoch, hipStream_t s) {
+static void launch_bd(Plan* P, int epoch, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
-    by_bwd2(D, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(D.H / B2_CB, 1, P->nz), dim3(B2_THREADS), P->smem_bwd2, s, D, W, epoch, P->bstride); });
-}
-static void launch_dw(Plan* P, int epoch, hipStream_t s) {
-    const Dims& D = P->D; const Ws& W = P->W;
-    by_nc(D.H, [&](auto nc) {
-        hipLaunchKernelGGL((k_dw<decltype(nc)::value>), dim3(D.H2 / DW_RPB + cdiv(D.OA + D.OB, DW_RPB), 1, P->nz),
-                           dim3(DW_BLOCK), P->smem_dw, s, D, W, epoch, P->bstride); });
-#ifdef CREG_STAMPS
-    hipLaunchKernelGGL(k_dw_fold, dim3(1), dim3(1), 0, s);
-#endif
+    const int per = D.H / B2_CB + D.H2 / DW_RPB + cdiv(D.OA + D.OB, DW_RPB);
+    by_bd(D, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(per * P->nz), dim3(BD_THREADS), P->smem_bd, s, D, W, epoch, P->bstride, P->nz); });
 }
 static void launch_nn(const Dims& D, const Ws& W, size_t bstride, int nz, hipStream_t s, int par = 0) {
     const EngineEpi epi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, bstride, &W.state[par].stopped};
@@ -1317,8 +1262,8 @@ static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nu
     launch_head(P, par, s); mark(1);
     launch_nn(D, W, P->bstride, P->nz, s, par); mark(2);
     hipLaunchKernelGGL(k_gradc, dim3(D.K, 1, P->nz), dim3(256), 0, s, D, W, epoch, D.nbx, D.nby, P->bstride); mark(3);
-    launch_bwd2(P, epoch, s); mark(4);
-    launch_dw(P, epoch, s); mark(5);
+    launch_bd(P, epoch, s); mark(4);
+    launch_l2(P, par ^ 1, s); mark(5);        // the next epoch's hidden activation: next encoder activation (B) x updated hidden rows (D)
 }
 
 // One launch copies up to 16 (source, destination, dword count) ranges: a problem's 10 parameter tensors + offsets in,
@@ -1502,27 +1447,22 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     if (P->branches > 8) P->branches = 8;
     P->gexec = nullptr; P->graph_ready = false;
     P->smem_l2 = (int)(sizeof(float) * rows_per_chunk(D.K, D.H) * D.H);
-    P->smem_bwd2 = (int)(sizeof(float) * b2_smem_floats(D.K, D.H2, D.IN));
-    P->smem_dw = (int)(sizeof(float) * (((DW_WAVES * DW_RPW * D.K + 3) & ~3) + STAGE_FLOATS + 64 * 4));
-    int rc_attr = 0;
-    // the dynamic-LDS limit is per kernel AND per device: raise it at every plan creation (a process may drive several
-    // GPUs; a cached "already set" flag would leave the second device at 64 KB) to the most any plan can ask for
-    by_nc(D.H, [&](auto nc) {
-        constexpr int NC = decltype(nc)::value;
-        constexpr int DW_LDS_MAX = (int)(sizeof(float) * (((DW_WAVES * DW_RPW * 160 + 3) & ~3) + STAGE_FLOATS + 64 * 4));
-        if (hipFuncSetAttribute((const void*)k_dw<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_MAX) != hipSuccess) rc_attr = 1;
-    });
-    CREG_REQUIRE(rc_attr == 0, "creg_train_plan_create: cannot raise the dynamic LDS limit of k_dw");
+    {   // one dynamic LDS size for the two roles of k_bd: the larger (B at K <= 20, hidden 512: 76 KB -> two workgroups per CU)
+        const int f_b = b2_smem_floats(D.K, D.H2, D.IN);
+        const int f_d = ((DW_WAVES * D.K + 3) & ~3) + STAGE_FLOATS + 64 * 4;
+        P->smem_bd = (int)(sizeof(float) * (f_b > f_d ? f_b : f_d));
+    }
+    CREG_REQUIRE(P->smem_bd <= 160 * 1024, "creg_train_plan_create: k_bd needs %d B of LDS (K too large)", P->smem_bd);
+    {   // the dynamic-LDS limit is per kernel AND per device: raise it at every plan creation (a process may drive several
+        // GPUs; a cached "already set" flag would leave the second device at 64 KB)
+        hipError_t e2 = hipSuccess;
+        by_bd(D, [&](auto kern) { e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        CREG_REQUIRE(e2 == hipSuccess, "creg_train_plan_create: cannot raise the dynamic LDS limit of k_bd");
+    }
     // the limit is per kernel, not per plan: always raise it to the largest any plan can ask for (16384 keys + boxes),
     // so that a small plan created later does not lower it under a large one
     if (D.npb) CREG_HIP(hipFuncSetAttribute((const void*)k_sort_p, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
     if (D.nyb) CREG_HIP(hipFuncSetAttribute((const void*)k_sort_y, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8 + 6 * 4 * 256));
-    CREG_REQUIRE(P->smem_bwd2 <= 160 * 1024, "creg_train_plan_create: k_bwd2 needs %d B of LDS (K too large)", P->smem_bwd2);
-    {   // per kernel and per device, like k_dw's
-        hipError_t e2 = hipSuccess;
-        by_bwd2(D, [&](auto kern) { e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        CREG_REQUIRE(e2 == hipSuccess, "creg_train_plan_create: cannot raise the dynamic LDS limit of k_bwd2");
-    }
     *plan = (creg_train_plan*)P;
     return CREG_OK;
 }
@@ -1560,6 +1500,7 @@ extern "C" int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train
         for (; e + P->graph_epochs <= D.epochs; e += P->graph_epochs) CREG_HIP(hipGraphLaunch(P->gexec, s));
     }
     for (; e < D.epochs; ++e) enqueue_epoch(P, e, s);
+    hipLaunchKernelGGL(k_params_home, dim3(64, 1, P->B), dim3(256), 0, s, D, P->W, P->bstride);
     CREG_LAUNCH_CHECK();
     // results out, parameters back into the callers' tensors
     ParamMap pm[10];
@@ -1645,15 +1586,8 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
     CREG_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
     us_out[6] = ms * 1000.f / REP;
     us_out[7] = (float)P->nz;       // problems carried by that launch
-    // us_out[8]: the dW + Adam kernel the same way (each launch is one more Adam step on the plan's copy of the
-    // parameters -- this is a measurement hook, the caller's tensors are not written back)
-    CREG_HIP(hipEventRecord(ev[0], s));
-    for (int i = 0; i < REP; ++i) launch_dw(P, i, s);
-    CREG_HIP(hipEventRecord(ev[1], s));
-    CREG_HIP(hipStreamSynchronize(s));
-    CREG_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
-    us_out[8] = ms * 1000.f / REP;
-    // us_out[9..11]: k_bwd2, k_head, k_gradc the same way (same caveat: a measurement hook, the plan's state moves on)
+    // us_out[8..11]: k_bd, k_l2, k_head, k_gradc the same way (measurement hooks: every k_bd launch is one more Adam step on
+    // the plan's copies of the parameters, alternating between the two buffers; the caller's tensors are not written back)
     auto b2b = [&](auto launch, float* out) -> int {
         CREG_HIP(hipEventRecord(ev[0], s));
         for (int i = 0; i < REP; ++i) launch(i);
@@ -1663,7 +1597,8 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
         *out = ms * 1000.f / REP;
         return CREG_OK;
     };
-    if (int rc2 = b2b([&](int i) { launch_bwd2(P, i, s); }, us_out + 9)) return rc2;
+    if (int rc2 = b2b([&](int i) { launch_bd(P, i, s); }, us_out + 8)) return rc2;
+    if (int rc2 = b2b([&](int i) { launch_l2(P, i & 1, s); }, us_out + 9)) return rc2;
     if (int rc2 = b2b([&](int i) { launch_head(P, i & 1, s); }, us_out + 10)) return rc2;
     if (int rc2 = b2b([&](int i) { hipLaunchKernelGGL(k_gradc, dim3(D.K, 1, P->nz), dim3(256), 0, s, D, W, i, D.nbx, D.nby, P->bstride); }, us_out + 11)) return rc2;
     CREG_LAUNCH_CHECK();
@@ -1692,18 +1627,3 @@ extern "C" int creg_train_plan_destroy(creg_train_plan* plan) {
     delete P;
     return CREG_OK;
 }
-
-#ifdef CREG_STAMPS
-extern "C" int creg_debug_dw_stamps(unsigned long long* out18, int reset) {
-    if (out18) {
-        CREG_HIP(hipMemcpyFromSymbol(out18, HIP_SYMBOL(creg::g_dw_stamps), sizeof(unsigned long long) * 16));
-        CREG_HIP(hipMemcpyFromSymbol(out18 + 16, HIP_SYMBOL(creg::g_dw_tot), sizeof(unsigned long long) * 2));
-    }
-    if (reset) {
-        unsigned long long z[16] = {0}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_dw_stamps), z, sizeof(z)));
-        unsigned long long t[2] = {0, 0}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_dw_tot), t, sizeof(t)));
-        unsigned long long l[2] = {~0ull, 0ull}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_dw_launch), l, sizeof(l)));
-    }
-    return CREG_OK;
-}
-#endif

@@ -605,7 +605,7 @@ class TrainPlan:
                                                 _stream()), "creg_train_plan_probe")
         return m2, pred, loss, gm
 
-    KERNELS = ("l2", "head", "nn_l1", "gradc", "bwd2", "dw")
+    KERNELS = ("_", "head", "nn_l1", "gradc", "bd", "l2")
 
     def profile(self, m, y, pts, offsets, params, n_epochs=50):
         """Average event-bracketed microseconds of each of the 5 epoch kernels, and the back-to-back launch time of each
@@ -615,11 +615,11 @@ class TrainPlan:
         _lib.check(self.L.creg_train_plan_profile(self.plan, ctypes.byref(a), n_epochs, out, _stream()),
                    "creg_train_plan_profile")
         d = dict(zip(self.KERNELS, [float(v) for v in out]))
-        d.pop("l2")                                     # no launch of its own since round 3 (k_dw computes the next hidden activation)
+        d.pop("_")
         d["nn_l1_back_to_back"] = float(out[6])
         d["nn_l1_problems_per_launch"] = int(out[7])
-        d["dw_back_to_back"] = float(out[8])
-        d["bwd2_back_to_back"] = float(out[9])
+        d["bd_back_to_back"] = float(out[8])
+        d["l2_back_to_back"] = float(out[9])
         d["head_back_to_back"] = float(out[10])
         d["gradc_back_to_back"] = float(out[11])
         return d

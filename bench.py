@@ -230,7 +230,7 @@ CHIP_SIMDS, CHIP_CLOCK_HZ = 256 * 4, 2.4e9              # MI355X_MICROARCH.md: 2
 
 
 def epoch_kernel_model(k_clusters, n_points, info):
-    """Algorithmic HBM bytes per PROBLEM and launch of the five kernels of an epoch (DESIGN.md section 4 has the derivation),
+    """Algorithmic HBM bytes per PROBLEM and launch of the five kernels of an epoch (head, nn, gradc, bd, l2) (DESIGN.md section 4 has the derivation),
     QRegMLP(True, hidden 512): H = 512, H2 = 768, IN = 56."""
     H, H2, IN, K, N = HIDDEN, HIDDEN + HIDDEN // 2, 56, k_clusters, n_points
     w1 = H * IN + H                                     # encoder rows (k_bwd2 updates them)
@@ -239,10 +239,13 @@ def epoch_kernel_model(k_clusters, n_points, info):
     nn_name = (f"k_nn_plan<{'true' if info['pruned_predicted_search'] else 'false'}, {info['nn_points_per_lane']}>"
                if info["pruned_target_search"] else "k_nn_l1<4>")
     return {
-        # parameters + both Adam moments read and written (24 B each), current / next activations, gradients
-        "dw": {"name": "k_dw<8>", "bound": "hbm", "bytes": 24 * w23 + 4 * (2 * K * H + 3 * K * H2 + 16 * K)},
-        # W2 read once (its columns), the encoder rows + moments read and written, g_h2, current / next encoder activation
-        "bwd2": {"name": "k_bwd2<8, 12>", "bound": "hbm", "bytes": 4 * H2 * H + 24 * w1 + 4 * (K * H2 + 2 * K * H + K * IN)},
+        # k_bd = two independent roles in one launch.  D: hidden + output rows, parameters + both Adam moments read and written
+        # (24 B each), current activations, gradients.  B: W2 read once (its columns), the encoder rows + moments read and written,
+        # g_h2, current / next encoder activation
+        "bd": {"name": "k_bd<8, 8, 12>", "bound": "hbm",
+               "bytes": 24 * w23 + 4 * (K * H + 2 * K * H2 + 16 * K) + 4 * H2 * H + 24 * w1 + 4 * (K * H2 + 2 * K * H + K * IN)},
+        # the next hidden activation: W2 + biases read again (from the freshly written buffer), next encoder activation read, h2 written
+        "l2": {"name": "k_l2<8>", "bound": "hbm", "bytes": 4 * (H2 * H + H2) + 4 * (K * H + K * H2)},
         # both clouds (16 B points, block-sorted copies) read once, sign bits + integer scatter counters written
         "nn_l1": {"name": nn_name, "bound": "valu", "bytes": 2 * 16 * N + 4 * N + 16 * N, "pruned": pruned},
         # points, counters, signs and predictions of the clusters read, best cloud written when the loss improved, g_h2 rows

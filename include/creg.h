@@ -349,13 +349,12 @@ int creg_train_plan_probe(creg_train_plan* plan, const creg_train_args* args, fl
                           float* pred, float* loss, float* grad_m2, creg_stream_t stream);
 
 /* Measurement hook: run n_epochs eagerly with a HIP event before / after each of the five kernels
- * of an epoch (order: head, nn_l1, gradc, bwd2, dw) on `stream`, synchronise, and write the
- * average microseconds per kernel to us_out (HOST, 16 floats): [0] 0 (round 2's k_l2 slot: the hidden forward is part
- * of dw now), [1..5] event-bracketed per kernel in that order,
+ * of an epoch (order: head, nn_l1, gradc, bd, l2) on `stream`, synchronise, and write the
+ * average microseconds per kernel to us_out (HOST, 16 floats): [0] 0, [1..5] event-bracketed per kernel in that order
+ * (they include the dispatch latency of the launch, i.e. they are an upper bound of the kernel time),
  * [6] the nearest-neighbour kernel alone as 200 back-to-back launches between two events (kernel + launch gap),
- * [7] the problems that launch carries, [8] the dW + Adam (+ next hidden activation) kernel the same way, [9] bwd2,
- * [10] head, [11] gradc the same way, [12..15] reserved.  Event-bracketed times include the dispatch latency of the
- * launch, i.e. they are an upper bound of the kernel time. */
+ * [7] the problems that launch carries, [8] the backward launch k_bd the same way, [9] k_l2, [10] head, [11] gradc,
+ * [12..15] reserved. */
 int creg_train_plan_profile(creg_train_plan* plan, const creg_train_args* args, int32_t n_epochs,
                             float* us_out, creg_stream_t stream);
 

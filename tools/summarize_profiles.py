@@ -12,8 +12,8 @@ import os
 import shutil
 import sys
 
-ROLES = (("dw", "k_dw<"), ("bwd2", "k_bwd2<"), ("nn_l1", "k_nn_"), ("gradc", "k_gradc"), ("head", "k_head<"))
-EXTRA = ("k_km_small", "k_sort_y", "k_sort_p", "k_masked_icp", "k_l2<", "k_l1")
+ROLES = (("bd", "k_bd<"), ("nn_l1", "k_nn_"), ("l2", "k_l2<"), ("gradc", "k_gradc"), ("head", "k_head<"))
+EXTRA = ("k_km_small", "k_sort_y", "k_sort_p", "k_masked_icp", "k_l1", "k_params_home")
 
 
 def agg(path):
