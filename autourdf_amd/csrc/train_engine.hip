@@ -1616,7 +1616,8 @@ extern "C" int creg_train_plan_info(const creg_train_plan* plan, creg_train_plan
     info->batch = P->B;
     info->epochs_per_graph = P->shape.use_graph ? P->graph_epochs : 0;
     info->reserved[0] = P->D.ppl;        /* points per lane and block visit of the pruned search (1: blocks of 64, 4: blocks of 256) */
-    info->reserved[1] = info->reserved[2] = 0;
+    info->reserved[1] = P->D.nbt;        /* boxes per lane: target frame, predicted cloud (the k_nn_plan instance) */
+    info->reserved[2] = P->D.nbp;
     return CREG_OK;
 }
 

@@ -326,7 +326,8 @@ typedef struct creg_train_plan_info_t {
     int32_t graph_branches;           /* parallel chains in the captured graph */
     int32_t batch;                    /* problems the plan advances per run_batch call */
     int32_t epochs_per_graph;         /* 0: eager launches */
-    int32_t reserved[3];              /* [0]: points per lane and block visit of the pruned search (1: 64-point blocks, 4: 256-point blocks) */
+    int32_t reserved[3];              /* [0]: points per lane and block visit of the pruned search (1: 64-point blocks, 4: 256-point blocks);
+                                         [1], [2]: boxes per lane of the search over the target frame / the predicted cloud */
 } creg_train_plan_info_t;
 
 size_t creg_train_workspace_bytes(const creg_train_shape* shape);   /* covers shape.batch problems */
