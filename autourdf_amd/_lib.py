@@ -66,6 +66,9 @@ SIGNATURES = {
     "creg_aabb_mask_f64": (ctypes.c_int, [vp, vp, i32, vp, i64, f64, vp, vp, vp, vp]),
     "creg_icp_p2p_f64": (ctypes.c_int, [vp, i64, vp, vp, i64, vp, i32, vp, f64, i32, vp, vp, vp, vp, sz, vp]),
     "creg_kabsch_f64": (ctypes.c_int, [vp, vp, vp, i64, vp, i32, vp, vp]),
+    "creg_knn_normals_f64": (ctypes.c_int, [vp, i64, f64, i32, vp, vp, vp, vp]),
+    "creg_kmeans_nd_workspace_bytes": (sz, [i64]),
+    "creg_kmeans_lloyd_nd_f64": (ctypes.c_int, [vp, i64, i32, vp, i32, i32, f64, vp, vp, vp, vp, vp, sz, vp]),
     "creg_sample_mesh_f64": (ctypes.c_int, [vp, vp, vp, i32, vp, i32, vp, i64, vp, vp, vp]),
     "creg_visibility_workspace_bytes": (sz, [i32, i32, i32]),
     "creg_visibility_f64": (ctypes.c_int, [vp, vp, i32, vp, i32, vp, i32, f64, f64, f64, f64, i32, i32, vp, i64, f64, vp, vp, sz, vp]),

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcreg.so")
-SOURCES = ["core.hip", "nn_l1.hip", "transform.hip", "se3.hip", "kmeans.hip", "icp.hip", "fps.hip", "coord_map.hip", "sample.hip", "train_engine.hip"]
+SOURCES = ["core.hip", "nn_l1.hip", "transform.hip", "se3.hip", "kmeans.hip", "icp.hip", "fps.hip", "coord_map.hip", "sample.hip", "kmeans_nd.hip", "normals.hip", "train_engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function",
          # MFMA accumulators in VGPRs: the default AGPR form costs 8 v_accvgpr_read per fp64 16x16x4 MFMA whose

@@ -187,15 +187,23 @@ class Segments:
         cluster a frame with R = I at the centroid and the points in that frame
         (cluster_icp.py:86-99).  Like the reference, the draw comes from numpy's GLOBAL RandomState unless
         ``seed`` is given (``np.random.seed(s)`` pins both implementations to the same segmentation)."""
-        if normal:
-            raise NotImplementedError("--normal needs Open3D normal estimation (out of scope, SURVEY.md 8)")
         _lib.load()
         dev = torch.device("cuda")
         pc_np = np.asarray(self.pc_list[pc_id].points)
         rs = np.random.RandomState(seed) if seed is not None else np.random.mtrand._rand
-        init = pc_np[kmeans_plusplus_sklearn(pc_np, num, rs)]            # data points: centring them in the kernel is exact
         X = torch.as_tensor(pc_np, dtype=torch.float64, device=dev)
-        _, labels, _, _ = ops.kmeans_lloyd(X, torch.as_tensor(init, dtype=torch.float64, device=dev))
+        if normal:
+            # cluster_icp.py:49-62: normals (hybrid radius 0.1 / 30 neighbours, consistently oriented), k-means++ and Lloyd
+            # over [xyz | 0.5 n]; everything after the labels uses xyz only
+            from .normals import point_features
+            feat, nrm = point_features(pc_np)
+            self.pc_list[pc_id].normals = nrm
+            init6 = feat[kmeans_plusplus_sklearn(feat, num, rs)]
+            _, labels, _, _ = ops.kmeans_lloyd_nd(torch.as_tensor(feat, dtype=torch.float64, device=dev).contiguous(),
+                                                  torch.as_tensor(init6, dtype=torch.float64, device=dev).contiguous())
+        else:
+            init = pc_np[kmeans_plusplus_sklearn(pc_np, num, rs)]        # data points: centring them in the kernel is exact
+            _, labels, _, _ = ops.kmeans_lloyd(X, torch.as_tensor(init, dtype=torch.float64, device=dev))
         lab = labels.long()
         counts = torch.zeros(num, dtype=torch.float64, device=dev).index_add_(0, lab, torch.ones_like(X[:, 0]))
         # np.mean over the cluster's own points (cluster_icp.py:86), not the Lloyd centre

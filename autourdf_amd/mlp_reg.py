@@ -32,6 +32,8 @@ from .model_utils import DQRegMLP, QRegMLP, RegMLP, RRegMLP
 # module globals, set by main() exactly like the reference's __main__ block; ROT has a default so
 # that `import mlp_reg; mlp_reg.train(...)` works without NameError.
 ROT = "q"
+NORMAL = False          # --normal (mlp_reg.py:399): normals + 6-D k-means in the re-segmentation
+MLP_ICP = False
 DEVICE = None
 EPOCHS = 300            # mlp_reg.py:60
 USE_GRAPH = True
@@ -137,8 +139,8 @@ def calculate_pc(local_clusters, matrices):
 def resample_cluster(segments, idx, n_clusters, matrices, normal=False, visual=False):
     """Re-segment frame ``idx`` around the current poses and express each cluster in its pose frame
     (mlp_reg.py:172-237): k_means(init = pose translations, n_init=1) -> labels -> inv(M_k).[p;1]."""
-    if normal or visual:
-        raise NotImplementedError("normal / visual branches need Open3D (out of scope)")
+    if visual:
+        raise NotImplementedError("visual=True needs Open3D's GUI (out of scope)")
     dev = torch.device("cuda")
     pc_np = np.asarray(segments.pc_list[idx].points)
     X = torch.as_tensor(pc_np, dtype=torch.float64, device=dev).contiguous()
@@ -146,7 +148,17 @@ def resample_cluster(segments, idx, n_clusters, matrices, normal=False, visual=F
     if matrices.shape[0] != n_clusters:
         raise ValueError("matrices must hold n_clusters poses")
     init = torch.as_tensor(matrices[:, :3, 3], device=dev).to(torch.float64).contiguous()
-    _, labels, _, _ = ops.kmeans_lloyd(X, init)
+    if normal:
+        # mlp_reg.py:190-203: normals (hybrid radius 0.1 / 30 neighbours, consistently oriented), then k_means over
+        # [xyz | 0.5 n] seeded at [translation | 0]
+        from .normals import point_features
+        feat, nrm = point_features(pc_np)
+        segments.pc_list[idx].normals = nrm                    # the reference leaves them on the point cloud too
+        X6 = torch.as_tensor(feat, dtype=torch.float64, device=dev).contiguous()
+        init6 = torch.cat([init, torch.zeros_like(init)], 1).contiguous()
+        _, labels, _, _ = ops.kmeans_lloyd_nd(X6, init6)
+    else:
+        _, labels, _, _ = ops.kmeans_lloyd(X, init)
     # mlp_reg.py:211: np.linalg.inv(matrices[i]) in the poses' own dtype (float32 on the default path, float64 after
     # masked_icp) -- the very same host call, so the inverse has the reference's bits on whatever BLAS numpy carries;
     # the (N,3) change of frame itself runs on the device
@@ -192,7 +204,7 @@ def register_sequence(seg, step_matrices, step_cluster_np, save_dir=None, mlp_ic
             best_losses.append(best_loss)
             step_m_np = step_m.detach().cpu().numpy()
             _, matrices = masked_icp(icp_src, pred_np, target_np, step_m_np, False, ori=False)
-            new_seg_np = resample_cluster(seg, i + 1, K, matrices)
+            new_seg_np = resample_cluster(seg, i + 1, K, matrices, NORMAL)
             m_t = torch.tensor(matrices, dtype=torch.float32).to(DEVICE)
             out_m = matrices
         else:
@@ -203,7 +215,7 @@ def register_sequence(seg, step_matrices, step_cluster_np, save_dir=None, mlp_ic
             m_t = step_m.detach().clone().to(DEVICE)
             best_losses.append(best_loss)
             out_m = step_m.detach().cpu().numpy()
-            new_seg_np = resample_cluster(seg, i + 1, K, out_m)
+            new_seg_np = resample_cluster(seg, i + 1, K, out_m, NORMAL)
         cl_t = [torch.tensor(new_seg_np[j], dtype=torch.float32).to(DEVICE) for j in range(K)]
         poses.append(out_m)
         if save_dir is not None:
@@ -263,7 +275,7 @@ def match_all(data_dirs):
     segs = [Segments(d) for d in data_dirs]
     same = len({(sg.data_size, len(sg.pc_list[0].points)) for sg in segs}) == 1 and \
         all(len(p.points) == len(segs[0].pc_list[0].points) for sg in segs for p in sg.pc_list)
-    if ROT not in ("q", "dq") or not same or len(segs) < 2:
+    if ROT not in ("q", "dq") or not same or len(segs) < 2 or NORMAL:      # (--normal: the 6-D re-segmentation has no batched form)
         for i, d in enumerate(data_dirs):
             match(d, i)
         return

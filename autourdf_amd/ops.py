@@ -136,6 +136,41 @@ def kmeans_lloyd(X: torch.Tensor, init: torch.Tensor, max_iter: int = 300, tol: 
     return centers, labels, inertia, n_iter
 
 
+def kmeans_lloyd_nd(X: torch.Tensor, init: torch.Tensor, max_iter: int = 300, tol: float = 1e-4):
+    """sklearn.cluster.k_means(X, init=init, n_init=1) over (n,6) features -- the `--normal` branch clusters [xyz | 0.5 normal]
+    (mlp_reg.py:196-203) -- in one workgroup (n <= 16384, k <= 128): (centers (k,d) f64, labels (n) int32, inertia (1) f64,
+    n_iter (1) int32), all on the device."""
+    L = _lib.load()
+    X, init = _need(X, torch.float64, "X"), _need(init, torch.float64, "init")
+    n, d, k = X.shape[0], X.shape[1], init.shape[0]
+    if init.shape[1] != d:
+        raise ValueError("kmeans_lloyd_nd: X and init disagree on the feature count")
+    ws_bytes = L.creg_kmeans_nd_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
+    centers = torch.empty(k, d, dtype=torch.float64, device=X.device)
+    labels = torch.empty(n, dtype=torch.int32, device=X.device)
+    inertia = torch.empty(1, dtype=torch.float64, device=X.device)
+    n_iter = torch.empty(1, dtype=torch.int32, device=X.device)
+    _lib.check(L.creg_kmeans_lloyd_nd_f64(_p(X), n, d, _p(init), k, max_iter, tol, _p(centers), _p(labels), _p(inertia), _p(n_iter),
+                                          _p(ws), ws_bytes, _stream()), "creg_kmeans_lloyd_nd_f64")
+    return centers, labels, inertia, n_iter
+
+
+def knn_normals(X: torch.Tensor, radius: float, max_nn: int, want_normals: bool = True, want_idx: bool = False):
+    """creg_knn_normals_f64: the (up to) max_nn nearest points of every point of X (n,3) f64 (itself included; radius > 0:
+    only squared distances < radius^2, open3d's SearchHybrid; radius <= 0: plain SearchKNN) and, from them, open3d's
+    estimate_normals (unoriented).  Returns (normals (n,3) f64 or None, idx (n,max_nn) int32 or None, counts (n) int32)."""
+    L = _lib.load()
+    X = _need(X, torch.float64, "X")
+    n = X.shape[0]
+    normals = torch.empty(n, 3, dtype=torch.float64, device=X.device) if want_normals else None
+    idx = torch.empty(n, max_nn, dtype=torch.int32, device=X.device) if want_idx else None
+    cnt = torch.empty(n, dtype=torch.int32, device=X.device)
+    _lib.check(L.creg_knn_normals_f64(_p(X), n, float(radius), int(max_nn), _p(idx) if want_idx else None, _p(cnt),
+                                      _p(normals) if want_normals else None, _stream()), "creg_knn_normals_f64")
+    return normals, idx, cnt
+
+
 KMEANS_BATCH_MAX_N = 16384         # labels + centres in one CU's LDS; the frame too up to 5120 points, from L2 above
 
 

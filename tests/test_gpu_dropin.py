@@ -28,7 +28,7 @@ def workdir(tmp_path, monkeypatch):
     return tmp_path
 
 
-@pytest.mark.parametrize("flags", [["--loss"], ["--mlp_icp"], ["--r", "dq"], ["--r", "6d"], ["--r", "rpy"]])
+@pytest.mark.parametrize("flags", [["--loss"], ["--mlp_icp"], ["--r", "dq"], ["--r", "6d"], ["--r", "rpy"], ["--normal"], ["--normal", "--mlp_icp"]])
 def test_match_writes_the_reference_file_layout(workdir, flags, monkeypatch):
     from autourdf_amd import mlp_reg
     monkeypatch.setattr(mlp_reg, "EPOCHS", 12)

@@ -1,0 +1,110 @@
+"""GPU: the `--normal` branch (reference mlp_reg.py:190-203, cluster_icp.py:49-62): neighbour search + normal estimation
+(csrc/normals.hip), orientation (autourdf_amd/normals.py), 6-D k-means (csrc/kmeans_nd.hip), the two drop-in call sites.
+open3d is absent: normals are checked against the oracle's restatement (parity unpinned); the 6-D k-means against LIVE
+scikit-learn, the library the reference calls."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(n=1500, seed=0):
+    from autourdf_amd.synthetic import make_sequence
+    return make_sequence("wx200_5", seed, 2, n)
+
+
+def test_knn_lists_and_unoriented_normals_vs_oracle():
+    from autourdf_amd import ops
+    from oracle import normals as onrm
+    P = _cloud()[0]
+    X = torch.as_tensor(P, device="cuda")
+    for radius, k in ((0.1, 30), (0.03, 30), (-1.0, 12)):
+        nrm, idx, cnt = ops.knn_normals(X, radius, k, want_normals=True, want_idx=True)
+        ref = onrm.hybrid_neighbours(P, radius, k)
+        idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+        assert [len(r) for r in ref] == list(cnt)
+        for i in range(len(P)):
+            assert (idx[i, :cnt[i]] == ref[i]).all() and (idx[i, cnt[i]:] == -1).all()
+        if radius > 0:
+            o = onrm.estimate_normals(P, radius, k)
+            g = nrm.cpu().numpy()
+            np.testing.assert_allclose(np.linalg.norm(g, axis=1), 1.0, atol=1e-12)
+            dots = np.abs((g * o).sum(1))                          # eigenvector signs are the solver's business
+            few = cnt < 3
+            assert (g[few] == np.array([0.0, 0.0, 1.0])).all()
+            # a direction is as well defined as the gap between the two smallest eigenvalues: compare where it is
+            assert np.quantile(dots[~few], 0.02) > 1 - 1e-6 and (dots[~few] > 0.999).mean() > 0.97
+
+
+def test_oriented_normals_vs_oracle():
+    """After orient_normals_consistent_tangent_plane the signs are determined (they do not depend on the eigen-solver's):
+    GPU neighbour lists + host walk against the oracle's independent Kruskal / queue walk."""
+    from autourdf_amd import normals as gn
+    from oracle import normals as onrm
+    P = _cloud(1200, 3)[0]
+    feat, N = gn.point_features(P)
+    ofeat, oN = onrm.point_features(P)
+    agree = ((N * oN).sum(1) > 0.999).mean()
+    assert agree > 0.98, agree                                     # (a tie between equal-weight edges may root a small patch differently)
+    assert N[np.argmax(P[:, 2]), 2] >= 0
+    np.testing.assert_array_equal(feat[:, :3], P)
+
+
+@pytest.mark.parametrize("k", [8, 20])
+def test_kmeans_6d_labels_vs_live_sklearn(k):
+    from sklearn.cluster import k_means
+    from autourdf_amd import ops
+    from oracle import normals as onrm
+    P = _cloud(2000, 5)[0]
+    feat, _ = onrm.point_features(P)
+    rng = np.random.default_rng(k)
+    init = np.hstack([P[rng.choice(len(P), k, replace=False)], np.zeros((k, 3))])       # [translation | 0], as mlp_reg.py:196
+    c, lab, inertia, n_it = ops.kmeans_lloyd_nd(torch.as_tensor(feat, device="cuda"), torch.as_tensor(init, device="cuda"))
+    sc, slab, sin_ = k_means(feat.copy(), init=init.copy(), n_clusters=k, n_init=1)
+    assert (lab.cpu().numpy() == slab).all()
+    np.testing.assert_allclose(c.cpu().numpy(), sc, atol=1e-12)
+    assert abs(float(inertia) - sin_) <= 1e-10 * sin_
+
+
+def test_kmeans_nd_at_dim3_equals_the_3d_kernel():
+    from autourdf_amd import ops
+    P = _cloud(3000, 7)[0]
+    init = P[:25].copy()
+    X, I = torch.as_tensor(P, device="cuda"), torch.as_tensor(init, device="cuda")
+    a, b = ops.kmeans_lloyd_nd(X, I), ops.kmeans_lloyd(X, I)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+    np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), atol=1e-13)
+
+
+def test_resample_cluster_and_k_means_cluster_with_normals(tmp_path):
+    """The two drop-in call sites with normal=True against the oracle's features + live sklearn."""
+    from sklearn.cluster import k_means
+    from autourdf_amd import mlp_reg
+    from autourdf_amd.cluster_icp import PointCloud, Segments
+    from autourdf_amd.synthetic import initial_segmentation
+    from oracle import normals as onrm
+    seq = _cloud(1024, 9)
+    mats, clusters, _ = initial_segmentation(seq[0], 8, seed=9)
+
+    class Seg:
+        pc_list = [PointCloud(f) for f in seq]
+
+    local = mlp_reg.resample_cluster(Seg, 1, 8, mats.astype(np.float32), normal=True)
+    feat, _ = onrm.point_features(seq[1])
+    _, slab, _ = k_means(feat, init=np.hstack([mats[:, :3, 3].astype(np.float32).astype(np.float64), np.zeros((8, 3))]), n_clusters=8, n_init=1)
+    assert [len(c) for c in local] == [int((slab == i).sum()) for i in range(8)]
+    inv = np.linalg.inv(mats.astype(np.float32)).astype(np.float64)
+    for i in range(8):
+        want = (inv[i] @ np.hstack([seq[1][slab == i], np.ones((int((slab == i).sum()), 1))]).T)[:3].T
+        np.testing.assert_allclose(local[i], want, atol=1e-9)
+    assert Seg.pc_list[1].normals.shape == (1024, 3)
+    # frame-0 segmentation with normals: runs, partitions the frame, poses at the centroids
+    seg = Segments.__new__(Segments)
+    seg.pc_list = [PointCloud(seq[0])]
+    seg.init_coord_list, seg.init_matrix_list, seg.init_segment_list = [], [], []
+    seg.k_means_cluster(0, 8, normal=True, seed=4)
+    assert sum(len(s) for s in seg.init_segment_list) == 1024 and len(seg.init_matrix_list) == 8
+    for M, s in zip(seg.init_matrix_list, seg.init_segment_list):
+        np.testing.assert_allclose(s.mean(0), 0.0, atol=1e-12)
+        np.testing.assert_allclose(M[:3, :3], np.eye(3), atol=0)
