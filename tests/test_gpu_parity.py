@@ -603,6 +603,16 @@ def test_train_three_steps_odd_shapes_vs_oracle(dev, rot, hidden, k):
     _, best_m, min_loss, hist = registration.train(m, y, model, clusters, rot=rot, epochs=3, learning_rate=1e-3)
     np.testing.assert_allclose(lh.cpu().numpy(), np.array(hist["loss"], np.float32), rtol=2e-5)
     np.testing.assert_allclose(bm.cpu().numpy(), best_m.detach().numpy(), atol=1e-5)
+    # the trained parameters come back from the buffer an ODD number of optimizer steps leaves them in (k_params_home): Adam's
+    # first steps move every weight by ~lr = 1e-3, so a stale buffer would be off by 1e-3, rounding by 1e-6
+    # (a weight whose gradient is a cancelling sum has m/sqrt(v) decided by rounding -- Adam normalises it to a full step --
+    # so a few elements in a thousand differ by a fraction of lr (measured: 0.3 % of W2 above 3e-5, none above 3e-4); a
+    # stale buffer would put the MEDIAN at ~5e-4.  Median inside rounding, 99 % inside 3e-5, all inside half a step.)
+    for name, p in zip(order, params):
+        d = np.abs(p.cpu().numpy() - model.state_dict()[name].numpy())
+        assert np.median(d) < 3e-6, (name, np.median(d))
+        assert (d < 3e-5).mean() >= 0.99, (name, (d < 3e-5).mean())
+        assert d.max() < 5e-4, (name, d.max())
 
 
 @pytest.mark.parametrize("rot", ["q", "dq"])
