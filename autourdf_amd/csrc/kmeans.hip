@@ -38,6 +38,11 @@ struct KmFlags {
     double shift_tot;
     double inertia;
     double fix_scale, fix_inv;   // fixed-point scale 2^s of the M-step accumulators and its inverse
+    unsigned long long gen;      // persistent Lloyd kernel: (M-step tails completed << 8) | 1 when the kernel is to exit
+    int abort;                   // persistent Lloyd kernel: a workgroup gave up waiting (never expected; the host reports it)
+    int pad2;
+    double amax;                 // largest |centred coordinate| of the frame
+    double guard;                // pruned E-step: slack on squared distances, far above the rounding of the fma chain (see k_km_assign_pruned)
 };
 
 // scale 2^s with n * range * 2^s < 2^62: the int64 sums of n fixed-point coordinates cannot overflow
@@ -91,6 +96,8 @@ __global__ __launch_bounds__(1024) void k_km_stats(const double* __restrict__ X,
         double r = 0;
         for (int w = 0; w < 16; ++w) r = fmax(r, s_amax[w]);
         f->fix_scale = km_fix_scale(r, n); f->fix_inv = 1.0 / f->fix_scale;
+        f->amax = r; f->guard = 3e-10 * r * r;
+        f->gen = 0ull; f->abort = 0;
         f->mean[0] = mean[0]; f->mean[1] = mean[1]; f->mean[2] = mean[2];
         f->tol = (var / 3.0) * tol_rel;
         f->changed = 0; f->done = 0; f->strict = 0; f->n_iter = 0; f->cur = 0; f->arrive = 0; f->reloc = 0;
@@ -103,11 +110,13 @@ __global__ __launch_bounds__(256) void k_km_center(const double* __restrict__ X,
                                                    const double* __restrict__ init, int k,
                                                    const KmFlags* __restrict__ f, double* __restrict__ Xc,
                                                    double* __restrict__ C, double* __restrict__ B,
-                                                   int* __restrict__ labels_prev) {
+                                                   int* __restrict__ labels_prev, const int* __restrict__ inv) {
+    // inv (pruned E-step): the centred copy goes out in the spatially sorted order, point i to row inv[i]
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
+        const size_t r = inv ? (size_t)inv[i] : (size_t)i;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) Xc[3 * (size_t)i + d] = X[3 * (size_t)i + d] - f->mean[d];
+        for (int d = 0; d < 3; ++d) Xc[3 * r + d] = X[3 * (size_t)i + d] - f->mean[d];
         labels_prev[i] = -1;
     }
     if (i < k) {
@@ -116,6 +125,88 @@ __global__ __launch_bounds__(256) void k_km_center(const double* __restrict__ X,
         for (int d = 0; d < 3; ++d) { c[d] = init[3 * i + d] - f->mean[d]; C[3 * i + d] = c[d]; }
         make_b(c, B + 4 * i);
     }
+}
+
+// ---- spatial order for the pruned E-step ------------------------------------------------------------------------
+// The points of a frame never move during a k_means() call, only the centres do.  Sorted once by the Morton code of a
+// 2^b-per-axis grid (counting sort: count, scan, scatter), every run of 256 PT consecutive points has a small bounding box,
+// and an E-step workgroup only evaluates the centres that can be nearest to SOME point of its box.  The order inside a grid
+// cell is whatever the scatter's atomics produce; nothing observable depends on it (a point's label depends on the point
+// alone, the M-step sums are exact integers, the relocation and the inertia keep the caller's order through `inv`).
+__device__ __forceinline__ unsigned km_spread3(unsigned v) {   // 10 bits -> bits 0, 3, 6, ...
+    v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ __launch_bounds__(256) void k_km_cell_count(const double* __restrict__ X, int n, const KmFlags* __restrict__ f, int bits,
+                                                       int* __restrict__ key, int* __restrict__ cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double r = f->amax, sc = r > 0.0 ? (double)(1 << bits) / (2.0 * r) : 0.0;
+    unsigned q[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double t = ((X[3 * (size_t)i + d] - f->mean[d]) + r) * sc;
+        q[d] = (unsigned)min(max((int)t, 0), (1 << bits) - 1);
+    }
+    const int c = (int)(km_spread3(q[0]) | (km_spread3(q[1]) << 1) | (km_spread3(q[2]) << 2));
+    key[i] = c;
+    atomicAdd(&cnt[c], 1);
+}
+// counts -> first rows, in place (one workgroup: thread t owns a contiguous run of cells).  The cells fall into 64 aligned
+// Morton ranges (boxes a quarter of the frame's extent per axis); each range starts on a multiple of `align` rows, the rows
+// skipped stay dummies (perm = -1, coordinates NaN).  A workgroup's run of `align` consecutive rows therefore never straddles
+// two of the ranges: without this, the handful of runs that span a big jump of the Morton order get boxes as large as the
+// frame, keep all k centres, and the whole iteration waits ~8 us for their full sweeps.
+__global__ __launch_bounds__(1024) void k_km_cell_scan(int* __restrict__ cnt, int ncell, int align) {
+    __shared__ int part[1024];
+    __shared__ int gbase[65];
+    const int per = (ncell + 1023) / 1024, c0 = min(ncell, (int)threadIdx.x * per), c1 = min(ncell, c0 + per);
+    int s = 0;
+    for (int c = c0; c < c1; ++c) s += cnt[c];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int g = 0;
+        for (int u = 0; u < 16; ++u) g += part[16 * threadIdx.x + u];
+        gbase[threadIdx.x + 1] = (g + align - 1) / align * align;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { gbase[0] = 0; for (int g = 0; g < 64; ++g) gbase[g + 1] += gbase[g]; }
+    __syncthreads();
+    int run = gbase[threadIdx.x >> 4];
+    for (int u = 0; u < (int)(threadIdx.x & 15); ++u) run += part[(threadIdx.x & ~15) + u];
+    for (int c = c0; c < c1; ++c) { const int v = cnt[c]; cnt[c] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void k_km_cell_scatter(int n, const int* __restrict__ key, int* __restrict__ cursor,
+                                                         int* __restrict__ perm, int* __restrict__ inv) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = atomicAdd(&cursor[key[i]], 1);
+    perm[r] = i; inv[i] = r;
+}
+// bounding box (min xyz, max xyz) of every run of `run` sorted points
+__global__ __launch_bounds__(256) void k_km_boxes(const double* __restrict__ Xs, int n, int run, double* __restrict__ box) {
+    __shared__ double sm[4][6];
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * run + threadIdx.x; i < min(n, (blockIdx.x + 1) * run); i += 256)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { const double v = Xs[3 * (size_t)i + d]; lo[d] = fmin(lo[d], v); hi[d] = fmax(hi[d], v); }
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { lo[d] = fmin(lo[d], __shfl_xor(lo[d], off, 64)); hi[d] = fmax(hi[d], __shfl_xor(hi[d], off, 64)); }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { sm[threadIdx.x >> 6][d] = lo[d]; sm[threadIdx.x >> 6][3 + d] = hi[d]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = sm[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fmin(v, sm[w][threadIdx.x]) : fmax(v, sm[w][threadIdx.x]);
+        box[6 * (size_t)blockIdx.x + threadIdx.x] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_km_unsort(const int* __restrict__ sorted, const int* __restrict__ perm, int n, int* __restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;                // n rows, dummies among them
+    if (r < n && perm[r] >= 0) out[perm[r]] = sorted[r];
 }
 
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
@@ -189,7 +280,10 @@ template <int NT>
 __device__ void km_mstep_tail(const double* __restrict__ X, int n, const int* __restrict__ labels, int k,
                               const unsigned long long* __restrict__ acc, double* __restrict__ C2, double* B,
                               double* __restrict__ Cw, double* far_d, double* segv, int* segi, int segsz, int nseg,
-                              KmFlags* __restrict__ f, KmTailSh& S, double* __restrict__ shift, bool relocate) {
+                              KmFlags* __restrict__ f, KmTailSh& S, double* __restrict__ shift, bool relocate,
+                              const int* __restrict__ inv = nullptr) {
+    // inv (pruned E-step): X and labels are stored in the spatially sorted order, point i in row inv[i]; the relocation keeps
+    // working in the caller's point order (far_d, the segments and the tie-breaks of the farthest-point choice index points by i)
     const int tid = threadIdx.x;
     const int cur = f->cur;
     const double finv = f->fix_inv, tol = f->tol;
@@ -242,8 +336,9 @@ __device__ void km_mstep_tail(const double* __restrict__ X, int n, const int* __
                     const int sb = bi / segsz;
                     if (tid == 0) {
                         st_agent(far_d + bi, -2.0);
-                        const int old = labels[bi];
-                        for (int d = 0; d < 3; ++d) { Cw[4 * old + d] -= X[3 * (size_t)bi + d]; Cw[4 * j + d] = X[3 * (size_t)bi + d]; }
+                        const size_t rb = inv ? (size_t)inv[bi] : (size_t)bi;
+                        const int old = labels[rb];
+                        for (int d = 0; d < 3; ++d) { Cw[4 * old + d] -= X[3 * rb + d]; Cw[4 * j + d] = X[3 * rb + d]; }
                         Cw[4 * j + 3] = 1.0; Cw[4 * old + 3] -= 1.0;
                     }
                     __syncthreads();
@@ -303,6 +398,11 @@ __device__ __forceinline__ void km_move(unsigned long long* sA, int lab, int pv,
     }
 }
 
+#ifndef CREG_STAMPS
+#define KM_PHASE(p_) do { } while (0)
+#define KM_BLK(p_) do { } while (0)
+#define KM_PP(p_) do { } while (0)
+#endif
 // Lloyd launches only: the M-step tail's operands (B = the rows `B` points at, writable), the relocation scratch (far: n
 // doubles, segv / segi: one entry per workgroup) and the label buffers.  A launch works on iteration t = f->n_iter: it
 // writes lab[t & 1] and compares with lab[(t - 1) & 1] (prev0 = "no label" at t = 0).
@@ -311,12 +411,32 @@ __device__ __forceinline__ void km_move(unsigned long long* sA, int lab, int pv,
 // last block end (arrival) [3] sum of tail end [4] blocks; scratch: g_km_w = {launch start (min), last arrival (max), tail end}
 __device__ unsigned long long g_km_stamps[8];
 __device__ unsigned long long g_km_w[4];
+__device__ unsigned long long g_km_pp[16];                      // persistent kernel: sums over workgroups and iterations of the time per phase (10 ns ticks), [15] = workgroup-iterations
+__device__ unsigned long long g_km_it[4][1024];                 // persistent kernel, iteration 150: per workgroup rows landed | arrived | tail done | saw gen
+__device__ unsigned long long g_km_blk[4][1024];                // per workgroup of the LAST launch: start, operands landed, E-step end, after arrival
+__device__ unsigned long long g_km_ph[8], g_km_phs[8];          // pruned E-step: latest block past phase p (max), summed over launches
+#define KM_PP(p_) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); pp[p_] += now_ - pp_t; pp_t = now_; \
+                       if (t == 150 && blockIdx.x < 1024 && ((p_) == 0 || (p_) == 3 || (p_) == 4 || (p_) == 5)) g_km_it[(p_) == 0 ? 0 : (p_) - 2][blockIdx.x] = now_; } } while (0)
+#define KM_BLK(p_) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_km_blk[p_][blockIdx.x] = wall_clock64(); } while (0)
+#define KM_PHASE(p_) do { if (threadIdx.x == 0 && lloyd && blockIdx.x == 300) g_km_ph[p_] = wall_clock64(); } while (0)   // one workgroup's timeline (atomics from all of them would serialise)
 __global__ void k_km_fold() {
     if (g_km_w[2] != 0ull) { g_km_stamps[0] += 1; g_km_stamps[2] += g_km_w[1] - g_km_w[0]; g_km_stamps[3] += g_km_w[2] - g_km_w[0]; g_km_stamps[5] += g_km_w[3] - g_km_w[0]; }
+    for (int p = 0; p < 8; ++p) { if (g_km_w[2] != 0ull && g_km_ph[p] != 0ull) g_km_phs[p] += g_km_ph[p] - g_km_w[0]; g_km_ph[p] = 0ull; }
     g_km_w[0] = ~0ull; g_km_w[1] = 0ull; g_km_w[2] = 0ull; g_km_w[3] = 0ull;
 }
 #endif
-struct KmTail { double* B; double* C2; double* Cw; double* far_d; double* segv; int* segi; int* lab[2]; const int* prev0; int max_iter; };
+struct KmTail { double* B; double* C2; double* Cw; double* far_d; double* segv; int* segi; int* lab[2]; const int* prev0; int max_iter; const int* inv;
+                double* ring; unsigned long long* genrep; unsigned long long* slots;
+                int nrow; const int* perm; };                  // pruned form: rows of the sorted copy (dummies: perm < 0)
+// persistent Lloyd kernel: centre rows of the iterations of ONE launch at distinct addresses (see k_km_persist), and copies of `gen`
+#ifndef KMP_GENREP_N
+#define KMP_GENREP_N 8
+#endif
+#ifndef KMP_SLEEP
+#define KMP_SLEEP 10
+#endif
+constexpr int KMP_RING = 320, KMP_GENREP = KMP_GENREP_N, KMP_GENREP_STRIDE = 512;       // (stride in 8-byte words: 4 KB apart)
+__host__ __device__ __forceinline__ size_t kmp_ring_stride(int k) { return ((size_t)4 * k + 15) & ~(size_t)15; }   // doubles, 128-byte multiple
 
 // The workgroup's table of sums goes to the global accumulators; the last workgroup of the launch to have done so runs
 // the M-step tail.
@@ -327,7 +447,9 @@ __device__ __forceinline__ void km_flush_and_tail(const unsigned long long* sA, 
     __shared__ KmTailSh S;
     __syncthreads();
     for (int i = threadIdx.x; i < 4 * k; i += NT) { const unsigned long long v = sA[i]; if (v) atomicAdd(&acc[i], v); }
-    if (!km_arrive_last(f, S)) return;
+    const bool last_wg = km_arrive_last(f, S);
+    KM_BLK(3);
+    if (!last_wg) return;
 #ifdef CREG_STAMPS
     if (threadIdx.x == 0) g_km_w[1] = wall_clock64();
 #endif
@@ -357,8 +479,9 @@ __device__ __forceinline__ bool km_lloyd_entry(const double* __restrict__ X, int
     const double* Cold = T.C2 + (size_t)f->cur * 3 * k;
     double bv = -1; int bi = 0x7fffffff;
     for (int i = sg * segsz + threadIdx.x; i < min(n, (sg + 1) * segsz); i += NT) {
-        const double* c = Cold + 3 * labels[i];
-        const double a = X[3 * (size_t)i] - c[0], b = X[3 * (size_t)i + 1] - c[1], e = X[3 * (size_t)i + 2] - c[2];
+        const size_t r = T.inv ? (size_t)T.inv[i] : (size_t)i;
+        const double* c = Cold + 3 * labels[r];
+        const double a = X[3 * r] - c[0], b = X[3 * r + 1] - c[1], e = X[3 * r + 2] - c[2];
         const double d = (a * a + b * b) + e * e;
         st_agent(T.far_d + i, d);
         if (d > bv) { bv = d; bi = i; }                          // ascending i: the first maximum stays
@@ -366,7 +489,7 @@ __device__ __forceinline__ bool km_lloyd_entry(const double* __restrict__ X, int
     km_block_argmax<NT>(bv, bi, S);
     if (threadIdx.x == 0) { st_agent(T.segv + sg, bv); st_agent(T.segi + sg, bi); }
     if (km_arrive_last(f, S))
-        km_mstep_tail<NT>(X, n, labels, k, acc, T.C2, T.B, T.Cw, T.far_d, T.segv, T.segi, segsz, nseg, f, S, lds_scratch, true);
+        km_mstep_tail<NT>(X, n, labels, k, acc, T.C2, T.B, T.Cw, T.far_d, T.segv, T.segi, segsz, nseg, f, S, lds_scratch, true, T.inv);
     return false;
 }
 
@@ -431,6 +554,400 @@ __global__ __launch_bounds__(256) void k_km_assign(const double* __restrict__ X,
         if ((threadIdx.x & 63) == 0 && diff) atomicAdd(&f->changed, diff);
     }
     if (acc) km_flush_and_tail<256>(sA, X, n, k, acc, f, T, sB);
+}
+
+// bounding box of a wave's points (dummy rows are NaN: fmin / fmax pass them over); wave-uniform result
+template <int PT>
+__device__ __forceinline__ void km_wave_box(const double (&x)[PT][3], double (&wb)[6]) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        double lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < PT; ++q) { lo = fmin(lo, x[q][d]); hi = fmax(hi, x[q][d]); }
+        for (int off = 32; off >= 1; off >>= 1) { lo = fmin(lo, __shfl_xor(lo, off, 64)); hi = fmax(hi, __shfl_xor(hi, off, 64)); }
+        wb[d] = lo; wb[3 + d] = hi;
+    }
+}
+
+// The pruned sweep of one workgroup (256 threads, PT points per thread in x, centre rows in sB, box = min xyz | max xyz): see
+// k_km_assign_pruned.  Called by every thread (barriers inside); lab = the sweep's first argmin per point.
+template <int PT>
+__device__ __forceinline__ void km_pruned_sweep(const double (&x)[PT][3], const double* sB, double* slb, int* cand, int k,
+                                                const double (&bx)[6], double guard, double* s_mub, int* s_cnt, int (&lab)[PT],
+                                                const double (&wb)[6], int* nc_out = nullptr) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool has_points = bx[0] <= bx[3];                      // a run of dummy rows only has the empty box (inf, -inf): no survivors
+    double mub = INFINITY;
+    for (int j = tid; j < k; j += 256) {
+        const double c0 = -0.5 * sB[4 * j], c1 = -0.5 * sB[4 * j + 1], c2 = -0.5 * sB[4 * j + 2];   // b = -2c exactly
+        const double a0 = bx[0] - c0, e0 = c0 - bx[3], a1 = bx[1] - c1, e1 = c1 - bx[4], a2 = bx[2] - c2, e2 = c2 - bx[5];
+        const double n0 = fmax(fmax(a0, e0), 0.0), n1 = fmax(fmax(a1, e1), 0.0), n2 = fmax(fmax(a2, e2), 0.0);
+        const double f0 = fmax(-a0, -e0), f1 = fmax(-a1, -e1), f2 = fmax(-a2, -e2);
+        slb[j] = fma(n2, n2, fma(n1, n1, n0 * n0));
+        mub = fmin(mub, fma(f2, f2, fma(f1, f1, f0 * f0)));
+    }
+    for (int off = 32; off >= 1; off >>= 1) mub = fmin(mub, __shfl_xor(mub, off, 64));
+    if (lane == 0) s_mub[wv] = mub;
+    __syncthreads();
+    const double thr = fmin(fmin(s_mub[0], s_mub[1]), fmin(s_mub[2], s_mub[3])) * (1.0 + 1e-9) + guard;
+    int nc = 0;
+    for (int j0 = 0; j0 < k; j0 += 256) {                        // ordered compaction, 256 centres per pass
+        const int j = j0 + tid;
+        const bool keep = has_points && j < k && slb[j] <= thr;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_cnt[wv] = __popcll(m);
+        __syncthreads();
+        int off = nc + __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wv; ++w) off += s_cnt[w];
+        if (keep) cand[off] = j;
+        nc += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+    // Second level, per wave, when the workgroup's list is long (its run spans a sparse corner of the frame): the same test
+    // against the box of the wave's own 64 PT points, over the listed centres only, into the wave's own list (cand + k (1 + wave)).
+    // The point's nearest centre is in both lists, each being a superset of the centres that can be nearest inside its box.
+    const int* mylist = cand;
+    if (nc > 12) {
+        int* wl = cand + k * (1 + wv);
+        const bool whas = wb[0] <= wb[3];
+        double wmub = INFINITY;
+        for (int c0 = 0; c0 < nc; c0 += 64) {
+            const int j = cand[min(c0 + lane, nc - 1)];
+            const double c0x = -0.5 * sB[4 * j], c1x = -0.5 * sB[4 * j + 1], c2x = -0.5 * sB[4 * j + 2];
+            const double f0 = fmax(c0x - wb[0], wb[3] - c0x), f1 = fmax(c1x - wb[1], wb[4] - c1x), f2 = fmax(c2x - wb[2], wb[5] - c2x);
+            wmub = fmin(wmub, fma(f2, f2, fma(f1, f1, f0 * f0)));
+        }
+        for (int off = 32; off >= 1; off >>= 1) wmub = fmin(wmub, __shfl_xor(wmub, off, 64));
+        const double wthr = wmub * (1.0 + 1e-9) + guard;
+        int wn = 0;
+        for (int c0 = 0; c0 < nc; c0 += 64) {
+            const int c = c0 + lane;
+            const int j = cand[min(c, nc - 1)];
+            const double c0x = -0.5 * sB[4 * j], c1x = -0.5 * sB[4 * j + 1], c2x = -0.5 * sB[4 * j + 2];
+            const double n0 = fmax(fmax(wb[0] - c0x, c0x - wb[3]), 0.0), n1 = fmax(fmax(wb[1] - c1x, c1x - wb[4]), 0.0), n2 = fmax(fmax(wb[2] - c2x, c2x - wb[5]), 0.0);
+            const bool keep = whas && c < nc && fma(n2, n2, fma(n1, n1, n0 * n0)) <= wthr;
+            const unsigned long long m = __ballot(keep);
+            if (keep) wl[wn + __popcll(m & ((1ull << lane) - 1ull))] = j;
+            wn += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        mylist = wl; nc = wn;
+    }
+    if (nc_out) *nc_out = nc;
+    double best[PT];
+#pragma unroll
+    for (int q = 0; q < PT; ++q) { best[q] = INFINITY; lab[q] = 0; }
+    // four survivors per step: their indices, then their rows, are in flight together (one survivor per step is a chain of two
+    // dependent LDS reads -- a workgroup whose box keeps 50-128 centres then takes 5-10 us and the whole iteration waits for it);
+    // the last step repeats the last survivor, which cannot pass the strict `<` twice
+    for (int c = 0; c < nc; c += 4) {
+        int j[4];
+        double b[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = mylist[min(c + u, nc - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { b[u][0] = sB[4 * j[u]]; b[u][1] = sB[4 * j[u] + 1]; b[u][2] = sB[4 * j[u] + 2]; b[u][3] = sB[4 * j[u] + 3]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < PT; ++q) {
+                const double d = fma(x[q][2], b[u][2], fma(x[q][1], b[u][1], fma(x[q][0], b[u][0], b[u][3])));
+                if (d < best[q]) { best[q] = d; lab[q] = j[u]; }
+            }
+    }
+}
+
+// E-step, pruned form (Lloyd launches and the final E-step of creg_kmeans_lloyd_f64's VALU path): X holds the centred frame in
+// the spatial order above, `box` the bounding box of every workgroup's 256 PT points.  With lb_j / ub_j the smallest / largest
+// squared distance from the box to centre j, no point of the box can have centre j nearest unless lb_j <= min_j' ub_j'; the
+// survivors (a handful of the 128 centres of a configs[4] frame) are listed in ascending j and evaluated with the SAME fma
+// chain and the same strict `<` as the full sweep, so the label is the sweep's first argmin: a pruned centre is farther from
+// every point of the box than the survivor that realises min ub by more than `guard` = 3e-10 amax^2, while the chain's value
+// differs from the true |x - c|^2 - |x|^2 by a few ulp of amax^2 (~1e-15 amax^2) -- it can neither win nor tie.
+template <int PT>
+__global__ __launch_bounds__(256) void k_km_assign_pruned(const double* __restrict__ X, int n, const double* B, int k,
+                                                          const double* __restrict__ box, int* labels_in,
+                                                          KmFlags* __restrict__ f, int lloyd, unsigned long long* __restrict__ acc, KmTail T) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double s_mub[4];
+    __shared__ int s_cnt[4];
+    double* sB = (double*)smem;
+    unsigned long long* sA = (unsigned long long*)(sB + 4 * k);
+    double* slb = (double*)(sA + 4 * k);
+    int* cand = (int*)(slb + k);
+    int* labels = labels_in;
+    const int* prev = nullptr;
+    // every kernel argument into registers NOW, in one batch of scalar loads (the compiler otherwise fetches each field of the
+    // argument block where it is first used -- a separate round trip to the argument buffer every time)
+    asm volatile("" :: "s"(X), "s"(n), "s"(B), "s"(k), "s"(box), "s"(labels_in), "s"(f), "s"(lloyd), "s"(acc));
+    asm volatile("" :: "s"(T.B), "s"(T.C2), "s"(T.Cw), "s"(T.far_d), "s"(T.segv), "s"(T.segi), "s"(T.lab[0]), "s"(T.lab[1]), "s"(T.prev0), "s"(T.max_iter), "s"(T.inv));
+#ifdef CREG_STAMPS
+    if (threadIdx.x == 0 && lloyd) atomicMin(&g_km_w[0], wall_clock64());
+#endif
+    KM_BLK(0);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // Every operand of the launch is requested before anything is waited for -- the points, the centre rows, the box, and the
+    // previous labels from BOTH label buffers (which one holds them depends on the iteration count, which arrives with the
+    // flags): one memory round trip for the flags and the operands together instead of two or three in a row.
+    const int i0 = blockIdx.x * (256 * PT) + wv * (64 * PT) + lane, nrow = T.nrow;   // a wave owns 64 PT consecutive rows
+    double x[PT][3];
+    int lab[PT], pv[PT], pa[PT], pb[PT], own[PT];
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int i = min(i0 + 64 * q, nrow - 1);
+        x[q][0] = X[3 * (size_t)i]; x[q][1] = X[3 * (size_t)i + 1]; x[q][2] = X[3 * (size_t)i + 2];
+        own[q] = T.perm[i];                                        // < 0: a dummy row
+        pa[q] = lloyd ? T.lab[0][i] : -1; pb[q] = lloyd ? T.lab[1][i] : -1;      // (first iteration: whatever the workspace holds, unused)
+    }
+    double br[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) br[u] = tid + 256 * u < 4 * k ? B[tid + 256 * u] : 0.0;       // k <= 128: the whole table
+    const double fscale = lloyd ? f->fix_scale : 0.0, guard = f->guard;
+    const double* bx = box + 6 * (size_t)blockIdx.x;
+    const double bx6[6] = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]};
+    if (lloyd && !km_lloyd_entry<256>(X, n, k, acc, f, T, sB, labels, prev)) return;
+    KM_PHASE(0);
+#pragma unroll
+    for (int q = 0; q < PT; ++q) pv[q] = prev == T.lab[0] ? pa[q] : prev == T.lab[1] ? pb[q] : -1;
+    if (lloyd) for (int i = tid; i < 4 * k; i += 256) sA[i] = 0ull;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) if (tid + 256 * u < 4 * k) sB[tid + 256 * u] = br[u];
+    for (int i = tid + 512; i < 4 * k; i += 256) sB[i] = B[i];
+    __syncthreads();
+    KM_PHASE(1); KM_BLK(1);
+    double wb[6];
+    km_wave_box<PT>(x, wb);
+    km_pruned_sweep<PT>(x, sB, slb, cand, k, bx6, guard, s_mub, s_cnt, lab, wb);
+    KM_PHASE(3);
+    int diff = 0;
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int i = i0 + 64 * q;
+        if (i < nrow) {
+            labels[i] = lab[q];
+            if (lloyd && own[q] >= 0 && pv[q] != lab[q]) { ++diff; km_move(sA, lab[q], pv[q], x[q][0], x[q][1], x[q][2], fscale); }
+        }
+    }
+#ifdef CREG_STAMPS
+    if (threadIdx.x == 0 && lloyd) atomicMax(&g_km_w[3], wall_clock64());
+#endif
+    KM_BLK(2);
+    if (lloyd) {
+        diff = wave_sum(diff);
+        if (lane == 0 && diff) atomicAdd(&f->changed, diff);
+        km_flush_and_tail<256>(sA, X, n, k, acc, f, T, sB);
+    }
+}
+
+// ---- persistent Lloyd kernel -------------------------------------------------------------------------------------
+// A launch boundary between two Lloyd iterations costs far more than the pruned E-step itself (measured at the configs[4]
+// shape, tests/measure/km_stamps.py: the workgroups finish their sweep 2-4 us after they start, yet an iteration took 26 us --
+// every launch begins by re-fetching its operands through caches the boundary has just written back and invalidated, and
+// ends with two more such round trips).  Here ONE launch runs iterations until convergence / max_iter / an empty cluster:
+// a workgroup keeps its points and their labels in registers for the whole call; per iteration it fetches the 4 k centre
+// words, runs the pruned sweep, moves the changed points between the exact integer sums, arrives; the last workgroup to arrive
+// runs the M-step tail and publishes `gen`; the others wait for it.  What crosses workgroups inside the launch goes through
+// agent-scope accesses on both sides, every wave draining its stores before the hand-off (km_arrive_last; the tail before
+// `gen`).  The state in memory between launches (flags, centres, sums, the two label buffers) is exactly the multi-launch
+// path's, so the two kinds of launch are interchangeable steps of one state machine: an empty cluster makes this kernel exit
+// with `reloc` set, the next ordinary launch relocates, and the host starts the kernel again.
+// All workgroups must be resident at once (the host checks the grid against the occupancy the runtime reports); the wait is
+// bounded all the same -- a workgroup that polls for ~2^20 round trips sets `abort` and leaves, and the host fails loudly.
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// common path of km_mstep_tail (same arithmetic, same order) with agent-scope loads and write-through stores; returns through
+// `gen`: bit 0 = leave the kernel (converged, max_iter reached, or an empty cluster awaits the relocation launch)
+template <int NT>
+__device__ void km_tail_persist(int k, const unsigned long long* __restrict__ acc, double* __restrict__ C2, double* __restrict__ B,
+                                KmFlags* __restrict__ f, KmTailSh& S, double* __restrict__ shift, int max_iter,
+                                double* __restrict__ Bnext, bool ring_full, unsigned long long* __restrict__ genrep,
+                                int cur, int it_done, unsigned long long gen_next, double finv, double tol, int changed) {
+    // cur / it_done / gen_next: every workgroup counts the launch's tails itself, so the tail reads nothing but the sums and
+    // the changed-label count (ONE round trip), and its centre and flag stores share one drain before `gen` goes out
+    const int tid = threadIdx.x;
+    const double* Cold = C2 + (size_t)cur * 3 * k;
+    double* Cnew = C2 + (size_t)(cur ^ 1) * 3 * k;
+    double* cpark = shift + k;
+    // changed: some label of the grid changed in this iteration (gathered from the arrival slots); f->changed stays 0 between
+    // iterations, as the multi-launch tail leaves it
+    if (tid == 0) S.nempty = 0;
+    __syncthreads();
+    for (int j = tid; j < k; j += NT) {
+        double a[4], co[3];
+        for (int d = 0; d < 3; ++d) a[d] = (double)(long long)ld_agent(acc + 4 * j + d);
+        a[3] = (double)(long long)ld_agent(acc + 4 * j + 3);
+        for (int d = 0; d < 3; ++d) co[d] = ld_agent(Cold + 3 * j + d);
+        for (int d = 0; d < 3; ++d) a[d] *= finv;
+        if (a[3] == 0.0) atomicAdd(&S.nempty, 1);
+        double s2 = 0;
+        const double alpha = 1.0 / a[3];
+        for (int d = 0; d < 3; ++d) { const double c = a[d] * alpha; cpark[3 * j + d] = c; const double t = c - co[d]; s2 += t * t; }
+        const double sh = sqrt(s2);
+        shift[j] = sh * sh;
+    }
+    __syncthreads();
+    const bool empty = S.nempty > 0;
+    if (!empty)
+        for (int j = tid; j < k; j += NT) {
+            const double c[3] = {cpark[3 * j], cpark[3 * j + 1], cpark[3 * j + 2]};
+            double b[4];
+            make_b(c, b);
+            for (int d = 0; d < 3; ++d) st_agent(Cnew + 3 * j + d, c[d]);
+            for (int d = 0; d < 4; ++d) { st_agent(B + 4 * j + d, b[d]); st_agent(Bnext + 4 * j + d, b[d]); }
+        }
+    int leave = 1;
+    if (tid == 0) {
+        if (empty) { st_agent(&f->reloc, 1); st_agent(&f->changed, changed ? 1 : 0); }   // deferred: the relocation launch finishes this iteration (and tests `changed`)
+        else {
+            double tot = 0;
+            for (int j0 = 0; j0 < k; j0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = shift[min(j0 + u, k - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (j0 + u < k) tot += v[u];
+            }
+            st_agent(&f->shift_tot, tot);
+            st_agent(&f->cur, cur ^ 1);
+            st_agent(&f->n_iter, it_done);
+            int done = 0;
+            if (changed == 0) { st_agent(&f->strict, 1); done = 1; }
+            else if (tot <= tol) done = 1;
+            if (done) st_agent(&f->done, 1);
+            leave = done || it_done >= max_iter || ring_full;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                             // every wave's centre and flag stores are acknowledged
+    if (tid == 0) {
+        const unsigned long long g = (gen_next << 8) | (unsigned long long)leave;
+        for (int r = 0; r < KMP_GENREP; ++r) st_agent(genrep + (size_t)r * KMP_GENREP_STRIDE, g);
+        st_agent(&f->gen, g);
+    }
+}
+
+template <int PT>
+__global__ __launch_bounds__(256, PT == 2 ? 3 : PT == 4 ? 2 : 1) void k_km_persist(const double* __restrict__ X, int n, double* B, int k,
+                                                    const double* __restrict__ box, KmFlags* __restrict__ f,
+                                                    unsigned long long* __restrict__ acc, KmTail T) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double s_mub[4];
+    __shared__ int s_cnt[4];
+    __shared__ KmTailSh S;
+    __shared__ unsigned long long s_gen;
+    double* sB = (double*)smem;
+    unsigned long long* sA = (unsigned long long*)(sB + 4 * k);
+    double* slb = (double*)(sA + 4 * k);
+    int* cand = (int*)(slb + k);
+    const int tid = threadIdx.x, lane = tid & 63;
+    asm volatile("" :: "s"(X), "s"(n), "s"(B), "s"(k), "s"(box), "s"(f), "s"(acc), "s"(T.C2), "s"(T.lab[0]), "s"(T.lab[1]), "s"(T.max_iter));
+    const int i0 = blockIdx.x * (256 * PT) + (tid >> 6) * (64 * PT) + lane, nrow = T.nrow;   // a wave owns 64 PT consecutive rows
+    double x[PT][3];
+    int lab[PT], pv[PT], pa[PT], pb[PT];
+    bool own[PT];
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int i = min(i0 + 64 * q, nrow - 1);
+        x[q][0] = X[3 * (size_t)i]; x[q][1] = X[3 * (size_t)i + 1]; x[q][2] = X[3 * (size_t)i + 2];
+        own[q] = i0 + 64 * q < nrow && T.perm[i] >= 0;             // not a dummy row
+        pa[q] = T.lab[0][i]; pb[q] = T.lab[1][i];
+    }
+    const double* bx = box + 6 * (size_t)blockIdx.x;
+    const double bx6[6] = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]};
+    const double fscale = f->fix_scale, guard = f->guard, finv = f->fix_inv, tol = f->tol;
+    const int cur0 = f->cur;
+    if (f->done || f->reloc) return;                             // (launch-uniform: nothing in this launch has written them yet)
+    double wb[6];
+    km_wave_box<PT>(x, wb);                                      // once per launch: the points do not move
+    int t = f->n_iter;
+    if (t >= T.max_iter) return;
+    unsigned long long want = (ld_agent(&f->gen) >> 8) + 1ull;     // no tail can run before this workgroup has arrived once
+#pragma unroll
+    for (int q = 0; q < PT; ++q) pv[q] = t == 0 ? -1 : ((t - 1) & 1) ? pb[q] : pa[q];
+    // Centre rows: iteration `my` of this launch reads slot my of a ring nobody has read in this launch (slot 0 = B itself,
+    // written before the launch), so ordinary cached loads are safe -- no stale copy can sit in an L2 -- and the 32 workgroups
+    // of an XCD share one fetch.  (Agent-scope loads of ONE 4 KB table by 256 workgroups queue on the few memory channels that
+    // hold it: 32 us per iteration measured, slower than a launch per iteration.)
+    const size_t rstride = kmp_ring_stride(k);
+    const unsigned long long* gen_mine = T.genrep + (size_t)(blockIdx.x % KMP_GENREP) * KMP_GENREP_STRIDE;
+#ifdef CREG_STAMPS
+    unsigned long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pp_t = wall_clock64(), pp_n = 0;
+#endif
+    for (int my = 0;; ++my) {
+        const double* Bt = my == 0 ? B : T.ring + (size_t)my * rstride;
+        for (int i = tid; i < 4 * k; i += 256) { sB[i] = Bt[i]; sA[i] = 0ull; }
+        __syncthreads();
+        KM_PP(0);
+        int nc_dbg = 0;
+        km_pruned_sweep<PT>(x, sB, slb, cand, k, bx6, guard, s_mub, s_cnt, lab, wb, &nc_dbg);
+        KM_PP(1);
+        int diff = 0;
+#pragma unroll
+        for (int q = 0; q < PT; ++q)
+            if (own[q] && pv[q] != lab[q]) { ++diff; km_move(sA, lab[q], pv[q], x[q][0], x[q][1], x[q][2], fscale); }
+#pragma unroll
+        for (int q = 0; q < PT; ++q) pv[q] = lab[q];
+        // Arrival without a shared word.  Hundreds of read-modify-writes (or write-through stores) of ONE word queue at the memory
+        // side -- ~12 ns each: the per-wave changed-label count alone made the workgroups that had changes arrive 10 us after the
+        // others (tests/measure/km_persist_phases.py).  Every workgroup instead drains its sum atomics and writes its OWN 8-byte
+        // slot, tagged with the iteration's generation: (gen << 32) | "one of my labels changed".  Workgroup 0 runs every tail of
+        // the launch: its 256 threads watch the slots (two each per look, one round trip) until all carry the generation.
+        const int blk_changed = __syncthreads_or(diff != 0);
+#ifdef CREG_STAMPS
+        if (tid == 0 && t == 150 && blockIdx.x > 0 && blockIdx.x < 1024) g_km_it[2][blockIdx.x] = ((unsigned long long)nc_dbg << 32) | (unsigned)wave_sum(diff);
+#endif
+        for (int i = tid; i < 4 * k; i += 256) { const unsigned long long v = sA[i]; if (v) atomicAdd(&acc[i], v); }
+        KM_PP(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const bool last_wg = blockIdx.x == 0;
+        int any_changed = blk_changed;
+        if (!last_wg) { if (tid == 0) st_agent(T.slots + blockIdx.x, (want << 32) | (unsigned long long)(blk_changed != 0)); }
+        else {
+            int spins = 0, ok;
+            do {
+                int mine = 1;
+                for (int i = tid; i < (int)gridDim.x; i += 256)
+                    if (i > 0) { const unsigned long long v = ld_agent(T.slots + i); mine &= (v >> 32) == want; any_changed |= mine ? (int)(v & 1ull) : 0; }
+                ok = __syncthreads_and(mine);
+                if (!ok && (++spins & 63) == 0 && (spins >= (1 << 20) || ld_agent(&f->abort))) { if (tid == 0) st_agent(&f->abort, 1); break; }
+            } while (!ok);
+            any_changed = __syncthreads_or(any_changed);
+        }
+        KM_PP(3);
+        if (last_wg)
+            km_tail_persist<256>(k, acc, T.C2, B, f, S, sB, T.max_iter, T.ring + (size_t)(my + 1) * rstride, my + 2 >= KMP_RING, T.genrep,
+                                 cur0 ^ (my & 1), t + 1, want, finv, tol, any_changed);
+#ifdef CREG_STAMPS
+        if (last_wg) KM_PP(4);
+        ++pp_n;
+#endif
+        if (tid == 0) {
+            unsigned long long g = 0ull;
+            int spins = 0;
+            for (;;) {
+                g = ld_agent(gen_mine);                          // one of 8 copies, a poll every ~0.3 us: the tail's own traffic is not queued behind the waiters
+                if ((g >> 8) >= want) break;
+                __builtin_amdgcn_s_sleep(KMP_SLEEP);
+                if ((++spins & 63) == 0 && (spins >= (1 << 20) || ld_agent(&f->abort))) { st_agent(&f->abort, 1); g = ~0ull; break; }
+            }
+            s_gen = g;
+        }
+        __syncthreads();
+        KM_PP(5);
+        const unsigned long long g = s_gen;
+        if (g == ~0ull) return;                                  // gave up: the host reports it, nothing of this call is used
+        if (g & 1ull) break;
+        ++want; ++t;
+    }
+    // (s_gen is rewritten only after the next arrival's barriers, which every thread reaches after reading it)
+#ifdef CREG_STAMPS
+    if (tid == 0) { for (int p = 0; p < 6; ++p) atomicAdd(&g_km_pp[p], pp[p]); atomicAdd(&g_km_pp[15], pp_n);
+                    if (blockIdx.x == 0) for (int p = 0; p < 6; ++p) g_km_pp[8 + p] = pp[p]; }
+#endif
+    int* out = (t & 1) ? T.lab[1] : T.lab[0];                    // the labels of iteration t, where the multi-launch path keeps them
+#pragma unroll
+    for (int q = 0; q < PT; ++q) if (i0 + 64 * q < nrow) out[i0 + 64 * q] = lab[q];
 }
 
 // E-step, matrix-core form: v_mfma_f64_16x16x4_f64 evaluates a 16-centre x 16-point tile of |c|^2 - 2 x.c as
@@ -563,13 +1080,16 @@ __global__ __launch_bounds__(1024) void k_km_finish(const double* __restrict__ X
                                                     const int* __restrict__ labels, int k,
                                                     const double* __restrict__ C2, KmFlags* __restrict__ f,
                                                     double* __restrict__ centers, double* __restrict__ inertia,
-                                                    int* __restrict__ n_iter) {
+                                                    int* __restrict__ n_iter, int raw) {
+    // raw: X is the caller's frame and is centred here (the same subtraction k_km_center stores: identical values) -- the
+    // pruned path keeps its centred copy in another order, and the inertia sum keeps the caller's point order
     __shared__ double sc[16];
     const double* C = C2 + (size_t)f->cur * 3 * k;
+    const double m0 = raw ? f->mean[0] : 0.0, m1 = raw ? f->mean[1] : 0.0, m2 = raw ? f->mean[2] : 0.0;
     double s = 0;
     for (int i = threadIdx.x; i < n; i += 1024) {
         const double* c = C + 3 * labels[i];
-        const double a = X[3 * (size_t)i] - c[0], b = X[3 * (size_t)i + 1] - c[1], e = X[3 * (size_t)i + 2] - c[2];
+        const double a = (X[3 * (size_t)i] - m0) - c[0], b = (X[3 * (size_t)i + 1] - m1) - c[1], e = (X[3 * (size_t)i + 2] - m2) - c[2];
         s += (a * a + b * b) + e * e;
     }
     s = block_sum<double, 1024>(s, sc);
@@ -960,17 +1480,50 @@ __global__ __launch_bounds__(1024) void k_group_scatter_big(const double* __rest
 
 static int seg_count(int64_t n) { int s = (int)((n + 16383) / 16384); return s < 1 ? 1 : (s > 64 ? 64 : s); }
 
-struct KmLayout { size_t xc, c2, b, cw, part, far, segv, segi, prev, lab2, flags, total; };
+// pruned E-step: points per workgroup and grid bits per axis of the spatial order
+static int km_pruned_pt(int64_t n) {                             // points per thread of the pruned E-step: 2 | 4 | 8
+    static int forced = -1;                                      // measurement knob CREG_KMP_PT
+    if (forced < 0) { const char* e = getenv("CREG_KMP_PT"); forced = e ? atoi(e) : 0; }
+    if (forced == 2 || forced == 4 || forced == 8) return forced;
+    return n <= 131072 ? 2 : n <= 262144 ? 4 : 8;                // at most 256 workgroups up to 524288 points (one per CU for the persistent kernel)
+}
+static bool km_persist_enabled() {
+    static int v = -1;                                           // measurement knob: CREG_KM_PERSIST=0 keeps one launch per iteration
+    if (v < 0) { const char* e = getenv("CREG_KM_PERSIST"); v = e ? atoi(e) != 0 : 1; }
+    return v != 0;
+}
+static int km_cell_bits(int64_t n) { return n >= 131072 ? 6 : n >= 16384 ? 5 : n >= 2048 ? 4 : 3; }   // ~8 points per cell of a surface
+static bool km_pruned_enabled() {
+    static int v = -1;                                           // measurement knob (tests/measure): CREG_KM_PRUNE=0 keeps the full sweep
+    if (v < 0) { const char* e = getenv("CREG_KM_PRUNE"); v = e ? atoi(e) != 0 : 1; }
+    return v != 0;
+}
+
+struct KmLayout { size_t xc, c2, b, cw, part, far, segv, segi, prev, lab2, flags, lab3, perm, inv, key, cell, box, ring, genrep, slots, total; };
+// rows of the sorted copy: the points plus the dummies that align the 64 Morton ranges to the workgroup runs (sized for the
+// longest run, 2048 rows)
+static int64_t km_rows_cap(int64_t n) { return n + 65 * 2048; }      // (>= km_rows(n, 8): 64 ranges of up to 2047 dummies, rounded up to a run)
+static int km_rows(int64_t n, int pt) { const int a = 256 * pt; return (int)((n + 64 * (int64_t)(a - 1) + a - 1) / a * a); }
 static KmLayout km_layout(int64_t n, int k) {
     KmLayout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-    L.xc = take(sizeof(double) * 3 * n); L.c2 = take(sizeof(double) * 6 * k); L.b = take(sizeof(double) * 4 * k);
+    const int64_t nr = km_rows_cap(n);
+    L.xc = take(sizeof(double) * 3 * nr); L.c2 = take(sizeof(double) * 6 * k); L.b = take(sizeof(double) * 4 * k);
     L.cw = take(sizeof(double) * 4 * k); L.part = take(sizeof(unsigned long long) * 4 * k);      // part: the int64 accumulators
     L.far = take(sizeof(double) * n);
-    const size_t nseg = (size_t)((n + 63) / 64);                 // relocation pass: one entry per workgroup of the E-step launch (at most n / 64: the matrix-core form)
+    // relocation pass: one entry per workgroup of the E-step launch (at most n / 64: the matrix-core form; the pruned form's
+    // grid covers the dummy rows too)
+    const size_t nseg = (size_t)((n + 63) / 64) + (size_t)(nr / 512) + 1;
     L.segv = take(sizeof(double) * nseg); L.segi = take(sizeof(int) * nseg);
-    L.prev = take(sizeof(int) * n); L.lab2 = take(sizeof(int) * n);
-    L.flags = take(sizeof(KmFlags)); L.total = o;
+    L.prev = take(sizeof(int) * n); L.lab2 = take(sizeof(int) * nr);
+    L.flags = take(sizeof(KmFlags));
+    L.lab3 = take(sizeof(int) * nr); L.perm = take(sizeof(int) * nr); L.inv = take(sizeof(int) * n); L.key = take(sizeof(int) * n);
+    L.cell = take(sizeof(int) * ((size_t)1 << (3 * km_cell_bits(n))));
+    L.box = take(sizeof(double) * 6 * (size_t)((nr + 511) / 512));
+    L.ring = take(sizeof(double) * kmp_ring_stride(k) * KMP_RING);
+    L.genrep = take(sizeof(unsigned long long) * KMP_GENREP_STRIDE * KMP_GENREP);
+    L.slots = take(sizeof(unsigned long long) * 1024);          // (the persistent grid is at most 512 workgroups; genrep and slots are zeroed together)
+    L.total = o;
     return L;
 }
 
@@ -983,7 +1536,7 @@ static int km_points_per_thread(int n) {
 
 static int launch_assign(const double* X, int n, const double* B, int k, int* labels, const int* prev,
                          KmFlags* f, int use_mfma, hipStream_t s, int raw = 0, unsigned long long* acc = nullptr,
-                         KmTail T = KmTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr}, nullptr, 0}) {
+                         KmTail T = KmTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr}, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr}) {
     constexpr int LDS_MAX = 128 * 1024;
     if (use_mfma) {
         const int ntile = cdiv(n, 16);
@@ -1017,6 +1570,47 @@ static int launch_assign(const double* X, int n, const double* B, int k, int* la
     return 0;
 }
 
+// the persistent kernel's grid must be resident all at once: 0 = not possible here (the caller keeps one launch per iteration)
+template <int PT>
+static int persist_fits(int blocks, size_t smem) {
+    if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_km_persist<PT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return 0;
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_km_persist<PT>, 256, smem) != hipSuccess) return 0;
+    return blocks <= (per_cu > 4 ? 4 : per_cu) * cus && blocks <= 1024;   // at most four per CU are counted on; one arrival slot each
+}
+static int launch_persist(const double* Xs, int n, double* B, int k, const double* box, KmFlags* f, unsigned long long* acc,
+                          const KmTail& T, int pt, hipStream_t s, bool probe_only) {
+    const size_t smem = sizeof(double) * 9 * k + sizeof(int) * 5 * k;   // centre rows, M-step sums, lower bounds, the workgroup's and the four waves' survivor lists
+    const int blocks = cdiv(T.nrow, 256 * pt);
+#define CREG_KM_PERSIST(PT_)                                                                                                     \
+    do {                                                                                                                          \
+        if (!persist_fits<PT_>(blocks, smem)) return 1;                                                                           \
+        if (!probe_only) hipLaunchKernelGGL(k_km_persist<PT_>, dim3(blocks), dim3(256), smem, s, Xs, n, B, k, box, f, acc, T);     \
+    } while (0)
+    if (pt == 8) CREG_KM_PERSIST(8);
+    else if (pt == 4) CREG_KM_PERSIST(4);
+    else CREG_KM_PERSIST(2);
+#undef CREG_KM_PERSIST
+    return 0;
+}
+
+static int launch_assign_pruned(const double* Xs, int n, const double* B, int k, const double* box, int* labels, KmFlags* f,
+                                int lloyd, unsigned long long* acc, const KmTail& T, hipStream_t s) {
+    const size_t smem = sizeof(double) * 9 * k + sizeof(int) * 5 * k;   // centre rows, M-step sums, lower bounds, the workgroup's and the four waves' survivor lists
+#define CREG_KM_PRUNED(PT_)                                                                                                      \
+    do {                                                                                                                          \
+        if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_km_assign_pruned<PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return 1; \
+        hipLaunchKernelGGL(k_km_assign_pruned<PT_>, dim3(cdiv(T.nrow, 256 * PT_)), dim3(256), smem, s, Xs, n, B, k, box, labels, f, lloyd, acc, T); \
+    } while (0)
+    const int pt = km_pruned_pt(n);
+    if (pt == 8) CREG_KM_PRUNED(8);
+    else if (pt == 4) CREG_KM_PRUNED(4);
+    else CREG_KM_PRUNED(2);
+#undef CREG_KM_PRUNED
+    return 0;
+}
+
 }  // namespace creg
 using namespace creg;
 
@@ -1038,27 +1632,60 @@ extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* i
     char* w = (char*)workspace;
     double* Xc = (double*)(w + L.xc); double* C2 = (double*)(w + L.c2); double* B = (double*)(w + L.b);
     double* Cw = (double*)(w + L.cw); unsigned long long* acc = (unsigned long long*)(w + L.part); double* far_d = (double*)(w + L.far);
-    int* lab[2] = {labels, (int*)(w + L.lab2)};
+    // VALU form: the E-step runs over a spatially sorted copy of the frame and prunes the centres per workgroup (labels in
+    // the sorted order in two workspace buffers, put back in the caller's order at the end); matrix-core form: full sweep
+    const bool pruned = !use_mfma && km_pruned_enabled() && n < (1ll << 30);
+    int* lab[2] = {pruned ? (int*)(w + L.lab3) : labels, (int*)(w + L.lab2)};
     int* prev0 = (int*)(w + L.prev);
+    int* perm = (int*)(w + L.perm); int* inv = (int*)(w + L.inv); double* box = (double*)(w + L.box);
     KmFlags* f = (KmFlags*)(w + L.flags);
-    const int ni = (int)n;
+    const int ni = (int)n, nrow = pruned ? km_rows(n, km_pruned_pt(n)) : (int)n;
+    CREG_REQUIRE((int64_t)nrow <= km_rows_cap(n), "creg_kmeans_lloyd_f64: internal: sorted copy larger than its workspace");
     CREG_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * 4 * k, s));
 
     hipLaunchKernelGGL(k_km_stats, dim3(1), dim3(1024), 0, s, X, ni, tol_rel, f);
-    hipLaunchKernelGGL(k_km_center, dim3(cdiv(n > k ? n : k, 256)), dim3(256), 0, s, X, ni, init, k, f, Xc, C2, B, prev0);
+    if (pruned) {
+        const int bits = km_cell_bits(n), ncell = 1 << (3 * bits);
+        int* key = (int*)(w + L.key); int* cell = (int*)(w + L.cell);
+        CREG_HIP(hipMemsetAsync(cell, 0, sizeof(int) * ncell, s));
+        hipLaunchKernelGGL(k_km_cell_count, dim3(cdiv(n, 256)), dim3(256), 0, s, X, ni, f, bits, key, cell);
+        hipLaunchKernelGGL(k_km_cell_scan, dim3(1), dim3(1024), 0, s, cell, ncell, 256 * km_pruned_pt(n));
+        CREG_HIP(hipMemsetAsync(Xc, 0xFF, sizeof(double) * 3 * (size_t)nrow, s));       // dummy rows: NaN coordinates (ignored by the boxes' fmin / fmax) ...
+        CREG_HIP(hipMemsetAsync(perm, 0xFF, sizeof(int) * (size_t)nrow, s));            // ... and perm = -1
+        hipLaunchKernelGGL(k_km_cell_scatter, dim3(cdiv(n, 256)), dim3(256), 0, s, ni, key, cell, perm, inv);
+    }
+    hipLaunchKernelGGL(k_km_center, dim3(cdiv(n > k ? n : k, 256)), dim3(256), 0, s, X, ni, init, k, f, Xc, C2, B, prev0, pruned ? inv : nullptr);
+    if (pruned) hipLaunchKernelGGL(k_km_boxes, dim3(cdiv(nrow, 256 * km_pruned_pt(n))), dim3(256), 0, s, Xc, nrow, 256 * km_pruned_pt(n), box);
     CREG_LAUNCH_CHECK();
     // labels ping-pong between the caller's buffer and lab2 so "previous labels" needs no copy;
     // iteration `it` writes lab[it & 1] and compares with the buffer written by it - 1.
     int done = 0, n_done = 0;
     KmFlags host;
-    const KmTail T{B, C2, Cw, far_d, (double*)(w + L.segv), (int*)(w + L.segi), {lab[0], lab[1]}, prev0, max_iter};
+    const KmTail T{B, C2, Cw, far_d, (double*)(w + L.segv), (int*)(w + L.segi), {lab[0], lab[1]}, prev0, max_iter, pruned ? inv : nullptr,
+                   (double*)(w + L.ring), (unsigned long long*)(w + L.genrep), (unsigned long long*)(w + L.slots), nrow, perm};
+    if (pruned) CREG_HIP(hipMemsetAsync(w + L.genrep, 0, L.slots + sizeof(unsigned long long) * 1024 - L.genrep, s));
+    // Pruned form: ONE ordinary launch (an E-step, or the relocation a persistent launch left pending), then the persistent
+    // kernel, which iterates until convergence / max_iter / the next empty cluster; one host round trip per such pair.
+    const bool persist = pruned && km_persist_enabled() && launch_persist(Xc, ni, B, k, box, f, acc, T, km_pruned_pt(n), s, true) == 0;
+    for (int round = 0; persist && n_done < max_iter && !done; ++round) {
+        // every pair completes at least the ordinary launch's step (an iteration, or a pending relocation)
+        CREG_REQUIRE(round <= 2 * max_iter + 2, "creg_kmeans_lloyd_f64: the Lloyd state machine makes no progress");
+        CREG_REQUIRE(launch_assign_pruned(Xc, ni, B, k, box, nullptr, f, 1, acc, T, s) == 0, "creg_kmeans_lloyd_f64: cannot raise the dynamic LDS limit of the E-step");
+        CREG_REQUIRE(launch_persist(Xc, ni, B, k, box, f, acc, T, km_pruned_pt(n), s, false) == 0, "creg_kmeans_lloyd_f64: the persistent Lloyd kernel does not fit");
+        CREG_LAUNCH_CHECK();
+        CREG_HIP(hipMemcpyAsync(&host, f, sizeof(KmFlags), hipMemcpyDeviceToHost, s));
+        CREG_HIP(hipStreamSynchronize(s));
+        CREG_REQUIRE(!host.abort, "creg_kmeans_lloyd_f64: the persistent Lloyd kernel gave up waiting for its M-step (workgroups not co-resident?)");
+        done = host.done; n_done = host.n_iter;
+    }
     while (n_done < max_iter && !done) {
         // 32 launches per host round trip.  A launch runs the E-step of iteration f->n_iter with the exact incremental sums, and
         // its last workgroup the M-step tail; launches after convergence (or after max_iter iterations) return at once, and a
         // launch that follows the discovery of an empty cluster runs the deferred tail instead (see km_lloyd_entry).
         for (int b = 0; b < 32; ++b)
         {
-            CREG_REQUIRE(launch_assign(Xc, ni, B, k, nullptr, nullptr, f, use_mfma, s, 0, acc, T) == 0,
+            CREG_REQUIRE((pruned ? launch_assign_pruned(Xc, ni, B, k, box, nullptr, f, 1, acc, T, s)
+                                 : launch_assign(Xc, ni, B, k, nullptr, nullptr, f, use_mfma, s, 0, acc, T)) == 0,
                          "creg_kmeans_lloyd_f64: cannot raise the dynamic LDS limit of the E-step");
 #ifdef CREG_STAMPS
             hipLaunchKernelGGL(k_km_fold, dim3(1), dim3(1), 0, s);
@@ -1072,10 +1699,12 @@ extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* i
     // which buffer holds the labels of the last executed iteration
     int* last = lab[(host.n_iter - 1) & 1];
     if (!host.strict) {      // rerun the E-step so labels match the final centres (_kmeans.py:736-748)
-        CREG_REQUIRE(launch_assign(Xc, ni, B, k, last, nullptr, nullptr, use_mfma, s) == 0, "creg_kmeans_lloyd_f64: E-step launch failed");
+        CREG_REQUIRE((pruned ? launch_assign_pruned(Xc, ni, B, k, box, last, f, 0, nullptr, T, s)
+                             : launch_assign(Xc, ni, B, k, last, nullptr, nullptr, use_mfma, s)) == 0, "creg_kmeans_lloyd_f64: E-step launch failed");
     }
-    if (last != labels) CREG_HIP(hipMemcpyAsync(labels, last, sizeof(int) * n, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_km_finish, dim3(1), dim3(1024), 0, s, Xc, ni, labels, k, C2, f, centers, inertia, n_iter);
+    if (pruned) hipLaunchKernelGGL(k_km_unsort, dim3(cdiv(nrow, 256)), dim3(256), 0, s, last, perm, nrow, labels);
+    else if (last != labels) CREG_HIP(hipMemcpyAsync(labels, last, sizeof(int) * n, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_km_finish, dim3(1), dim3(1024), 0, s, pruned ? X : Xc, ni, labels, k, C2, f, centers, inertia, n_iter, pruned ? 1 : 0);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
 }
@@ -1164,7 +1793,13 @@ extern "C" int creg_kmeans_lloyd_batch_f64(const double* const* X, int64_t n, co
 #ifdef CREG_STAMPS
 extern "C" int creg_debug_km_stamps(unsigned long long* out8, int reset) {
     if (out8) CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_km_stamps), sizeof(unsigned long long) * 8));
+    if (out8 && reset == 3) { CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_km_blk), sizeof(unsigned long long) * 4096)); return CREG_OK; }
+    if (out8 && reset == 5) { CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_km_it), sizeof(unsigned long long) * 4096)); return CREG_OK; }
+    if (out8 && reset == 4) { CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_km_pp), sizeof(unsigned long long) * 16)); return CREG_OK; }
+    if (out8 && reset == 2) { CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_km_phs), sizeof(unsigned long long) * 8)); return CREG_OK; }
     if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_km_stamps), z, sizeof(z)));
+                 { unsigned long long z16[16] = {0}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_km_pp), z16, sizeof(z16))); }
+                 CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_km_phs), z, sizeof(z))); CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_km_ph), z, sizeof(z)));
                  unsigned long long m[4] = {~0ull, 0ull, 0ull, 0ull}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_km_w), m, sizeof(m))); }
     return CREG_OK;
 }

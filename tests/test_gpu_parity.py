@@ -178,6 +178,44 @@ def test_kmeans_full_run_vs_oracle_random_and_empty_cluster(dev):
     assert len(np.unique(lab.cpu().numpy())) == 4
 
 
+@pytest.mark.parametrize("n,k,kind", [(17, 3, "normal"), (300, 40, "normal"), (300, 1, "normal"), (5000, 20, "surface"),
+                                      (20000, 128, "surface"), (20000, 300, "normal"), (70000, 64, "dupes"),
+                                      (70000, 128, "lattice"), (150000, 33, "surface"), (300000, 128, "surface")])
+def test_kmeans_pruned_persistent_form_identical_to_full_sweep(dev, n, k, kind):
+    """creg_kmeans_lloyd_f64's VALU form (spatially sorted copy with dummy rows, centres pruned per workgroup and per wave, the
+    persistent kernel with its in-launch hand-offs, relocation launches in between) against the matrix-core form (caller's
+    order, every centre for every point, one launch per iteration): labels, iteration count, centres and inertia must be
+    IDENTICAL -- the pruning may never change an argmin, the exact integer sums make the M-step order-independent, and the
+    inertia is summed in the caller's order by both.  Shapes: n < 64, k = 1, k > 256 (several compaction passes), exact
+    duplicates and a lattice (ties, points on cell borders), seeds far from the data (empty clusters -> relocation launches in
+    the middle of a persistent run), sizes on both sides of the points-per-thread switches."""
+    from autourdf_amd import ops
+    rng = np.random.default_rng(n * 7 + k)
+    if kind == "normal":
+        X = rng.normal(size=(n, 3)) * np.array([1.0, 0.5, 0.25])
+    elif kind == "surface":                          # a folded sheet: what a depth-camera frame looks like to the spatial sort
+        u, v = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        X = np.stack([u, v, 0.3 * np.sin(3 * u) * np.cos(2 * v) + 0.01 * rng.normal(size=n)], 1)
+    elif kind == "dupes":
+        base = rng.normal(size=(n // 7, 3))
+        X = base[rng.integers(0, len(base), n)]
+    else:                                            # lattice
+        g = np.stack(np.meshgrid(*[np.arange(42)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+        X = g[rng.choice(len(g), n, replace=False)] / 8.0
+    init = X[rng.choice(n, k, replace=False)].copy()
+    if k >= 8:
+        init[: k // 4] += 40.0                       # a quarter of the seeds own nothing at first
+    Xd, Id = _cuda(X, dev), _cuda(init, dev)
+    a = ops.kmeans_lloyd(Xd, Id, max_iter=60)
+    b = ops.kmeans_lloyd(Xd, Id, max_iter=60, use_mfma=True)
+    assert a[3].item() == b[3].item()
+    assert torch.equal(a[1], b[1])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    assert len(torch.unique(a[1])) == k or kind == "dupes"
+    again = ops.kmeans_lloyd(Xd, Id, max_iter=60)
+    assert torch.equal(a[1], again[1]) and torch.equal(a[0], again[0])
+
+
 def test_resample_group_to_local_vs_reference_golden(dev, golden):
     from autourdf_amd import ops
     g = golden("resample_reference.npz")
