@@ -17,6 +17,11 @@
 //                    label equality first, then tol), next b / |c|^2 rows.
 // The host enqueues iterations in batches of 32 and reads the `done` word between batches; launches of
 // iterations after convergence return immediately.
+// VALU form of creg_kmeans_lloyd_f64 (round 3): the E-step runs over a spatially sorted copy of the frame and evaluates, per
+// workgroup and per wave, only the centres that can be nearest inside the bounding box of its points (k_km_assign_pruned:
+// labels identical to the full sweep), and a persistent kernel (k_km_persist) iterates inside ONE launch with the points and
+// labels in registers -- 38 -> 17 us per Lloyd iteration at N = 262144, K = 128.  The matrix-core form keeps the full sweep
+// in the caller's order, one launch per iteration; both give identical labels, centres, inertia and iteration counts.
 #include <cstdlib>
 #include "creg_common.h"
 #include "creg_dev.h"
@@ -39,7 +44,7 @@ struct KmFlags {
     double inertia;
     double fix_scale, fix_inv;   // fixed-point scale 2^s of the M-step accumulators and its inverse
     unsigned long long gen;      // persistent Lloyd kernel: (M-step tails completed << 8) | 1 when the kernel is to exit
-    int abort;                   // persistent Lloyd kernel: a workgroup gave up waiting (never expected; the host reports it)
+    int abort;                   // persistent Lloyd kernel: a workgroup gave up waiting (the host starts the call over without that kernel)
     int pad2;
     double amax;                 // largest |centred coordinate| of the frame
     double guard;                // pruned E-step: slack on squared distances, far above the rounding of the fma chain (see k_km_assign_pruned)
@@ -427,15 +432,9 @@ __global__ void k_km_fold() {
 #endif
 struct KmTail { double* B; double* C2; double* Cw; double* far_d; double* segv; int* segi; int* lab[2]; const int* prev0; int max_iter; const int* inv;
                 double* ring; unsigned long long* genrep; unsigned long long* slots;
-                int nrow; const int* perm; };                  // pruned form: rows of the sorted copy (dummies: perm < 0)
+                int nrow; const int* perm; int spin_limit; };                  // pruned form: rows of the sorted copy (dummies: perm < 0)
 // persistent Lloyd kernel: centre rows of the iterations of ONE launch at distinct addresses (see k_km_persist), and copies of `gen`
-#ifndef KMP_GENREP_N
-#define KMP_GENREP_N 8
-#endif
-#ifndef KMP_SLEEP
-#define KMP_SLEEP 10
-#endif
-constexpr int KMP_RING = 320, KMP_GENREP = KMP_GENREP_N, KMP_GENREP_STRIDE = 512;       // (stride in 8-byte words: 4 KB apart)
+constexpr int KMP_RING = 320, KMP_GENREP = 8, KMP_GENREP_STRIDE = 512;       // (stride in 8-byte words: 4 KB apart)
 __host__ __device__ __forceinline__ size_t kmp_ring_stride(int k) { return ((size_t)4 * k + 15) & ~(size_t)15; }   // doubles, 128-byte multiple
 
 // The workgroup's table of sums goes to the global accumulators; the last workgroup of the launch to have done so runs
@@ -752,7 +751,9 @@ __global__ __launch_bounds__(256) void k_km_assign_pruned(const double* __restri
 // path's, so the two kinds of launch are interchangeable steps of one state machine: an empty cluster makes this kernel exit
 // with `reloc` set, the next ordinary launch relocates, and the host starts the kernel again.
 // All workgroups must be resident at once (the host checks the grid against the occupancy the runtime reports); the wait is
-// bounded all the same -- a workgroup that polls for ~2^20 round trips sets `abort` and leaves, and the host fails loudly.
+// bounded all the same -- a workgroup that polls for ~2^20 round trips (~1 s: other streams kept the device so busy that the
+// grid never was resident together) sets `abort` and leaves; the host then discards the attempt and runs the whole call
+// again with one launch per iteration (same results).
 __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // common path of km_mstep_tail (same arithmetic, same order) with agent-scope loads and write-through stores; returns through
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(256, PT == 2 ? 3 : PT == 4 ? 2 : 1) void k_km_persi
                 for (int i = tid; i < (int)gridDim.x; i += 256)
                     if (i > 0) { const unsigned long long v = ld_agent(T.slots + i); mine &= (v >> 32) == want; any_changed |= mine ? (int)(v & 1ull) : 0; }
                 ok = __syncthreads_and(mine);
-                if (!ok && (++spins & 63) == 0 && (spins >= (1 << 20) || ld_agent(&f->abort))) { if (tid == 0) st_agent(&f->abort, 1); break; }
+                if (!ok && (++spins >= T.spin_limit || ((spins & 63) == 0 && ld_agent(&f->abort)))) { if (tid == 0) st_agent(&f->abort, 1); break; }
             } while (!ok);
             any_changed = __syncthreads_or(any_changed);
         }
@@ -928,8 +929,8 @@ __global__ __launch_bounds__(256, PT == 2 ? 3 : PT == 4 ? 2 : 1) void k_km_persi
             for (;;) {
                 g = ld_agent(gen_mine);                          // one of 8 copies, a poll every ~0.3 us: the tail's own traffic is not queued behind the waiters
                 if ((g >> 8) >= want) break;
-                __builtin_amdgcn_s_sleep(KMP_SLEEP);
-                if ((++spins & 63) == 0 && (spins >= (1 << 20) || ld_agent(&f->abort))) { st_agent(&f->abort, 1); g = ~0ull; break; }
+                __builtin_amdgcn_s_sleep(10);                        // (8 or 32 copies, a poll every 0.3 or 1 us: no measurable difference)
+                if (++spins >= T.spin_limit || ((spins & 63) == 0 && ld_agent(&f->abort))) { st_agent(&f->abort, 1); g = ~0ull; break; }
             }
             s_gen = g;
         }
@@ -1487,6 +1488,11 @@ static int km_pruned_pt(int64_t n) {                             // points per t
     if (forced == 2 || forced == 4 || forced == 8) return forced;
     return n <= 131072 ? 2 : n <= 262144 ? 4 : 8;                // at most 256 workgroups up to 524288 points (one per CU for the persistent kernel)
 }
+static int km_spin_limit() {                                     // polls before a waiting workgroup gives up (test knob CREG_KM_SPIN_LIMIT: 1 forces the fallback)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CREG_KM_SPIN_LIMIT"); v = e && atoi(e) > 0 ? atoi(e) : (1 << 20); }
+    return v;
+}
 static bool km_persist_enabled() {
     static int v = -1;                                           // measurement knob: CREG_KM_PERSIST=0 keeps one launch per iteration
     if (v < 0) { const char* e = getenv("CREG_KM_PERSIST"); v = e ? atoi(e) != 0 : 1; }
@@ -1536,7 +1542,7 @@ static int km_points_per_thread(int n) {
 
 static int launch_assign(const double* X, int n, const double* B, int k, int* labels, const int* prev,
                          KmFlags* f, int use_mfma, hipStream_t s, int raw = 0, unsigned long long* acc = nullptr,
-                         KmTail T = KmTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr}, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr}) {
+                         KmTail T = KmTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr}, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0}) {
     constexpr int LDS_MAX = 128 * 1024;
     if (use_mfma) {
         const int ntile = cdiv(n, 16);
@@ -1619,10 +1625,11 @@ extern "C" size_t creg_kmeans_workspace_bytes(int64_t n, int32_t k) {
     return km_layout(n, k).total;
 }
 
-extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* init, int32_t k,
-                                     int32_t max_iter, double tol_rel, int32_t use_mfma, double* centers,
-                                     int32_t* labels, double* inertia, int32_t* n_iter, void* workspace,
-                                     size_t workspace_bytes, creg_stream_t stream) {
+constexpr int KM_RETRY_WITHOUT_PERSIST = 1000;
+static int km_lloyd_run(const double* X, int64_t n, const double* init, int32_t k,
+                        int32_t max_iter, double tol_rel, int32_t use_mfma, double* centers,
+                        int32_t* labels, double* inertia, int32_t* n_iter, void* workspace,
+                        size_t workspace_bytes, creg_stream_t stream, bool allow_persist) {
     CREG_REQUIRE(X && init && centers && labels && inertia && n_iter && workspace, "creg_kmeans_lloyd_f64: null pointer");
     CREG_REQUIRE(n >= 1 && n < (1ll << 31) && k >= 1 && k <= 1024 && max_iter >= 1,
                  "creg_kmeans_lloyd_f64: need 1 <= n < 2^31, 1 <= k <= 1024, max_iter >= 1");
@@ -1662,11 +1669,11 @@ extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* i
     int done = 0, n_done = 0;
     KmFlags host;
     const KmTail T{B, C2, Cw, far_d, (double*)(w + L.segv), (int*)(w + L.segi), {lab[0], lab[1]}, prev0, max_iter, pruned ? inv : nullptr,
-                   (double*)(w + L.ring), (unsigned long long*)(w + L.genrep), (unsigned long long*)(w + L.slots), nrow, perm};
+                   (double*)(w + L.ring), (unsigned long long*)(w + L.genrep), (unsigned long long*)(w + L.slots), nrow, perm, km_spin_limit()};
     if (pruned) CREG_HIP(hipMemsetAsync(w + L.genrep, 0, L.slots + sizeof(unsigned long long) * 1024 - L.genrep, s));
     // Pruned form: ONE ordinary launch (an E-step, or the relocation a persistent launch left pending), then the persistent
     // kernel, which iterates until convergence / max_iter / the next empty cluster; one host round trip per such pair.
-    const bool persist = pruned && km_persist_enabled() && launch_persist(Xc, ni, B, k, box, f, acc, T, km_pruned_pt(n), s, true) == 0;
+    const bool persist = allow_persist && pruned && km_persist_enabled() && launch_persist(Xc, ni, B, k, box, f, acc, T, km_pruned_pt(n), s, true) == 0;
     for (int round = 0; persist && n_done < max_iter && !done; ++round) {
         // every pair completes at least the ordinary launch's step (an iteration, or a pending relocation)
         CREG_REQUIRE(round <= 2 * max_iter + 2, "creg_kmeans_lloyd_f64: the Lloyd state machine makes no progress");
@@ -1675,7 +1682,9 @@ extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* i
         CREG_LAUNCH_CHECK();
         CREG_HIP(hipMemcpyAsync(&host, f, sizeof(KmFlags), hipMemcpyDeviceToHost, s));
         CREG_HIP(hipStreamSynchronize(s));
-        CREG_REQUIRE(!host.abort, "creg_kmeans_lloyd_f64: the persistent Lloyd kernel gave up waiting for its M-step (workgroups not co-resident?)");
+        // a workgroup waited ~1 s for the others (the device was kept busy by other streams' kernels, so the grid was not
+        // resident together): nothing of this attempt is used, the call starts over with one launch per iteration
+        if (host.abort) return KM_RETRY_WITHOUT_PERSIST;
         done = host.done; n_done = host.n_iter;
     }
     while (n_done < max_iter && !done) {
@@ -1707,6 +1716,16 @@ extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* i
     hipLaunchKernelGGL(k_km_finish, dim3(1), dim3(1024), 0, s, pruned ? X : Xc, ni, labels, k, C2, f, centers, inertia, n_iter, pruned ? 1 : 0);
     CREG_LAUNCH_CHECK();
     return CREG_OK;
+}
+
+extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* init, int32_t k,
+                                     int32_t max_iter, double tol_rel, int32_t use_mfma, double* centers,
+                                     int32_t* labels, double* inertia, int32_t* n_iter, void* workspace,
+                                     size_t workspace_bytes, creg_stream_t stream) {
+    int rc = km_lloyd_run(X, n, init, k, max_iter, tol_rel, use_mfma, centers, labels, inertia, n_iter, workspace, workspace_bytes, stream, true);
+    if (rc == KM_RETRY_WITHOUT_PERSIST)
+        rc = km_lloyd_run(X, n, init, k, max_iter, tol_rel, use_mfma, centers, labels, inertia, n_iter, workspace, workspace_bytes, stream, false);
+    return rc;
 }
 
 extern "C" int creg_kmeans_assign_f64(const double* X, int64_t n, const double* C, int32_t k, int32_t use_mfma,

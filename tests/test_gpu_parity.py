@@ -3,11 +3,14 @@
 Bar: bit-exact for indices, labels and the integer-order-independent quantities (L1 distances,
 fp64 k-means distances); fp32 poses / losses within the tolerances written at each assert.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -214,6 +217,32 @@ def test_kmeans_pruned_persistent_form_identical_to_full_sweep(dev, n, k, kind):
     assert len(torch.unique(a[1])) == k or kind == "dupes"
     again = ops.kmeans_lloyd(Xd, Id, max_iter=60)
     assert torch.equal(a[1], again[1]) and torch.equal(a[0], again[0])
+
+
+def test_kmeans_persistent_kernel_gives_up_and_the_call_starts_over(dev, tmp_path):
+    """A workgroup of the persistent Lloyd kernel that waits too long sets `abort`; the host then discards the attempt and runs
+    the call again with one launch per iteration.  Forced here with CREG_KM_SPIN_LIMIT=1 in a child process (the knob is read
+    once per process): same labels, centres, inertia and iteration count as the unforced run in this process."""
+    import subprocess
+    import sys
+    from autourdf_amd import ops
+    rng = np.random.default_rng(11)
+    u, v = rng.uniform(-1, 1, 40000), rng.uniform(-1, 1, 40000)
+    X = np.stack([u, v, 0.2 * np.sin(4 * u) + 0.01 * rng.normal(size=40000)], 1)
+    init = X[rng.choice(40000, 48, replace=False)]
+    c, lab, inertia, n_iter = ops.kmeans_lloyd(_cuda(X, dev), _cuda(init, dev), max_iter=40)
+    np.savez(tmp_path / "in.npz", X=X, init=init)
+    code = ("import numpy as np, torch, sys; sys.path.insert(0, %r); from autourdf_amd import ops; g = np.load(%r); "
+            "o = ops.kmeans_lloyd(torch.as_tensor(g['X'], device='cuda'), torch.as_tensor(g['init'], device='cuda'), max_iter=40); "
+            "np.savez(%r, c=o[0].cpu().numpy(), lab=o[1].cpu().numpy(), inertia=o[2].cpu().numpy(), n_iter=o[3].cpu().numpy())"
+            % (ROOT, str(tmp_path / "in.npz"), str(tmp_path / "out.npz")))
+    env = dict(os.environ, CREG_KM_SPIN_LIMIT="1")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=200)
+    o = np.load(tmp_path / "out.npz")
+    np.testing.assert_array_equal(o["lab"], lab.cpu().numpy())
+    np.testing.assert_array_equal(o["c"], c.cpu().numpy())
+    np.testing.assert_array_equal(o["inertia"], inertia.cpu().numpy())
+    assert int(o["n_iter"][0]) == n_iter.item()
 
 
 def test_resample_group_to_local_vs_reference_golden(dev, golden):
