@@ -252,4 +252,20 @@ __device__ __forceinline__ void dq_to_se3_vjp(const T dq[8], const T G[9], const
     gdq[3] += T(2) * (-dy * a + dx * b - dw * c);
 }
 
+// 16 bytes written through (sc1): the line goes to the memory side while the kernel is still running instead of waiting,
+// dirty, for the write-back the end of the kernel performs -- a kernel that rewrites tens of MB (the Adam state) otherwise
+// pays that drain at its boundary (MI355X_MICROARCH.md, "boundary": + B / 6 TB/s behind B dirty bytes).
+// `base` must be wave-uniform (it becomes the buffer descriptor), `elem` is the lane's float index from it.  A buffer store
+// with sc1 (aux bit 4) is the 16-byte write-through store the compiler counts like any other (the agent-scope atomic store is
+// 8 bytes at most; an inline-asm global_store ... sc1 would be invisible to the s_waitcnt insertion).  Measured on the train
+// plan's k_bd (15 MB of parameters and Adam moments per launch): headline 145.7 -> 150.1 frames/s; a non-temporal store: no gain.
+__device__ __forceinline__ void st4_wt(float* base, int elem, float4 v) {
+#ifdef CREG_ST4_PLAIN                                            // A/B measurement build only
+    *(float4*)(base + elem) = v; return;
+#endif
+    typedef int int4v __attribute__((ext_vector_type(4)));
+    const int4v x = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(x, __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000), elem * 4, 0, 16);
+}
+
 }  // namespace creg

@@ -953,7 +953,7 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
     nw.w = adam_value(pw.w, pm.w, pv.w, ag.w, S.step_size, S.bc2_sqrt);
     pb = adam_value(pb, mb, vb, gsum, S.step_size, S.bc2_sqrt);        // every lane of the row (same operands, same result)
     if (live && half == 0) {
-        if (ain) { *(float4*)(Pn + wi) = nw; *(float4*)(W.AM + wi) = pm; *(float4*)(W.AV + wi) = pv; }
+        if (ain) { st4_wt(Pn, wi, nw); st4_wt(W.AM, wi, pm); st4_wt(W.AV, wi, pv); }
         if (i4 == 0) { Pn[D.ob1 + hu] = pb; W.AM[D.ob1 + hu] = mb; W.AV[D.ob1 + hu] = vb; }
     }
     for (int r = half; r < D.K; r += 2) {
@@ -1060,7 +1060,7 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
         nw.z = adam_value(pw[v].z, pm[v].z, pv[v].z, acc[v].z, S.step_size, S.bc2_sqrt);
         nw.w = adam_value(pw[v].w, pm[v].w, pv[v].w, acc[v].w, S.step_size, S.bc2_sqrt);
         if (i < R.n_in) {
-            *(float4*)(Pn + R.oW + i) = nw; *(float4*)(W.AM + R.oW + i) = pm[v]; *(float4*)(W.AV + R.oW + i) = pv[v];
+            st4_wt(Pn, R.oW + i, nw); st4_wt(W.AM, R.oW + i, pm[v]); st4_wt(W.AV, R.oW + i, pv[v]);
         }
     }
     float sum = 0.f;
