@@ -157,30 +157,46 @@ __global__ __launch_bounds__(256) void k_km_cell_count(const double* __restrict_
     key[i] = c;
     atomicAdd(&cnt[c], 1);
 }
-// counts -> first rows, in place (one workgroup: thread t owns a contiguous run of cells).  The cells fall into 64 aligned
-// Morton ranges (boxes a quarter of the frame's extent per axis); each range starts on a multiple of `align` rows, the rows
-// skipped stay dummies (perm = -1, coordinates NaN).  A workgroup's run of `align` consecutive rows therefore never straddles
-// two of the ranges: without this, the handful of runs that span a big jump of the Morton order get boxes as large as the
-// frame, keep all k centres, and the whole iteration waits ~8 us for their full sweeps.
-__global__ __launch_bounds__(1024) void k_km_cell_scan(int* __restrict__ cnt, int ncell, int align) {
-    __shared__ int part[1024];
-    __shared__ int gbase[65];
-    const int per = (ncell + 1023) / 1024, c0 = min(ncell, (int)threadIdx.x * per), c1 = min(ncell, c0 + per);
+// counts -> first rows, in place.  The cells fall into 64 aligned Morton ranges (boxes a quarter of the frame's extent per
+// axis), one workgroup each; a range starts on a multiple of `align` rows, the rows skipped stay dummies (perm = -1, coordinates
+// NaN).  A workgroup's run of `align` consecutive rows therefore never straddles two of the ranges: without this, the handful of
+// runs that span a big jump of the Morton order get boxes as large as the frame, keep all k centres, and the whole iteration
+// waits ~8 us for their full sweeps.  Two launches: the ranges' totals, then every range scans its own cells behind the aligned
+// totals of the ranges before it (coalesced; one workgroup walking all 2^18 cells took 385 us).
+__global__ __launch_bounds__(256) void k_km_cell_totals(const int* __restrict__ cnt, int ncell, int* __restrict__ gtot) {
+    __shared__ int sc[4];
+    const int per = ncell / 64, c0 = blockIdx.x * per;           // ncell = 8^b >= 512: a multiple of 64
     int s = 0;
-    for (int c = c0; c < c1; ++c) s += cnt[c];
-    part[threadIdx.x] = s;
+    for (int c = threadIdx.x; c < per; c += 256) s += cnt[c0 + c];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x < 64) {
-        int g = 0;
-        for (int u = 0; u < 16; ++u) g += part[16 * threadIdx.x + u];
-        gbase[threadIdx.x + 1] = (g + align - 1) / align * align;
+    if (threadIdx.x == 0) gtot[blockIdx.x] = sc[0] + sc[1] + sc[2] + sc[3];
+}
+__global__ __launch_bounds__(256) void k_km_cell_scan(int* __restrict__ cnt, int ncell, int align, const int* __restrict__ gtot) {
+    __shared__ int wsum[4];
+    __shared__ int s_run;
+    const int per = ncell / 64, c0 = blockIdx.x * per, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        int base = 0;
+        for (int g = 0; g < (int)blockIdx.x; ++g) base += (gtot[g] + align - 1) / align * align;
+        s_run = base;
     }
     __syncthreads();
-    if (threadIdx.x == 0) { gbase[0] = 0; for (int g = 0; g < 64; ++g) gbase[g + 1] += gbase[g]; }
-    __syncthreads();
-    int run = gbase[threadIdx.x >> 4];
-    for (int u = 0; u < (int)(threadIdx.x & 15); ++u) run += part[(threadIdx.x & ~15) + u];
-    for (int c = c0; c < c1; ++c) { const int v = cnt[c]; cnt[c] = run; run += v; }
+    for (int t0 = 0; t0 < per; t0 += 256) {                      // 256 cells per step: wave scans, then the waves' offsets
+        const int c = t0 + threadIdx.x;
+        const int v = c < per ? cnt[c0 + c] : 0;
+        int inc = v;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int base = s_run + inc - v;
+        for (int w = 0; w < wv; ++w) base += wsum[w];
+        if (c < per) cnt[c0 + c] = base;
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
 }
 __global__ __launch_bounds__(256) void k_km_cell_scatter(int n, const int* __restrict__ key, int* __restrict__ cursor,
                                                          int* __restrict__ perm, int* __restrict__ inv) {
@@ -1486,7 +1502,9 @@ static int km_pruned_pt(int64_t n) {                             // points per t
     static int forced = -1;                                      // measurement knob CREG_KMP_PT
     if (forced < 0) { const char* e = getenv("CREG_KMP_PT"); forced = e ? atoi(e) : 0; }
     if (forced == 2 || forced == 4 || forced == 8) return forced;
-    return n <= 131072 ? 2 : n <= 262144 ? 4 : 8;                // at most 256 workgroups up to 524288 points (one per CU for the persistent kernel)
+    // 2 while the persistent grid (rows / 512, dummies included) fits three workgroups per CU; measured at n = 262144: 17.2 us
+    // per Lloyd iteration with 2 (576 workgroups), 19.5 with 4 (288)
+    return n <= 327680 ? 2 : n <= 425984 ? 4 : 8;
 }
 static int km_spin_limit() {                                     // polls before a waiting workgroup gives up (test knob CREG_KM_SPIN_LIMIT: 1 forces the fallback)
     static int v = -1;
@@ -1524,7 +1542,7 @@ static KmLayout km_layout(int64_t n, int k) {
     L.prev = take(sizeof(int) * n); L.lab2 = take(sizeof(int) * nr);
     L.flags = take(sizeof(KmFlags));
     L.lab3 = take(sizeof(int) * nr); L.perm = take(sizeof(int) * nr); L.inv = take(sizeof(int) * n); L.key = take(sizeof(int) * n);
-    L.cell = take(sizeof(int) * ((size_t)1 << (3 * km_cell_bits(n))));
+    L.cell = take(sizeof(int) * (((size_t)1 << (3 * km_cell_bits(n))) + 64));   // cell counts / first rows, then the 64 ranges' totals
     L.box = take(sizeof(double) * 6 * (size_t)((nr + 511) / 512));
     L.ring = take(sizeof(double) * kmp_ring_stride(k) * KMP_RING);
     L.genrep = take(sizeof(unsigned long long) * KMP_GENREP_STRIDE * KMP_GENREP);
@@ -1653,10 +1671,11 @@ static int km_lloyd_run(const double* X, int64_t n, const double* init, int32_t 
     hipLaunchKernelGGL(k_km_stats, dim3(1), dim3(1024), 0, s, X, ni, tol_rel, f);
     if (pruned) {
         const int bits = km_cell_bits(n), ncell = 1 << (3 * bits);
-        int* key = (int*)(w + L.key); int* cell = (int*)(w + L.cell);
+        int* key = (int*)(w + L.key); int* cell = (int*)(w + L.cell); int* gtot = cell + ncell;
         CREG_HIP(hipMemsetAsync(cell, 0, sizeof(int) * ncell, s));
         hipLaunchKernelGGL(k_km_cell_count, dim3(cdiv(n, 256)), dim3(256), 0, s, X, ni, f, bits, key, cell);
-        hipLaunchKernelGGL(k_km_cell_scan, dim3(1), dim3(1024), 0, s, cell, ncell, 256 * km_pruned_pt(n));
+        hipLaunchKernelGGL(k_km_cell_totals, dim3(64), dim3(256), 0, s, cell, ncell, gtot);
+        hipLaunchKernelGGL(k_km_cell_scan, dim3(64), dim3(256), 0, s, cell, ncell, 256 * km_pruned_pt(n), gtot);
         CREG_HIP(hipMemsetAsync(Xc, 0xFF, sizeof(double) * 3 * (size_t)nrow, s));       // dummy rows: NaN coordinates (ignored by the boxes' fmin / fmax) ...
         CREG_HIP(hipMemsetAsync(perm, 0xFF, sizeof(int) * (size_t)nrow, s));            // ... and perm = -1
         hipLaunchKernelGGL(k_km_cell_scatter, dim3(cdiv(n, 256)), dim3(256), 0, s, ni, key, cell, perm, inv);

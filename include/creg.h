@@ -86,10 +86,15 @@ int creg_cluster_transform_bwd_f32(const float* pts, const int32_t* seg_offsets,
  *   distance  d = fma(x2,b2, fma(x1,b1, fma(x0,b0, |c|^2))),  b = -2c   (first minimum wins)
  * X (n,3) fp64 is read only (centring happens on an internal copy), init (k,3) fp64.
  * Outputs: centers (k,3) fp64, labels (n) int32, inertia (1) fp64, n_iter (1) int32 -- device.
- * use_mfma != 0 selects the v_mfma_f64_16x16x4_f64 assignment kernel (bit-identical results).
- * One launch per Lloyd iteration (E-step, exact incremental M-step sums, M-step tail; the convergence test runs on the
- * device and later launches return at once); the host enqueues 32 launches at a time and synchronises the stream in
- * between to read the `done` word. */
+ * use_mfma != 0 selects the v_mfma_f64_16x16x4_f64 assignment kernel: every centre for every point, in the caller's order,
+ * one launch per Lloyd iteration (E-step, exact incremental M-step sums, M-step tail; the convergence test runs on the
+ * device and later launches return at once; the host enqueues 32 launches at a time and synchronises the stream in between
+ * to read the `done` word).
+ * use_mfma == 0 (the default of the drop-ins): the E-step runs over a spatially sorted copy of the frame and evaluates, per
+ * workgroup and per wave, only the centres that can be nearest inside the bounding box of its points, and a persistent
+ * kernel iterates inside one launch (the host synchronises once per run of iterations between two empty-cluster
+ * relocations; when the device cannot hold the kernel's grid at once, one launch per iteration as above).  Both forms return
+ * identical labels, centres, inertia and iteration counts. */
 size_t creg_kmeans_workspace_bytes(int64_t n, int32_t k);
 int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* init, int32_t k,
                           int32_t max_iter, double tol_rel, int32_t use_mfma,
