@@ -595,10 +595,11 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
             unsigned long long st2 = clock64();
             if (tid == 0) g_icp_stamps[stamp_b * 16 + 8] += st2 - stamp_t;
 #endif
-            // first minimum in scan order (strict <) and last one (<=): they differ exactly when a second candidate as near
-            // as the best was seen -- then the wave rescans with the frame-index tie-break.  5 VALU ops per target on top
-            // of the 8 of the distance: two compares, one v_min_f64, two selects.
-            double best = INFINITY; int bm = -1, bl = -1;
+            // first minimum in scan order (strict <); a second candidate as near as the best -- inside a trip or in a later one --
+            // raises the tie flag, and the wave rescans with the frame-index tie-break.  The four distances of a trip and their
+            // minimum do not depend on the running best: one compare against it per trip (a compare / select / min per target is
+            // a chain of dependent fp64 operations the length of the list).
+            double best = INFINITY; int bm = -1; bool tieflag = false;
             const double* tp = sT + 3 * base;
             // whole trips of four: the last one may run up to three entries past the lane's share -- the next lane's targets
             // (scanned twice: harmless) or the padding behind the list
@@ -609,14 +610,16 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
                     const double dx = s0 - tp[3 * (st + u)], dy = s1 - tp[3 * (st + u) + 1], dz = s2 - tp[3 * (st + u) + 2];
                     d2[u] = (dx * dx + dy * dy) + dz * dz;
                 }
+                const double m = vmin_f64(vmin_f64(d2[0], d2[1]), vmin_f64(d2[2], d2[3]));
+                int first = 3, eq = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    bm = d2[u] < best ? st + u : bm;
-                    bl = d2[u] <= best ? st + u : bl;
-                    best = vmin_f64(best, d2[u]);
-                }
+                for (int u = 3; u >= 0; --u) { const bool e = d2[u] == m; first = e ? u : first; eq += e ? 1 : 0; }
+                const bool lt = m < best;
+                tieflag |= m == best || (lt && eq > 1);
+                bm = lt ? st + first : bm;
+                best = lt ? m : best;
             }
-            const unsigned long long tie = __ballot(bm != bl);
+            const unsigned long long tie = __ballot(tieflag);
             int bj = 0x7fffffff;
             if (tie) {                                // equidistant candidates somewhere in the wave: the lowest frame index wins
                 best = INFINITY; bm = -1;
@@ -1207,6 +1210,12 @@ __device__ void icp_fit_cluster(const IcpLarge& P, int k, int max_iter, int lane
 // (x - r, x + r) squares touch, r = distance to the previous match.  A row of the rectangle is one contiguous run of the
 // cell-sorted target list; the runs are staged 16 targets per row at a time in the wave's own LDS slice (no block barrier
 // in the scan), entries past a run's end as far-away points.
+#ifdef CREG_ICP_BLK
+// debug build only (tests/measure/icp_tail_blocks.py): per workgroup of the launches with at most 4 clusters iterating -- [0] start
+// [1] end of the search (10 ns wall ticks) [2] entries per lane group scanned by wave 0 [3] rows << 16 | columns of wave 0's
+// rectangle [4] cluster [5] launch grid
+__device__ unsigned long long g_icp_blk[6][8192];
+#endif
 __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2, int max_iter) {
     constexpr int SB = ICP_SB, SR = ICP_SB + 2;                       // staged targets per lane group and batch; slice stride
                                                                       // (+2: the four groups' equal slots fall into different LDS banks)
@@ -1225,6 +1234,11 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
 #define NN_STAMP(slot) do { const unsigned long long now_ = clock64(); if (tid == 0 && tailonly) atomicAdd(&g_icp_stamps[slot], now_ - nst); nst = now_; } while (0)
 #else
 #define NN_STAMP(slot) do { } while (0)
+#endif
+#ifdef CREG_ICP_BLK
+    const bool blk_rec = *P.running <= 4 && blockIdx.x < 8192;
+    unsigned long long blk_per = 0;
+    const unsigned long long blk_t0 = wall_clock64();
 #endif
     if (blk >= P.chunk0[k_total]) return;
     const int c = P.chunk_cl[blk];
@@ -1297,6 +1311,9 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
         int pr = L;
         for (int o = ICP_SPW; o < 64; o <<= 1) pr = max(pr, __shfl_xor(pr, o, 64));
         per = __builtin_amdgcn_readfirstlane(pr);                     // the longest of the four sequences
+#ifdef CREG_ICP_BLK
+        blk_per += per;
+#endif
 #ifdef CREG_STAMPS
         if (lane == 0 && tailonly) { atomicAdd(&g_icp_stamps[0], (unsigned long long)per); atomicAdd(&g_icp_stamps[4], 1ull); }
 #endif
@@ -1347,20 +1364,31 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
             __builtin_amdgcn_wave_barrier();
             if (t0 + SB < per) fetch(t0 + SB);
             NN_STAMP(10);
-            const int cnt = min(SB, per - t0);                        // uniform; rounded up to a multiple of 4 (padding is harmless)
-            int bm = -1, bl = -1;                                     // slots of this batch
+            const int cnt = min(SB, per - t0);                        // uniform; rounded up to a multiple of 8 (padding is harmless)
+            int bm = -1;                                              // slot of this batch's improvement
             if (pass == 0) {
-                for (int t = 0; t < cnt; t += 4) {
+                // Eight entries per step, their distances independent of one another and of `best`; one comparison of the
+                // step's minimum with `best`.  (One entry at a time -- compare, select, min against the running best -- is a
+                // chain of dependent fp64 operations: 75 ns per entry when a wave has its SIMD to itself, which is the tail
+                // of a frame, tests/measure/icp_tail_blocks.py; 60 ns this way.)  bm = the first slot of the batch's minimum
+                // if it beats `best` strictly, as before; the tie flag is raised whenever the minimum is attained twice --
+                // inside a step, or again in a later step or batch -- which is all the rescan needs.
+                for (int t = 0; t < cnt; t += 8) {
+                    double d[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 8; ++u) {
                         const double dx = s0 - px[t + u], dy = s1 - py[t + u], dz = s2 - pz[t + u];
-                        const double d2 = (dx * dx + dy * dy) + dz * dz;
-                        bm = d2 < best ? t + u : bm;
-                        bl = d2 <= best ? t + u : bl;
-                        best = vmin_f64(best, d2);
+                        d[u] = (dx * dx + dy * dy) + dz * dz;
                     }
+                    const double m = vmin_f64(vmin_f64(vmin_f64(d[0], d[1]), vmin_f64(d[2], d[3])), vmin_f64(vmin_f64(d[4], d[5]), vmin_f64(d[6], d[7])));
+                    int first = 7, eq = 0;
+#pragma unroll
+                    for (int u = 7; u >= 0; --u) { const bool e = d[u] == m; first = e ? u : first; eq += e ? 1 : 0; }
+                    const bool lt = m < best;
+                    tief |= m == best || (lt && eq > 1);
+                    bm = lt ? t + first : bm;
+                    best = lt ? m : best;
                 }
-                tief |= bl >= 0 && bl != bm;                          // a candidate as near as the best (of this or an earlier batch)
             } else {
                 for (int t = 0; t < cnt; ++t) {
                     const double dx = s0 - px[t], dy = s1 - py[t], dz = s2 - pz[t];
@@ -1379,6 +1407,11 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
             best = 1e299; bslot = -1; bj = 0x7fffffff;
         }
     }
+#ifdef CREG_ICP_BLK
+    if (tid == 0 && blk_rec) { g_icp_blk[0][blockIdx.x] = blk_t0; g_icp_blk[5][blockIdx.x] = gridDim.x;
+                               g_icp_blk[1][blockIdx.x] = wall_clock64(); g_icp_blk[2][blockIdx.x] = blk_per;
+                               g_icp_blk[3][blockIdx.x] = ((unsigned long long)nrows_all << 16) | (unsigned)(cb1 - cb0 + 1); g_icp_blk[4][blockIdx.x] = c; }
+#endif
     if (bslot < 0) { best = INFINITY; bj = 0x7fffffff; }              // a lane group whose rows were all empty has no candidate
 #ifdef CREG_STAMPS
     if (lane == 0 && any && tailonly) { atomicAdd(&g_icp_stamps[7], clock64() - stt); if (tief) atomicAdd(&g_icp_stamps[2], 1ull); }
@@ -1705,6 +1738,12 @@ extern "C" int creg_icp_p2p_f64(const double* src, int64_t n_src, const int32_t*
                       "creg_icp_p2p_f64");
 }
 
+#ifdef CREG_ICP_BLK
+extern "C" int creg_debug_icp_blk(unsigned long long* out) {
+    CREG_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(creg::g_icp_blk), sizeof(unsigned long long) * 6 * 8192));
+    return CREG_OK;
+}
+#endif
 #ifdef CREG_STAMPS
 extern "C" int creg_debug_icp_wall(unsigned long long* out8, int reset) {
     if (out8) CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_icp_wall), sizeof(unsigned long long) * 8));
