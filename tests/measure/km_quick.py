@@ -17,4 +17,4 @@ for f in seq[1:]:
         _, _, _, n_it = ops.kmeans_lloyd(X, init)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    print(f"PT={os.environ.get('CREG_KMP_PT','2')}: {int(n_it)} Lloyd iterations in {dt*1e3:.2f} ms = {dt*1e6/int(n_it):.1f} us per iteration")
+    print(f"{int(n_it)} Lloyd iterations in {dt*1e3:.2f} ms = {dt*1e6/int(n_it):.1f} us per iteration")

@@ -17,6 +17,8 @@ python $R/bench.py --mode replay --workload allegro --steps 50 --warmup 5 --no-c
 python $R/bench.py --workload c5 --steps 12 --warmup 2 > $O/bench_c5.log 2>/dev/null
 python $R/tests/measure/bench_c5_resegment.py > $O/c5_resegment.log 2>/dev/null
 python $R/tests/measure/profile_icp_frame.py both 2>/dev/null | grep -v amdgpu.ids > $O/icp_frame_phases.log
+python $R/tests/measure/stress_handoffs.py 2>/dev/null | grep -v amdgpu.ids > $O/handoff_stress.log
+(for pe in 1 0; do for pr in 1 0; do [ $pe = 1 ] && [ $pr = 0 ] && continue; echo "# CREG_KM_PRUNE=$pr CREG_KM_PERSIST=$pe"; CREG_KM_PRUNE=$pr CREG_KM_PERSIST=$pe python $R/tests/measure/km_quick.py 2>/dev/null | grep Lloyd; done; done) > $O/km_quick.log
 CMD="python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats -- $CMD > $O/prof_run.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o c5 -- python $R/bench.py --workload c5 --steps 4 --warmup 1 > $O/prof_c5.log 2>&1
@@ -29,9 +31,25 @@ for wl in wx200_5 franka allegro; do
   done
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O -o pmc_${wl}_sq -- $W > $O/pmc_${wl}_sq.log 2>&1
 done
+# the ICP-style configs[4] frame: the SQ set for its kernels (k_icp_nn, k_km_persist, ...)
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O -o pmc_c5_sq -- python $R/bench.py --workload c5 --steps 3 --warmup 1 > $O/pmc_c5_sq.log 2>&1
+python - <<PYEOF > $R/gpurun_out/r03_c5_pmc_summary.txt
+import csv, glob, collections
+f = glob.glob("$O/**/pmc_c5_sq*counter_collection.csv", recursive=True)
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in csv.DictReader(open(f[0])) if f else []:
+    agg[r["Kernel_Name"][:48]][r["Counter_Name"]] += float(r["Counter_Value"])
+print("# bench.py --workload c5 --steps 3 --warmup 1 under rocprofv3 --pmc (SQ set), summed over all launches of a kernel; ratios per wave-cycle")
+for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:6]:
+    wc = d.get("SQ_WAVE_CYCLES", 1) or 1
+    print(f"{k:48s} waves {d.get('SQ_WAVES', 0):.3g}  VALU insts {d.get('SQ_INSTS_VALU', 0):.3g}  LDS insts {d.get('SQ_INSTS_LDS', 0):.3g}  "
+          f"active VALU / wave-cycle {d.get('SQ_ACTIVE_INST_VALU', 0) / wc:.3f}  active LDS {d.get('SQ_ACTIVE_INST_LDS', 0) / wc:.3f}  "
+          f"wait any {d.get('SQ_WAIT_ANY', 0) / wc:.3f}  wait inst {d.get('SQ_WAIT_INST_ANY', 0) / wc:.3f}")
+PYEOF
 rm -f $O/*_kernel_trace.csv $O/*_agent_info.csv $O/*_domain_stats.csv
 # summaries on the box (gpurun brings back at most 64 MiB; the raw counter CSVs are ~18 MB each), raw files dropped
 cd $R && python tools/summarize_profiles.py $O r03 $R/gpurun_out/r03_profiles > $R/gpurun_out/r03_profiles_summary.log 2>&1
 rm -f $O/*_counter_collection.csv
+cp $R/gpurun_out/r03_c5_pmc_summary.txt $R/gpurun_out/r03_profiles/ 2>/dev/null
 ls -la $R/gpurun_out/r03_profiles | head -40
 tail -c 600 $O/bench.log

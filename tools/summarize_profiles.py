@@ -83,6 +83,8 @@ def main(src, tag, dst="profiles"):
     cat(["bench_replay_allegro.log", "bench_c5.log"], f"{tag}_final_bench_replay_and_c5.log")
     cp("c5_resegment.log", f"{tag}_c5_resegment_bench.log")
     cp("icp_frame_phases.log", f"{tag}_icp_frame_phases.log")
+    cp("handoff_stress.log", f"{tag}_handoff_stress.log")
+    cp("km_quick.log", f"{tag}_kmeans_lloyd_iteration.log")
     print("\n".join(lines))
     if os.path.exists(f"{src}/stats_kernel_stats.csv"):
         for r in list(csv.DictReader(open(f"{src}/stats_kernel_stats.csv")))[:8]:
