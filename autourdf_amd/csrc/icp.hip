@@ -595,11 +595,11 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
             unsigned long long st2 = clock64();
             if (tid == 0) g_icp_stamps[stamp_b * 16 + 8] += st2 - stamp_t;
 #endif
-            // first minimum in scan order (strict <); a second candidate as near as the best -- inside a trip or in a later one --
-            // raises the tie flag, and the wave rescans with the frame-index tie-break.  The four distances of a trip and their
-            // minimum do not depend on the running best: one compare against it per trip (a compare / select / min per target is
-            // a chain of dependent fp64 operations the length of the list).
-            double best = INFINITY; int bm = -1; bool tieflag = false;
+            // first minimum in scan order (strict <) and last one (<=): they differ exactly when a second candidate as near
+            // as the best was seen -- then the wave rescans with the frame-index tie-break.  5 VALU ops per target on top
+            // of the 8 of the distance: two compares, one v_min_f64, two selects.  (The one-compare-per-trip form of k_icp_nn
+            // measured 1 % slower here: two workgroups of 8 waves per CU hide the chain.)
+            double best = INFINITY; int bm = -1, bl = -1;
             const double* tp = sT + 3 * base;
             // whole trips of four: the last one may run up to three entries past the lane's share -- the next lane's targets
             // (scanned twice: harmless) or the padding behind the list
@@ -610,16 +610,14 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
                     const double dx = s0 - tp[3 * (st + u)], dy = s1 - tp[3 * (st + u) + 1], dz = s2 - tp[3 * (st + u) + 2];
                     d2[u] = (dx * dx + dy * dy) + dz * dz;
                 }
-                const double m = vmin_f64(vmin_f64(d2[0], d2[1]), vmin_f64(d2[2], d2[3]));
-                int first = 3, eq = 0;
 #pragma unroll
-                for (int u = 3; u >= 0; --u) { const bool e = d2[u] == m; first = e ? u : first; eq += e ? 1 : 0; }
-                const bool lt = m < best;
-                tieflag |= m == best || (lt && eq > 1);
-                bm = lt ? st + first : bm;
-                best = lt ? m : best;
+                for (int u = 0; u < 4; ++u) {
+                    bm = d2[u] < best ? st + u : bm;
+                    bl = d2[u] <= best ? st + u : bl;
+                    best = vmin_f64(best, d2[u]);
+                }
             }
-            const unsigned long long tie = __ballot(tieflag);
+            const unsigned long long tie = __ballot(bm != bl);
             int bj = 0x7fffffff;
             if (tie) {                                // equidistant candidates somewhere in the wave: the lowest frame index wins
                 best = INFINITY; bm = -1;

@@ -5,6 +5,8 @@ in libcreg.so.  Every function requires CUDA tensors and raises otherwise -- no 
 """
 import ctypes
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -523,8 +525,17 @@ DQ_PARAM_ORDER = ["encoder.0.weight", "encoder.0.bias", "decoder.0.weight", "dec
                   "decoder.2.weight", "decoder.2.bias"]
 
 
+TRAIN_HIDDEN_TILES = (64, 128, 256, 512)      # widths the train kernels are instantiated for
+
+
 class TrainPlan:
-    """Device-resident `train` loop (mlp_reg.py:17-152) for one (rot, K, hidden, N) shape."""
+    """Device-resident `train` loop (mlp_reg.py:17-152) for one (rot, K, hidden, N) shape.
+
+    `hidden` may be any width up to 512, like the reference's models (model_utils.py:65-168): a width the kernels are not
+    instantiated for runs on the next one that is, with the extra units' weights and biases zero.  Such a unit's activation is
+    exactly 0 (LeakyReLU / ReLU of 0), it adds exactly 0 to every sum it enters, and every gradient of its parameters is a
+    product with that 0 or with the zero column that leads out of it -- so Adam leaves them at 0 and the trained model, losses
+    and poses are those of the unpadded model; the caller's tensors keep their own shapes."""
 
     def __init__(self, rot: str, k: int, hidden: int, n_pred: int, n_tgt: int, epochs: int = 300,
                  use_graph: bool = True, device=None, batch: int = 1, graph_branches: int = 0,
@@ -533,6 +544,10 @@ class TrainPlan:
         self.rot = {"q": 0, "dq": 1}[rot]
         self.device = torch.device(device if device is not None else "cuda")
         self.batch = int(batch)
+        self.hidden_model = int(hidden)                                     # the caller's width
+        if hidden < 2 or hidden > TRAIN_HIDDEN_TILES[-1]:
+            raise ValueError(f"unsupported train shape: hidden {hidden} (2 .. {TRAIN_HIDDEN_TILES[-1]})")
+        hidden = next(t for t in TRAIN_HIDDEN_TILES if t >= hidden)         # the width the kernels run at
         self.shape = _lib.TrainShape(self.rot, k, hidden, epochs, n_pred, n_tgt, int(use_graph), self.batch,
                                      int(graph_branches), int(nn_search))
         need = self.L.creg_train_workspace_bytes(ctypes.byref(self.shape))
@@ -580,14 +595,23 @@ class TrainPlan:
             raise ValueError(f"pts must be ({self.n_pred},3) for this plan, got {tuple(keep[2].shape)}")
         if keep[3].numel() != self.k + 1:
             raise ValueError(f"offsets must hold {self.k + 1} entries, got {keep[3].numel()}")
-        numels = self._param_numels()
-        for p, want in zip(params, numels):
+        shapes_model = self._param_shapes(self.hidden_model)
+        for p, want in zip(params, shapes_model):
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                 raise TypeError("model parameters must be contiguous fp32 CUDA tensors")
-            if p.numel() != want:
-                raise ValueError(f"parameter tensor of {p.numel()} elements where the plan's model has {want}")
+            if p.numel() != int(np.prod(want)):
+                raise ValueError(f"parameter tensor of {p.numel()} elements where the plan's model has {int(np.prod(want))}")
+        self._padded = None
+        if self.hidden_model != self.hidden:                                # zero-padded copies at the kernels' width (class docstring)
+            padded = []
+            for p, sm, sp in zip(params, shapes_model, self._param_shapes(self.hidden)):
+                q = torch.zeros(sp, dtype=torch.float32, device=p.device)
+                q[tuple(slice(0, d) for d in sm)] = p.view(sm)
+                padded.append(q)
+            self._padded = (padded, list(params), shapes_model)
+            params = padded
         arr = (ctypes.c_void_p * n)(*[p.data_ptr() for p in params])
-        self._keep = getattr(self, "_keep", [])[-64:] + [keep, arr]      # alive until the enqueued work has read them
+        self._keep = getattr(self, "_keep", [])[-64:] + [keep, arr, params]      # alive until the enqueued work has read them
         a = _lib.TrainArgs()
         a.m, a.y, a.local_pts, a.seg_offsets = [t.data_ptr() for t in keep]
         a.params = ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
@@ -595,12 +619,21 @@ class TrainPlan:
         a.best_m, a.best_pred, a.loss_hist, a.lr_hist, a.result = [o.data_ptr() if o is not None else None for o in outs]
         return a
 
-    def _param_numels(self):
-        """Element counts of the model's tensors in Q_PARAM_ORDER / DQ_PARAM_ORDER (model_utils.py:65-168)."""
-        H = self.hidden
+    def _param_shapes(self, H):
+        """Shapes of the model's tensors in Q_PARAM_ORDER / DQ_PARAM_ORDER at width H (model_utils.py:65-168)."""
         if self.rot == 0:      # QRegMLP: enc 56->H, dec1 H->H/2->3, dec2 H->H->4
-            return [56 * H, H, H * (H // 2), H // 2, 3 * (H // 2), 3, H * H, H, 4 * H, 4]
-        return [64 * H, H, H * H, H, 8 * H, 8]        # DQRegMLP: enc 64->H, H->H, H->8
+            return [(H, 56), (H,), (H // 2, H), (H // 2,), (3, H // 2), (3,), (H, H), (H,), (4, H), (4,)]
+        return [(H, 64), (H,), (H, H), (H,), (8, H), (8,)]        # DQRegMLP: enc 64->H, H->H, H->8
+
+    def _param_numels(self):
+        """Element counts of the model's tensors at the kernels' width."""
+        return [int(np.prod(s)) for s in self._param_shapes(self.hidden)]
+
+    def _unpad(self, padded):
+        """Trained parameters back into the caller's tensors (stream-ordered copies of the leading blocks)."""
+        if padded is not None:
+            for q, p, sm in zip(*padded):
+                p.view(sm).copy_(q[tuple(slice(0, d) for d in sm)])
 
     def _outs(self):
         dev = self.device
@@ -621,12 +654,15 @@ class TrainPlan:
         if len(problems) != self.batch:
             raise ValueError(f"this plan advances {self.batch} problems per launch, got {len(problems)}")
         arr = (_lib.TrainArgs * self.batch)()
-        outs = []
+        outs, padded = [], []
         for b, (m, y, pts, offsets, params) in enumerate(problems):
             best_m, best_pred, lh, lrh, result = o = self._outs()
             arr[b] = self._args(m, y, pts, offsets, params, lr, factor, patience, stop, o)
+            padded.append(self._padded)
             outs.append((best_m, best_pred, result, lh, lrh))
         _lib.check(self.L.creg_train_plan_run_batch(self.plan, arr, self.batch, _stream()), "creg_train_plan_run_batch")
+        for pd in padded:
+            self._unpad(pd)
         return outs
 
     def probe(self, m, y, pts, offsets, params):
