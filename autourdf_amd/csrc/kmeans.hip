@@ -448,7 +448,7 @@ __global__ void k_km_fold() {
 #endif
 struct KmTail { double* B; double* C2; double* Cw; double* far_d; double* segv; int* segi; int* lab[2]; const int* prev0; int max_iter; const int* inv;
                 double* ring; unsigned long long* genrep; unsigned long long* slots;
-                int nrow; const int* perm; int spin_limit; };                  // pruned form: rows of the sorted copy (dummies: perm < 0)
+                int nrow; const int* perm; int spin_limit; int rw; };                  // pruned form: rows of the sorted copy (dummies: perm < 0)
 // persistent Lloyd kernel: centre rows of the iterations of ONE launch at distinct addresses (see k_km_persist), and copies of `gen`
 constexpr int KMP_RING = 320, KMP_GENREP = 8, KMP_GENREP_STRIDE = 512;       // (stride in 8-byte words: 4 KB apart)
 __host__ __device__ __forceinline__ size_t kmp_ring_stride(int k) { return ((size_t)4 * k + 15) & ~(size_t)15; }   // doubles, 128-byte multiple
@@ -704,14 +704,16 @@ __global__ __launch_bounds__(256) void k_km_assign_pruned(const double* __restri
     // Every operand of the launch is requested before anything is waited for -- the points, the centre rows, the box, and the
     // previous labels from BOTH label buffers (which one holds them depends on the iteration count, which arrives with the
     // flags): one memory round trip for the flags and the operands together instead of two or three in a row.
-    const int i0 = blockIdx.x * (256 * PT) + wv * (64 * PT) + lane, nrow = T.nrow;   // a wave owns 64 PT consecutive rows
+    // a wave owns T.rw <= 64 PT consecutive rows (lane l: rows l, 64 + l, ...; the last slot is partly masked)
+    const int rw = T.rw, i0 = (blockIdx.x * 4 + wv) * rw + lane, nrow = T.nrow;
     double x[PT][3];
     int lab[PT], pv[PT], pa[PT], pb[PT], own[PT];
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
         const int i = min(i0 + 64 * q, nrow - 1);
         x[q][0] = X[3 * (size_t)i]; x[q][1] = X[3 * (size_t)i + 1]; x[q][2] = X[3 * (size_t)i + 2];
-        own[q] = T.perm[i];                                        // < 0: a dummy row
+        own[q] = 64 * q + lane < rw ? T.perm[i] : -1;              // < 0: a dummy row, or a slot beyond the wave's rows
+        if (64 * q + lane >= rw) { x[q][0] = x[q][1] = x[q][2] = __builtin_nan(""); }   // (kept out of the wave's box like a dummy)
         pa[q] = lloyd ? T.lab[0][i] : -1; pb[q] = lloyd ? T.lab[1][i] : -1;      // (first iteration: whatever the workspace holds, unused)
     }
     double br[2];
@@ -738,7 +740,7 @@ __global__ __launch_bounds__(256) void k_km_assign_pruned(const double* __restri
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
         const int i = i0 + 64 * q;
-        if (i < nrow) {
+        if (64 * q + lane < rw) {
             labels[i] = lab[q];
             if (lloyd && own[q] >= 0 && pv[q] != lab[q]) { ++diff; km_move(sA, lab[q], pv[q], x[q][0], x[q][1], x[q][2], fscale); }
         }
@@ -858,7 +860,7 @@ __global__ __launch_bounds__(256, PT == 2 ? 3 : PT == 4 ? 2 : 1) void k_km_persi
     int* cand = (int*)(slb + k);
     const int tid = threadIdx.x, lane = tid & 63;
     asm volatile("" :: "s"(X), "s"(n), "s"(B), "s"(k), "s"(box), "s"(f), "s"(acc), "s"(T.C2), "s"(T.lab[0]), "s"(T.lab[1]), "s"(T.max_iter));
-    const int i0 = blockIdx.x * (256 * PT) + (tid >> 6) * (64 * PT) + lane, nrow = T.nrow;   // a wave owns 64 PT consecutive rows
+    const int rw = T.rw, i0 = (blockIdx.x * 4 + (tid >> 6)) * rw + lane, nrow = T.nrow;   // a wave owns T.rw <= 64 PT consecutive rows
     double x[PT][3];
     int lab[PT], pv[PT], pa[PT], pb[PT];
     bool own[PT];
@@ -866,7 +868,8 @@ __global__ __launch_bounds__(256, PT == 2 ? 3 : PT == 4 ? 2 : 1) void k_km_persi
     for (int q = 0; q < PT; ++q) {
         const int i = min(i0 + 64 * q, nrow - 1);
         x[q][0] = X[3 * (size_t)i]; x[q][1] = X[3 * (size_t)i + 1]; x[q][2] = X[3 * (size_t)i + 2];
-        own[q] = i0 + 64 * q < nrow && T.perm[i] >= 0;             // not a dummy row
+        own[q] = 64 * q + lane < rw && T.perm[i] >= 0;             // one of the wave's rows and not a dummy
+        if (64 * q + lane >= rw) { x[q][0] = x[q][1] = x[q][2] = __builtin_nan(""); }   // (kept out of the wave's box like a dummy)
         pa[q] = T.lab[0][i]; pb[q] = T.lab[1][i];
     }
     const double* bx = box + 6 * (size_t)blockIdx.x;
@@ -964,7 +967,7 @@ __global__ __launch_bounds__(256, PT == 2 ? 3 : PT == 4 ? 2 : 1) void k_km_persi
 #endif
     int* out = (t & 1) ? T.lab[1] : T.lab[0];                    // the labels of iteration t, where the multi-launch path keeps them
 #pragma unroll
-    for (int q = 0; q < PT; ++q) if (i0 + 64 * q < nrow) out[i0 + 64 * q] = lab[q];
+    for (int q = 0; q < PT; ++q) if (64 * q + lane < rw) out[i0 + 64 * q] = lab[q];
 }
 
 // E-step, matrix-core form: v_mfma_f64_16x16x4_f64 evaluates a 16-centre x 16-point tile of |c|^2 - 2 x.c as
@@ -1498,14 +1501,31 @@ __global__ __launch_bounds__(1024) void k_group_scatter_big(const double* __rest
 static int seg_count(int64_t n) { int s = (int)((n + 16383) / 16384); return s < 1 ? 1 : (s > 64 ? 64 : s); }
 
 // pruned E-step: points per workgroup and grid bits per axis of the spatial order
-static int km_pruned_pt(int64_t n) {                             // points per thread of the pruned E-step: 2 | 4 | 8
-    static int forced = -1;                                      // measurement knob CREG_KMP_PT
+// Geometry of the pruned E-step: G workgroups of 4 waves, each wave RW consecutive rows of the sorted copy (PT = ceil(RW / 64) row
+// slots per lane), rows = 4 G RW >= n + 64 (RW - 1) -- every one of the 64 Morton ranges starts on a WAVE boundary (the per-wave
+// filter is the level that must not straddle two ranges; 3 % dummy rows at n = 262144 instead of 12 % with workgroup-aligned runs).
+// G is a multiple of 256 above 256, so that every CU holds the same number of workgroups of the persistent kernel: two slots per
+// lane while that gives at most 768 workgroups (three per CU), then four (512), then eight.  (Measured at n = 262144: 768 x 4 x 88
+// rows 16.0 us per Lloyd iteration, 576 x 4 x 128 -- 64 CUs with three workgroups -- 16.2: the late arrivals are the waves whose
+// box lies in the sparse end of the Morton order and keeps 40-55 centres, not the CUs with one workgroup more.)
+struct KmGeom { int G, RW, PT; };
+static KmGeom km_geometry(int64_t n) {
+    static int forced = -1;                                      // measurement knob CREG_KMP_PT (2 | 4 | 8)
     if (forced < 0) { const char* e = getenv("CREG_KMP_PT"); forced = e ? atoi(e) : 0; }
-    if (forced == 2 || forced == 4 || forced == 8) return forced;
-    // 2 while the persistent grid (rows / 512, dummies included) fits three workgroups per CU; measured at n = 262144: 17.2 us
-    // per Lloyd iteration with 2 (576 workgroups), 19.5 with 4 (288)
-    return n <= 327680 ? 2 : n <= 425984 ? 4 : 8;
+    for (int pt = 2; pt <= 8; pt *= 2) {
+        if ((forced == 2 || forced == 4 || forced == 8) && pt != forced) continue;
+        int64_t g = ((n - 64 + 64 * pt - 1) / (64 * pt) + 64 + 3) / 4;                          // 4 g - 64 waves of 64 pt rows cover n - 64
+        if (g < 32) g = 32;
+        if (g > 256) g = (g + 255) / 256 * 256;
+        const int64_t cap = pt == 2 ? 768 : 512;
+        if (g <= cap || pt == 8 || pt == forced) {
+            const int64_t rw = (n - 64 + (4 * g - 64) - 1) / (4 * g - 64);
+            return KmGeom{(int)g, (int)(rw < 1 ? 1 : rw), pt};
+        }
+    }
+    return KmGeom{32, 1, 2};
 }
+static int km_pruned_pt(int64_t n) { return km_geometry(n).PT; }
 static int km_spin_limit() {                                     // polls before a waiting workgroup gives up (test knob CREG_KM_SPIN_LIMIT: 1 forces the fallback)
     static int v = -1;
     if (v < 0) { const char* e = getenv("CREG_KM_SPIN_LIMIT"); v = e && atoi(e) > 0 ? atoi(e) : (1 << 20); }
@@ -1527,7 +1547,7 @@ struct KmLayout { size_t xc, c2, b, cw, part, far, segv, segi, prev, lab2, flags
 // rows of the sorted copy: the points plus the dummies that align the 64 Morton ranges to the workgroup runs (sized for the
 // longest run, 2048 rows)
 static int64_t km_rows_cap(int64_t n) { return n + 65 * 2048; }      // (>= km_rows(n, 8): 64 ranges of up to 2047 dummies, rounded up to a run)
-static int km_rows(int64_t n, int pt) { const int a = 256 * pt; return (int)((n + 64 * (int64_t)(a - 1) + a - 1) / a * a); }
+static int64_t km_rows(int64_t n) { const KmGeom g = km_geometry(n); return (int64_t)4 * g.G * g.RW; }
 static KmLayout km_layout(int64_t n, int k) {
     KmLayout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -1537,13 +1557,13 @@ static KmLayout km_layout(int64_t n, int k) {
     L.far = take(sizeof(double) * n);
     // relocation pass: one entry per workgroup of the E-step launch (at most n / 64: the matrix-core form; the pruned form's
     // grid covers the dummy rows too)
-    const size_t nseg = (size_t)((n + 63) / 64) + (size_t)(nr / 512) + 1;
+    const size_t nseg = (size_t)((n + 63) / 64) + (size_t)(nr / 512) + 1025;
     L.segv = take(sizeof(double) * nseg); L.segi = take(sizeof(int) * nseg);
     L.prev = take(sizeof(int) * n); L.lab2 = take(sizeof(int) * nr);
     L.flags = take(sizeof(KmFlags));
     L.lab3 = take(sizeof(int) * nr); L.perm = take(sizeof(int) * nr); L.inv = take(sizeof(int) * n); L.key = take(sizeof(int) * n);
     L.cell = take(sizeof(int) * (((size_t)1 << (3 * km_cell_bits(n))) + 64));   // cell counts / first rows, then the 64 ranges' totals
-    L.box = take(sizeof(double) * 6 * (size_t)((nr + 511) / 512));
+    L.box = take(sizeof(double) * 6 * (size_t)((nr + 511) / 512 + 1024));   // one per workgroup of the pruned E-step
     L.ring = take(sizeof(double) * kmp_ring_stride(k) * KMP_RING);
     L.genrep = take(sizeof(unsigned long long) * KMP_GENREP_STRIDE * KMP_GENREP);
     L.slots = take(sizeof(unsigned long long) * 1024);          // (the persistent grid is at most 512 workgroups; genrep and slots are zeroed together)
@@ -1560,7 +1580,7 @@ static int km_points_per_thread(int n) {
 
 static int launch_assign(const double* X, int n, const double* B, int k, int* labels, const int* prev,
                          KmFlags* f, int use_mfma, hipStream_t s, int raw = 0, unsigned long long* acc = nullptr,
-                         KmTail T = KmTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr}, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0}) {
+                         KmTail T = KmTail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr}, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0}) {
     constexpr int LDS_MAX = 128 * 1024;
     if (use_mfma) {
         const int ntile = cdiv(n, 16);
@@ -1606,7 +1626,7 @@ static int persist_fits(int blocks, size_t smem) {
 static int launch_persist(const double* Xs, int n, double* B, int k, const double* box, KmFlags* f, unsigned long long* acc,
                           const KmTail& T, int pt, hipStream_t s, bool probe_only) {
     const size_t smem = sizeof(double) * 9 * k + sizeof(int) * 5 * k;   // centre rows, M-step sums, lower bounds, the workgroup's and the four waves' survivor lists
-    const int blocks = cdiv(T.nrow, 256 * pt);
+    const int blocks = T.nrow / (4 * T.rw);
 #define CREG_KM_PERSIST(PT_)                                                                                                     \
     do {                                                                                                                          \
         if (!persist_fits<PT_>(blocks, smem)) return 1;                                                                           \
@@ -1625,7 +1645,7 @@ static int launch_assign_pruned(const double* Xs, int n, const double* B, int k,
 #define CREG_KM_PRUNED(PT_)                                                                                                      \
     do {                                                                                                                          \
         if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_km_assign_pruned<PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return 1; \
-        hipLaunchKernelGGL(k_km_assign_pruned<PT_>, dim3(cdiv(T.nrow, 256 * PT_)), dim3(256), smem, s, Xs, n, B, k, box, labels, f, lloyd, acc, T); \
+        hipLaunchKernelGGL(k_km_assign_pruned<PT_>, dim3(T.nrow / (4 * T.rw)), dim3(256), smem, s, Xs, n, B, k, box, labels, f, lloyd, acc, T); \
     } while (0)
     const int pt = km_pruned_pt(n);
     if (pt == 8) CREG_KM_PRUNED(8);
@@ -1664,8 +1684,10 @@ static int km_lloyd_run(const double* X, int64_t n, const double* init, int32_t 
     int* prev0 = (int*)(w + L.prev);
     int* perm = (int*)(w + L.perm); int* inv = (int*)(w + L.inv); double* box = (double*)(w + L.box);
     KmFlags* f = (KmFlags*)(w + L.flags);
-    const int ni = (int)n, nrow = pruned ? km_rows(n, km_pruned_pt(n)) : (int)n;
-    CREG_REQUIRE((int64_t)nrow <= km_rows_cap(n), "creg_kmeans_lloyd_f64: internal: sorted copy larger than its workspace");
+    const KmGeom geo = km_geometry(n);
+    CREG_REQUIRE(!pruned || (km_rows(n) <= km_rows_cap(n) && km_rows(n) >= n + 64 * (int64_t)(geo.RW - 1) && geo.RW <= 64 * geo.PT),
+                 "creg_kmeans_lloyd_f64: internal: geometry of the sorted copy (%d workgroups x 4 x %d rows)", geo.G, geo.RW);
+    const int ni = (int)n, nrow = pruned ? (int)km_rows(n) : (int)n;
     CREG_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * 4 * k, s));
 
     hipLaunchKernelGGL(k_km_stats, dim3(1), dim3(1024), 0, s, X, ni, tol_rel, f);
@@ -1675,20 +1697,20 @@ static int km_lloyd_run(const double* X, int64_t n, const double* init, int32_t 
         CREG_HIP(hipMemsetAsync(cell, 0, sizeof(int) * ncell, s));
         hipLaunchKernelGGL(k_km_cell_count, dim3(cdiv(n, 256)), dim3(256), 0, s, X, ni, f, bits, key, cell);
         hipLaunchKernelGGL(k_km_cell_totals, dim3(64), dim3(256), 0, s, cell, ncell, gtot);
-        hipLaunchKernelGGL(k_km_cell_scan, dim3(64), dim3(256), 0, s, cell, ncell, 256 * km_pruned_pt(n), gtot);
+        hipLaunchKernelGGL(k_km_cell_scan, dim3(64), dim3(256), 0, s, cell, ncell, geo.RW, gtot);
         CREG_HIP(hipMemsetAsync(Xc, 0xFF, sizeof(double) * 3 * (size_t)nrow, s));       // dummy rows: NaN coordinates (ignored by the boxes' fmin / fmax) ...
         CREG_HIP(hipMemsetAsync(perm, 0xFF, sizeof(int) * (size_t)nrow, s));            // ... and perm = -1
         hipLaunchKernelGGL(k_km_cell_scatter, dim3(cdiv(n, 256)), dim3(256), 0, s, ni, key, cell, perm, inv);
     }
     hipLaunchKernelGGL(k_km_center, dim3(cdiv(n > k ? n : k, 256)), dim3(256), 0, s, X, ni, init, k, f, Xc, C2, B, prev0, pruned ? inv : nullptr);
-    if (pruned) hipLaunchKernelGGL(k_km_boxes, dim3(cdiv(nrow, 256 * km_pruned_pt(n))), dim3(256), 0, s, Xc, nrow, 256 * km_pruned_pt(n), box);
+    if (pruned) hipLaunchKernelGGL(k_km_boxes, dim3(geo.G), dim3(256), 0, s, Xc, nrow, 4 * geo.RW, box);
     CREG_LAUNCH_CHECK();
     // labels ping-pong between the caller's buffer and lab2 so "previous labels" needs no copy;
     // iteration `it` writes lab[it & 1] and compares with the buffer written by it - 1.
     int done = 0, n_done = 0;
     KmFlags host;
     const KmTail T{B, C2, Cw, far_d, (double*)(w + L.segv), (int*)(w + L.segi), {lab[0], lab[1]}, prev0, max_iter, pruned ? inv : nullptr,
-                   (double*)(w + L.ring), (unsigned long long*)(w + L.genrep), (unsigned long long*)(w + L.slots), nrow, perm, km_spin_limit()};
+                   (double*)(w + L.ring), (unsigned long long*)(w + L.genrep), (unsigned long long*)(w + L.slots), nrow, perm, km_spin_limit(), geo.RW};
     if (pruned) CREG_HIP(hipMemsetAsync(w + L.genrep, 0, L.slots + sizeof(unsigned long long) * 1024 - L.genrep, s));
     // Pruned form: ONE ordinary launch (an E-step, or the relocation a persistent launch left pending), then the persistent
     // kernel, which iterates until convergence / max_iter / the next empty cluster; one host round trip per such pair.

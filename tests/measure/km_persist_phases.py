@@ -41,13 +41,13 @@ for p, nm in enumerate(names):
     print(f"    {nm:48s} {v[8 + p] / int(n_it) / 100:6.2f} us")
 big = (ctypes.c_ulonglong * 4096)()
 fn(big, 5)
-b = np.array(list(big), dtype=np.float64).reshape(4, 1024)[:, :512] / 100.0
+b = np.array(list(big), dtype=np.float64).reshape(4, 1024)[:, :768] / 100.0
 t0 = b[0, 0]
 print("  iteration 150, absolute times relative to workgroup 0's start of the iteration (us):")
 for name, row in zip(("centre rows landed", "arrived (wg 0: all seen)", "tail done (wg 0 only)", "saw gen"), b):
-    r = np.sort(row[1:] - t0)
+    r = np.sort(row[1:768] - t0)
     print(f"    {name:28s}: wg0 {row[0] - t0:6.2f} | others min {r[0]:6.2f}  25% {r[len(r)//4]:6.2f}  50% {r[len(r)//2]:6.2f}  75% {r[3*len(r)//4]:6.2f}  max {r[-1]:6.2f}")
-raw = np.array(list(big), dtype=np.uint64).reshape(4, 1024)[:, :512]
+raw = np.array(list(big), dtype=np.uint64).reshape(4, 1024)[:, :768]
 arr = raw[1].astype(np.float64) / 100.0 - t0
 order = np.argsort(-arr[1:])[:12] + 1
 print("  latest arrivals: " + "  ".join(f"wg {i}: {arr[i]:.1f} us, survivors {int(raw[2][i] >> np.uint64(32))}, changed(w0) {int(raw[2][i] & np.uint64(0xffffffff))}" for i in order))
