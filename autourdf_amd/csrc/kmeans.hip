@@ -1544,14 +1544,12 @@ static bool km_pruned_enabled() {
 }
 
 struct KmLayout { size_t xc, c2, b, cw, part, far, segv, segi, prev, lab2, flags, lab3, perm, inv, key, cell, box, ring, genrep, slots, total; };
-// rows of the sorted copy: the points plus the dummies that align the 64 Morton ranges to the workgroup runs (sized for the
-// longest run, 2048 rows)
-static int64_t km_rows_cap(int64_t n) { return n + 65 * 2048; }      // (>= km_rows(n, 8): 64 ranges of up to 2047 dummies, rounded up to a run)
+// rows of the sorted copy: the points plus the dummies that align the 64 Morton ranges to the waves' runs
 static int64_t km_rows(int64_t n) { const KmGeom g = km_geometry(n); return (int64_t)4 * g.G * g.RW; }
 static KmLayout km_layout(int64_t n, int k) {
     KmLayout L; size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-    const int64_t nr = km_rows_cap(n);
+    const int64_t nr = km_rows(n);                                // rows of the sorted copy: the points plus the dummies that align the ranges
     L.xc = take(sizeof(double) * 3 * nr); L.c2 = take(sizeof(double) * 6 * k); L.b = take(sizeof(double) * 4 * k);
     L.cw = take(sizeof(double) * 4 * k); L.part = take(sizeof(unsigned long long) * 4 * k);      // part: the int64 accumulators
     L.far = take(sizeof(double) * n);
@@ -1685,7 +1683,7 @@ static int km_lloyd_run(const double* X, int64_t n, const double* init, int32_t 
     int* perm = (int*)(w + L.perm); int* inv = (int*)(w + L.inv); double* box = (double*)(w + L.box);
     KmFlags* f = (KmFlags*)(w + L.flags);
     const KmGeom geo = km_geometry(n);
-    CREG_REQUIRE(!pruned || (km_rows(n) <= km_rows_cap(n) && km_rows(n) >= n + 64 * (int64_t)(geo.RW - 1) && geo.RW <= 64 * geo.PT),
+    CREG_REQUIRE(!pruned || (km_rows(n) >= n + 64 * (int64_t)(geo.RW - 1) && geo.RW <= 64 * geo.PT && km_rows(n) < (1ll << 31)),
                  "creg_kmeans_lloyd_f64: internal: geometry of the sorted copy (%d workgroups x 4 x %d rows)", geo.G, geo.RW);
     const int ni = (int)n, nrow = pruned ? (int)km_rows(n) : (int)n;
     CREG_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * 4 * k, s));
