@@ -838,6 +838,7 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
 //   k_icp_compact (one workgroup)     between batches: the chunks of the clusters still iterating (the next batch's grid)
 //   k_icp_finish  (cluster)           outputs
 // The host enqueues the search in batches of 16 and reads "clusters / chunks still running" between batches.
+typedef float nn_f2 __attribute__((ext_vector_type(2)));          // (v_pk_* float32 pairs: the screen of k_icp_nn)
 struct IcpLarge {                          // per problem
     const double* local; const float* world; const int* off; const int* woff; const double* frame; const double* Min;
     double* Mout; double* world_out; int* n_iter_out;
@@ -852,6 +853,7 @@ struct IcpLarge {                          // per problem
     int* live;                                 // [chunks] chunks of the clusters still iterating (k_icp_compact), read when `use_live`
     int use_live;
     int pool_cap;
+    int screen;                                // k_icp_nn: float32 screen in front of the fp64 scan (0: measurement / identity knob)
 };
 constexpr int ICP_CH = 64;                 // sources per k_icp_nn workgroup (4 waves of 16)
 #ifndef ICP_LG
@@ -1221,6 +1223,8 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
     double* tx = (double*)smem;                                       // [waves][4 rows][SR] x | y | z, then the frame indices
     double* ty = tx + ICP_NNW * ICP_G * SR; double* tz = ty + ICP_NNW * ICP_G * SR;
     int* tj = (int*)(tz + ICP_NNW * ICP_G * SR);
+    float* txf = (float*)(tj + ICP_NNW * ICP_G * SR);                  // the same targets relative to the wave's origin, float32 (the screen)
+    float* tyf = txf + ICP_NNW * ICP_G * SR; float* tzf = tyf + ICP_NNW * ICP_G * SR;
     __shared__ double sc[ICP_NNW * ICP_NM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int blk = P.use_live ? P.live[blockIdx.x] : (int)blockIdx.x;     // the chunk this workgroup takes
@@ -1252,6 +1256,7 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
     const int axa = (int)st[38], axb = (int)st[44], gd = (int)st[45];
     const double shc0 = st[39], shc1 = st[40], shc2 = st[41];
     double s0 = 0, s1 = 0, s2 = 0, alo = INFINITY, ahi = -INFINITY, blo = INFINITY, bhi = -INFINITY;
+    double seed = 1e299;                                              // 1e299: below the staged padding's 3e300, above any real squared distance
     if (live) {
         // the rigid update the last fit left pending (identity before the first one); the four lanes of a source agree,
         // lane group 0 stores
@@ -1269,6 +1274,10 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
             const double r0 = (d2p > 1e-280 ? d2p * fast_rsqrt(d2p) : 1e-140) * (1.0 + 1e-12) + 1e-300;
             const double ra = r0 + 4e-16 * fabs(sa), rb = r0 + 4e-16 * fabs(sb);
             alo = sa - ra; ahi = sa + ra; blo = sb - rb; bhi = sb + rb;
+            // the previous match lies inside the rectangle and will be scanned with exactly this value (same operands, same
+            // association): starting `best` a hair above it changes no result -- the match itself still passes the strict `<` --
+            // and lets the float32 screen below reject almost every other target from the first trip on
+            if (P.screen) seed = d2p * (1.0 + 0x1p-40) + 1e-300;
         }
     }
     NN_STAMP(8);
@@ -1288,6 +1297,30 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
 #endif
     double* px = tx + (wv * ICP_G + g) * SR; double* py = ty + (wv * ICP_G + g) * SR; double* pz = tz + (wv * ICP_G + g) * SR;
     int* pj = tj + (wv * ICP_G + g) * SR;
+    float* pxf = txf + (wv * ICP_G + g) * SR; float* pyf = tyf + (wv * ICP_G + g) * SR; float* pzf = tzf + (wv * ICP_G + g) * SR;
+    // ---- float32 screen ----------------------------------------------------------------------------------------------
+    // Coordinates relative to a wave origin o (the first live source), rounded to float32; d_f = the float32 squared distance.
+    // With u = 2^-24, L >= every |coordinate - o| (the mask box holds the targets, the sources are measured) and D the
+    // fp64 squared distance:  d_f <= D + 8 u (L sqrt(D) + D) + 13 u^2 L^2   (input rounding 2 u L per difference, three
+    // roundings of the sum).  So D <= best implies d_f <= thr = best + 2^-20 (L sqrt(best) + best) + 2^-43 L^2 (twice the
+    // bound), and a trip whose smallest d_f exceeds thr (rounded up to float32) in EVERY lane cannot change `best`, the slot
+    // or the tie flag: it is skipped; every other trip runs the fp64 code below unchanged.  The screen only ever skips work.
+    const int flive = __builtin_ctzll(__ballot(live) | (1ull << 63));
+    const double o0 = __shfl(s0, flive, 64), o1 = __shfl(s1, flive, 64), o2 = __shfl(s2, flive, 64);
+    const float sf0 = (float)(s0 - o0), sf1 = (float)(s1 - o1), sf2 = (float)(s2 - o2);
+    double Lb = 0.0;
+    {
+        const float* bx6 = P.box + 6 * c;
+        const double od[3] = {o0, o1, o2};
+        for (int d = 0; d < 3; ++d) Lb = fmax(Lb, fmax(fabs((double)bx6[d] - od[d]), fabs((double)bx6[3 + d] - od[d])));
+        const double ls = live ? fmax(fabs(s0 - o0), fmax(fabs(s1 - o1), fabs(s2 - o2))) : 0.0;
+        Lb = fmax(Lb, wave_max_fast(ls)) * (1.0 + 0x1p-20) + 1e-30;   // (box corners are float32: slack for their rounding)
+    }
+    auto screen_thr = [&](double b) -> float {
+        if (!(b < 1e290)) return INFINITY;
+        const double rt = (double)sqrtf((float)b) * (1.0 + 0x1p-20);
+        return (float)((b + 0x1p-20 * (Lb * rt + b) + 0x1p-43 * Lb * Lb) * (1.0 + 0x1p-22));
+    };
     const int tb = P.tbase[c];                                        // >= 0: coordinates in the pool, in the order of tidx
     // Lane group g walks the runs of grid rows rb + g, + 4, + 8, + 12 of a band of <= 16 rows as ONE sequence of L entries
     // (entry p -> run and offset by three compares), so the scan is a flat loop over batches of SB entries and the four groups
@@ -1347,9 +1380,11 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
             const int e = ICP_SPW * u + l16;
             const bool in = jv[u] >= 0;
             px[e] = in ? cx[u] : 1e150; py[e] = in ? cy[u] : 1e150; pz[e] = in ? cz[u] : 1e150; pj[e] = in ? jv[u] : 0x7fffffff;
+            pxf[e] = in ? (float)(cx[u] - o0) : 1e30f; pyf[e] = in ? (float)(cy[u] - o1) : 1e30f; pzf[e] = in ? (float)(cz[u] - o2) : 1e30f;
         }
     };
-    double best = 1e299; int bslot = -1, bj = 0x7fffffff;             // 1e299: below the staged padding's 3e300, above any real squared distance
+    double best = seed; int bslot = -1, bj = 0x7fffffff;
+    float thr_f = screen_thr(best);
     double bx = 0, by = 0, bz = 0;                                    // the best target's coordinates, picked up from LDS after its batch
     bool tief = false;
     NN_STAMP(9);
@@ -1372,6 +1407,17 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
                 // if it beats `best` strictly, as before; the tie flag is raised whenever the minimum is attained twice --
                 // inside a step, or again in a later step or batch -- which is all the rescan needs.
                 for (int t = 0; t < cnt; t += 8) {
+                    if (P.screen) {
+                        float mf = INFINITY;
+#pragma unroll
+                        for (int u = 0; u < 8; u += 2) {
+                            const nn_f2 X = *(const nn_f2*)(pxf + t + u), Y = *(const nn_f2*)(pyf + t + u), Z = *(const nn_f2*)(pzf + t + u);
+                            const nn_f2 fx = nn_f2{sf0, sf0} - X, fy = nn_f2{sf1, sf1} - Y, fz = nn_f2{sf2, sf2} - Z;
+                            const nn_f2 e = __builtin_elementwise_fma(fz, fz, __builtin_elementwise_fma(fy, fy, fx * fx));
+                            mf = fminf(mf, fminf(e.x, e.y));
+                        }
+                        if (!__ballot(mf <= thr_f)) continue;             // no lane has a target that could matter in this trip
+                    }
                     double d[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -1386,6 +1432,7 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
                     tief |= m == best || (lt && eq > 1);
                     bm = lt ? t + first : bm;
                     best = lt ? m : best;
+                    if (P.screen && __ballot(lt)) thr_f = screen_thr(best);
                 }
             } else {
                 for (int t = 0; t < cnt; ++t) {
@@ -1549,7 +1596,8 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
         set_error("creg_masked_icp: point-to-point mode (tgt_offsets) is not available in the large-cluster regime");
         return CREG_EINVAL;
     }
-    const int nn_smem = ICP_NNW * ICP_G * (ICP_SB + 2) * 28;  // k_icp_nn: per wave 4 lane groups x ICP_SB (+2: bank offset) staged targets (x, y, z, frame index)
+    const int nn_smem = ICP_NNW * ICP_G * (ICP_SB + 2) * 40;  // k_icp_nn: per wave 4 lane groups x ICP_SB (+2: bank offset) staged targets (x, y, z fp64, frame index, x, y, z float32)
+    { static int scr = -1; if (scr < 0) { const char* e = getenv("CREG_ICP_SCREEN"); scr = e ? atoi(e) != 0 : 1; } P.screen = scr; }
     CREG_HIP(hipFuncSetAttribute((const void*)k_icp_nn, hipFuncAttributeMaxDynamicSharedMemorySize, nn_smem));
     hipLaunchKernelGGL(k_icp_mask, dim3(k), dim3(1024), 0, s, P, (int)nf, (float)(0.5 * scale), q.world ? 0 : 1, 1);
     hipLaunchKernelGGL(k_icp_init, dim3(k), dim3(1024), 0, s, P, k);

@@ -1194,6 +1194,48 @@ def test_full_size_c5_masked_icp_spot_check_vs_oracle(dev):
         assert int(n_it[j]) == it
 
 
+_ICP_SCREEN_CODE = '''import sys, numpy as np, torch
+sys.path.insert(0, ROOT)
+from autourdf_amd import ops
+from autourdf_amd.synthetic import make_sequence
+n, k = 65536, 24
+fr = make_sequence("chain32", 3, 3, n)
+dev = torch.device("cuda")
+X = [torch.as_tensor(f, dtype=torch.float64, device=dev) for f in fr]
+init = X[0][torch.as_tensor(np.random.default_rng(5).choice(n, k, replace=False), device=dev)].clone()
+c, lab, _, _ = ops.kmeans_lloyd(X[0], init, max_iter=20)
+M = torch.eye(4, dtype=torch.float64, device=dev).repeat(k, 1, 1)
+M[:, :3, 3] = c
+local, off = ops.group_to_local(X[0], lab, M.contiguous())
+assert ops.masked_icp_regime(local.shape[0], n, k) == "many_workgroups"
+out = {}
+for t in (1, 2):
+    world32 = ops.cluster_transform(local.to(torch.float32), off, M.to(torch.float32))
+    M, w, it = ops.masked_icp(local, world32, off, X[t], M.contiguous())
+    out[f"M{t}"], out[f"w{t}"], out[f"it{t}"] = M.cpu().numpy(), w.cpu().numpy(), it.cpu().numpy()
+np.savez(OUT, **out)
+'''
+
+
+def test_masked_icp_float32_screen_changes_no_bit(dev, tmp_path):
+    """k_icp_nn skips a trip of eight targets when a float32 evaluation proves that none of them can reach the running best
+    (bound derived in csrc/icp.hip), and starts the running best a hair above the previous match: both only ever skip work.
+    Two frames of a chain32-shaped sequence in the many-workgroup regime (N = 65536, K = 24: clusters of ~2700 points), the second
+    from the first's poses so that previous matches exist -- poses, world clouds and iteration counts must be IDENTICAL to a run
+    with CREG_ICP_SCREEN=0 in a child process (the knob is read once per process)."""
+    import subprocess
+    import sys
+    outs = {}
+    for scr in ("1", "0"):
+        path = str(tmp_path / f"icp_{scr}.npz")
+        env = dict(os.environ, CREG_ICP_SCREEN=scr)
+        subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}; OUT = {path!r}\n" + _ICP_SCREEN_CODE], check=True, env=env, timeout=400)
+        outs[scr] = np.load(path)
+    assert int(outs["1"]["it1"].max()) > 20 and int(outs["1"]["it2"].max()) > 20
+    for key in outs["1"].files:
+        np.testing.assert_array_equal(outs["1"][key], outs["0"][key], err_msg=key)
+
+
 def _icp_vs_oracle(dev, clusters, mats, frame, scale=1.2, atol=1e-8):
     from autourdf_amd import ops
     from oracle import icp as oicp
