@@ -8,6 +8,7 @@
 //      4x4 profile matrix by cyclic Jacobi; equals Umeyama/Kabsch with the det correction) ->
 //      compose on the left, move the source incrementally like open3d does
 //   3. stop when |d fitness| < 1e-6 and |d rmse| < 1e-6, or after max_iteration
+#include <type_traits>
 #include "creg_common.h"
 #include "creg_dev.h"
 
@@ -848,6 +849,8 @@ struct IcpLarge {                          // per problem
     int* chunk_cl;                             // [chunks] cluster of every chunk (k_icp_nn's block -> cluster map)
     double* prevt;                             // [n][3] coordinates of every source's current match (the next search's bound)
     double* tcx; double* tcy; double* tcz;     // pool of the clusters' masked target coordinates in cell order (coalesced staging)
+    float4* tcf;                               // the same entries as (float32 coordinates relative to the cluster's box centre, frame index): what the screen stages
+    unsigned* tlmax;                           // [k] bits of the largest |coordinate - box centre| among a cluster's masked targets (float32, rounded up)
     int* tbase;                                // [k] a cluster's first pool entry, -1: did not fit (its targets are gathered through tidx)
     int* arrive;                               // [k] chunks of the cluster that have finished the running search
     int* live;                                 // [chunks] chunks of the clusters still iterating (k_icp_compact), read when `use_live`
@@ -1076,6 +1079,7 @@ __global__ __launch_bounds__(1024) void k_icp_init(IcpLarge P, int k_total) {
             for (int j = 0; j < k_total; ++j) {
                 const int ntj = P.tcount[j];
                 if (pb + ntj <= P.pool_cap) { P.tbase[j] = pb; pb += ntj; } else P.tbase[j] = -1;
+                P.tlmax[j] = 0u;
             }
         }
     }
@@ -1102,10 +1106,19 @@ __global__ __launch_bounds__(256) void k_icp_pool(IcpLarge P, int nf) {
     if (tb < 0) return;
     const int nt = P.tcount[c];
     const int* tidx = P.tidx + (size_t)c * nf;
+    const float* bx6 = P.box + 6 * c;
+    const double oc0 = 0.5 * ((double)bx6[0] + (double)bx6[3]), oc1 = 0.5 * ((double)bx6[1] + (double)bx6[4]), oc2 = 0.5 * ((double)bx6[2] + (double)bx6[5]);
+    float lm = 0.f;
     for (int t = blockIdx.y * 256 + threadIdx.x; t < nt; t += gridDim.y * 256) {
         const int j = tidx[t];
-        P.tcx[tb + t] = P.frame[3 * (size_t)j]; P.tcy[tb + t] = P.frame[3 * (size_t)j + 1]; P.tcz[tb + t] = P.frame[3 * (size_t)j + 2];
+        const double x = P.frame[3 * (size_t)j], y = P.frame[3 * (size_t)j + 1], z = P.frame[3 * (size_t)j + 2];
+        P.tcx[tb + t] = x; P.tcy[tb + t] = y; P.tcz[tb + t] = z;
+        const float fx = (float)(x - oc0), fy = (float)(y - oc1), fz = (float)(z - oc2);
+        P.tcf[tb + t] = make_float4(fx, fy, fz, __int_as_float(j));
+        lm = fmaxf(lm, fmaxf(fabsf(fx), fmaxf(fabsf(fy), fabsf(fz))));
     }
+    lm = -wave_min_fast(-lm);
+    if ((threadIdx.x & 63) == 0 && lm > 0.f) atomicMax(P.tlmax + c, __float_as_uint(lm));      // (non-negative floats order like their bits)
 }
 
 // One workgroup: the chunks of the clusters that have not converged, in order, into P.live; their number behind the
@@ -1216,7 +1229,7 @@ __device__ void icp_fit_cluster(const IcpLarge& P, int k, int max_iter, int lane
 // rectangle [4] cluster [5] launch grid
 __device__ unsigned long long g_icp_blk[6][8192];
 #endif
-__global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2, int max_iter) {
+__global__ __launch_bounds__(64 * ICP_NNW, 3) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2, int max_iter) {
     constexpr int SB = ICP_SB, SR = ICP_SB + 2;                       // staged targets per lane group and batch; slice stride
                                                                       // (+2: the four groups' equal slots fall into different LDS banks)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1257,6 +1270,7 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
     const double shc0 = st[39], shc1 = st[40], shc2 = st[41];
     double s0 = 0, s1 = 0, s2 = 0, alo = INFINITY, ahi = -INFINITY, blo = INFINITY, bhi = -INFINITY;
     double seed = 1e299;                                              // 1e299: below the staged padding's 3e300, above any real squared distance
+    double pd2 = 0, pq0 = 0, pq1 = 0, pq2 = 0; int pmv = -2;          // the previous match: its squared distance now, its coordinates, its frame index
     if (live) {
         // the rigid update the last fit left pending (identity before the first one); the four lanes of a source agree,
         // lane group 0 stores
@@ -1278,6 +1292,7 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
             // association): starting `best` a hair above it changes no result -- the match itself still passes the strict `<` --
             // and lets the float32 screen below reject almost every other target from the first trip on
             if (P.screen) seed = d2p * (1.0 + 0x1p-40) + 1e-300;
+            pd2 = d2p; pq0 = q0; pq1 = q1; pq2 = q2; pmv = pm;
         }
     }
     NN_STAMP(8);
@@ -1349,8 +1364,151 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
         if (lane == 0 && tailonly) { atomicAdd(&g_icp_stamps[0], (unsigned long long)per); atomicAdd(&g_icp_stamps[4], 1ull); }
 #endif
     };
-    // staging registers of one batch: the loads of batch b + 1 are in flight while batch b is scanned from LDS
     constexpr int EPL = SB / ICP_SPW;                                 // staged entries per lane and batch
+    double best = seed; int bslot = -1, bj = 0x7fffffff;
+    double bx = 0, by = 0, bz = 0;                                    // the best target's coordinates
+    bool tief = false;
+    NN_STAMP(9);
+    if (P.screen && tb >= 0) {
+        // ---- pool path: only what the screen needs is staged ---------------------------------------------------------------
+        // The pool holds every masked target of the cluster as (float32 coordinates relative to the box centre oc, frame index):
+        // one 16-byte load per entry, 16 bytes of LDS, and TWO batches of loads in flight (16 VGPRs a batch instead of 28).
+        // The fp64 coordinates stay in the pool: the rare trip that passes the screen reads its eight entries from there (L2).
+        // Same bound as above with o = oc and L from the cluster's own extent (k_icp_pool) and the wave's sources.
+        const float* bxc = P.box + 6 * c;
+        const double oc0 = 0.5 * ((double)bxc[0] + (double)bxc[3]), oc1 = 0.5 * ((double)bxc[1] + (double)bxc[4]), oc2 = 0.5 * ((double)bxc[2] + (double)bxc[5]);
+        const float cf0 = (float)(s0 - oc0), cf1 = (float)(s1 - oc1), cf2 = (float)(s2 - oc2);
+        const double lsrc = live ? fmax(fabs(s0 - oc0), fmax(fabs(s1 - oc1), fabs(s2 - oc2))) : 0.0;
+        const double Lc = fmax((double)__uint_as_float(P.tlmax[c]), wave_max_fast(lsrc)) * (1.0 + 0x1p-20) + 1e-30;
+        auto thr_of = [&](double b) -> float {
+            if (!(b < 1e290)) return INFINITY;
+            const double rt = (double)sqrtf((float)b) * (1.0 + 0x1p-20);
+            return (float)((b + 0x1p-20 * (Lc * rt + b) + 0x1p-43 * Lc * Lc) * (1.0 + 0x1p-22));
+        };
+        // The previous match is a target of this very list, and its squared distance from the moved source is pd2 exactly as the scan
+        // would compute it: the search STARTS from it (best = pd2, its index and coordinates) and leaves that one entry out (the
+        // screen would let it through in every scan: a trip's fp64 operands come from L2, ~1.5 us).  Any other target at exactly
+        // pd2 passes the screen and raises the tie flag as before; the rescan of pass 1 starts from nothing.
+        if (pmv >= 0) { best = pd2; bj = pmv; bx = pq0; by = pq1; bz = pq2; bslot = 0; }
+        float thr = thr_of(best);
+        const float4* tcf = P.tcf + tb;
+        const double* gx = P.tcx + tb; const double* gy = P.tcy + tb; const double* gz = P.tcz + tb;
+        auto seqpos = [&](int pq) { return pq < c1 ? rs0 + pq : (pq < c2 ? rs1 + (pq - c1) : (pq < c3 ? rs2 + (pq - c2) : rs3 + (pq - c3))); };
+        float4 v2[2][EPL];
+        auto fetchp = [&](auto SET, int t0) {
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const int pq = t0 + ICP_SPW * u + l16;
+                const bool in = pq < L;
+                const float4 v = tcf[in ? seqpos(pq) : 0];
+                v2[decltype(SET)::value][u] = in ? v : make_float4(1e30f, 1e30f, 1e30f, __int_as_float(0x7fffffff));
+            }
+        };
+        auto publishp = [&](auto SET) {
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const int e = ICP_SPW * u + l16;
+                const float4 v = v2[decltype(SET)::value][u];
+                pxf[e] = v.x; pyf[e] = v.y; pzf[e] = v.z; pj[e] = __float_as_int(v.w);
+            }
+        };
+        for (int pass = 0; pass < 2; ++pass) {                        // pass 1 only after a tie was seen: frame-index tie-break
+          for (int rb = ra0; rb < ra0 + nrows_all; rb += 16) {
+            band(rb);
+            using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+            if (per > 0) fetchp(S0{}, 0);
+            if (per > SB) fetchp(S1{}, SB);
+            auto scan_batch = [&](int t0) {
+                const int cnt = min(SB, per - t0);
+                int bm = -1;
+                if (pass == 0) {
+                    for (int t = 0; t < cnt; t += 8) {
+                        float mf = INFINITY, ef[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u += 2) {
+                            const nn_f2 X = *(const nn_f2*)(pxf + t + u), Y = *(const nn_f2*)(pyf + t + u), Z = *(const nn_f2*)(pzf + t + u);
+                            const nn_f2 fx = nn_f2{cf0, cf0} - X, fy = nn_f2{cf1, cf1} - Y, fz = nn_f2{cf2, cf2} - Z;
+                            const nn_f2 e = __builtin_elementwise_fma(fz, fz, __builtin_elementwise_fma(fy, fy, fx * fx));
+                            ef[u] = e.x; ef[u + 1] = e.y;
+                            mf = fminf(mf, fminf(e.x, e.y));
+                        }
+                        if (!__ballot(mf <= thr)) continue;
+                        int own = 0;                                      // bit u: entry u is this source's previous match (pass 0 starts from it)
+                        {
+                            bool cand = false;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { const bool mine = pj[t + u] == pmv; own |= mine ? 1 << u : 0; cand |= ef[u] <= thr && !mine; }
+                            if (!__ballot(cand)) continue;            // only previous matches came through
+                        }
+                        // the fp64 evaluation of the trip, exactly as in the other path, operands from the pool
+                        double d[8];
+#pragma unroll
+                        for (int h = 0; h < 8; h += 4) {                  // four entries' operands at a time (registers: the kernel must keep three waves per SIMD)
+                            double X[4], Y[4], Z[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int pq = t0 + t + h + u;
+                                const bool in = pq < L;
+                                const int tp = in ? seqpos(pq) : 0;
+                                const double x = gx[tp], y = gy[tp], z = gz[tp];
+                                X[u] = in ? x : 1e150; Y[u] = in ? y : 1e150; Z[u] = in ? z : 1e150;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const double dx = s0 - X[u], dy = s1 - Y[u], dz = s2 - Z[u];
+                                d[h + u] = (own >> (h + u)) & 1 ? 1e300 : (dx * dx + dy * dy) + dz * dz;
+                            }
+                            asm volatile("" ::: "memory");
+                        }
+                        const double m = vmin_f64(vmin_f64(vmin_f64(d[0], d[1]), vmin_f64(d[2], d[3])), vmin_f64(vmin_f64(d[4], d[5]), vmin_f64(d[6], d[7])));
+                        int first = 7, eq = 0;
+#pragma unroll
+                        for (int u = 7; u >= 0; --u) { const bool e = d[u] == m; first = e ? u : first; eq += e ? 1 : 0; }
+                        const bool lt = m < best;
+                        tief |= m == best || (lt && eq > 1);
+                        bm = lt ? t + first : bm;
+                        best = lt ? m : best;
+                        if (__ballot(lt)) {
+                            if (lt) { const int tp = seqpos(t0 + t + first); bx = gx[tp]; by = gy[tp]; bz = gz[tp]; }   // (a winner is a real entry)
+                        }
+                        if (__ballot(lt)) thr = thr_of(best);
+                    }
+                    if (bm >= 0) { bj = pj[bm]; bslot = bm; }
+                } else {
+                    for (int t = 0; t < cnt; ++t) {
+                        const int pq = t0 + t;
+                        const bool in = pq < L;
+                        const int tp = in ? seqpos(pq) : 0;
+                        const double x = in ? gx[tp] : 1e150, y = in ? gy[tp] : 1e150, z = in ? gz[tp] : 1e150;
+                        const double dx = s0 - x, dy = s1 - y, dz = s2 - z;
+                        const double d2 = (dx * dx + dy * dy) + dz * dz;
+                        const int j = pj[t];
+                        if (d2 < best || (d2 == best && j < bj)) { best = d2; bj = j; bx = x; by = y; bz = z; bslot = t; }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            };
+            for (int t0 = 0; t0 < per; t0 += 2 * SB) {
+                publishp(S0{});
+                __builtin_amdgcn_wave_barrier();
+                if (t0 + 2 * SB < per) fetchp(S0{}, t0 + 2 * SB);
+                scan_batch(t0);
+                if (t0 + SB < per) {
+                    publishp(S1{});
+                    __builtin_amdgcn_wave_barrier();
+                    if (t0 + 3 * SB < per) fetchp(S1{}, t0 + 3 * SB);
+                    scan_batch(t0 + SB);
+                }
+            }
+          }
+          if (pass == 0) {
+              if (!__ballot(tief)) break;
+              best = 1e299; bslot = -1; bj = 0x7fffffff;
+          }
+        }
+    } else {
+    float thr_f = screen_thr(best);
+    // staging registers of one batch: the loads of batch b + 1 are in flight while batch b is scanned from LDS
     int jv[EPL];
     double cx[EPL], cy[EPL], cz[EPL];
     auto fetch = [&](int t0) {
@@ -1383,11 +1541,6 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
             pxf[e] = in ? (float)(cx[u] - o0) : 1e30f; pyf[e] = in ? (float)(cy[u] - o1) : 1e30f; pzf[e] = in ? (float)(cz[u] - o2) : 1e30f;
         }
     };
-    double best = seed; int bslot = -1, bj = 0x7fffffff;
-    float thr_f = screen_thr(best);
-    double bx = 0, by = 0, bz = 0;                                    // the best target's coordinates, picked up from LDS after its batch
-    bool tief = false;
-    NN_STAMP(9);
     for (int pass = 0; pass < 2; ++pass) {                            // pass 1 only after a tie was seen: frame-index tie-break
       for (int rb = ra0; rb < ra0 + nrows_all; rb += 16) {
         band(rb);
@@ -1451,6 +1604,7 @@ __global__ __launch_bounds__(64 * ICP_NNW) void k_icp_nn(IcpLarge P, int n, int 
             if (!__ballot(tief)) break;
             best = 1e299; bslot = -1; bj = 0x7fffffff;
         }
+    }
     }
 #ifdef CREG_ICP_BLK
     if (tid == 0 && blk_rec) { g_icp_blk[0][blockIdx.x] = blk_t0; g_icp_blk[5][blockIdx.x] = gridDim.x;
@@ -1541,7 +1695,7 @@ __global__ __launch_bounds__(256) void k_icp_finish(IcpLarge P, int keep_t) {
     }
 }
 
-struct IcpLargeLayout { size_t srcw, tidx, tcount, box, nn, part, state, running, chunk0, tst, chunk_cl, prevt, tcx, tcy, tcz, tbase, arrive, live, total; int pool_cap; };
+struct IcpLargeLayout { size_t srcw, tidx, tcount, box, nn, part, state, running, chunk0, tst, chunk_cl, prevt, tcx, tcy, tcz, tbase, arrive, live, tcf, tlmax, total; int pool_cap; };
 static IcpLargeLayout icp_large_layout(int64_t n, int64_t nf, int k) {
     IcpLargeLayout L; size_t o = 0;
     auto take = [&](size_t b) { size_t r = o; o = align_up(o + b, 256); return r; };
@@ -1556,7 +1710,8 @@ static IcpLargeLayout icp_large_layout(int64_t n, int64_t nf, int k) {
     const int64_t cap = 4 * nf < (int64_t)k * nf ? 4 * nf : (int64_t)k * nf;
     L.pool_cap = (int)(cap < (1ll << 30) ? cap : (1ll << 30));
     L.tcx = take(sizeof(double) * (size_t)L.pool_cap); L.tcy = take(sizeof(double) * (size_t)L.pool_cap); L.tcz = take(sizeof(double) * (size_t)L.pool_cap);
-    L.tbase = take(sizeof(int) * k); L.arrive = take(sizeof(int) * k); L.live = take(sizeof(int) * (size_t)(n / ICP_CH + k + 1)); L.total = o;
+    L.tbase = take(sizeof(int) * k); L.arrive = take(sizeof(int) * k); L.live = take(sizeof(int) * (size_t)(n / ICP_CH + k + 1));
+    L.tcf = take(sizeof(float4) * (size_t)L.pool_cap); L.tlmax = take(sizeof(unsigned) * k); L.total = o;
     return L;
 }
 // the regime switch (host-side sizes only): average cluster above the LDS source budget, or a frame too large for the
@@ -1592,6 +1747,7 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
     P.nn = (int*)(ws + L.nn); P.part = (double*)(ws + L.part); P.state = (double*)(ws + L.state); P.running = (int*)(ws + L.running);
     P.chunk0 = (int*)(ws + L.chunk0); P.tst = (int*)(ws + L.tst); P.chunk_cl = (int*)(ws + L.chunk_cl); P.prevt = (double*)(ws + L.prevt);
     P.tcx = (double*)(ws + L.tcx); P.tcy = (double*)(ws + L.tcy); P.tcz = (double*)(ws + L.tcz); P.tbase = (int*)(ws + L.tbase); P.arrive = (int*)(ws + L.arrive); P.live = (int*)(ws + L.live); P.use_live = 0; P.pool_cap = L.pool_cap;
+    P.tcf = (float4*)(ws + L.tcf); P.tlmax = (unsigned*)(ws + L.tlmax);
     if (q.tgt_offsets) {
         set_error("creg_masked_icp: point-to-point mode (tgt_offsets) is not available in the large-cluster regime");
         return CREG_EINVAL;
