@@ -1121,6 +1121,36 @@ __global__ __launch_bounds__(256) void k_icp_pool(IcpLarge P, int nf) {
     if ((threadIdx.x & 63) == 0 && lm > 0.f) atomicMax(P.tlmax + c, __float_as_uint(lm));      // (non-negative floats order like their bits)
 }
 
+// Before the first iteration of a frame no source has a previous match, and a search without one scans its cluster's whole grid
+// (one launch of 350-1100 us at configs[4]).  This gives every source SOME target to start from: the first one listed in its own grid
+// cell, or in the nearest ring of cells (up to 3) that holds any.  Any target of the list is a valid start -- k_icp_nn's result is the
+// lexicographic minimum over a square that contains the nearest target, whatever it starts from -- and a near one makes that square small.
+__global__ __launch_bounds__(256) void k_icp_seed(IcpLarge P, int nf) {
+    const int c = blockIdx.x;
+    const double* st = P.state + ICP_ST * c;
+    const double x0a = st[36], inv_a = st[37], x0b = st[42], inv_b = st[43];
+    const int axa = (int)st[38], axb = (int)st[44], gd = (int)st[45];
+    const int* tst = P.tst + (size_t)c * (ICP_NCELL + 1);
+    const int* tidx = P.tidx + (size_t)c * nf;
+    const int tb = P.tbase[c];
+    for (int i = P.off[c] + blockIdx.y * 256 + threadIdx.x; i < P.off[c + 1]; i += gridDim.y * 256) {
+        const double s[3] = {P.srcw[3 * (size_t)i], P.srcw[3 * (size_t)i + 1], P.srcw[3 * (size_t)i + 2]};
+        const int ia = icp_bin(s[axa], x0a, inv_a, gd), ib = icp_bin(s[axb], x0b, inv_b, gd);
+        int t = -1;
+        for (int e = 0; e <= 3 && t < 0; ++e)
+            for (int r = max(ia - e, 0); r <= min(ia + e, gd - 1) && t < 0; ++r) {
+                const int q0 = tst[r * gd + max(ib - e, 0)], q1 = tst[r * gd + min(ib + e, gd - 1) + 1];
+                if (q1 > q0) t = q0;
+            }
+        if (t >= 0) {
+            const int j = tidx[t];
+            P.nn[i] = j;
+            if (tb >= 0) { P.prevt[3 * (size_t)i] = P.tcx[tb + t]; P.prevt[3 * (size_t)i + 1] = P.tcy[tb + t]; P.prevt[3 * (size_t)i + 2] = P.tcz[tb + t]; }
+            else { P.prevt[3 * (size_t)i] = P.frame[3 * (size_t)j]; P.prevt[3 * (size_t)i + 1] = P.frame[3 * (size_t)j + 1]; P.prevt[3 * (size_t)i + 2] = P.frame[3 * (size_t)j + 2]; }
+        }
+    }
+}
+
 // One workgroup: the chunks of the clusters that have not converged, in order, into P.live; their number behind the
 // "clusters still running" word the host reads between batches (the next batch of searches launches only those chunks:
 // in the tail of a frame a few clusters iterate on, and the thousands of workgroups that would only find "done" and leave
@@ -1758,6 +1788,7 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
     hipLaunchKernelGGL(k_icp_mask, dim3(k), dim3(1024), 0, s, P, (int)nf, (float)(0.5 * scale), q.world ? 0 : 1, 1);
     hipLaunchKernelGGL(k_icp_init, dim3(k), dim3(1024), 0, s, P, k);
     hipLaunchKernelGGL(k_icp_pool, dim3(k, 8), dim3(256), 0, s, P, (int)nf);
+    if (P.screen) hipLaunchKernelGGL(k_icp_seed, dim3(k, 8), dim3(256), 0, s, P, (int)nf);
     const int nblk = cdiv(n, ICP_CH) + k;                // an upper bound of sum_c ceil(ns_c / ICP_CH); the surplus blocks exit
     int running[2] = {k, nblk};                                      // clusters still iterating, their chunks
     // every launch is one search + (last chunk of each cluster) one fit = one convergence test and, unless converged, one
