@@ -171,9 +171,13 @@ struct NnBlocks { const float4* ts4; const float* tbox; int nblk; const int* nbl
 
 // stop_flag (optional, wave-uniform address): non-zero = the caller's train has stopped early -- the block returns before
 // its search (the flag is requested with the first loads and tested after the box bounds, so a live search pays nothing).
+// T / st (PPL > 1 only): the targets in their ORIGINAL order (the same values the blocks hold).  With several points per lane and
+// visit the launch is VALU-issue bound, so the running best is one 64-bit key (distance bits : original index -- distances are
+// non-negative, their bit patterns order like the values) compared once per point, and the winner's coordinates are not carried
+// along but read from T by its index at the end.
 template <int NB, int PPL, typename Epi>
 __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int sq, NnBlocks tb, int dir, Epi& epi, int blk,
-                                                   const int* stop_flag = nullptr) {
+                                                   const int* stop_flag = nullptr, const float* T = nullptr, int st = 0) {
     constexpr int QW = 4;
     const int stop = stop_flag ? *stop_flag : 0;
     __shared__ float s_partp[NN_BLOCK / 64];
@@ -249,13 +253,26 @@ __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int s
 #pragma unroll
                 for (int g = 0; g < NB; ++g)
                     if ((b[u] >> 6) == g && lane == (b[u] & 63)) lb[u][g] = INFINITY;     // visited: never again
+                if constexpr (PPL > 1) {
+                    unsigned long long key = ((unsigned long long)__float_as_uint(bd[u]) << 32) | (unsigned)bi[u];
 #pragma unroll
-                for (int k = 0; k < PPL; ++k) {
-                    const float d = l1_dist(qx[u], qy[u], qz[u], v[k].x, v[k].y, v[k].z);
-                    const int oi = __float_as_int(v[k].w);
-                    const bool take = d < bd[u] || (d == bd[u] && oi < bi[u]);
-                    bd[u] = take ? d : bd[u]; bi[u] = take ? oi : bi[u];
-                    tx[u] = take ? v[k].x : tx[u]; ty[u] = take ? v[k].y : ty[u]; tz[u] = take ? v[k].z : tz[u];
+                    for (int k = 0; k < PPL; ++k) {
+                        const float d = l1_dist(qx[u], qy[u], qz[u], v[k].x, v[k].y, v[k].z);
+                        // (a NaN distance has the bits of a huge key and is never taken, like the comparisons of the other form;
+                        //  -0.0 cannot occur: a sum of absolute values)
+                        const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(v[k].w);
+                        key = kk < key ? kk : key;
+                    }
+                    bd[u] = __uint_as_float((unsigned)(key >> 32)); bi[u] = (int)(unsigned)key;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < PPL; ++k) {
+                        const float d = l1_dist(qx[u], qy[u], qz[u], v[k].x, v[k].y, v[k].z);
+                        const int oi = __float_as_int(v[k].w);
+                        const bool take = d < bd[u] || (d == bd[u] && oi < bi[u]);
+                        bd[u] = take ? d : bd[u]; bi[u] = take ? oi : bi[u];
+                        tx[u] = take ? v[k].x : tx[u]; ty[u] = take ? v[k].y : ty[u]; tz[u] = take ? v[k].z : tz[u];
+                    }
                 }
                 wb[u] = wave_min_fast(bd[u]);
 #pragma unroll
@@ -277,6 +294,9 @@ __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int s
         const float fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty[u]), src));
         const float fz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tz[u]), src));
         if (lane == u) { mv = wb[u]; mi = i; mqx = qx[u]; mqy = qy[u]; mqz = qz[u]; mtx = fx; mty = fy; mtz = fz; }
+    }
+    if constexpr (PPL > 1) {
+        if (lane < QW && q0 + lane < nq && mi != 0x7fffffff) { const float* p = T + (size_t)mi * st; mtx = p[0]; mty = p[1]; mtz = p[2]; }
     }
     if (lane < QW && q0 + lane < nq) epi(dir, q0 + lane, mi, mv, mqx, mqy, mqz, mtx, mty, mtz, acc);
     acc = wave_sum_fast(acc);

@@ -593,12 +593,12 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_plan(const float* A, int na, co
     yb.ts4 = (const float4*)((const char*)yb.ts4 + zb);
     yb.tbox = (const float*)((const char*)yb.tbox + zb);
     epi.shift(z);
-    if (bx < blocksA) nn_l1_block_pruned<NBT, PPL, EngineEpi>(A, na, 4, yb, 0, epi, bx, epi.stopped);
+    if (bx < blocksA) nn_l1_block_pruned<NBT, PPL, EngineEpi>(A, na, 4, yb, 0, epi, bx, epi.stopped, B, 4);
     else if constexpr (P1) {
         pb.ts4 = (const float4*)((const char*)pb.ts4 + zb);
         pb.tbox = (const float*)((const char*)pb.tbox + zb);
         pb.nblk_dev = (const int*)((const char*)pb.nblk_dev + zb);
-        nn_l1_block_pruned<NBP, PPL, EngineEpi>(B, nb, 4, pb, 1, epi, bx - blocksA, epi.stopped);
+        nn_l1_block_pruned<NBP, PPL, EngineEpi>(B, nb, 4, pb, 1, epi, bx - blocksA, epi.stopped, A, 4);
     } else nn_l1_block<4, int, EngineEpi>(A, na, 4, B, nb, 4, nullptr, nullptr, nullptr, nullptr, blocksA, epi, bx);
 }
 
