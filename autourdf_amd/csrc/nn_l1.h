@@ -269,7 +269,9 @@ __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int s
                     for (int k = 0; k < PPL; ++k) {
                         const float d = l1_dist(qx[u], qy[u], qz[u], v[k].x, v[k].y, v[k].z);
                         const int oi = __float_as_int(v[k].w);
-                        const bool take = d < bd[u] || (d == bd[u] && oi < bi[u]);
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(bd[u]) << 32) | (unsigned)bi[u];
+                        const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)oi;
+                        const bool take = kk < key;
                         bd[u] = take ? d : bd[u]; bi[u] = take ? oi : bi[u];
                         tx[u] = take ? v[k].x : tx[u]; ty[u] = take ? v[k].y : ty[u]; tz[u] = take ? v[k].z : tz[u];
                     }
