@@ -7,18 +7,6 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py > $O/bench.log 2>$O/bench.err
-python $R/bench.py --sequences 1 --steps 8 --warmup 2 --no-cpu-baseline --no-icp-variant > $O/bench_b1.log 2>/dev/null
-python $R/bench.py --sequences 8 --steps 40 --warmup 8 --no-cpu-baseline --no-icp-variant > $O/bench_b8.log 2>/dev/null
-python $R/bench.py --workload franka --steps 10 --warmup 5 --no-cpu-baseline --no-icp-variant > $O/bench_franka.log 2>/dev/null
-python $R/bench.py --workload allegro --steps 20 --warmup 5 --no-cpu-baseline --no-icp-variant > $O/bench_allegro.log 2>/dev/null
-# BASELINE configs[3] / [4] in replay (independent-frame) mode, one GPU: the items an 8-GPU job would deal out
-python $R/bench.py --mode replay --workload allegro --steps 50 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_replay_allegro.log 2>/dev/null
-python $R/bench.py --workload c5 --steps 12 --warmup 2 > $O/bench_c5.log 2>/dev/null
-python $R/tests/measure/bench_c5_resegment.py > $O/c5_resegment.log 2>/dev/null
-python $R/tests/measure/profile_icp_frame.py both 2>/dev/null | grep -v amdgpu.ids > $O/icp_frame_phases.log
-python $R/tests/measure/stress_handoffs.py 2>/dev/null | grep -v amdgpu.ids > $O/handoff_stress.log
-(for pe in 1 0; do for pr in 1 0; do [ $pe = 1 ] && [ $pr = 0 ] && continue; echo "# CREG_KM_PRUNE=$pr CREG_KM_PERSIST=$pe"; CREG_KM_PRUNE=$pr CREG_KM_PERSIST=$pe python $R/tests/measure/km_quick.py 2>/dev/null | grep Lloyd; done; done) > $O/km_quick.log
 CMD="python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats -- $CMD > $O/prof_run.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o c5 -- python $R/bench.py --workload c5 --steps 4 --warmup 1 > $O/prof_c5.log 2>&1
@@ -47,6 +35,22 @@ for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[
           f"wait any {d.get('SQ_WAIT_ANY', 0) / wc:.3f}  wait inst {d.get('SQ_WAIT_INST_ANY', 0) / wc:.3f}")
 PYEOF
 rm -f $O/*_kernel_trace.csv $O/*_agent_info.csv $O/*_domain_stats.csv
+# counters first, bench lines after: `roofline.traffic` / the measured VALU utilisation of a bench line come from profiles/r03_pmc.json,
+# which must describe the kernels that line runs (a line benched before its counters were re-collected divides old cycles by new times)
+cd $R && python tools/summarize_profiles.py $O r03 $R/gpurun_out/r03_profiles > /dev/null 2>&1 && cp $R/gpurun_out/r03_profiles/r03_pmc.json $R/profiles/r03_pmc.json
+cd /tmp
+python $R/bench.py > $O/bench.log 2>$O/bench.err
+python $R/bench.py --sequences 1 --steps 8 --warmup 2 --no-cpu-baseline --no-icp-variant > $O/bench_b1.log 2>/dev/null
+python $R/bench.py --sequences 8 --steps 40 --warmup 8 --no-cpu-baseline --no-icp-variant > $O/bench_b8.log 2>/dev/null
+python $R/bench.py --workload franka --steps 10 --warmup 5 --no-cpu-baseline --no-icp-variant > $O/bench_franka.log 2>/dev/null
+python $R/bench.py --workload allegro --steps 20 --warmup 5 --no-cpu-baseline --no-icp-variant > $O/bench_allegro.log 2>/dev/null
+# BASELINE configs[3] / [4] in replay (independent-frame) mode, one GPU: the items an 8-GPU job would deal out
+python $R/bench.py --mode replay --workload allegro --steps 50 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_replay_allegro.log 2>/dev/null
+python $R/bench.py --workload c5 --steps 12 --warmup 2 > $O/bench_c5.log 2>/dev/null
+python $R/tests/measure/bench_c5_resegment.py > $O/c5_resegment.log 2>/dev/null
+python $R/tests/measure/profile_icp_frame.py both 2>/dev/null | grep -v amdgpu.ids > $O/icp_frame_phases.log
+python $R/tests/measure/stress_handoffs.py 2>/dev/null | grep -v amdgpu.ids > $O/handoff_stress.log
+(for pe in 1 0; do for pr in 1 0; do [ $pe = 1 ] && [ $pr = 0 ] && continue; echo "# CREG_KM_PRUNE=$pr CREG_KM_PERSIST=$pe"; CREG_KM_PRUNE=$pr CREG_KM_PERSIST=$pe python $R/tests/measure/km_quick.py 2>/dev/null | grep Lloyd; done; done) > $O/km_quick.log
 # summaries on the box (gpurun brings back at most 64 MiB; the raw counter CSVs are ~18 MB each), raw files dropped
 cd $R && python tools/summarize_profiles.py $O r03 $R/gpurun_out/r03_profiles > $R/gpurun_out/r03_profiles_summary.log 2>&1
 rm -f $O/*_counter_collection.csv
