@@ -96,17 +96,32 @@ __device__ __forceinline__ void wave_argmin_fast(float& v, int& i) {
     i = __builtin_amdgcn_readlane(i, 63);
 }
 
-// Wave-uniform minimum of a float / int over the 64 lanes (same DPP tree as wave_argmin_fast).
-#define CREG_DPP_FMIN_STEP(ctrl, mask) v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, mask, 0xF, false)));
-#define CREG_DPP_IMIN_STEP(ctrl, mask) v = min(v, __builtin_amdgcn_update_dpp(v, v, ctrl, mask, 0xF, false));
+// Wave-uniform minimum of a float / int over the 64 lanes (same DPP tree as wave_argmin_fast), as v_min_*_dpp instructions: through
+// __builtin_amdgcn_update_dpp + fminf hipcc emits FIVE instructions a step (v_mov_b32_dpp, a canonicalising v_max, v_min, a copy, s_nop),
+// and the nearest-neighbour search runs ~17 of these reductions per wave -- a third of its instructions.  Hazards are ours inside the
+// asm: a DPP operand written by the previous VALU instruction needs 2 wait states (s_nop 1 between the steps), a DPP instruction
+// after an EXEC write 5 (the leading s_nop 4 covers both for whatever precedes).  row_mask limits the last two steps to the rows
+// that receive a broadcast, the others keep their value -- what update_dpp(old = v) did.
 __device__ __forceinline__ float wave_min_fast(float v) {
-    CREG_DPP_FMIN_STEP(0xB1, 0xF) CREG_DPP_FMIN_STEP(0x4E, 0xF) CREG_DPP_FMIN_STEP(0x141, 0xF)
-    CREG_DPP_FMIN_STEP(0x140, 0xF) CREG_DPP_FMIN_STEP(0x142, 0xA) CREG_DPP_FMIN_STEP(0x143, 0xC)
+    asm("s_nop 4\n\t"
+        "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ int wave_min_fast(int v) {
-    CREG_DPP_IMIN_STEP(0xB1, 0xF) CREG_DPP_IMIN_STEP(0x4E, 0xF) CREG_DPP_IMIN_STEP(0x141, 0xF)
-    CREG_DPP_IMIN_STEP(0x140, 0xF) CREG_DPP_IMIN_STEP(0x142, 0xA) CREG_DPP_IMIN_STEP(0x143, 0xC)
+    asm("s_nop 4\n\t"
+        "v_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
 }
 
