@@ -1442,7 +1442,14 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     P->shape = *shape; P->D = D; P->base = (char*)workspace; P->bytes = workspace_bytes;
     carve(D, P->base, &P->W);
     P->B = batch_of(shape); P->nz = P->B; P->bstride = one;
-    P->branches = shape->graph_branches > 0 ? shape->graph_branches : (P->B >= 2 ? 2 : 1);
+    // Default branch count, measured on MI355X (bench.py --graph-branches, three runs each on one box):
+    // frames above 4096 points (several points per lane in the NN kernels) spend most of a step in the
+    // two NN searches, which leave CUs idle near their tails, and a third branch fills them: the
+    // 16384-point shape runs at 71.1 / 76.0 / 67.4 frames/s with 2 / 3 / 4 branches.  At 4096 points
+    // and below the step is a chain of short kernels and a third branch only adds interleaving:
+    // 149 frames/s with 2 branches, 117-124 with 3.
+    const int auto_branches = (D.ppl > 1 && P->B >= 3) ? 3 : (P->B >= 2 ? 2 : 1);
+    P->branches = shape->graph_branches > 0 ? shape->graph_branches : auto_branches;
     if (P->branches > P->B) P->branches = P->B;
     if (P->branches > 8) P->branches = 8;
     P->gexec = nullptr; P->graph_ready = false;

@@ -318,7 +318,8 @@ typedef struct creg_train_shape {
     int32_t graph_branches; /* parallel chains in the captured graph: the batch is split into this many contiguous
                                groups whose epochs are captured as independent branches (different hardware queues,
                                so one group's small kernels overlap the other's NN launch).  0 = auto (2 when
-                               batch >= 2), 1 = single chain.  Results do not depend on it. */
+                               batch >= 2; 3 when batch >= 3 and n_tgt > 4096, where the NN searches dominate),
+                               1 = single chain.  Results do not depend on it. */
     int32_t nn_search;    /* 0 = auto: the nearest-neighbour searches run over k-d leaf blocks with boxes (exact
                              pruning) when n_tgt <= 16384 (and, for the target -> predicted direction, when the
                              predicted cloud fits 128 blocks); 1 = exhaustive in both directions.  Results do not

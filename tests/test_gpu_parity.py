@@ -948,6 +948,34 @@ def test_graph_branches_bench_shape_bit_identical_to_single_runs(dev):
                 assert torch.equal(got.cpu().nan_to_num(), want.nan_to_num())
 
 
+def test_graph_branches_big_frame_default_is_three_chains_and_bit_identical_to_single_runs(dev):
+    """Frames above 4096 points default to three chains (2 + 2 + 1 of 5 problems); the 4096-point shape keeps two."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    from oracle import models
+    n = 6000
+    seq = make_sequence("wx200_5", 5, 2, n)
+    mats, cl, _ = initial_segmentation(seq[0], 12, seed=0)
+    m = torch.tensor(mats, dtype=torch.float32, device=dev)
+    ys = [torch.tensor(seq[1] + 0.0005 * b, dtype=torch.float32, device=dev) for b in range(5)]
+    pts, off = ops.pack_clusters([torch.tensor(c, dtype=torch.float32) for c in cl], dev)
+    torch.manual_seed(2)
+    model = models.QRegMLP(True, 64)
+    mk = lambda: [model.state_dict()[k].clone().to(dev) for k in ops.Q_PARAM_ORDER]
+    single = ops.TrainPlan("q", 12, 64, n, n, epochs=40, use_graph=True, device=dev)
+    assert single.info["graph_branches"] == 1
+    assert ops.TrainPlan("q", 12, 64, 4096, 4096, epochs=40, use_graph=True, device=dev, batch=5).info["graph_branches"] == 2
+    assert ops.TrainPlan("q", 12, 64, n, n, epochs=40, use_graph=True, device=dev, batch=2).info["graph_branches"] == 2
+    ref = [[t.cpu() for t in single.run(m, ys[b], pts, off, mk())] for b in range(5)]
+    for _ in range(3):
+        plan = ops.TrainPlan("q", 12, 64, n, n, epochs=40, use_graph=True, device=dev, batch=5)
+        assert plan.info["graph_branches"] == 3
+        outs = plan.run_batch([(m, ys[b], pts, off, mk()) for b in range(5)])
+        for b in range(5):
+            for got, want in zip(outs[b], ref[b]):
+                assert torch.equal(got.cpu().nan_to_num(), want.nan_to_num())
+
+
 @pytest.mark.parametrize("rot,k,hidden,n_pred,n_tgt,lattice", [
     ("q", 20, 512, 4096, 4096, False),      # the bench shape
     ("dq", 8, 64, 1000, 777, False),        # ragged last block of targets
