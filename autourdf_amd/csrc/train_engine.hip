@@ -1087,6 +1087,9 @@ __global__ __launch_bounds__(BD_THREADS, 4) void k_bd(Dims D, Ws W0, int epoch, 
     if (!roleB) i -= nB * nz;
     const int n = roleB ? nB : nD, z = i / n, blk = i - z * n;
     const Ws W = ws_shift(W0, (size_t)z * bstride);
+#ifdef CREG_BD_ONLY                                   // measurement build: one role alone (1: backward to the encoder, 2: dW + Adam)
+    if ((CREG_BD_ONLY == 1) != roleB) return;
+#endif
     if (roleB) bwd2_role<AW, OPS>(D, W, epoch, blk, (float*)smem);
     else dw_role<NC>(D, W, epoch, blk, (float*)smem);
 }
