@@ -793,6 +793,28 @@ __device__ __forceinline__ float adam_value(float p, float& mm, float& vv, float
 // the slice partials of a (pose row, column) are summed in a fixed tree: the 8 slices of a wave (row_ror DPP, two lane
 // permutes), then the waves in order through LDS.  The rows of a pass are straight-line code (rows past the end repeat the
 // last one and are not stored): per-row branches kept hipcc from overlapping the rows' LDS reads and lane permutes.
+#ifdef CREG_BD_STAMPS
+// Measurement build (tests/measure/bd_stamps.py): where the two roles of k_bd spend a launch.  Thread 0 of every workgroup reads the
+// 100 MHz wall clock at its phase boundaries; per launch slot (epoch & 255) the earliest start and the latest end of each role, per
+// role the summed phase durations and workgroup counts.  Recorded only while the host has armed it (the back-to-back leg of
+// creg_train_plan_profile).
+struct BdStamps {
+    unsigned long long first[256], endB[256], endD[256], startB[256], startD[256];
+    unsigned long long phase[2][8], blocks[2];
+    int armed;
+};
+__device__ BdStamps g_bd_st;
+#define BD_T0 unsigned long long bd_t[8]; int bd_n = 0; if (threadIdx.x == 0) bd_t[bd_n++] = wall_clock64();
+#define BD_T  if (threadIdx.x == 0) bd_t[bd_n++] = wall_clock64();
+#define BD_TEND(role, epoch) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0) { bd_t[bd_n++] = wall_clock64(); \
+    if (g_bd_st.armed) { const int sl_ = (epoch) & 255; atomicMin(&g_bd_st.first[sl_], bd_t[0]); \
+        atomicMin(role ? &g_bd_st.startD[sl_] : &g_bd_st.startB[sl_], bd_t[0]); atomicMax(role ? &g_bd_st.endD[sl_] : &g_bd_st.endB[sl_], bd_t[bd_n - 1]); \
+        for (int k_ = 1; k_ < bd_n; ++k_) atomicAdd(&g_bd_st.phase[role][k_ - 1], bd_t[k_] - bd_t[k_ - 1]); atomicAdd(&g_bd_st.blocks[role], 1ull); } } } while (0)
+#else
+#define BD_T0
+#define BD_T
+#define BD_TEND(role, epoch)
+#endif
 constexpr int BD_THREADS = 512;       // workgroups of the backward launch k_bd (both roles)
 constexpr int B2_THREADS = BD_THREADS;
 constexpr int B2_WAVES = B2_THREADS / 64;
@@ -846,6 +868,7 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
     float* x1next = par ? W.x1[0] : W.x1[1];
     const float* Pc = par ? W.P1 : W.P;               // this epoch's parameters; the updated rows go to the other buffer
     float* Pn = par ? W.P : W.P1;
+    BD_T0
     // every load of the first pass is requested before the first wait
     stage_issue<B2_THREADS>((float4*)gh, (const float4*)W.g_h2, RB * D.H2 / 4);
     stage_issue<B2_THREADS>((float4*)encs, (const float4*)W.enc, D.K * D.IN / 4);
@@ -877,6 +900,7 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
         }
         stage_wait();
         __syncthreads();
+        if (r0 == 0) { BD_T }                          // B1: the staged g_h2 rows, the features and this thread's W2 slice requested -> landed
         if (!live) return;                             // a stopped train: nothing below may be stored (workgroup-uniform)
         if (fma_wave) {
             // B2_HB rows at a time, straight-line (rows past nr repeat the last one and are not stored): per-row branches
@@ -916,6 +940,7 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
                 }
             }
         }
+        if (r0 == 0) { BD_T }                          // B2: the packed FMAs and slice sums of wave 0 (first pass)
         __syncthreads();
         float out = 0.f;
         if (tid < nr * B2_CB) {                        // tid = (pose row of the pass) * 16 + column
@@ -937,6 +962,7 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
         if (tid < nr * B2_CB) gxs[r0 * B2_CB + tid] = out;
     }
     __syncthreads();
+    BD_T                                               // B3: barrier, cross-wave reduction, activation gradient, g_x1 into LDS (+ further passes at K > 20)
     // ---- encoder rows: dW1 = g_x1^T enc, Adam, next x1
     float4 ag = make_float4(0.f, 0.f, 0.f, 0.f);
     float gsum = 0.f;
@@ -956,6 +982,7 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
         if (ain) { st4_wt(Pn, wi, nw); st4_wt(W.AM, wi, pm); st4_wt(W.AV, wi, pv); }
         if (i4 == 0) { Pn[D.ob1 + hu] = pb; W.AM[D.ob1 + hu] = mb; W.AV[D.ob1 + hu] = vb; }
     }
+    BD_T                                               // B4: dW1 over the pose rows, Adam, the encoder rows' stores issued
     for (int r = half; r < D.K; r += 2) {
         const float4 e = *(const float4*)(encs + r * D.IN + ei);
         float v = ain ? fmaf(nw.w, e.w, fmaf(nw.z, e.z, fmaf(nw.y, e.y, nw.x * e.x))) : 0.f;
@@ -968,6 +995,7 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
             const int r = t >> 3, c2 = 2 * (t & 7);
             *(nn_f2*)(x1next + (size_t)r * D.H + c0 + c2) = nn_f2{xt[r * B2_CB + c2], xt[r * B2_CB + c2 + 1]};
         }
+    BD_TEND(0, epoch);                                 // B5: the next activation tile, its stores and the encoder rows' stores acknowledged
 }
 
 // ------------------------------------------------------------------------------------------ dW + Adam of the hidden / output rows
@@ -1012,6 +1040,7 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
     const float* amat = bkind == 0 ? x1cur : h2cur;
     const int awidth = bkind == 0 ? D.H : D.H2;
     const int rc = rows_per_chunk(D.K, awidth);
+    BD_T0
     stage_issue<BD_THREADS>((float4*)as, (const float4*)amat, min(rc, D.K) * awidth / 4);
     // a lane owns 4 consecutive inputs per 256-wide slab: parameters / Adam state move as dwordx4, the
     // staged activations are read as ds_read_b128
@@ -1037,6 +1066,7 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
         }
         stage_wait();
         __syncthreads();
+        if (r0 == 0) { BD_T }                          // D1: activations staged (the row's parameter / moment loads are in flight)
         if (!live) return;                             // a stopped train: nothing below may be stored (workgroup-uniform)
 #pragma unroll 2
         for (int r = 0; r < nr; ++r) {
@@ -1050,6 +1080,7 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
             }
         }
     }
+    BD_T                                               // D2: the accumulation over the pose rows (waits for the row's parameters)
     if (!R.active) return;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -1067,6 +1098,7 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
     for (int r = 0; r < D.K; ++r) sum += gall[wib * D.K + r];
     pb = adam_value(pb, mb, vb, sum, S.step_size, S.bc2_sqrt);
     if (lane == 0) { Pn[R.ob] = pb; W.AM[R.ob] = mb; W.AV[R.ob] = vb; }
+    BD_TEND(1, epoch);                                 // D3: Adam, the write-through stores acknowledged
 }
 
 // ------------------------------------------------------------------------------------------ the backward launch: k_bd
@@ -1561,10 +1593,17 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
     CREG_REQUIRE(P && a && a->m && a->y && a->local_pts && a->seg_offsets && a->params && us_out && n_epochs >= 1,
                  "creg_train_plan_profile: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    int rc = stage_inputs(P, a, 1, s);
+    // the launches as the timed region issues them: the problems of the first (largest) graph branch in grid.z, EVERY one of them
+    // staged from `a` and advanced through the bracketed epochs.  (Until the end of round 3 only problem 0 was staged: the others
+    // kept the state of the caller's last trains, and a train that had stopped early leaves `stopped` set -- its workgroups in the
+    // back-to-back launches below requested their loads and returned, so those launches carried less work than their label said.)
+    const int br = P->shape.use_graph ? P->branches : 1;
+    const int nzb = P->B / br + (P->B % br ? 1 : 0);
+    std::vector<creg_train_args> all((size_t)nzb, *a);
+    int rc = stage_inputs(P, all.data(), nzb, s);
     if (rc) return rc;
-    launch_sorts(P, s, 1);
-    P->nz = 1;
+    launch_sorts(P, s, nzb);
+    P->nz = nzb;
     std::vector<hipEvent_t> ev((size_t)(NKERN + 1) * n_epochs);
     for (auto& e : ev) CREG_HIP(hipEventCreate(&e));
     for (int e = 0; e < n_epochs; ++e) enqueue_epoch(P, e, s, ev.data() + (NKERN + 1) * e);
@@ -1584,9 +1623,6 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
     // launch-to-launch gap, so it upper-bounds the rocprofv3 kernel duration by ~1 us).
     const int REP = 200;
     const Dims& D = P->D; const Ws& W = P->W;
-    // the launch as the timed region issues it: the problems of the first (largest) graph branch in grid.z
-    const int br = P->shape.use_graph ? P->branches : 1;
-    P->nz = P->B / br + (P->B % br ? 1 : 0);
     CREG_HIP(hipEventRecord(ev[0], s));
     for (int i = 0; i < REP; ++i)
         launch_nn(D, W, P->bstride, P->nz, s);
@@ -1607,7 +1643,15 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
         *out = ms * 1000.f / REP;
         return CREG_OK;
     };
+#ifdef CREG_BD_STAMPS
+    {   BdStamps* z = new BdStamps; memset(z, 0, sizeof(*z)); memset(z->first, 0xff, sizeof(z->first)); memset(z->startB, 0xff, sizeof(z->startB));
+        memset(z->startD, 0xff, sizeof(z->startD)); z->armed = 1;
+        CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bd_st), z, sizeof(*z))); delete z; }
+#endif
     if (int rc2 = b2b([&](int i) { launch_bd(P, i, s); }, us_out + 8)) return rc2;
+#ifdef CREG_BD_STAMPS
+    { const int zero = 0; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bd_st), &zero, sizeof(int), offsetof(BdStamps, armed))); }
+#endif
     if (int rc2 = b2b([&](int i) { launch_l2(P, i & 1, s); }, us_out + 9)) return rc2;
     if (int rc2 = b2b([&](int i) { launch_head(P, i & 1, s); }, us_out + 10)) return rc2;
     if (int rc2 = b2b([&](int i) { hipLaunchKernelGGL(k_gradc, dim3(D.K, 1, P->nz), dim3(256), 0, s, D, W, i, D.nbx, D.nby, P->bstride); }, us_out + 11)) return rc2;
@@ -1616,6 +1660,31 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
     for (auto& e : ev) (void)hipEventDestroy(e);
     return CREG_OK;
 }
+
+#ifdef CREG_BD_STAMPS
+// out[0..4]: mean launch span, B start, B end, D start, D end relative to the launch's first workgroup (us); out[5], out[6]: B / D
+// workgroups per launch; out[8..15] / out[16..23]: mean phase durations of a B / D workgroup (us)
+extern "C" int creg_debug_bd_stamps(double* out) {
+    BdStamps* z = new BdStamps;
+    if (hipMemcpyFromSymbol(z, HIP_SYMBOL(g_bd_st), sizeof(*z)) != hipSuccess) { delete z; return CREG_EHIP; }
+    for (int i = 0; i < 24; ++i) out[i] = 0.0;
+    int n = 0;
+    for (int sl = 0; sl < 256; ++sl) {
+        if (z->first[sl] == ~0ull || !z->endB[sl] || !z->endD[sl]) continue;
+        ++n;
+        const double f = (double)z->first[sl];
+        out[0] += ((double)(z->endB[sl] > z->endD[sl] ? z->endB[sl] : z->endD[sl]) - f) / 100.0;
+        out[1] += ((double)z->startB[sl] - f) / 100.0; out[2] += ((double)z->endB[sl] - f) / 100.0;
+        out[3] += ((double)z->startD[sl] - f) / 100.0; out[4] += ((double)z->endD[sl] - f) / 100.0;
+    }
+    for (int i = 0; i < 5; ++i) out[i] /= n ? n : 1;
+    out[5] = n ? (double)z->blocks[0] / n : 0; out[6] = n ? (double)z->blocks[1] / n : 0; out[7] = n;
+    for (int r = 0; r < 2; ++r)
+        for (int k = 0; k < 8; ++k) out[8 + 8 * r + k] = z->blocks[r] ? (double)z->phase[r][k] / (double)z->blocks[r] / 100.0 : 0.0;
+    delete z;
+    return CREG_OK;
+}
+#endif
 
 extern "C" int creg_train_plan_info(const creg_train_plan* plan, creg_train_plan_info_t* info) {
     CREG_REQUIRE(plan && info, "creg_train_plan_info: null pointer");
