@@ -840,8 +840,19 @@ __device__ __forceinline__ float row_sum16(float v) {
 // sum over the 8 lanes of a wave that share (lane & 7): lanes l, l^8 (row_ror:8), then l^16, l^32; every lane receives it
 __device__ __forceinline__ float slice_sum8(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));
+    // lanes l ^ 16 and l ^ 32 by gfx950's row / half swaps (one VALU instruction each, no LDS crossbar round trip like the
+    // ds_bpermute behind __shfl_xor): with both operands = v, permlane16_swap leaves (rows 0,0,2,2 | rows 1,1,3,3) and
+    // permlane32_swap (low half twice | high half twice); the sum of the two is v[l] + v[l ^ 16] resp. v[l] + v[l ^ 32] in every
+    // lane -- the same pairs in the same tree as before (a + b == b + a), bit-identical
+#ifndef CREG_SLICE_SHFL
+    {   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    {   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+#else
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
+#endif
     return v;
 }
 __device__ __forceinline__ nn_f2 fma2(float g, nn_f2 w, nn_f2 a) {        // one v_pk_fma_f32: both columns of the pair
