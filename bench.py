@@ -347,7 +347,9 @@ def run_c5(args, robot, n_points, k_clusters, wl_tag):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it as `python bench.py --gpus N`, which launches "
+                         "the ranks itself, or under torch.distributed.run with --nproc-per-node equal to --gpus)")
     total = args.steps + args.warmup
     t_gen = time.perf_counter()
     seq = make_sequence(robot, 0, total + 1, n_points)
@@ -458,6 +460,44 @@ def run_c5(args, robot, n_points, k_clusters, wl_tag):
         dist.destroy_process_group()
 
 
+
+# ------------------------------------------------------------------------------------------ multi-GPU launch + replay batching
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(gpus, argv):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no RANK in the environment): run this very command line under
+    `torch.distributed.run`, one rank per GPU on 127.0.0.1, and return its exit code -- the driver's own N > 1 invocation
+    (which already goes through torch.distributed.run and sets RANK) never gets here."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this driver (RCCL needs it)
+    return subprocess.call(cmd, env=env)
+
+
+REPLAY_MAX_BATCH = 8          # most problems per launch of a replay round (8 in flight: 198.7 frames/s on one GPU against 157 at 5)
+
+
+def replay_batches(n_items, max_batch=REPLAY_MAX_BATCH):
+    """Batch sizes of one rank's replay rounds: the fewest rounds of at most `max_batch` problems, sizes differing by at
+    most one (larger first), NO padding -- 7 items: [7]; 6: [6]; 50: [8, 7, 7, 7, 7, 7, 7]; 0: [].  (Round 3 padded every
+    rank's items to a multiple of --sequences: 50 frames over 8 ranks were two rounds of 5 per rank instead of one of 6-7.)"""
+    if n_items <= 0:
+        return []
+    rounds = (n_items + max_batch - 1) // max_batch
+    lo, extra = divmod(n_items, rounds)
+    return [lo + 1] * extra + [lo] * (rounds - extra)
+
+
 # ------------------------------------------------------------------------------------------ main
 def main(argv=None):
     ap = argparse.ArgumentParser()
@@ -477,6 +517,9 @@ def main(argv=None):
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="wx200_5",
                     help="default = the configuration BASELINE.json's metric is quoted on")
     args = ap.parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        import sys
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:] if argv is None else argv))
     robot, n_points, k_clusters, wl_tag = WORKLOADS[args.workload]
     if args.workload == "c5":
         args.mode = "replay"
@@ -500,7 +543,9 @@ def main(argv=None):
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it as `python bench.py --gpus N`, which launches "
+                         "the ranks itself, or under torch.distributed.run with --nproc-per-node equal to --gpus)")
 
     from autourdf_amd.distributed import gather_poses
     from autourdf_amd.synthetic import initial_segmentation, make_sequence
@@ -543,38 +588,64 @@ def main(argv=None):
     reg.stop = args.stop
     epochs_log = []
 
-    def note_epochs():
-        le = getattr(reg, "last_epochs", None)
+    def note_epochs(r=None):
+        le = getattr(r if r is not None else reg, "last_epochs", None)
         if le is not None:
             epochs_log.append(le)
 
     if replay:
         items = capture_items(reg, frames64, frames32, cap_rounds, clone_params=not STUB)[:total_items]
-        warm_items = [clone_item(it) for it in items[:args.warmup]]
         job = items[args.warmup:]
         mine = job[rank::world]                                   # round-robin: no rank holds more than one item extra
-        while len(mine) % S:                                      # the last batch is padded with a repeat (timed, not counted)
-            mine.append(clone_item(mine[-1]))
-        n_mine = len(job[rank::world])
-        poses = torch.zeros(max(len(mine), 1), k_clusters, 4, 4, dtype=torch.float32, device=dev)
-        for b in range(0, len(warm_items) - len(warm_items) % S, S):
-            load_items(reg, warm_items[b:b + S])
-            reg.step([it["f64"] for it in warm_items[b:b + S]], [it["f32"] for it in warm_items[b:b + S]])
+        n_mine = len(mine)
+        # Every rank sizes its OWN batches: the fewest rounds of <= 8 problems, no padding (configs[3]: 50 frames over 8 ranks are
+        # ONE round of 7 or 6 problems per rank; on one GPU 7 rounds of 8 / 7).  A plan is built for a batch size, so a rank owns
+        # one registrar per distinct size (at most two; the capture registrar serves its own size).
+        sizes = replay_batches(n_mine)
+        regs = {S: reg}
+
+        def reg_for(b):
+            if b not in regs:
+                regs[b] = Registrar(mats0, clusters0, n_points, b, "q", HIDDEN, EPOCHS, not args.eager, dev,
+                                    seeds=list(range(b)), graph_branches=args.graph_branches)
+                regs[b].stop = args.stop
+            return regs[b]
+
+        def run_batch(batch, record=None, at=0):
+            rb = reg_for(len(batch))
+            load_items(rb, batch)
+            out = rb.step([it["f64"] for it in batch], [it["f32"] for it in batch])
+            if record is not None:
+                note_epochs(rb)
+                for i, (m, _) in enumerate(out):
+                    record[at + i].copy_(m)
+
+        poses = torch.zeros(max(n_mine, 1), k_clusters, 4, 4, dtype=torch.float32, device=dev)
+        # untimed: the --warmup items, then one round on clones per distinct batch size of the timed region (graph capture,
+        # first touch of every plan's workspace)
+        warm_items = [clone_item(it) for it in items[:args.warmup]]
+        pos = 0
+        for b in replay_batches(len(warm_items)):
+            run_batch(warm_items[pos:pos + b])
+            pos += b
+        for b in sorted(set(sizes)):
+            run_batch([clone_item(mine[i % n_mine]) for i in range(b)])
         fence()
+        epochs_log.clear()
         t0 = time.perf_counter()
-        for b in range(0, len(mine), S):
-            batch = mine[b:b + S]
-            load_items(reg, batch)
-            out = reg.step([it["f64"] for it in batch], [it["f32"] for it in batch])
-            note_epochs()
-            for i, (m, _) in enumerate(out):
-                poses[b + i].copy_(m)
+        pos = 0
+        for b in sizes:
+            run_batch(mine[pos:pos + b], poses, pos)
+            pos += b
         counts = [len(job[r::world]) for r in range(world)]
         gathered = gather_poses(poses[:n_mine], counts=counts if dist is not None else None)
         fence()
         elapsed = time.perf_counter() - t0
         n_counted = args.steps
-        padded = len(mine) - n_mine
+        padded = 0
+        rank_rounds = [replay_batches(c) for c in counts]
+        if sizes:
+            reg = regs[sizes[0]]                                  # the plan the roofline leg times: this rank's (largest) replay batch
     else:
         poses = torch.zeros((warm_rounds + timed_rounds) * S, k_clusters, 4, 4, dtype=torch.float32, device=dev)
 
@@ -597,6 +668,7 @@ def main(argv=None):
         elapsed = time.perf_counter() - t0
         n_counted = world * args.steps
         padded = timed_rounds * S - args.steps
+        rank_rounds = [[S] * timed_rounds for _ in range(world)]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -606,9 +678,9 @@ def main(argv=None):
     if rank == 0:
         ep = {}
         if epochs_log:
-            e = torch.stack([torch.stack([x.to(torch.float32) for x in pair]) for pair in epochs_log]).cpu()     # (rounds, 2, S)
-            ep = {"epochs_run_step": {"min": int(e[:, 0].min()), "mean": round(float(e[:, 0].mean()), 1)},
-                  "epochs_run_anchor": {"min": int(e[:, 1].min()), "mean": round(float(e[:, 1].mean()), 1)},
+            e = torch.stack([torch.cat([pair[i].to(torch.float32).reshape(-1) for pair in epochs_log]) for i in (0, 1)]).cpu()   # (2, problems)
+            ep = {"epochs_run_step": {"min": int(e[0].min()), "mean": round(float(e[0].mean()), 1)},
+                  "epochs_run_anchor": {"min": int(e[1].min()), "mean": round(float(e[1].mean()), 1)},
                   "early_stop": bool((e < EPOCHS).any()),
                   "stop_patience": args.stop,
                   "early_stop_note": "early stopping is live (mlp_reg.py:107-111; stop=200 unless --stop says otherwise); the epochs of a "
@@ -626,7 +698,11 @@ def main(argv=None):
                                    "round-robin to the ranks (SURVEY 8(e); frames of a sequence cannot be sharded otherwise)") if replay else
                                   "sequences: every rank registers its own sequences frame by frame (weak scaling)",
                           "epochs_per_frame": 2 * EPOCHS, **ep, "launch": "eager" if args.eager else "hipGraph",
-                          "sequences_in_flight_per_gpu": S, "padded_steps_timed_not_counted": padded,
+                          "sequences_in_flight_per_gpu": max(rank_rounds[0]) if (replay and rank_rounds[0]) else S,
+                          "padded_steps_timed_not_counted": padded,
+                          # what every rank ran inside the timed region: its rounds and the problems each carried
+                          "rounds_per_rank": [len(rr) for rr in rank_rounds], "batch_sizes_per_rank": rank_rounds,
+                          "padded_steps_per_rank": [0] * world if replay else [padded] * world,
                           "sharding": ("items round-robin over ranks" if replay else "sequences per rank") + ", final all_gather of poses"
                                       if world > 1 else "single GPU"},
                "pose_checksum": round(float(gathered.double().abs().sum()), 6)}
