@@ -176,7 +176,7 @@ def g_train_h64():
                 return r
 
             ref_reg.chamfer_distance = spy
-            ref_reg.range = lambda n, _n=n_ep: builtins.range(min(n, _n))
+            ref_reg.range = lambda n, _n=n_ep: builtins.range(_n if n == 300 else n)     # only the epoch loop (mlp_reg.py:60); calculate_pc also calls range (k = 5 < 6 here: same fixture)
             try:
                 pred_np, _, best_m, min_loss = ref_reg.train(
                     torch.from_numpy(mats), y, model, [torch.from_numpy(c) for c in clusters])

@@ -648,6 +648,74 @@ def test_train_vs_reference_train_directly_hidden64(dev, golden, rot):
             np.testing.assert_allclose(bm.cpu().numpy(), g[f"{rot}_e300_best_m"], atol=2e-3)
 
 
+def _c1_case(golden, dev):
+    from autourdf_amd import ops
+    g = golden("train_reference_c1.npz")
+    sd = {k[5:]: torch.from_numpy(g[k].astype(np.float32)) for k in g.files if k.startswith("sd16.")}
+    m, y = torch.from_numpy(g["m"]).to(dev), torch.from_numpy(g["y"]).to(dev)
+    pts, off = ops.pack_clusters([torch.from_numpy(c) for c in _split(g["local"], g["offsets"])], dev)
+    return g, sd, m, y, pts, off
+
+
+def test_train_c1_headline_shape_vs_reference_train_directly(dev, golden):
+    """A1 at the shape the metric is quoted on (BASELINE configs[1]: N = 4096, K = 20, the reference's default QRegMLP(True, 512)),
+    against the REFERENCE's own train() (tests/golden/train_reference_c1.npz, minted under ref_shims), no oracle in between:
+    every loss of the first six epochs 1e-5 relative, the best pose and cloud of those epochs 1e-5 (the north star's bound),
+    a strided sample of the parameters after six Adam steps (a parameter whose gradient is rounding noise moves by +-lr per step
+    whatever the implementation: 6 x 2e-4 is the cap, the bulk agrees to 3e-6)."""
+    from autourdf_amd import ops
+    g, sd, m, y, pts, off = _c1_case(golden, dev)
+    order = ops.Q_PARAM_ORDER
+    params = [sd[k].clone().to(dev) for k in order]
+    plan = ops.TrainPlan("q", 20, 512, pts.shape[0], y.shape[0], epochs=6, use_graph=True, device=dev)
+    bm, bp, res, lh, _ = plan.run(m, y, pts, off, params)
+    np.testing.assert_allclose(lh.cpu().numpy().astype(np.float64), g["loss_hist"][:6], rtol=1e-5)
+    assert abs(float(res[0]) - float(g["e6_min_loss"])) <= 1e-5 * float(g["e6_min_loss"])
+    np.testing.assert_allclose(bm.cpu().numpy(), g["e6_best_m"], atol=1e-5)
+    np.testing.assert_allclose(bp.cpu().numpy(), g["e6_best_pred"], atol=1e-5)
+    stride = int(g["sample_stride"])
+    for k, p in zip(order, params):
+        d = np.abs(p.cpu().numpy().reshape(-1)[::stride] - g[f"e6.final_sample.{k}"])
+        assert np.median(d) < 3e-6 and (d < 3e-5).mean() >= 0.99 and d.max() < 1.25e-3, (k, np.median(d), d.max())
+        assert abs(float(p.double().sum()) - float(g[f"e6.final_sum.{k}"])) < 2e-2, k
+
+
+def test_train_c1_divergence_stays_inside_the_measured_oracle_envelope(dev, golden):
+    """How tight can pose parity be after e epochs at the headline shape?  tests/golden/divergence_envelope_c1.npz
+    (tests/measure/divergence_envelope.py cpu) MEASURES it: the float32 oracle -- which reproduces the reference's trajectory bit for
+    bit -- against itself with the points of every cluster and the target rows permuted (six seeds) and against a float64 run.
+    Up to N_e (8 on this problem) every variant stays within the north star's 1e-5; from then on two correct float32 implementations
+    of the same mathematics are 1e-3..6e-2 apart (Adam turns rounding noise into +-lr steps, nearest-neighbour switches are kinks).
+    The plan is held to exactly that: its pose after e Adam steps (a run of e epochs, then the forward of the trained parameters)
+    against the REFERENCE's pose_hist[e]
+      * e <= N_e: within 1e-5 (measured 3e-7..1e-6),
+      * e = 30, 299: within twice the envelope of the permuted oracle runs at that epoch,
+    and what train() returns after 300 epochs -- min_loss, best pose -- within twice the spread of the oracle variants."""
+    from autourdf_amd import ops
+    g, sd, m, y, pts, off = _c1_case(golden, dev)
+    env = golden("divergence_envelope_c1.npz")
+    n_e = int(env["n_e"])
+    order = ops.Q_PARAM_ORDER
+    probe_plan = ops.TrainPlan("q", 20, 512, pts.shape[0], y.shape[0], epochs=2, use_graph=False, device=dev)
+    ref = g["pose_hist"]
+    seen = {}
+    for e in sorted({1, 2, 6, n_e, 30, 299}):
+        params = [sd[k].clone().to(dev) for k in order]
+        plan = ops.TrainPlan("q", 20, 512, pts.shape[0], y.shape[0], epochs=e, use_graph=e >= 2, device=dev)
+        plan.run(m, y, pts, off, params, stop=10 ** 6)
+        m2, _, _, _ = probe_plan.probe(m, y, pts, off, params)
+        d = float(np.abs(m2.cpu().numpy()[:, :3, :] - ref[e][:, :3, :]).max())
+        seen[e] = d
+        tol = 1e-5 if e <= n_e else 2.0 * float(env["envelope"][e])
+        assert d <= tol, (e, d, tol, seen)
+    params = [sd[k].clone().to(dev) for k in order]
+    plan = ops.TrainPlan("q", 20, 512, pts.shape[0], y.shape[0], epochs=300, use_graph=True, device=dev)
+    bm, _, res, _, _ = plan.run(m, y, pts, off, params)
+    ml = float(g["e300_min_loss"])
+    assert abs(float(res[0]) - ml) <= 2.0 * float(env["min_loss_rel_envelope"]) * ml, (float(res[0]), ml)
+    assert float(np.abs(bm.cpu().numpy()[:, :3, :] - g["e300_best_m"][:, :3, :]).max()) <= 2.0 * float(env["best_pose_envelope"])
+
+
 @pytest.mark.parametrize("rot", ["q", "dq"])
 def test_train_hidden32_reference_golden_runs_on_the_plan(dev, golden, rot):
     """tests/golden/train_reference.npz is the reference's own train() at hidden 32 (300 epochs) -- a width the kernels are not

@@ -129,6 +129,47 @@ def test_train_hidden64_matches_reference_six_epochs_and_300(golden, rot, ctor):
     np.testing.assert_allclose(best_m.detach().numpy(), g[f"{rot}_e300_best_m"], atol=2e-5)
 
 
+def test_train_c1_headline_shape_oracle_reproduces_the_reference(golden):
+    """train_reference_c1.npz: the reference's own train() with its default model (QRegMLP(True, hidden_dim=512), mlp_reg.py:281-282)
+    at the BASELINE configs[1] shape (N = 4096, K = 20).  The oracle is the same op sequence on the same torch build: six epochs of
+    it reproduce the reference's losses, the pose every epoch evaluated, the best pose / cloud and the trained parameters (a strided
+    sample + per-tensor sums) to rounding."""
+    g = golden("train_reference_c1.npz")
+    sd = {k[5:]: torch.from_numpy(g[k].astype(np.float32)) for k in g.files if k.startswith("sd16.")}
+    for k, v in sd.items():                                            # float16-representable: the fixture stores them exactly
+        assert torch.equal(v, v.to(torch.float16).to(torch.float32)), k
+    clusters = [torch.from_numpy(c) for c in _split(g["local"], g["offsets"])]
+    assert len(clusters) == 20 and g["local"].shape == (4096, 3) and g["y"].shape == (4096, 3)
+    model = models.QRegMLP(True, 512)
+    model.load_state_dict(sd)
+    pred, best_m, min_loss, hist = registration.train(torch.from_numpy(g["m"]), torch.from_numpy(g["y"]), model, clusters, rot="q", epochs=6)
+    np.testing.assert_allclose(np.array(hist["loss"]), g["loss_hist"][:6], rtol=1e-6)
+    np.testing.assert_allclose(np.array(hist["loss"]), g["e6_loss_hist"], rtol=1e-6)
+    assert abs(min_loss - float(g["e6_min_loss"])) <= 1e-6 * min_loss
+    np.testing.assert_allclose(best_m.detach().numpy(), g["e6_best_m"], atol=1e-6)
+    np.testing.assert_allclose(np.concatenate(pred), g["e6_best_pred"], atol=1e-6)
+    stride = int(g["sample_stride"])
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.reshape(-1)[::stride].numpy(), g[f"e6.final_sample.{k}"], atol=2e-6, err_msg=k)
+        assert abs(float(v.double().sum()) - float(g[f"e6.final_sum.{k}"])) < 1e-4, k
+    # the best pose of a run is one of the poses it evaluated
+    i = int(np.argmin(g["loss_hist"]))
+    np.testing.assert_array_equal(g["pose_hist"][i], g["e300_best_m"])
+    assert float(g["loss_hist"][i]) == float(g["e300_min_loss"])
+
+
+def test_divergence_envelope_fixture_is_consistent(golden):
+    """tests/golden/divergence_envelope_c1.npz (tests/measure/divergence_envelope.py cpu): the float32 oracle reproduces the reference
+    trajectory exactly, permuted / float64 variants stay within the north star's 1e-5 up to N_e and then leave it by orders of magnitude."""
+    e = golden("divergence_envelope_c1.npz")
+    n_e = int(e["n_e"])
+    assert float(e["oracle_vs_reference"].max()) == 0.0
+    assert 3 <= n_e < 60
+    assert float(np.maximum(e["envelope"], e["f64"])[: n_e + 1].max()) <= 1e-5
+    assert float(np.maximum(e["envelope"], e["f64"])[n_e + 1]) > 1e-5
+    assert float(e["envelope"][30:].max()) > 1e-3            # two correct float32 implementations are centimetres apart later on
+
+
 def test_resample_matches_reference_and_live_sklearn(golden):
     g = golden("resample_reference.npz")
     local, labels = registration.resample_cluster(g["frame"], len(g["mats"]), g["mats"])
