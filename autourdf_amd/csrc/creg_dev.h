@@ -283,4 +283,19 @@ __device__ __forceinline__ void st4_wt(float* base, int elem, float4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(x, __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000), elem * 4, 0, 16);
 }
 
+
+// Raw buffer loads: base in four SGPRs, ONE 32-bit byte offset per lane, a scalar offset and an immediate -- a dozen loads of a
+// strided pattern share one address VGPR (global_load needs a 64-bit address pair per distinct row), and bytes past `bytes` read as 0.
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float4 ld_buf4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
 }  // namespace creg

@@ -31,7 +31,7 @@
 namespace creg {
 
 struct Dims {
-    int rot, K, IN, H, HA, HB, H2, OA, OB, NP, NT, epochs;
+    int rot, K, KP, IN, H, HA, HB, H2, OA, OB, NP, NT, epochs;      // KP: K rounded up to the k_bd D role's contraction chunk (rows K..KP-1 of x1 / h2 / g_h2 / g_out stay 0)
     float slope;
     // flat parameter offsets
     int oW1, ob1, oW2, ob2, oW3A, ob3A, oW3B, ob3B, NPAR;
@@ -118,6 +118,10 @@ __global__ __launch_bounds__(256) void k_prep(Dims D, Ws W0, size_t bstride, Pre
         W.y4[j] = make_float4(y[3 * (size_t)j], y[3 * (size_t)j + 1], y[3 * (size_t)j + 2], 0.f);
     for (int i = t; i < D.NPAR; i += stride) { W.AM[i] = 0.f; W.AV[i] = 0.f; }
     for (int i = t; i < D.epochs; i += stride) { W.loss_hist[i] = NAN; W.lr_hist[i] = NAN; }
+    // pose rows K .. KP-1 of the K-row matrices: zero for the whole train (k_bd's D role contracts over KP rows; nobody writes them)
+    for (int i = t; i < (D.KP - D.K) * D.H; i += stride) { W.x1[0][D.K * D.H + i] = 0.f; W.x1[1][D.K * D.H + i] = 0.f; }
+    for (int i = t; i < (D.KP - D.K) * D.H2; i += stride) { W.h2[0][D.K * D.H2 + i] = 0.f; W.h2[1][D.K * D.H2 + i] = 0.f; W.g_h2[D.K * D.H2 + i] = 0.f; }
+    for (int i = t; i < (D.KP - D.K) * 16; i += stride) W.g_out[D.K * 16 + i] = 0.f;
     for (int i = t; i <= D.epochs; i += stride) { W.bc1[i] = 1.0 - pow(0.9, (double)i); W.bc2s[i] = (float)sqrt(1.0 - pow(0.999, (double)i)); }
     if (blockIdx.x == 0) {
         for (int r = threadIdx.x; r < D.K; r += 256) {
@@ -804,7 +808,7 @@ struct BdStamps {
     int armed;
 };
 __device__ BdStamps g_bd_st;
-#define BD_T0 unsigned long long bd_t[8]; int bd_n = 0; if (threadIdx.x == 0) bd_t[bd_n++] = wall_clock64();
+#define BD_T0 unsigned long long bd_t[8]; int bd_n = 0; if (threadIdx.x == 0) bd_t[bd_n++] = bd_entry;
 #define BD_T  if (threadIdx.x == 0) bd_t[bd_n++] = wall_clock64();
 #define BD_TEND(role, epoch) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0) { bd_t[bd_n++] = wall_clock64(); \
     if (g_bd_st.armed) { const int sl_ = (epoch) & 255; atomicMin(&g_bd_st.first[sl_], bd_t[0]); \
@@ -818,16 +822,12 @@ __device__ BdStamps g_bd_st;
 constexpr int BD_THREADS = 512;       // workgroups of the backward launch k_bd (both roles)
 constexpr int B2_THREADS = BD_THREADS;
 constexpr int B2_WAVES = B2_THREADS / 64;
-constexpr int B2_CB = 16;
-constexpr int B2_RB = 20;             // pose rows per pass (K = 20: one pass)
-constexpr int B2_HB = 5;              // rows of a pass whose accumulators are live together
-constexpr int B2_MAXP = (160 + B2_RB - 1) / B2_RB;
-__host__ __device__ inline int b2_rows(int K) { return K < B2_RB ? K : B2_RB; }
-__host__ __device__ inline int b2_area(int K, int H2) { const int a = b2_rows(K) * H2, b = K * 2 * B2_CB; return a > b ? a : b; }
-__host__ __device__ inline int b2_smem_floats(int K, int H2, int IN) {
-    // [RB][H2] g_h2 rows of a pass (after the last pass the same region holds g_x1 [K][16] and the next-activation tile
-    // [K][16]), the per-wave partial sums [8][RB][16], the features [K][IN]
-    return b2_area(K, H2) + B2_WAVES * b2_rows(K) * B2_CB + K * IN;
+constexpr int B2_CB = 16;             // columns of W2 (= hidden units of the encoder) per workgroup: ONE 16-wide MFMA tile
+constexpr int B2_RB = 32;             // pose rows per pass: two 16-row MFMA tiles (K <= 32: one pass)
+__host__ __device__ inline int b2_smem_floats(int K, int IN, int H2) {
+    // the per-wave partial tiles [8][32][16], the features [K][IN], g_x1 [K][16] and the next-activation tile [K][16] of this block's
+    // columns, the block's slab of W2 [H2][16]
+    return B2_WAVES * B2_RB * B2_CB + K * IN + 2 * K * B2_CB + H2 * B2_CB;
 }
 // sum over the 16 lanes of a DPP row; every lane of the row receives it
 __device__ __forceinline__ float row_sum16(float v) {
@@ -837,43 +837,45 @@ __device__ __forceinline__ float row_sum16(float v) {
     CREG_DPP_STEP(v, 0x140, 0xF);   // row_mirror
     return v;
 }
-// sum over the 8 lanes of a wave that share (lane & 7): lanes l, l^8 (row_ror:8), then l^16, l^32; every lane receives it
-__device__ __forceinline__ float slice_sum8(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));
-    // lanes l ^ 16 and l ^ 32 by gfx950's row / half swaps (one VALU instruction each, no LDS crossbar round trip like the
-    // ds_bpermute behind __shfl_xor): with both operands = v, permlane16_swap leaves (rows 0,0,2,2 | rows 1,1,3,3) and
-    // permlane32_swap (low half twice | high half twice); the sum of the two is v[l] + v[l ^ 16] resp. v[l] + v[l ^ 32] in every
-    // lane -- the same pairs in the same tree as before (a + b == b + a), bit-identical
-#ifndef CREG_SLICE_SHFL
-    {   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
-    {   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
-#else
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-#endif
-    return v;
-}
-__device__ __forceinline__ nn_f2 fma2(float g, nn_f2 w, nn_f2 a) {        // one v_pk_fma_f32: both columns of the pair
-    const nn_f2 gg = {g, g};
-    return __builtin_elementwise_fma(gg, w, a);
-}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int AW, int OPS>            // AW waves of the workgroup take part in the W2 product: H2 = 8 AW OPS
-__device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch, int blk, float* sh) {
-    const int RB = b2_rows(D.K);
-    float* gh = sh;                            // [RB][H2]   g_h2 rows of the pass
-    float* red = sh + b2_area(D.K, D.H2);      // [8][RB][16] per-wave partial sums of the pass
-    float* encs = red + B2_WAVES * RB * B2_CB; // [K][IN] MLP input features
-    float* gxs = sh;                           // after the passes: [K][16] g_x1 of this block's columns,
-    float* xt = gxs + D.K * B2_CB;             //   [K][16] next encoder activation of this block's units
-    // (no early exit on `stopped`: every store below is gated; an exit branch here would let hipcc sink the
-    //  loads below it and serialise them)
-    const TrainState S = W.state[(epoch + 1) & 1];
-    const bool live = !S.stopped;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, cp = tid & 7, sl = tid >> 3;
-    const bool fma_wave = wv < AW;             // wave-uniform
+// Round 4: the product g_h2 . W2 of a block is a [K x H2] . [H2 x 16] GEMM and runs on the matrix cores as
+// v_mfma_f32_16x16x4_f32 tiles -- exact float32, bit for bit a k-ordered fmaf chain (cdna_hip_programming.md section 3), so the
+// plan stays deterministic and bit-reproducible; only the association of the sum over the hidden rows differs from round 3's
+// (8 lane slices x 8 waves then, 8 waves x one in-order chain of H2 / 8 rows now).  Tiles: M = 16 pose rows (K = 20: two tiles, the
+// second one mostly padding -- rows past K repeat row K - 1 and land in accumulator rows nobody reads), N = the block's 16 columns,
+// contraction over the hidden rows o: wave w owns rows [w KW, (w + 1) KW), KW / 4 k-steps.  MFMA operand layout: lane l holds
+// A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; D[i = 4 (l >> 4) + v][j = l & 15] in accumulator register v.
+//   B operand = W2[o][c0 + j]: the block's slab W2[:, c0 .. c0 + 16) goes to LDS by LDS-DMA, 16 bytes per lane (a wave-instruction
+//     moves 16 rows of 64 bytes), each wave staging exactly the rows it multiplies -- so its own vmcnt wait is all the
+//     synchronisation the slab needs -- and is read back one dword per lane and k-step.  (First build: one global dword load per
+//     lane and k-step.  A CU's address path takes ~16 cycles per wave-instruction whatever its width, so those 24 quarter-width
+//     loads per lane cost 3 000 cycles per workgroup: the block spent 2.5 us just ISSUING its loads.)
+//   A operand = g_h2[r][o]: straight from global memory too (k_gradc wrote it a launch earlier) -- with the rows of a wave ordered
+//     o(g, i, kk) = 16 g + 4 kk + i (k-step 4 g + i, k index kk: any bijection works as long as A and B agree) a lane's operands of
+//     four consecutive k-steps are ONE 16-byte load g_h2[r][16 g + 4 kk .. + 3] (KW % 16 == 0: hidden 256 / 512); narrower shapes
+//     load a dword per k-step with o(s, kk) = 4 s + kk.
+// Nothing of the GEMM is staged in LDS any more (round 3 staged all of g_h2, 61 KB per workgroup, and waited for ALL of it before the
+// first FMA): every load is in flight at once and the MFMAs start on the first operands that land.  The per-wave partial tiles are
+// summed over the waves in wave order through LDS as before.  Then, unchanged: activation gradient, the 16 encoder rows' weight
+// gradients + Adam, and the NEXT epoch's encoder activation of the block's 16 units from the registers that hold the updated rows.
+template <int KW>                      // W2 rows per wave: H2 = 8 KW
+__device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch, int blk, float* sh, unsigned long long bd_entry) {
+    constexpr int NS = KW / 4;                 // k-steps of a wave
+    constexpr bool V4 = KW % 16 == 0;          // A operand as 16-byte loads
+    constexpr int NA = V4 ? NS / 4 : NS;       // A loads per tile and lane
+    float* red = sh;                                   // [8][32][16] per-wave partial tiles of the pass
+    float* encs = red + B2_WAVES * B2_RB * B2_CB;      // [K][IN] MLP input features
+    float* gxs = encs + D.K * D.IN;                    // [K][16] g_x1 of this block's columns,
+    float* xt = gxs + D.K * B2_CB;                     // [K][16] next encoder activation of this block's units
+    float* w2s = xt + D.K * B2_CB;                     // [H2][16] the block's slab of W2 (16-byte aligned: every size above is a multiple of 4 floats)
+    // (no early exit on `stopped` before the loads are issued: every store below is gated; an exit branch here would let hipcc
+    //  sink the loads below it and serialise them)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lj = lane & 15, kk = lane >> 4;
+    // The two roles are one function to hipcc: its wait-count pass lets the OTHER role's requests count as possibly pending here and
+    // put a vmcnt(0) in the middle of this role's own requests (before the first redefinition of a register the other role loads
+    // into).  A wait it can see -- free at run time: nothing is outstanding when a role starts -- clears that state.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
     const int c0 = blk * B2_CB, par = epoch & 1;
     const float* x1cur = par ? W.x1[1] : W.x1[0];     // (a runtime index into the shifted struct would go to scratch)
     float* x1next = par ? W.x1[0] : W.x1[1];
@@ -881,14 +883,28 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
     float* Pn = par ? W.P : W.P1;
     BD_T0
     // every load of the first pass is requested before the first wait
-    stage_issue<B2_THREADS>((float4*)gh, (const float4*)W.g_h2, RB * D.H2 / 4);
-    stage_issue<B2_THREADS>((float4*)encs, (const float4*)W.enc, D.K * D.IN / 4);
-    nn_f2 w[OPS];
-    {
-        const float* wbase = Pc + D.oW2 + (size_t)(min(sl, 8 * AW - 1) * OPS) * D.H + c0 + 2 * cp;
+    {   // this wave's KW rows of the slab: lane l moves the 16 bytes W2[row 16 i + (l >> 2)][c0 + 4 (l & 3) ..] to slab row-major
+        const float* src = Pc + D.oW2 + (size_t)(wv * KW + (lane >> 2)) * D.H + c0 + 4 * (lane & 3);
+        float* dst = w2s + wv * KW * B2_CB;
 #pragma unroll
-        for (int j = 0; j < OPS; ++j) w[j] = *(const nn_f2*)(wbase + (size_t)j * D.H);
+        for (int i = 0; i < KW; i += 16)
+            if (i + (lane >> 2) < KW)                  // (KW = 8, 12, 24: the last instruction is partial; inactive lanes write nothing)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)i * D.H),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * B2_CB), 16, 0, 0);
     }
+    const float* gbase = W.g_h2 + wv * KW + (V4 ? 4 * kk : kk);        // + row * H2 (+ 16 g | 4 s)
+    auto load_a = [&](int row, float* dst) {                           // one tile's A operands of this lane: pose row `row` (clamped)
+        const float* g = gbase + (size_t)min(row, D.K - 1) * D.H2;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            if constexpr (V4) { const float4 v = *(const float4*)(g + 16 * q); dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w; }
+            else dst[q] = g[4 * q];
+        }
+    };
+    float a0[NS], a1[NS];
+    load_a(lj, a0);
+    const bool two0 = D.K > 16;                        // workgroup-uniform
+    if (two0) load_a(16 + lj, a1);
     // encoder rows: thread = (half, row of the block, float4 of its IN inputs); both halves hold the row (same operands,
     // same Adam result) and share the pose rows of the next-activation loop
     const int half = tid >> 8, t2 = tid & 255, row = t2 >> 4, i4 = t2 & 15, hu = c0 + row;
@@ -897,83 +913,71 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
     const size_t wi = (size_t)D.oW1 + (size_t)hu * D.IN + ei;
     float4 pw = *(const float4*)(Pc + wi), pm = *(const float4*)(W.AM + wi), pv = *(const float4*)(W.AV + wi);
     float pb = Pc[D.ob1 + hu], mb = W.AM[D.ob1 + hu], vb = W.AV[D.ob1 + hu];
-    float xv0 = 0.f;                            // post-activation of this thread's (pose row, column) output of pass 0
-    if (tid < RB * B2_CB) xv0 = x1cur[(size_t)(tid >> 4) * D.H + c0 + (tid & 15)];
-    float gxv[B2_MAXP];                         // this thread's g_x1 outputs, one per pass (K <= 160, 20 rows x 16 columns per pass)
-    int np = 0;
-    for (int r0 = 0; r0 < D.K; r0 += RB, ++np) {
-        const int nr = min(RB, D.K - r0);
+    float xv0 = x1cur[(size_t)min(tid >> 4, D.K - 1) * D.H + c0 + (tid & 15)];      // post-activation of this thread's (pose row, column) output of pass 0
+    {   // the features [K][IN] by LDS-DMA, straight-line (K <= 160: at most five 16-byte pieces per thread) and AFTER the other requests:
+        // behind stage_issue's loop hipcc puts a full vmcnt(0) -- in front of everything requested after it
+        const int n = D.K * D.IN / 4;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int i = c * B2_THREADS + tid;
+            if (i < n)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const float4*)W.enc + i),
+                                                 (__attribute__((address_space(3))) void*)((float4*)encs + c * B2_THREADS + (tid & ~63)), 16, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // the loads above stay above
+    // the state is requested LAST: hipcc makes `stopped` wave-uniform (v_readfirstlane) the moment it can, i.e. it waits for this load
+    // right where it is issued -- at the top of the role that put a whole memory round trip in front of every other request
+    const TrainState S = W.state[(epoch + 1) & 1];
+    const bool live = !S.stopped;
+    __builtin_amdgcn_sched_barrier(0);
+    BD_T                                               // B1: everything requested
+    stage_wait();                                      // this wave's slab rows (and the features, and its A operands) have landed
+    float wb[NS];                                      // B operands: this wave's W2 rows, column c0 + lj
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int o = V4 ? 16 * (s >> 2) + 4 * kk + (s & 3) : 4 * s + kk;
+        wb[s] = w2s[(wv * KW + o) * B2_CB + lj];
+    }
+    for (int r0 = 0; r0 < D.K; r0 += B2_RB) {          // K <= 32: one pass
+        const int nr = min(B2_RB, D.K - r0);
+        const bool two = nr > 16;                      // workgroup-uniform
         float xv = xv0;
         if (r0) {
-            __syncthreads();                       // the previous pass has read gh and red
-            stage_issue<B2_THREADS>((float4*)gh, (const float4*)(W.g_h2 + (size_t)r0 * D.H2), nr * D.H2 / 4);
-            if (tid < nr * B2_CB) xv = x1cur[(size_t)(r0 + (tid >> 4)) * D.H + c0 + (tid & 15)];
+            load_a(r0 + lj, a0);
+            if (two) load_a(r0 + 16 + lj, a1);
+            xv = x1cur[(size_t)min(r0 + (tid >> 4), D.K - 1) * D.H + c0 + (tid & 15)];
         }
-        stage_wait();
-        __syncthreads();
-        if (r0 == 0) { BD_T }                          // B1: the staged g_h2 rows, the features and this thread's W2 slice requested -> landed
-        if (!live) return;                             // a stopped train: nothing below may be stored (workgroup-uniform)
-        if (fma_wave) {
-            // B2_HB rows at a time, straight-line (rows past nr repeat the last one and are not stored): per-row branches
-            // kept hipcc from overlapping the rows' LDS reads and lane permutes; all 20 rows' accumulators beside the W2
-            // registers spill at the 128 VGPRs two workgroups per CU leave a wave
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (two) {
 #pragma unroll
-            for (int qb = 0; qb < B2_RB; qb += B2_HB) {
-                if (qb < nr) {                        // block-uniform
-                    nn_f2 acc[B2_HB];
-#pragma unroll
-                    for (int q = 0; q < B2_HB; ++q) {
-                        acc[q] = nn_f2{0.f, 0.f};
-                        const float* g = gh + min(qb + q, nr - 1) * D.H2 + sl * OPS;
-                        if constexpr (OPS % 4 == 0) {
-#pragma unroll
-                            for (int j = 0; j < OPS; j += 4) {
-                                const float4 v = *(const float4*)(g + j);
-                                acc[q] = fma2(v.x, w[j], acc[q]); acc[q] = fma2(v.y, w[j + 1], acc[q]);
-                                acc[q] = fma2(v.z, w[j + 2], acc[q]); acc[q] = fma2(v.w, w[j + 3], acc[q]);
-                            }
-                        } else if constexpr (OPS % 2 == 0) {
-#pragma unroll
-                            for (int j = 0; j < OPS; j += 2) {
-                                const nn_f2 v = *(const nn_f2*)(g + j);
-                                acc[q] = fma2(v.x, w[j], acc[q]); acc[q] = fma2(v.y, w[j + 1], acc[q]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < OPS; ++j) acc[q] = fma2(g[j], w[j], acc[q]);
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < B2_HB; ++q) { acc[q].x = slice_sum8(acc[q].x); acc[q].y = slice_sum8(acc[q].y); }
-#pragma unroll
-                    for (int q = 0; q < B2_HB; ++q)
-                        if (lane < 8 && qb + q < nr) *(nn_f2*)(red + (wv * RB + qb + q) * B2_CB + 2 * cp) = acc[q];
-                }
+            for (int s = 0; s < NS; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], wb[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], wb[s], acc1, 0, 0, 0);
             }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], wb[s], acc0, 0, 0, 0);
         }
-        if (r0 == 0) { BD_T }                          // B2: the packed FMAs and slice sums of wave 0 (first pass)
+        if (r0) __syncthreads();                       // the previous pass has read red
+        {   // D[4 kk + v][lj] of tile t -> red[wave][16 t + 4 kk + v][lj]
+            float* o = red + (wv * B2_RB + 4 * kk) * B2_CB + lj;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { o[v * B2_CB] = acc0[v]; if (two) o[(16 + v) * B2_CB] = acc1[v]; }
+        }
+        stage_wait();                                  // (the features' LDS-DMA; every other load has been consumed)
         __syncthreads();
-        float out = 0.f;
+        if (r0 == 0) { BD_T }                          // B2: operands landed, MFMAs, partial tiles in LDS
+        if (!live) return;                             // a stopped train: nothing below may be stored (workgroup-uniform)
         if (tid < nr * B2_CB) {                        // tid = (pose row of the pass) * 16 + column
             float sum = red[tid];
 #pragma unroll
-            for (int w2 = 1; w2 < AW; ++w2) sum += red[w2 * RB * B2_CB + tid];
-            out = sum * act_grad(xv, D.slope);
+            for (int w2 = 1; w2 < B2_WAVES; ++w2) sum += red[w2 * B2_RB * B2_CB + tid];
+            gxs[r0 * B2_CB + tid] = sum * act_grad(xv, D.slope);
         }
-#pragma unroll
-        for (int u = 0; u < B2_MAXP; ++u) if (u == np) gxv[u] = out;
-    }
-    __syncthreads();                                   // gh is free: g_x1 moves in
-    np = 0;
-    for (int r0 = 0; r0 < D.K; r0 += RB, ++np) {
-        const int nr = min(RB, D.K - r0);
-        float out = 0.f;
-#pragma unroll
-        for (int u = 0; u < B2_MAXP; ++u) if (u == np) out = gxv[u];
-        if (tid < nr * B2_CB) gxs[r0 * B2_CB + tid] = out;
     }
     __syncthreads();
-    BD_T                                               // B3: barrier, cross-wave reduction, activation gradient, g_x1 into LDS (+ further passes at K > 20)
+    BD_T                                               // B3: cross-wave reduction, activation gradient, g_x1 into LDS (+ further passes at K > 32)
     // ---- encoder rows: dW1 = g_x1^T enc, Adam, next x1
     float4 ag = make_float4(0.f, 0.f, 0.f, 0.f);
     float gsum = 0.f;
@@ -1009,107 +1013,135 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
     BD_TEND(0, epoch);                                 // B5: the next activation tile, its stores and the encoder rows' stores acknowledged
 }
 
+
 // ------------------------------------------------------------------------------------------ dW + Adam of the hidden / output rows
-// One wave per parameter row, 8 rows per block.  The block stages its rows' input activation matrix
-// ([K][H] encoder activation for hidden rows, [K][H2] hidden activation for output rows) in LDS by LDS-DMA; a
-// row's parameter / Adam-state loads are all issued together.  No loop over K contains a global load.
-constexpr int DW_WAVES = BD_THREADS / 64;
-constexpr int DW_RPB = DW_WAVES;      // rows per block sharing one LDS copy of the activations (one row per wave: measured best in
-                                      // round 1 -- 27 us vs 30 (2 rows) vs 42 (4): fewer, fatter waves cost more than the staging they save)
-struct DwRow { int oW, ob, o, n_in, aoff, kind; bool active; };
+// Round 4: the weight gradient of a block of rows, dW[u][i] = sum_r g[r][u] act[r][i], is a [inputs x K] . [K x units] GEMM and runs
+// on the matrix cores (v_mfma_f32_16x16x4_f32: exact float32, a k-ordered fmaf chain over the pose rows -- the same order as round 3's
+// per-row VALU chain).  A workgroup owns 16 units (parameter rows), wave w their inputs [64 w, 64 w + 64) as four 16 x 16 tiles with
+// M = inputs, N = units, contraction over the pose rows r: lane l holds D[i = 4 (l >> 4) + v][j = l & 15], gradients of unit
+// u0 + (l & 15) -- the very bytes of the row it loads, updates (Adam, torch's arithmetic) and stores (write-through) as dwordx4 (how
+// tiles map to inputs: in the body).  Operands straight from global memory: A = act[r = 4 s + (l >> 4)][..] (the K-row
+// activation matrix, 40 KB per problem, L2-resident after the first touch), B[k][j] = g[r][u0 + (l & 15)] (rows K .. KP-1 are zero:
+// the contraction is padded to a multiple of 20 rows).  Round 3 staged the whole activation matrix in LDS per workgroup (40 KB LDS-DMA, a wait
+// for ALL loads, a barrier) and then ran 20 dependent steps of 2 ds_read_b128 + 8 FMA per wave; now there is no LDS, no barrier, and
+// a wave's tiles are consumed in the order their loads were issued, so the stores of its first tiles overlap the loads of its last.
+// Blocks of a problem: H2 / 16 hidden blocks, then one for the output rows of decoder_1 (width HA, 'q' only) and one for those of
+// decoder_2 / the single decoder (width HB): the same code with fewer than 16 live units.
+constexpr int DW_UNITS = 16;          // parameter rows per block (one MFMA N-tile)
+constexpr int DW_TILES = 4;           // 16-input tiles per wave: 8 waves x 64 inputs = 512
+constexpr int DW_KC = 5;              // k-steps (4 pose rows each) per chunk of operand loads: K = 20 is one chunk
+__host__ __device__ inline int dw_blocks(const Dims& D) { return D.H2 / DW_UNITS + 2; }
 
-__device__ __forceinline__ DwRow dw_row(const Dims& D, int bkind, int row) {
-    DwRow R;
-    R.aoff = 0; R.active = true;
-    if (bkind == 0) { R.kind = 0; R.o = row; R.oW = D.oW2 + row * D.H; R.ob = D.ob2 + row; R.n_in = D.H; }
-    else if (row < D.OA) { R.kind = 1; R.o = row; R.oW = D.oW3A + row * D.HA; R.ob = D.ob3A + row; R.n_in = D.HA; }
-    else if (row < D.OA + D.OB) { R.kind = 2; R.o = row - D.OA; R.oW = D.oW3B + R.o * D.HB; R.ob = D.ob3B + R.o; R.n_in = D.HB; R.aoff = D.HA; }
-    else { R.kind = 2; R.o = 0; R.active = false; R.oW = D.oW3B; R.ob = D.ob3B; R.n_in = D.HB; R.aoff = D.HA; }   // idle: mirrors a valid row, stores nothing
-    return R;
-}
-
-template <int NC>
-__device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, int blk, float* sh) {
-    const TrainState S = W.state[(epoch + 1) & 1];
-    const bool live = !S.stopped;                   // gates every store (no early exit before the loads: see bwd2_role)
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int gsz = (DW_WAVES * D.K + 3) & ~3;
-    float* gall = sh;                               // [8 waves][K] gradient columns
-    float* as = sh + gsz;                           // staged activations [rc][width]
+__device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, int blk, unsigned long long bd_entry) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lj = lane & 15, q = lane >> 4;
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): see bwd2_role
     const int par = epoch & 1;
     const float* Pc = par ? W.P1 : W.P;             // this epoch's parameters; the updated rows go to the other buffer
     float* Pn = par ? W.P : W.P1;
-    // block -> row kind.  Blocks: [hidden rows / RPB][output rows / RPB]
-    const int nb2 = D.H2 / DW_RPB;
-    const int bkind = blk < nb2 ? 0 : 1;                                          // block-uniform
-    const int row0 = (bkind == 0 ? blk : blk - nb2) * DW_RPB + wib;
     // (two selects of values, kept apart: hipcc folds a nested select over the four neighbouring members of the shifted
     //  struct into ONE load with a computed offset -- which puts the whole struct, 40 pointers, into scratch memory)
     const float* x1cur = par ? W.x1[1] : W.x1[0];
     const float* h2cur = par ? W.h2[1] : W.h2[0];
     asm volatile("" : "+s"(x1cur), "+s"(h2cur));
-    const float* amat = bkind == 0 ? x1cur : h2cur;
-    const int awidth = bkind == 0 ? D.H : D.H2;
-    const int rc = rows_per_chunk(D.K, awidth);
+    // block -> (units, width, parameter offsets, activation matrix, gradient matrix); everything block-uniform
+    const int nb2 = D.H2 / DW_UNITS;
+    int u0, nu, n_in, oW, ob, astride, gstride;
+    const float *amat, *gmat;
+    if (blk < nb2) { u0 = blk * DW_UNITS; nu = DW_UNITS; n_in = D.H; oW = D.oW2 + u0 * D.H; ob = D.ob2 + u0; amat = x1cur; astride = D.H; gmat = W.g_h2 + u0; gstride = D.H2; }
+    else if (blk == nb2) { u0 = 0; nu = D.OA; n_in = D.HA; oW = D.oW3A; ob = D.ob3A; amat = h2cur; astride = D.H2; gmat = W.g_out; gstride = 16; }
+    else { u0 = 0; nu = D.OB; n_in = D.HB; oW = D.oW3B; ob = D.ob3B; amat = h2cur + D.HA; astride = D.H2; gmat = W.g_out + 4; gstride = 16; }
+    if (nu == 0 || 64 * wv >= n_in) return;         // no decoder_1 ('dq'), or a wave past the row's width (wave-uniform)
     BD_T0
-    stage_issue<BD_THREADS>((float4*)as, (const float4*)amat, min(rc, D.K) * awidth / 4);
-    // a lane owns 4 consecutive inputs per 256-wide slab: parameters / Adam state move as dwordx4, the
-    // staged activations are read as ds_read_b128
-    constexpr int NV = (NC + 3) / 4;
-    const DwRow R = dw_row(D, bkind, row0);
-    float4 pw[NV], pm[NV], pv[NV], acc[NV];
+    const int unit = min(lj, nu - 1);               // lanes past the live units mirror the last one and store nothing
+    const bool ulive = lj < nu;
+    // Every load is a raw buffer load (base in SGPRs, one byte offset per lane and matrix, pose rows as scalar offsets): with 64-bit
+    // global addresses the loads of a lane needed so many address pairs that hipcc split them into two batches with a full wait in
+    // between.  And every load but the gradients' is 16 bytes wide: a CU's address path takes ~16 cycles per wave-instruction
+    // whatever its width (first build: 20 dword loads of the activations per lane -- the workgroup spent 2.2 us ISSUING its loads).
+    // Hence the tiles are INTERLEAVED: a lane's A operands of one k-step are ONE float4 of the activation row, component t going to
+    // tile t.  Which float4: the accumulator register v of tile t in lane (q, j) is M index 4 q + v of that tile, and it has to be
+    // the gradient of input i0 + 16 v + 4 q + t of unit j -- then float4 v = (acc[0][v] .. acc[3][v]) of the lane sits at inputs
+    // i0 + 16 v + 4 q .. + 3, and the four lanes q of a unit cover 64 CONTIGUOUS bytes per load / store instruction.  (A lane owning 64
+    // consecutive bytes instead -- float4 v at i0 + 16 q + 4 v -- makes every instruction touch 64 different 64-byte segments, 16 bytes
+    // of each: the write-through stores then took 7 us instead of 3.6.)  So M index a = 4 q + v loads the float4 at i0 + 16 (a & 3) +
+    // 4 (a >> 2): the 16 lanes of a k index read the wave's 256 bytes of the row in a permuted order.
+    const int i0 = 64 * wv;                         // this wave's first input
+    const int po = (oW + unit * n_in + i0 + 4 * q) * 4;              // byte offset of this lane's float4 0 in the parameter arrays; float4 v is 64 v bytes on
+    const __amdgpu_buffer_rsrc_t rP = buf_rsrc(Pc, D.NPAR * 4), rM = buf_rsrc(W.AM, D.NPAR * 4), rV = buf_rsrc(W.AV, D.NPAR * 4);
+    // Request order = order of use, because requests return in order: (1) the MFMA operands of the first 20 pose rows, (2) the
+    // state, (3) the biases, (4) the parameter / moment float4s v = 0 .. 3.  The MFMAs then run as soon as the few operand bytes
+    // are in, and float4 v is updated and STORED while the later ones are still arriving -- the workgroup's write-through stores
+    // (48 KB) overlap its loads (first build: parameters first, operands last, every store behind the last load: 2.0 us of loads,
+    // then 4.7 us of Adam + stores).
+    f32x4 acc[DW_TILES];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int i = min(v * 256 + lane * 4, R.n_in - 4);
-        pw[v] = *(const float4*)(Pc + R.oW + i); pm[v] = *(const float4*)(W.AM + R.oW + i);
-        pv[v] = *(const float4*)(W.AV + R.oW + i); acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float pb = Pc[R.ob], mb = W.AM[R.ob], vb = W.AV[R.ob];
-    // dL/d(pre-activation of this wave's unit) for every pose row
-    for (int r = lane; r < D.K; r += 64)
-        gall[wib * D.K + r] = R.kind == 0 ? W.g_h2[(size_t)r * D.H2 + R.o] : W.g_out[16 * r + (R.kind == 1 ? R.o : 4 + R.o)];
-    // accumulate g[r] * act[r][i] over the pose rows from the LDS-staged activation matrix
-    for (int r0 = 0; r0 < D.K; r0 += rc) {
-        const int nr = min(rc, D.K - r0);
-        if (r0) {
-            __syncthreads();
-            stage_issue<BD_THREADS>((float4*)as, (const float4*)(amat + (size_t)r0 * awidth), nr * awidth / 4);
+    for (int t = 0; t < DW_TILES; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gb = 0.f;                                 // this lane's share of the bias gradient: sum over its pose rows r = 4 s + q
+    // the contraction runs over KP rows: rows K .. KP-1 of g are zero (k_prep), those of the activations finite (zero) -- no select
+    // after a load (it made hipcc wait for every gradient load on the spot) and no clamp
+    const __amdgpu_buffer_rsrc_t rA = buf_rsrc(amat, (D.KP * astride - (int)(amat - (blk < nb2 ? x1cur : h2cur))) * 4);
+    const __amdgpu_buffer_rsrc_t rG = buf_rsrc(gmat, (D.KP * gstride - (blk < nb2 ? u0 : (blk == nb2 ? 0 : 4))) * 4);
+    const int aoff = (q * astride + i0 + 16 * (lj & 3) + 4 * (lj >> 2)) * 4, goff = (q * gstride + unit) * 4;
+    float bop[DW_KC];
+    float4 aop[DW_KC];
+    auto load_ops = [&](int s0) {
+#pragma unroll
+        for (int s = 0; s < DW_KC; ++s) {
+            const int r4 = 4 * (s0 + s);             // scalar: rows r4 + q
+            bop[s] = ld_buf(rG, goff, r4 * gstride * 4);
+            aop[s] = ld_buf4(rA, aoff, r4 * astride * 4);             // (inputs past the row's width read the next row or 0: their gradients are not used)
         }
-        stage_wait();
-        __syncthreads();
-        if (r0 == 0) { BD_T }                          // D1: activations staged (the row's parameter / moment loads are in flight)
-        if (!live) return;                             // a stopped train: nothing below may be stored (workgroup-uniform)
-#pragma unroll 2
-        for (int r = 0; r < nr; ++r) {
-            const float* a = as + r * awidth;
-            const float gr = gall[wib * D.K + r0 + r];
+    };
+    auto mfma_ops = [&]() {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const float4 av = *(const float4*)(a + R.aoff + min(v * 256 + lane * 4, R.n_in - 4));
-                acc[v].x = fmaf(gr, av.x, acc[v].x); acc[v].y = fmaf(gr, av.y, acc[v].y);
-                acc[v].z = fmaf(gr, av.z, acc[v].z); acc[v].w = fmaf(gr, av.w, acc[v].w);
-            }
+        for (int s = 0; s < DW_KC; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[s].x, bop[s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[s].y, bop[s], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[s].z, bop[s], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[s].w, bop[s], acc[3], 0, 0, 0);
         }
-    }
-    BD_T                                               // D2: the accumulation over the pose rows (waits for the row's parameters)
-    if (!R.active) return;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int i = v * 256 + lane * 4;
+        for (int s = 0; s < DW_KC; ++s) gb += bop[s];
+    };
+    load_ops(0);
+    __builtin_amdgcn_sched_barrier(0);              // (the scheduler otherwise interleaves requests with the MFMAs and their waits)
+    const TrainState S = W.state[(epoch + 1) & 1];
+    float pb = Pc[ob + unit], mb = W.AM[ob + unit], vb = W.AV[ob + unit];
+    __builtin_amdgcn_sched_barrier(0);
+    float4 pw[DW_TILES], pm[DW_TILES], pv[DW_TILES];
+    bool vl[DW_TILES];
+#pragma unroll
+    for (int v = 0; v < DW_TILES; ++v) {
+        vl[v] = ulive && i0 + 16 * v + 4 * q < n_in;                 // (HA = 32 at hidden 64: half a wave's inputs exist)
+        pw[v] = ld_buf4(rP, po + 64 * v, 0); pm[v] = ld_buf4(rM, po + 64 * v, 0); pv[v] = ld_buf4(rV, po + 64 * v, 0);      // (past the arrays: 0)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    BD_T                                            // D1: everything requested
+    mfma_ops();
+    for (int s0 = DW_KC; 4 * s0 < D.KP; s0 += DW_KC) {               // K > 20: further chunks of 20 pose rows (a round trip each)
+        load_ops(s0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_ops();
+    }
+    BD_T                                            // D2: operands landed, MFMAs
+    if (S.stopped) return;                          // a stopped train: nothing below may be stored (block-uniform)
+#pragma unroll
+    for (int v = 0; v < DW_TILES; ++v) {
         float4 nw;
-        nw.x = adam_value(pw[v].x, pm[v].x, pv[v].x, acc[v].x, S.step_size, S.bc2_sqrt);
-        nw.y = adam_value(pw[v].y, pm[v].y, pv[v].y, acc[v].y, S.step_size, S.bc2_sqrt);
-        nw.z = adam_value(pw[v].z, pm[v].z, pv[v].z, acc[v].z, S.step_size, S.bc2_sqrt);
-        nw.w = adam_value(pw[v].w, pm[v].w, pv[v].w, acc[v].w, S.step_size, S.bc2_sqrt);
-        if (i < R.n_in) {
-            st4_wt(Pn, R.oW + i, nw); st4_wt(W.AM, R.oW + i, pm[v]); st4_wt(W.AV, R.oW + i, pv[v]);
-        }
+        nw.x = adam_value(pw[v].x, pm[v].x, pv[v].x, acc[0][v], S.step_size, S.bc2_sqrt);
+        nw.y = adam_value(pw[v].y, pm[v].y, pv[v].y, acc[1][v], S.step_size, S.bc2_sqrt);
+        nw.z = adam_value(pw[v].z, pm[v].z, pv[v].z, acc[2][v], S.step_size, S.bc2_sqrt);
+        nw.w = adam_value(pw[v].w, pm[v].w, pv[v].w, acc[3][v], S.step_size, S.bc2_sqrt);
+        if (vl[v]) { const int e = po / 4 + 16 * v; st4_wt(Pn, e, nw); st4_wt(W.AM, e, pm[v]); st4_wt(W.AV, e, pv[v]); }
     }
-    float sum = 0.f;
-    for (int r = 0; r < D.K; ++r) sum += gall[wib * D.K + r];
-    pb = adam_value(pb, mb, vb, sum, S.step_size, S.bc2_sqrt);
-    if (lane == 0) { Pn[R.ob] = pb; W.AM[R.ob] = mb; W.AV[R.ob] = vb; }
-    BD_TEND(1, epoch);                                 // D3: Adam, the write-through stores acknowledged
+    if (wv == 0) {                                  // the units' biases: gradient = sum over the pose rows of g[r][u], the four lane groups q in order
+        float sum = gb;
+        sum += __shfl_xor(gb, 16, 64);              // (q, q ^ 1)
+        sum += __shfl_xor(sum, 32, 64);             // ((0,1), (2,3))
+        pb = adam_value(pb, mb, vb, sum, S.step_size, S.bc2_sqrt);
+        if (q == 0 && ulive) { Pn[ob + unit] = pb; W.AM[ob + unit] = mb; W.AV[ob + unit] = vb; }
+    }
+    BD_TEND(1, epoch);                              // D3: Adam, the write-through stores acknowledged
 }
 
 // ------------------------------------------------------------------------------------------ the backward launch: k_bd
@@ -1121,10 +1153,24 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
 // side the launch takes what the longer role takes, and the next hidden activation, the one thing that needs BOTH results (the
 // next encoder activation from B, the updated hidden rows from D), is k_l2 again, a launch boundary later.
 // grid.x = (H / 16 + H2 / 8 + 1) * problems: the B blocks of ALL problems first (the longer chain of dependent phases).
-template <int NC, int AW, int OPS>
+template <int NC, int KW>
 __global__ __launch_bounds__(BD_THREADS, 4) void k_bd(Dims D, Ws W0, int epoch, size_t bstride, int nz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nB = D.H / B2_CB, nD = D.H2 / DW_RPB + (D.OA + D.OB + DW_RPB - 1) / DW_RPB;
+#ifdef CREG_BD_STAMPS
+    const unsigned long long bd_entry = wall_clock64();
+#else
+    const unsigned long long bd_entry = 0;
+#endif
+#ifndef CREG_BD_NO_TOUCH
+    // Every kernel argument the roles read, fetched in the ENTRY block with one wait: hipcc otherwise loads arguments where a basic
+    // block first needs them -- three dependent scalar round trips to the argument buffer (cold for every node of a replayed graph)
+    // before the first request of a role went out.
+    asm volatile("" :: "s"(W0.P), "s"(W0.P1), "s"(W0.AM), "s"(W0.AV), "s"(W0.enc), "s"(W0.x1[0]), "s"(W0.x1[1]), "s"(W0.h2[0]), "s"(W0.h2[1]),
+                 "s"(W0.g_out), "s"(W0.g_h2), "s"(W0.state), "s"(D.K), "s"(D.KP), "s"(D.IN), "s"(D.H), "s"(D.H2), "s"(D.HA), "s"(D.HB), "s"(D.OA),
+                 "s"(D.OB), "s"(D.oW1), "s"(D.ob1), "s"(D.oW2), "s"(D.ob2), "s"(D.oW3A), "s"(D.ob3A), "s"(D.oW3B), "s"(D.ob3B), "s"(D.NPAR),
+                 "s"(D.slope), "s"(epoch), "s"(bstride), "s"(nz));
+#endif
+    const int nB = D.H / B2_CB, nD = dw_blocks(D);
     int i = blockIdx.x;
     const bool roleB = i < nB * nz;
     if (!roleB) i -= nB * nz;
@@ -1133,8 +1179,8 @@ __global__ __launch_bounds__(BD_THREADS, 4) void k_bd(Dims D, Ws W0, int epoch, 
 #ifdef CREG_BD_ONLY                                   // measurement build: one role alone (1: backward to the encoder, 2: dW + Adam)
     if ((CREG_BD_ONLY == 1) != roleB) return;
 #endif
-    if (roleB) bwd2_role<AW, OPS>(D, W, epoch, blk, (float*)smem);
-    else dw_role<NC>(D, W, epoch, blk, (float*)smem);
+    if (roleB) bwd2_role<KW>(D, W, epoch, blk, (float*)smem, bd_entry);
+    else dw_role(D, W, epoch, blk, bd_entry);
 }
 
 // after the last epoch: the parameters of an odd number of optimizer steps sit in the second buffer; the copy-out reads the first
@@ -1166,7 +1212,7 @@ static bool make_dims(const creg_train_shape* s, Dims* D) {
         s->n_tgt >= (1ll << 31))
         return false;
     memset(D, 0, sizeof(*D));
-    D->rot = s->rot; D->K = s->k; D->H = s->hidden; D->NP = (int)s->n_pred; D->NT = (int)s->n_tgt; D->epochs = s->epochs;
+    D->rot = s->rot; D->K = s->k; D->KP = (s->k + 19) / 20 * 20; D->H = s->hidden; D->NP = (int)s->n_pred; D->NT = (int)s->n_tgt; D->epochs = s->epochs;
     if (s->rot == 0) { D->IN = 56; D->HA = D->H / 2; D->HB = D->H; D->OA = 3; D->OB = 4; D->slope = 0.01f; }
     else { D->IN = 64; D->HA = 0; D->HB = D->H; D->OA = 0; D->OB = 8; D->slope = 0.f; }
     D->H2 = D->HA + D->HB;
@@ -1204,8 +1250,8 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     Ws w;
     w.P = (float*)take(f * D.NPAR); w.P1 = (float*)take(f * D.NPAR); w.AM = (float*)take(f * D.NPAR); w.AV = (float*)take(f * D.NPAR);
     w.pose_in = (float*)take(f * 8 * D.K); w.enc = (float*)take(f * D.K * D.IN);
-    w.x1[0] = (float*)take(f * D.K * D.H); w.x1[1] = (float*)take(f * D.K * D.H);
-    w.h2[0] = (float*)take(f * D.K * D.H2); w.h2[1] = (float*)take(f * D.K * D.H2); w.head_save = (float*)take(f * 16 * D.K);
+    w.x1[0] = (float*)take(f * D.KP * D.H); w.x1[1] = (float*)take(f * D.KP * D.H);
+    w.h2[0] = (float*)take(f * D.KP * D.H2); w.h2[1] = (float*)take(f * D.KP * D.H2); w.head_save = (float*)take(f * 16 * D.K);
     w.m2 = (float*)take(f * 16 * D.K); w.gm2 = (float*)take(f * 16 * D.K);
     w.pts4 = (float4*)take(sizeof(float4) * D.NP); w.y4 = (float4*)take(sizeof(float4) * D.NT);
     w.pred4 = (float4*)take(sizeof(float4) * D.NP);
@@ -1216,7 +1262,7 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     w.sgn_x = (int*)take(sizeof(int) * D.NP);
     w.cnt4 = (int4*)take(sizeof(int4) * D.NP);
     w.lossp_x = (float*)take(f * D.nbx); w.lossp_y = (float*)take(f * D.nby);
-    w.g_out = (float*)take(f * 16 * D.K); w.g_h2 = (float*)take(f * D.K * D.H2);
+    w.g_out = (float*)take(f * 16 * D.KP); w.g_h2 = (float*)take(f * D.KP * D.H2);
     w.state = (TrainState*)take(sizeof(TrainState) * 2);
     w.bc1 = (double*)take(sizeof(double) * (D.epochs + 1)); w.bc2s = (float*)take(f * (D.epochs + 1));
     w.best_m = (float*)take(f * 16 * D.K); w.best_pred = (float*)take(f * 3 * D.NP);
@@ -1244,20 +1290,18 @@ static void launch_head(Plan* P, int par, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
     by_nc(D.H, [&](auto nc) { hipLaunchKernelGGL((k_head<decltype(nc)::value>), dim3(D.K, 1, P->nz), dim3(512), 0, s, D, W, par, P->bstride); });
 }
-// the k_bd instance of a shape: NC = H / 64; AW waves x 8 slices x OPS rows = H2 ('q': H2 = 96 NC, 'dq': 64 NC)
+// the k_bd instance of a shape: NC = H / 64; the B role's 8 waves own KW = H2 / 8 rows of W2 each ('q': H2 = 96 NC, 'dq': 64 NC)
 template <typename F>
 static void by_bd(const Dims& D, F f) {
     by_nc(D.H, [&](auto nc) {
         constexpr int NC = decltype(nc)::value;
-        if (D.rot == 0) {
-            if constexpr (NC == 1) f(k_bd<1, 4, 3>);                   // H2 = 96: 32 slices of 3 rows
-            else f(k_bd<NC, 8, (3 * NC) / 2>);                         // H2 = 96 NC: 64 slices
-        } else f(k_bd<NC, 8, NC>);                                     // H2 = 64 NC
+        if (D.rot == 0) f(k_bd<NC, 12 * NC>);
+        else f(k_bd<NC, 8 * NC>);
     });
 }
 static void launch_bd(Plan* P, int epoch, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
-    const int per = D.H / B2_CB + D.H2 / DW_RPB + cdiv(D.OA + D.OB, DW_RPB);
+    const int per = D.H / B2_CB + dw_blocks(D);
     by_bd(D, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(per * P->nz), dim3(BD_THREADS), P->smem_bd, s, D, W, epoch, P->bstride, P->nz); });
 }
 static void launch_nn(const Dims& D, const Ws& W, size_t bstride, int nz, hipStream_t s, int par = 0) {
@@ -1500,10 +1544,8 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     if (P->branches > 8) P->branches = 8;
     P->gexec = nullptr; P->graph_ready = false;
     P->smem_l2 = (int)(sizeof(float) * rows_per_chunk(D.K, D.H) * D.H);
-    {   // one dynamic LDS size for the two roles of k_bd: the larger (B at K <= 20, hidden 512: 76 KB -> two workgroups per CU)
-        const int f_b = b2_smem_floats(D.K, D.H2, D.IN);
-        const int f_d = ((DW_WAVES * D.K + 3) & ~3) + STAGE_FLOATS + 64 * 4;
-        P->smem_bd = (int)(sizeof(float) * (f_b > f_d ? f_b : f_d));
+    {   // the dynamic LDS of k_bd is the B role's (71 KB at K = 20, hidden 512: its 48 KB slab of W2 + 23 KB; the D role uses none)
+        P->smem_bd = (int)(sizeof(float) * b2_smem_floats(D.K, D.IN, D.H2));
     }
     CREG_REQUIRE(P->smem_bd <= 160 * 1024, "creg_train_plan_create: k_bd needs %d B of LDS (K too large)", P->smem_bd);
     {   // the dynamic-LDS limit is per kernel AND per device: raise it at every plan creation (a process may drive several

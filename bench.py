@@ -247,7 +247,7 @@ def epoch_kernel_model(k_clusters, n_points, info):
         # k_bd = two independent roles in one launch.  D: hidden + output rows, parameters + both Adam moments read and written
         # (24 B each), current activations, gradients.  B: W2 read once (its columns), the encoder rows + moments read and written,
         # g_h2, current / next encoder activation
-        "bd": {"name": "k_bd<8, 8, 12>", "bound": "hbm",
+        "bd": {"name": f"k_bd<{HIDDEN // 64}, {12 * (HIDDEN // 64)}>", "bound": "hbm",
                "bytes": 24 * w23 + 4 * (K * H + 2 * K * H2 + 16 * K) + 4 * H2 * H + 24 * w1 + 4 * (K * H2 + 2 * K * H + K * IN)},
         # the next hidden activation: W2 + biases read again (from the freshly written buffer), next encoder activation read, h2 written
         "l2": {"name": "k_l2<8>", "bound": "hbm", "bytes": 4 * (H2 * H + H2) + 4 * (K * H + K * H2)},

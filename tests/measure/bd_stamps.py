@@ -23,7 +23,7 @@ v = list(out)
 print(f"\nk_bd, {v[7]:.0f} launch slots: span first workgroup start -> last workgroup end {v[0]:.2f} us")
 print(f"  B role (backward to the encoder): {v[5]:5.0f} workgroups per launch, first starts at {v[1]:5.2f} us, last ends at {v[2]:5.2f} us")
 print(f"  D role (dW + Adam of the rows)  : {v[6]:5.0f} workgroups per launch, first starts at {v[3]:5.2f} us, last ends at {v[4]:5.2f} us")
-names_b = ["B1 requests -> g_h2 rows / features / W2 slice landed", "B2 packed FMAs + slice sums (wave 0)", "B3 barrier, reduction, activation gradient, g_x1 to LDS",
+names_b = ["B1 every load requested", "B2 operands landed, MFMAs, partial tiles to LDS, barrier", "B3 cross-wave reduction, activation gradient, g_x1 to LDS",
            "B4 dW1, Adam, encoder-row stores issued", "B5 next activation tile + all stores acknowledged"]
 names_d = ["D1 activations staged", "D2 accumulation over the pose rows (incl. waiting for the row's parameters)", "D3 Adam + write-through stores acknowledged"]
 print("  mean phase durations of a B workgroup (us): " + "; ".join(f"{n} {v[8 + i]:.2f}" for i, n in enumerate(names_b)) + f"; total {sum(v[8:13]):.2f}")
