@@ -176,62 +176,83 @@ __global__ __launch_bounds__(256) void k_l1(Dims D, Ws W0, int par, size_t bstri
     }
 }
 
-// rows of the K-row activation matrix staged per LDS chunk (<= 64 KB)
-constexpr int STAGE_FLOATS = 10240;   // 40 KB: K=20 rows of H=512 in one chunk, and 3 workgroups per CU
-__host__ __device__ inline int rows_per_chunk(int K, int width) {
-    int rc = STAGE_FLOATS / width;
-    return rc < K ? rc : K;
-}
-
-// ------------------------------------------------------------------------------------------ layer 2 (epoch 0 only)
-// (later epochs: k_dw computes a hidden row's next activation from the weights it has just updated, with this
-//  kernel's arithmetic: lane-owned float4 slabs, fmaf chain over the slabs, DPP wave sum, + bias)
-// One wave per hidden unit; the block stages the encoder activation in LDS with one round trip
-// (all threads loading) instead of K dependent global reads per wave.  NC = H / 64 is a template
-// parameter so the per-row dot is straight-line code (runtime bounds made hipcc emit a branch and an
-// lgkmcnt(0) per element).
-constexpr int MLP_BLOCK = 1024;      // 16 waves = 16 parameter rows share one LDS copy of the activations
+// ------------------------------------------------------------------------------------------ layer 2
+// The hidden activation h2 = act(x1 . W2^T + b2), [K x H] . [H x H2]: once for epoch 0 and at the end of every epoch (the next
+// epoch's activation from the freshly updated rows and the next encoder activation).  Round 4: on the matrix cores
+// (v_mfma_f32_16x16x4_f32, exact float32: a k-ordered fmaf chain).  A workgroup owns 16 hidden units (one N-tile), its 8 waves split
+// the H inputs (wave w: inputs [KW w, KW (w + 1)), KW = H / 8), M-tiles = 16 pose rows, two per pass.  Operands straight from
+// global memory, 16 bytes per lane where the width allows (KW % 16 == 0; k order inside a wave o(g, i, kk) = 16 g + 4 kk + i as in
+// k_bd's B role): B[k][j] = W2[u0 + j][o], A[i][k] = x1[r][o] (rows past K repeat row K - 1 into accumulator rows nobody reads).
+// The eight partial tiles are summed in wave order through LDS, + bias, activation.  (Round 3: 1024-thread workgroups staged all of
+// x1 in LDS -- LDS-DMA, a full wait, a barrier -- then every wave ran 20 dependent steps of two ds_read_b128, 8 FMAs and a DPP wave sum.)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int L2_THREADS = 512;
+constexpr int L2_RB = 32;             // pose rows per pass (two M-tiles)
+constexpr int L2_SMEM = (L2_THREADS / 64) * L2_RB * 16 * 4;
 template <int NC>
-__global__ __launch_bounds__(MLP_BLOCK) void k_l2(Dims D, Ws W0, int par, size_t bstride) {
+__global__ __launch_bounds__(L2_THREADS) void k_l2(Dims D, Ws W0, int par, size_t bstride) {
+    constexpr int KW = 8 * NC, NS = KW / 4;
+    constexpr bool V4 = KW % 16 == 0;
+    constexpr int NL = V4 ? NS / 4 : NS;           // loads per operand tile and lane
+    __shared__ __attribute__((aligned(16))) float red[(L2_THREADS / 64) * L2_RB * 16];
+    // every kernel argument in the entry block, one wait (see k_bd)
+    asm volatile("" :: "s"(W0.P), "s"(W0.P1), "s"(W0.x1[0]), "s"(W0.x1[1]), "s"(W0.h2[0]), "s"(W0.h2[1]), "s"(W0.state), "s"(D.K), "s"(D.H),
+                 "s"(D.H2), "s"(D.oW2), "s"(D.ob2), "s"(D.slope), "s"(par), "s"(bstride));
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
     const float* Pc = par ? W.P1 : W.P;
-    const int stopped = W.state[par].stopped;        // (the state the epoch that ENDS with this launch has produced; tested at the barrier)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = (float*)smem;                      // [rc][H]
-    constexpr int H = NC * 64;
-    const int lane = threadIdx.x & 63;
-    const int o = min((int)(blockIdx.x * 16 + (threadIdx.x >> 6)), D.H2 - 1);    // grid covers H2 exactly (H2 % 16 == 0)
-    const int rc = rows_per_chunk(D.K, H);
     const float* x1cur = par ? W.x1[1] : W.x1[0];     // (a runtime index into the shifted struct would go to scratch)
-    stage_issue<MLP_BLOCK>((float4*)xs, (const float4*)x1cur, min(rc, D.K) * H / 4);
-    // a lane owns 4 consecutive inputs per 256-wide slab: one global_load_dwordx4 / ds_read_b128 each
-    constexpr int NV = (NC + 3) / 4;
-    float4 wr[NV];
+    float* h2out = par ? W.h2[1] : W.h2[0];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lj = lane & 15, kk = lane >> 4;
+    const int u0 = blockIdx.x * 16, H = D.H;         // grid covers H2 exactly (H2 % 32 == 0)
+    auto load_t = [&](const float* rowp, float* dst) {     // one operand tile of this lane: its wave's KW inputs of row `rowp`
+        const float* p = rowp + wv * KW + (V4 ? 4 * kk : kk);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int i = v * 256 + lane * 4;
-        wr[v] = i < H ? *(const float4*)(Pc + D.oW2 + (size_t)o * H + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const float b = Pc[D.ob2 + o];
-    for (int r0 = 0; r0 < D.K; r0 += rc) {
-        const int nr = min(rc, D.K - r0);
-        if (r0) {
-            __syncthreads();
-            stage_issue<MLP_BLOCK>((float4*)xs, (const float4*)(x1cur + (size_t)r0 * H), nr * H / 4);
+        for (int q = 0; q < NL; ++q) {
+            if constexpr (V4) { const float4 v = *(const float4*)(p + 16 * q); dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w; }
+            else dst[q] = p[4 * q];
         }
-        stage_wait();
-        __syncthreads();
-        if (stopped) return;                            // a stopped train keeps its activations (workgroup-uniform)
-        for (int r = 0; r < nr; ++r) {
-            float s = 0.f;
+    };
+    float bw[NS], a0[NS], a1[NS];
+    load_t(Pc + D.oW2 + (size_t)(u0 + lj) * H, bw);
+    load_t(x1cur + (size_t)min(lj, D.K - 1) * H, a0);
+    const bool two0 = D.K > 16;                        // workgroup-uniform
+    if (two0) load_t(x1cur + (size_t)min(16 + lj, D.K - 1) * H, a1);
+    const float bias = Pc[D.ob2 + u0 + (tid & 15)];
+    __builtin_amdgcn_sched_barrier(0);
+    const int stopped = W.state[par].stopped;          // requested LAST (hipcc waits for it where it is issued: see k_bd); the state
+                                                       //   the epoch that ENDS with this launch has produced
+    __builtin_amdgcn_sched_barrier(0);
+    for (int r0 = 0; r0 < D.K; r0 += L2_RB) {          // K <= 32: one pass
+        const int nr = min(L2_RB, D.K - r0);
+        const bool two = nr > 16;
+        if (r0) {
+            load_t(x1cur + (size_t)min(r0 + lj, D.K - 1) * H, a0);
+            if (two) load_t(x1cur + (size_t)min(r0 + 16 + lj, D.K - 1) * H, a1);
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (two) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const int i = min(v * 256 + lane * 4, H - 4);
-                const float4 a = *(const float4*)(xs + r * H + i);
-                s = fmaf(wr[v].x, a.x, s); s = fmaf(wr[v].y, a.y, s); s = fmaf(wr[v].z, a.z, s); s = fmaf(wr[v].w, a.w, s);
+            for (int s = 0; s < NS; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bw[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bw[s], acc1, 0, 0, 0);
             }
-            s = wave_sum_fast(s) + b;
-            if (lane == 0) (par ? W.h2[1] : W.h2[0])[(size_t)(r0 + r) * D.H2 + o] = act_f(s, D.slope);
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bw[s], acc0, 0, 0, 0);
+        }
+        if (r0) __syncthreads();                       // the previous pass has read red
+        {   // D[4 kk + v][lj] of tile t -> red[wave][16 t + 4 kk + v][lj]
+            float* o = red + (wv * L2_RB + 4 * kk) * 16 + lj;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { o[v * 16] = acc0[v]; if (two) o[(16 + v) * 16] = acc1[v]; }
+        }
+        __syncthreads();
+        if (stopped) return;                           // a stopped train keeps its activations (workgroup-uniform)
+        if (tid < nr * 16) {                           // tid = (pose row of the pass) * 16 + unit
+            float sum = red[tid];
+#pragma unroll
+            for (int w2 = 1; w2 < L2_THREADS / 64; ++w2) sum += red[w2 * L2_RB * 16 + tid];
+            h2out[(size_t)(r0 + (tid >> 4)) * D.H2 + u0 + (tid & 15)] = act_f(sum + bias, D.slope);
         }
     }
 }
@@ -837,7 +858,6 @@ __device__ __forceinline__ float row_sum16(float v) {
     CREG_DPP_STEP(v, 0x140, 0xF);   // row_mirror
     return v;
 }
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Round 4: the product g_h2 . W2 of a block is a [K x H2] . [H2 x 16] GEMM and runs on the matrix cores as
 // v_mfma_f32_16x16x4_f32 tiles -- exact float32, bit for bit a k-ordered fmaf chain (cdna_hip_programming.md section 3), so the
@@ -1203,7 +1223,7 @@ struct Plan {
     int B;                    // problems the workspace holds
     int nz;                   // problems per launch right now (grid.z): B for run, 1 for probe / profile
     size_t bstride;           // bytes between consecutive problems' workspaces
-    int smem_l2, smem_bd;
+    int smem_bd;
     int branches;             // parallel chains in the captured graph (groups of problems)
 };
 
@@ -1284,7 +1304,7 @@ static void by_nc(int H, F f) {            // H in {64, 128, 256, 512}
 static void launch_l2(Plan* P, int par, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
     by_nc(D.H, [&](auto nc) {
-        hipLaunchKernelGGL((k_l2<decltype(nc)::value>), dim3(D.H2 / 16, 1, P->nz), dim3(MLP_BLOCK), P->smem_l2, s, D, W, par, P->bstride); });
+        hipLaunchKernelGGL((k_l2<decltype(nc)::value>), dim3(D.H2 / 16, 1, P->nz), dim3(L2_THREADS), 0, s, D, W, par, P->bstride); });
 }
 static void launch_head(Plan* P, int par, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
@@ -1543,7 +1563,6 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     if (P->branches > P->B) P->branches = P->B;
     if (P->branches > 8) P->branches = 8;
     P->gexec = nullptr; P->graph_ready = false;
-    P->smem_l2 = (int)(sizeof(float) * rows_per_chunk(D.K, D.H) * D.H);
     {   // the dynamic LDS of k_bd is the B role's (71 KB at K = 20, hidden 512: its 48 KB slab of W2 + 23 KB; the D role uses none)
         P->smem_bd = (int)(sizeof(float) * b2_smem_floats(D.K, D.IN, D.H2));
     }

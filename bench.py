@@ -514,6 +514,9 @@ def main(argv=None):
     ap.add_argument("--stop", type=int, default=200,
                     help="early-stopping patience of train() (mlp_reg.py:17: stop=200, the default and the headline's); a small value "
                          "forces early stops to show what a stopped train costs")
+    ap.add_argument("--seed-offset", type=int, default=0,
+                    help="shift the synthetic sequence ids (other frames, other model initialisations): the headline depends on the "
+                         "trajectories the trains take -- a numerically different build is compared over several offsets")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="wx200_5",
                     help="default = the configuration BASELINE.json's metric is quoted on")
     args = ap.parse_args(argv)
@@ -572,12 +575,12 @@ def main(argv=None):
         total_items = args.steps + args.warmup
         cap_rounds = (total_items + S - 1) // S
         n_frames = cap_rounds + 1
-        seq_ids = list(range(S))
+        seq_ids = [args.seed_offset + s for s in range(S)]
     else:
         warm_rounds = (args.warmup + S - 1) // S
         timed_rounds = (args.steps + S - 1) // S
         n_frames = warm_rounds + timed_rounds + 1
-        seq_ids = [rank * 1000 + s for s in range(S)]
+        seq_ids = [args.seed_offset + rank * 1000 + s for s in range(S)]
     seq0 = make_sequence(robot, 0, max(n_frames, FRAMES_PER_SEQ), n_points)
     mats0, clusters0, _ = initial_segmentation(seq0[0], k_clusters, seed=0)      # shared frame-0 state (mlp_reg.py:242-253)
     seqs = [make_sequence(robot, sid, max(n_frames, FRAMES_PER_SEQ), n_points) for sid in seq_ids]
