@@ -175,22 +175,26 @@ struct NnBlocks { const float4* ts4; const float* tbox; int nblk; const int* nbl
 // visit the launch is VALU-issue bound, so the running best is one 64-bit key (distance bits : original index -- distances are
 // non-negative, their bit patterns order like the values) compared once per point, and the winner's coordinates are not carried
 // along but read from T by its index at the end.
-template <int NB, int PPL, typename Epi>
+// STOP / NBDEV: the flag / the device-side block count exist (compile time: as run-time null tests each became a branch with its own
+// scalar round trip in front of the first box load -- two dependent memory round trips per launch before the search had requested anything).
+template <int NB, int PPL, typename Epi, bool STOP = false, bool NBDEV = false>
 __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int sq, NnBlocks tb, int dir, Epi& epi, int blk,
                                                    const int* stop_flag = nullptr, const float* T = nullptr, int st = 0) {
     constexpr int QW = 4;
-    const int stop = stop_flag ? *stop_flag : 0;
+    int stop = 0;
+    if constexpr (STOP) stop = *stop_flag;
     __shared__ float s_partp[NN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q0 = (blk * (NN_BLOCK / 64) + wave) * QW;
-    const int nblk = tb.nblk_dev ? *tb.nblk_dev : tb.nblk;
+    int nblk = tb.nblk;
+    if constexpr (NBDEV) nblk = *tb.nblk_dev;
     float lox[NB], loy[NB], loz[NB], hix[NB], hiy[NB], hiz[NB];
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
         // (the box table is allocated for 64 * NB entries: no dependence of these loads on nblk_dev's round trip;
         //  entries past nblk get an infinite bound below)
-        const float* bx = tb.tbox + (tb.nblk_dev ? 64 * g + lane : min(64 * g + lane, nblk - 1));
+        const float* bx = tb.tbox + (NBDEV ? 64 * g + lane : min(64 * g + lane, nblk - 1));
         constexpr int BP = 64 * NB;                             // plane stride
         lox[g] = bx[0]; loy[g] = bx[BP]; loz[g] = bx[2 * BP]; hix[g] = bx[3 * BP]; hiy[g] = bx[4 * BP]; hiz[g] = bx[5 * BP];
     }
@@ -202,6 +206,20 @@ __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int s
     for (int u = 0; u < QW; ++u) {
         const int qi = min(q0 + u, nq - 1);
         qx[u] = Q[(size_t)qi * sq]; qy[u] = Q[(size_t)qi * sq + 1]; qz[u] = Q[(size_t)qi * sq + 2];
+    }
+    if constexpr (STOP || NBDEV) {
+        // wave-uniform values that arrive through vector loads (requested together with the boxes) go back to SGPRs: as VGPRs the four
+        // queries' coordinates cost the launch a wave per SIMD (82 registers instead of 71 at one point per lane)
+        stop = __builtin_amdgcn_readfirstlane(stop); nblk = __builtin_amdgcn_readfirstlane(nblk);
+#pragma unroll
+        for (int u = 0; u < QW; ++u) {
+            qx[u] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qx[u])));
+            qy[u] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qy[u])));
+            qz[u] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qz[u])));
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < QW; ++u) {
         float lm = INFINITY;
 #pragma unroll
         for (int g = 0; g < NB; ++g) {

@@ -577,12 +577,12 @@ __global__ __launch_bounds__(512) void k_sort_p(Dims D, Ws W0, size_t bstride) {
 struct EngineEpi {
     int* sgn_x; int4* cnt4; float* lossp_x; float* lossp_y;
     size_t bstride;
-    const int* stopped;            // &state[epoch & 1].stopped of problem 0 (nullptr: no early exit)
+    const int* stopped;            // &state[epoch & 1].stopped of problem 0
     __device__ __forceinline__ void shift(int z) {
         const size_t b = (size_t)z * bstride;
         sgn_x = (int*)((char*)sgn_x + b); cnt4 = (int4*)((char*)cnt4 + b);
         lossp_x = (float*)((char*)lossp_x + b); lossp_y = (float*)((char*)lossp_y + b);
-        if (stopped) stopped = (const int*)((const char*)stopped + b);
+        stopped = (const int*)((const char*)stopped + b);
     }
     __device__ __forceinline__ void operator()(int dir, int q, int idx, float d, float qx, float qy, float qz,
                                                float tx, float ty, float tz, float& acc) const {
@@ -608,6 +608,9 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_plan(const float* A, int na, co
     // grid.x = (blocksA + blocksB) * problems, direction 1 (the long blocks when it is exhaustive) of ALL problems
     // first: the dispatcher hands workgroups out in index order, so the long ones spread over the CUs before the
     // short ones fill in
+    // every kernel argument in the entry block, one wait (see k_bd)
+    asm volatile("" :: "s"(A), "s"(na), "s"(B), "s"(nb), "s"(blocksA), "s"(blocksB), "s"(epi.sgn_x), "s"(epi.cnt4), "s"(epi.lossp_x), "s"(epi.lossp_y),
+                 "s"(epi.bstride), "s"(epi.stopped), "s"(yb.ts4), "s"(yb.tbox), "s"(yb.nblk), "s"(pb.ts4), "s"(pb.tbox), "s"(pb.nblk_dev), "s"(zstride));
     const int nz = gridDim.x / (blocksA + blocksB);
     int i = blockIdx.x, z, bx;
     if (i < blocksB * nz) { z = i / blocksB; bx = blocksA + (i - z * blocksB); }
@@ -618,12 +621,12 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_plan(const float* A, int na, co
     yb.ts4 = (const float4*)((const char*)yb.ts4 + zb);
     yb.tbox = (const float*)((const char*)yb.tbox + zb);
     epi.shift(z);
-    if (bx < blocksA) nn_l1_block_pruned<NBT, PPL, EngineEpi>(A, na, 4, yb, 0, epi, bx, epi.stopped, B, 4);
+    if (bx < blocksA) nn_l1_block_pruned<NBT, PPL, EngineEpi, true, false>(A, na, 4, yb, 0, epi, bx, epi.stopped, B, 4);
     else if constexpr (P1) {
         pb.ts4 = (const float4*)((const char*)pb.ts4 + zb);
         pb.tbox = (const float*)((const char*)pb.tbox + zb);
         pb.nblk_dev = (const int*)((const char*)pb.nblk_dev + zb);
-        nn_l1_block_pruned<NBP, PPL, EngineEpi>(B, nb, 4, pb, 1, epi, bx - blocksA, epi.stopped, A, 4);
+        nn_l1_block_pruned<NBP, PPL, EngineEpi, true, true>(B, nb, 4, pb, 1, epi, bx - blocksA, epi.stopped, A, 4);
     } else nn_l1_block<4, int, EngineEpi>(A, na, 4, B, nb, 4, nullptr, nullptr, nullptr, nullptr, blocksA, epi, bx);
 }
 
