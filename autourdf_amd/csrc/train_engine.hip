@@ -263,6 +263,11 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2(Dims D, Ws W0, int par, size_
 // launch of its own and nothing is recomputed.
 template <int NC>
 __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bstride) {
+    // every kernel argument in the entry block, one wait (see k_bd)
+    asm volatile("" :: "s"(W0.P), "s"(W0.P1), "s"(W0.h2[0]), "s"(W0.h2[1]), "s"(W0.pose_in), "s"(W0.head_save), "s"(W0.m2), "s"(W0.pts4), "s"(W0.pred4),
+                 "s"(W0.psl4), "s"(W0.ps4), "s"(W0.pbox), "s"(W0.sb), "s"(W0.cnt4), "s"(W0.state), "s"(W0.off), "s"(D.rot), "s"(D.K), "s"(D.H2), "s"(D.HA),
+                 "s"(D.HB), "s"(D.OA), "s"(D.OB), "s"(D.NP), "s"(D.npb), "s"(D.ppl), "s"(D.nbp), "s"(D.oW3A), "s"(D.ob3A), "s"(D.oW3B), "s"(D.ob3B), "s"(par),
+                 "s"(bstride));
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
     const float* h2cur = par ? W.h2[1] : W.h2[0];
     const float* Pc = par ? W.P1 : W.P;
@@ -270,30 +275,36 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bst
     __shared__ float m2s[12];
     const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NO = D.OA + D.OB;
+    // Request order.  Round 3 issued, in this order, the pose row, the cluster's bounds, its first block, the first point (which needs
+    // the block index) and only then the operands of the dot products -- hipcc turned the wave-uniform ones into scalar loads and
+    // waited for them one after the other: FOUR dependent memory round trips in front of the dot products' loads.  Now the dot
+    // products' operands go out first (every wave: waves past the output units mirror the last one), then everything scalar.
+    const int o = min(wave, NO - 1);
+    const float *w, *a; int n;
+    if (o < D.OA) { w = Pc + D.oW3A + (size_t)o * D.HA; a = h2cur + (size_t)r * D.H2; n = D.HA; }
+    else { w = Pc + D.oW3B + (size_t)(o - D.OA) * D.HB; a = h2cur + (size_t)r * D.H2 + D.HA; n = D.HB; }
+    float wv[NC], av[NC];                          // n <= 64 NC: every load of the dot in flight at once
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { const int i = min(c * 64 + lane, n - 1); wv[c] = w[i]; av[c] = a[i]; }
+    const float bias = o < D.OA ? Pc[D.ob3A + o] : Pc[D.ob3B + o - D.OA];
+    __builtin_amdgcn_sched_barrier(0);
     const int stopped = W.state[par].stopped;      // early stop (mlp_reg.py:107-111): the remaining epochs of a captured graph
-                                                   // return at their first barrier (requested with the first loads: no extra wait)
-    // loads that do not depend on the dot products go first so they share its round trip
+                                                   // return at their first barrier
     float pin[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) pin[i] = W.pose_in[8 * r + i];
     const int b = W.off[r], e = W.off[r + 1];
     // block-sorted walk (D.npb): cluster r owns the slots of blocks [sb[r], sb[r + 1])
     const int BS = 64 * D.ppl;
-    const int s0 = D.npb ? BS * W.sb[r] : 0, s1 = D.npb ? BS * W.sb[r + 1] : 0;
+    const int sb0 = W.sb[r], sb1 = W.sb[r + 1];    // (unconditional, so that both come in the batch above: behind `D.npb ? ... : 0` they were two more dependent round trips)
+    const int s0 = D.npb ? BS * sb0 : 0, s1 = D.npb ? BS * sb1 : 0;
     const float4 p_first = D.npb ? W.psl4[min(s0 + (int)threadIdx.x, BS * D.npb - 1)] : W.pts4[min(b + (int)threadIdx.x, D.NP - 1)];
-    if (wave < NO) {
-        const int o = wave;
-        const float *w, *a; int n; float bias;
-        if (o < D.OA) { w = Pc + D.oW3A + (size_t)o * D.HA; a = h2cur + (size_t)r * D.H2; n = D.HA; bias = Pc[D.ob3A + o]; }
-        else { w = Pc + D.oW3B + (size_t)(o - D.OA) * D.HB; a = h2cur + (size_t)r * D.H2 + D.HA; n = D.HB; bias = Pc[D.ob3B + o - D.OA]; }
-        float wv[NC], av[NC];                      // n <= 64 NC: every load of the dot in flight at once
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { const int i = min(c * 64 + lane, n - 1); wv[c] = w[i]; av[c] = a[i]; }
+    {
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) s = fmaf(c * 64 + lane < n ? wv[c] : 0.f, av[c], s);
         s = wave_sum_fast(s) + bias;
-        if (lane == 0) outs[o] = s;
+        if (lane == 0 && wave < NO) outs[o] = s;
     }
     __syncthreads();
     if (stopped) return;
@@ -666,6 +677,12 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
     __shared__ float red[4][14];
     __shared__ float s_loss;
     __shared__ float s_go[16];
+    // every kernel argument in the entry block, one wait (see k_bd)
+    asm volatile("" :: "s"(W0.P), "s"(W0.P1), "s"(W0.h2[0]), "s"(W0.h2[1]), "s"(W0.head_save), "s"(W0.m2), "s"(W0.gm2), "s"(W0.pts4), "s"(W0.pred4),
+                 "s"(W0.sgn_x), "s"(W0.cnt4), "s"(W0.lossp_x), "s"(W0.lossp_y), "s"(W0.g_out), "s"(W0.g_h2), "s"(W0.state), "s"(W0.bc1), "s"(W0.bc2s),
+                 "s"(W0.best_m), "s"(W0.best_pred), "s"(W0.loss_hist), "s"(W0.lr_hist), "s"(W0.result), "s"(W0.off), "s"(W0.hyper),
+                 "s"(D.rot), "s"(D.K), "s"(D.H2), "s"(D.HA), "s"(D.HB), "s"(D.OA), "s"(D.OB), "s"(D.NP), "s"(D.NT), "s"(D.epochs), "s"(D.slope),
+                 "s"(D.oW3A), "s"(D.oW3B), "s"(epoch), "s"(nbx), "s"(nby), "s"(bstride));
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // ONE round trip for everything that does not depend on another load: the state (with the bias corrections of the
     // coming step), the cluster bounds, the hyper-parameters, the NN launch's loss partials, the pose row, and the
@@ -692,6 +709,14 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
         for (int j = 0; j < 8; ++j) w3v[q][j] = wb[(size_t)min(j, nj - 1) * stride];
         h2v[q] = h2cur[(size_t)k * D.H2 + o];
     }
+    // hipcc sinks a load into the block that uses it -- here past the early exit below, i.e. BEHIND the state's round trip: a use it
+    // cannot move keeps the whole batch above in one round trip with the state
+    asm volatile("" :: "v"(a), "v"(b), "v"(m2v), "v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]), "v"(sv[4]), "v"(sv[5]), "v"(sv[6]), "v"(sv[7]),
+                 "v"(sv[8]), "v"(sv[9]), "v"(sv[10]), "v"(sv[11]), "v"(sv[12]), "v"(sv[13]), "v"(sv[14]), "v"(sv[15]), "v"(b0), "v"(e0), "v"(hy.lr));
+#pragma unroll
+    for (int q = 0; q < GC_QMAX; ++q)
+        asm volatile("" :: "v"(h2v[q]), "v"(w3v[q][0]), "v"(w3v[q][1]), "v"(w3v[q][2]), "v"(w3v[q][3]), "v"(w3v[q][4]), "v"(w3v[q][5]), "v"(w3v[q][6]),
+                     "v"(w3v[q][7]));
     if (S.stopped) {
         if (k == 0 && tid == 0) W.state[(epoch + 1) & 1] = S;
         return;
