@@ -22,7 +22,7 @@ class TrainArgs(ctypes.Structure):
     _fields_ = [("m", vp), ("y", vp), ("local_pts", vp), ("seg_offsets", vp),
                 ("params", ctypes.POINTER(vp)), ("lr", f32), ("sched_factor", f32),
                 ("sched_patience", i32), ("stop", i32), ("best_m", vp), ("best_pred", vp),
-                ("loss_hist", vp), ("lr_hist", vp), ("result", vp)]
+                ("loss_hist", vp), ("lr_hist", vp), ("result", vp), ("y_unchanged", i32), ("reserved_", i32)]
 
 
 class IcpProblem(ctypes.Structure):

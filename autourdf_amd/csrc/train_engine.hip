@@ -1253,6 +1253,7 @@ struct Plan {
     size_t bstride;           // bytes between consecutive problems' workspaces
     int smem_bd;
     int branches;             // parallel chains in the captured graph (groups of problems)
+    bool target_blocks_valid; // ys4 / ybox hold the k-d leaves of every problem's last run_batch frame (probe / profile overwrite them)
 };
 
 static bool make_dims(const creg_train_shape* s, Dims* D) {
@@ -1447,9 +1448,9 @@ static int ps_sort_smem(const Dims& D) {       // a cluster can hold every point
     const int np = pow2_at_least((D.NP + BS - 1) / BS * BS);
     return (np < YS_CHUNK ? np : YS_CHUNK) * 8;
 }
-static void launch_sorts(Plan* P, hipStream_t s, int nz) {
+static void launch_sorts(Plan* P, hipStream_t s, int nz, bool keep_target_blocks = false) {
     const Dims& D = P->D;
-    if (D.nyb) hipLaunchKernelGGL(k_sort_y, dim3(cdiv(D.NT, YS_CHUNK), 1, nz), dim3(1024), ys_sort_smem(D), s, D, P->W, P->bstride, ys_sort_npow(D));
+    if (D.nyb && !keep_target_blocks) hipLaunchKernelGGL(k_sort_y, dim3(cdiv(D.NT, YS_CHUNK), 1, nz), dim3(1024), ys_sort_smem(D), s, D, P->W, P->bstride, ys_sort_npow(D));
     if (D.npb) hipLaunchKernelGGL(k_sort_p, dim3(D.K, 1, nz), dim3(512), ps_sort_smem(D), s, D, P->W, P->bstride);
 }
 
@@ -1590,7 +1591,7 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     P->branches = shape->graph_branches > 0 ? shape->graph_branches : auto_branches;
     if (P->branches > P->B) P->branches = P->B;
     if (P->branches > 8) P->branches = 8;
-    P->gexec = nullptr; P->graph_ready = false;
+    P->gexec = nullptr; P->graph_ready = false; P->target_blocks_valid = false;
     {   // the dynamic LDS of k_bd is the B role's (71 KB at K = 20, hidden 512: its 48 KB slab of W2 + 23 KB; the D role uses none)
         P->smem_bd = (int)(sizeof(float) * b2_smem_floats(D.K, D.IN, D.H2));
     }
@@ -1625,7 +1626,12 @@ extern "C" int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train
         int rc = stage_inputs(P, args, n, s);
         if (rc) return rc;
     }
-    launch_sorts(P, s, P->B);
+    {   // the target frame's k-d leaves survive from the previous run when the caller vouches for every problem's frame
+        bool keep = P->target_blocks_valid;
+        for (int b = 0; b < n; ++b) keep = keep && args[b].y_unchanged != 0;
+        launch_sorts(P, s, P->B, keep);
+        P->target_blocks_valid = true;
+    }
     P->nz = P->B;
     int e = 0;
     if (P->shape.use_graph && D.epochs >= 2) {
@@ -1674,6 +1680,7 @@ extern "C" int creg_train_plan_probe(creg_train_plan* plan, const creg_train_arg
     const Dims& D = P->D; const Ws& W = P->W;
     int rc = stage_inputs(P, a, 1, s);
     if (rc) return rc;
+    P->target_blocks_valid = false;
     launch_sorts(P, s, 1);
     P->nz = 1;
     launch_head(P, 0, s);
@@ -1702,6 +1709,7 @@ extern "C" int creg_train_plan_profile(creg_train_plan* plan, const creg_train_a
     std::vector<creg_train_args> all((size_t)nzb, *a);
     int rc = stage_inputs(P, all.data(), nzb, s);
     if (rc) return rc;
+    P->target_blocks_valid = false;
     launch_sorts(P, s, nzb);
     P->nz = nzb;
     std::vector<hipEvent_t> ev((size_t)(NKERN + 1) * n_epochs);
@@ -1794,9 +1802,9 @@ extern "C" int creg_train_plan_info(const creg_train_plan* plan, creg_train_plan
     info->graph_branches = P->branches;
     info->batch = P->B;
     info->epochs_per_graph = P->shape.use_graph ? P->graph_epochs : 0;
-    info->reserved[0] = P->D.ppl;        /* points per lane and block visit of the pruned search (1: blocks of 64, 4: blocks of 256) */
-    info->reserved[1] = P->D.nbt;        /* boxes per lane: target frame, predicted cloud (the k_nn_plan instance) */
-    info->reserved[2] = P->D.nbp;
+    info->nn_points_per_lane = P->D.ppl;
+    info->nn_boxes_target = P->D.nbt;
+    info->nn_boxes_predicted = P->D.nbp;
     return CREG_OK;
 }
 

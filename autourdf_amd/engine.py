@@ -66,7 +66,7 @@ class SequenceRegistrar:
         """Register the next frame ((N,3) fp64 on the device).  Returns (poses (K,4,4) fp32, result (4))."""
         y = frame32 if frame32 is not None else frame64.to(torch.float32)
         m1, _, _, _, _ = self.plan.run(self.m, y, self.pts, self.off, self.p_step, lr=2e-4)            # "Step"
-        m2, _, res, _, _ = self.plan.run(m1, y, self.pts_init, self.off_init, self.p_anchor, lr=1e-4)  # "Anchor"
+        m2, _, res, _, _ = self.plan.run(m1, y, self.pts_init, self.off_init, self.p_anchor, lr=1e-4, same_target=True)  # "Anchor": the frame's k-d leaves are Step's
         ev = self.host_inverse.mark()
         _, labels, _, _ = ops.kmeans_lloyd(frame64, m2[:, :3, 3].to(torch.float64).contiguous())
         local, self.off = ops.group_to_local(frame64, labels, self.host_inverse(m2, ev), m_is_inverse=True)
@@ -98,18 +98,19 @@ class BatchRegistrar:
                                   use_graph=use_graph, device=self.device, batch=n_sequences, graph_branches=graph_branches,
                                  nn_search=nn_search)
 
-    def _train(self, problems, lr):
+    def _train(self, problems, lr, same_target=False):
         """One batched `train` (mlp_reg.py:17-152) of the S problems (m, y, pts, offsets, params); a seam so the
         match-level golden test can replay the reference's loop with the deterministic stub the golden was minted
-        with (tests/_match_stub.py).  Returns per problem (best_m, best_pred, result, ...)."""
-        return self.plan.run_batch(problems, lr=lr, stop=getattr(self, "stop", 200))
+        with (tests/_match_stub.py).  Returns per problem (best_m, best_pred, result, ...).  same_target: "Anchor" right
+        after "Step" on the same frames -- the plan keeps the frames' k-d leaf blocks."""
+        return self.plan.run_batch(problems, lr=lr, stop=getattr(self, "stop", 200), same_target=same_target)
 
     def step(self, frames64, frames32=None):
         """frames64: list of S (N,3) fp64 device tensors (the next frame of every sequence)."""
         ys = frames32 if frames32 is not None else [f.to(torch.float32) for f in frames64]
         step = self._train([(r.m, y, r.pts, r.off, r.p_step) for r, y in zip(self.seqs, ys)], lr=2e-4)
         anchor = self._train([(o[0], y, r.pts_init, r.off_init, r.p_anchor)
-                              for r, y, o in zip(self.seqs, ys, step)], lr=1e-4)
+                              for r, y, o in zip(self.seqs, ys, step)], lr=1e-4, same_target=True)
         out = []
         # epochs each train ran (result[1]; < the plan's epochs after an early stop) -- bench.py reports them
         self.last_epochs = (torch.stack([o[2][1] for o in step]), torch.stack([o[2][1] for o in anchor]))

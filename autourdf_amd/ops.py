@@ -643,14 +643,16 @@ class TrainPlan:
                 torch.empty(self.epochs, dtype=torch.float32, device=dev),
                 torch.empty(4, dtype=torch.float32, device=dev))
 
-    def run(self, m, y, pts, offsets, params, lr=2e-4, factor=0.7, patience=5, stop=200):
+    def run(self, m, y, pts, offsets, params, lr=2e-4, factor=0.7, patience=5, stop=200, same_target=False):
         """Returns (best_m (k,4,4), best_pred (n_pred,3), result (4) = [min_loss, epochs_run, lr,
         best_epoch], loss_hist (epochs), lr_hist (epochs)); all device tensors, stream-ordered."""
-        return self.run_batch([(m, y, pts, offsets, params)], lr, factor, patience, stop)[0]
+        return self.run_batch([(m, y, pts, offsets, params)], lr, factor, patience, stop, same_target)[0]
 
-    def run_batch(self, problems, lr=2e-4, factor=0.7, patience=5, stop=200):
+    def run_batch(self, problems, lr=2e-4, factor=0.7, patience=5, stop=200, same_target=False):
         """problems: list of `batch` tuples (m, y, pts, offsets, params) of identical shape, advanced
-        together (one launch carries all of them).  Returns one result tuple per problem, as `run`."""
+        together (one launch carries all of them).  Returns one result tuple per problem, as `run`.
+        same_target: the caller vouches that every problem's `y` holds the values of this plan's previous run of that slot
+        ("Anchor" after "Step" on the same frame, mlp_reg.py:338-356): the frame's k-d leaf blocks are kept instead of rebuilt."""
         if len(problems) != self.batch:
             raise ValueError(f"this plan advances {self.batch} problems per launch, got {len(problems)}")
         arr = (_lib.TrainArgs * self.batch)()
@@ -658,6 +660,7 @@ class TrainPlan:
         for b, (m, y, pts, offsets, params) in enumerate(problems):
             best_m, best_pred, lh, lrh, result = o = self._outs()
             arr[b] = self._args(m, y, pts, offsets, params, lr, factor, patience, stop, o)
+            arr[b].y_unchanged = 1 if same_target else 0
             padded.append(self._padded)
             outs.append((best_m, best_pred, result, lh, lrh))
         _lib.check(self.L.creg_train_plan_run_batch(self.plan, arr, self.batch, _stream()), "creg_train_plan_run_batch")

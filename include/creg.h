@@ -321,9 +321,10 @@ typedef struct creg_train_shape {
                                batch >= 2; 3 when batch >= 3 and n_tgt > 4096, where the NN searches dominate),
                                1 = single chain.  Results do not depend on it. */
     int32_t nn_search;    /* 0 = auto: the nearest-neighbour searches run over k-d leaf blocks with boxes (exact
-                             pruning) when n_tgt <= 16384 (and, for the target -> predicted direction, when the
-                             predicted cloud fits 128 blocks); 1 = exhaustive in both directions.  Results do not
-                             depend on it. */
+                             pruning) when n_tgt <= 65536 (four chunks of 16384 sorted per workgroup) and, for the
+                             target -> predicted direction, when the predicted cloud fits 512 blocks (n_pred / 64 + k,
+                             or n_pred / 256 + k above 4096 targets) with n_pred < 65535; 1 = exhaustive in both
+                             directions.  Results do not depend on it (creg_train_plan_info says what a plan chose). */
 } creg_train_shape;
 
 typedef struct creg_train_args {
@@ -341,6 +342,11 @@ typedef struct creg_train_args {
     float* loss_hist;           /* (epochs) out, entries after an early stop are NaN; may be NULL */
     float* lr_hist;             /* (epochs) out (lr used by that epoch's Adam step); may be NULL */
     float* result;              /* (4) out: [min_loss, epochs_run, final_lr, best_epoch] */
+    int32_t y_unchanged;        /* != 0: the caller guarantees that `y` holds the values it held in this plan's PREVIOUS run of this problem
+                                   slot -- match() registers every frame twice, "Step" then "Anchor" (mlp_reg.py:338-356).  When every
+                                   problem of a call says so the plan keeps the target frame's k-d leaf blocks (one bitonic sort per
+                                   frame instead of one per train: 145 us at 4096 points, 673 us at 16384).  0 is always correct. */
+    int32_t reserved_;
 } creg_train_args;
 
 typedef struct creg_train_plan creg_train_plan;
@@ -354,8 +360,9 @@ typedef struct creg_train_plan_info_t {
     int32_t graph_branches;           /* parallel chains in the captured graph */
     int32_t batch;                    /* problems the plan advances per run_batch call */
     int32_t epochs_per_graph;         /* 0: eager launches */
-    int32_t reserved[3];              /* [0]: points per lane and block visit of the pruned search (1: 64-point blocks, 4: 256-point blocks);
-                                         [1], [2]: boxes per lane of the search over the target frame / the predicted cloud */
+    int32_t nn_points_per_lane;       /* points per lane and block visit of the pruned search (1: 64-point blocks, 4: 256-point blocks) */
+    int32_t nn_boxes_target;          /* boxes per lane of the search over the target frame (the k_nn_plan instance) */
+    int32_t nn_boxes_predicted;       /* ... and over the predicted cloud */
 } creg_train_plan_info_t;
 
 size_t creg_train_workspace_bytes(const creg_train_shape* shape);   /* covers shape.batch problems */

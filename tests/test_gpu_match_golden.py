@@ -61,7 +61,7 @@ def test_batch_registrar_replays_reference_golden(golden, tag, mlp_icp):
     reg = BatchRegistrar(np.asarray(g["mats0"], np.float32), clusters0, frames[0].shape[0], S, "q", 64, 2, True, dev)
     stubs = [TrainStub() for _ in range(S)]
 
-    def stub_train(problems, lr):
+    def stub_train(problems, lr, same_target=False):
         outs = []
         for r, st, (m, y, pts, off, params) in zip(reg.seqs, stubs, problems):
             o = off.cpu().numpy()

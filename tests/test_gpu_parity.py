@@ -716,6 +716,42 @@ def test_train_c1_divergence_stays_inside_the_measured_oracle_envelope(dev, gold
     assert float(np.abs(bm.cpu().numpy()[:, :3, :] - g["e300_best_m"][:, :3, :]).max()) <= 2.0 * float(env["best_pose_envelope"])
 
 
+def test_train_same_target_keeps_the_frames_leaves_bit_identical(dev):
+    """creg_train_args.y_unchanged (ops: same_target=True): "Anchor" after "Step" on the same frame keeps the target frame's k-d leaf
+    blocks instead of sorting the frame again -- every output bit of the second train is what a rebuilding run gives, single and
+    batched, also right after a probe (which overwrites the blocks and must invalidate them)."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    from oracle import models
+    seq = make_sequence("wx200_5", 31, 3, 1500)
+    mats, cl, _ = initial_segmentation(seq[0], 7, seed=2)
+    m = torch.tensor(mats, dtype=torch.float32, device=dev)
+    pts, off = ops.pack_clusters([torch.tensor(c, dtype=torch.float32) for c in cl], dev)
+    ys = [torch.tensor(seq[i], dtype=torch.float32, device=dev) for i in (1, 2)]
+    torch.manual_seed(5)
+    sds = [models.QRegMLP(True, 64).state_dict() for _ in range(4)]
+
+    def params(i):
+        return [sds[i][k].clone().to(dev) for k in ops.Q_PARAM_ORDER]
+
+    for batch in (1, 2):
+        outs = {}
+        for keep in (False, True):
+            plan = ops.TrainPlan("q", 7, 64, pts.shape[0], ys[0].shape[0], epochs=12, use_graph=True, device=dev, batch=batch)
+            probs = lambda base, mm: [(mm[b], ys[b % 2], pts, off, params(base + b)) for b in range(batch)]
+            step = plan.run_batch(probs(0, [m] * batch), lr=2e-4)
+            anchor = plan.run_batch(probs(2, [o[0] for o in step]), lr=1e-4, same_target=keep)
+            outs[keep] = [torch.cat([t.reshape(-1) for t in o[:4]]) for o in anchor]
+            if keep:                               # a probe rebuilds the blocks for ITS frame: the flag must not trust them afterwards
+                plan.probe(m, ys[1], pts, off, params(3))
+                again = plan.run_batch(probs(2, [o[0] for o in step]), lr=1e-4, same_target=True)
+                for a, b in zip(outs[True], again):
+                    assert torch.equal(a, torch.cat([t.reshape(-1) for t in b[:4]]))
+            torch.cuda.synchronize()
+        for a, b in zip(outs[False], outs[True]):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("rot", ["q", "dq"])
 def test_train_hidden32_reference_golden_runs_on_the_plan(dev, golden, rot):
     """tests/golden/train_reference.npz is the reference's own train() at hidden 32 (300 epochs) -- a width the kernels are not
