@@ -648,7 +648,7 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
             }
             // every lane of the source knows the winner; lane 0 records it, lanes 0..3 share the 17 moments between them
             // (5 + 5 + 5 + 2: a quarter of the wave reductions below for each)
-            const bool ok = live && bm >= 0 && best <= th2;
+            const bool ok = live && bm >= 0 && best < th2;          // strict: open3d KDTreeFlann::SearchHybrid keeps d^2 < r^2
             if (live && lg_g == 0) nn[i] = ok ? bm : -1;
             if (ok && lg_g < 4) {
                 const double sv[3] = {s0 - shc[0], s1 - shc[1], s2 - shc[2]};
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
                 best = sB[pi]; bm = sM[pi];
 #pragma unroll
                 for (int q = 1; q < ICP_PARTS; ++q) { const double d = sB[q * ICP_ROWS + pi]; if (d < best) { best = d; bm = sM[q * ICP_ROWS + pi]; } }
-                const bool ok = bm >= 0 && best <= th2;
+                const bool ok = bm >= 0 && best < th2;
                 nn[i] = ok ? bm : -1;
                 if (ok) {
                     double sv[3], dv[3];
@@ -1655,7 +1655,7 @@ __global__ __launch_bounds__(64 * ICP_NNW, 3) void k_icp_nn(IcpLarge P, int n, i
     double cm[ICP_NM];
     for (int a = 0; a < ICP_NM; ++a) cm[a] = 0;
     if (live && g == 0) {
-        const bool ok = bj != 0x7fffffff && best <= th2;
+        const bool ok = bj != 0x7fffffff && best < th2;
         P.nn[i] = ok ? bj : -1;
         if (ok) {
             P.prevt[3 * (size_t)i] = bx; P.prevt[3 * (size_t)i + 1] = by; P.prevt[3 * (size_t)i + 2] = bz;

@@ -22,6 +22,7 @@
 // labels identical to the full sweep), and a persistent kernel (k_km_persist) iterates inside ONE launch with the points and
 // labels in registers -- 38 -> 17 us per Lloyd iteration at N = 262144, K = 128.  The matrix-core form keeps the full sweep
 // in the caller's order, one launch per iteration; both give identical labels, centres, inertia and iteration counts.
+#include <atomic>
 #include <cstdlib>
 #include "creg_common.h"
 #include "creg_dev.h"
@@ -925,13 +926,30 @@ __global__ __launch_bounds__(256, PT == 2 ? 3 : PT == 4 ? 2 : 1) void k_km_persi
         if (!last_wg) { if (tid == 0) st_agent(T.slots + blockIdx.x, (want << 32) | (unsigned long long)(blk_changed != 0)); }
         else {
             int spins = 0, ok;
+            bool gave_up = false;
             do {
                 int mine = 1;
                 for (int i = tid; i < (int)gridDim.x; i += 256)
                     if (i > 0) { const unsigned long long v = ld_agent(T.slots + i); mine &= (v >> 32) == want; any_changed |= mine ? (int)(v & 1ull) : 0; }
                 ok = __syncthreads_and(mine);
-                if (!ok && (++spins >= T.spin_limit || ((spins & 63) == 0 && ld_agent(&f->abort)))) { if (tid == 0) st_agent(&f->abort, 1); break; }
+                if (!ok) {
+                    // block-uniform decision (`spins` is): ONE thread reads the abort word and the barrier spreads it -- per-thread reads
+                    // could disagree and leave part of the workgroup in the barrier above while the rest had left the loop
+                    int ab = ++spins >= T.spin_limit;
+                    if ((spins & 63) == 0) ab |= __syncthreads_or(tid == 0 ? ld_agent(&f->abort) : 0);
+                    if (ab) { gave_up = true; break; }
+                }
             } while (!ok);
+            if (gave_up) {
+                // nothing of this attempt is used (the host sees `abort` and starts the call over): tell the others to leave NOW
+                // -- generation `want` with the leave bit -- instead of letting each of them spin to its own limit, and return
+                // without running a tail on partial sums
+                if (tid == 0) {
+                    st_agent(&f->abort, 1);
+                    for (int r = 0; r < KMP_GENREP; ++r) st_agent(T.genrep + (size_t)r * KMP_GENREP_STRIDE, (want << 8) | 1ull);
+                }
+                return;
+            }
             any_changed = __syncthreads_or(any_changed);
         }
         KM_PP(3);
@@ -1662,6 +1680,7 @@ extern "C" size_t creg_kmeans_workspace_bytes(int64_t n, int32_t k) {
 }
 
 constexpr int KM_RETRY_WITHOUT_PERSIST = 1000;
+constexpr int KM_PERSIST_BACKOFF = 64;       // calls that skip the persistent kernel after an abandoned attempt
 static int km_lloyd_run(const double* X, int64_t n, const double* init, int32_t k,
                         int32_t max_iter, double tol_rel, int32_t use_mfma, double* centers,
                         int32_t* labels, double* inertia, int32_t* n_iter, void* workspace,
@@ -1761,9 +1780,17 @@ extern "C" int creg_kmeans_lloyd_f64(const double* X, int64_t n, const double* i
                                      int32_t max_iter, double tol_rel, int32_t use_mfma, double* centers,
                                      int32_t* labels, double* inertia, int32_t* n_iter, void* workspace,
                                      size_t workspace_bytes, creg_stream_t stream) {
-    int rc = km_lloyd_run(X, n, init, k, max_iter, tol_rel, use_mfma, centers, labels, inertia, n_iter, workspace, workspace_bytes, stream, true);
-    if (rc == KM_RETRY_WITHOUT_PERSIST)
+    // A persistent attempt that had to be abandoned (the device was kept busy by other streams, so the grid was not resident
+    // together) costs a spin of ~1 s before it is noticed: after one, the next KM_PERSIST_BACKOFF calls of this process go
+    // straight to one launch per iteration before the persistent kernel is tried again.
+    static std::atomic<int> backoff{0};
+    const bool try_persist = backoff.load(std::memory_order_relaxed) <= 0;
+    if (!try_persist) backoff.fetch_sub(1, std::memory_order_relaxed);
+    int rc = km_lloyd_run(X, n, init, k, max_iter, tol_rel, use_mfma, centers, labels, inertia, n_iter, workspace, workspace_bytes, stream, try_persist);
+    if (rc == KM_RETRY_WITHOUT_PERSIST) {
+        backoff.store(KM_PERSIST_BACKOFF, std::memory_order_relaxed);
         rc = km_lloyd_run(X, n, init, k, max_iter, tol_rel, use_mfma, centers, labels, inertia, n_iter, workspace, workspace_bytes, stream, false);
+    }
     return rc;
 }
 

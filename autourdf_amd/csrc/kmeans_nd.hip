@@ -41,6 +41,7 @@ __global__ __launch_bounds__(KND_NT) void k_km_nd(const double* __restrict__ X, 
     unsigned short* lab[2] = {lab0, lab0 + n};
     __shared__ double sc[16], s_mean[DIM], s_tol, s_fscale, s_finv, s_dmax, s_fv[16];
     __shared__ int s_changed, s_done, s_strict, s_it, s_nempty, s_argmax, s_fi[16];
+    __shared__ unsigned char s_emp[128];                          // (k <= 128) the clusters that were empty when the relocation started
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // ---- mean, variance -> tol, range -> fixed-point scale
     for (int d = 0; d < DIM; ++d) {
@@ -163,8 +164,13 @@ __global__ __launch_bounds__(KND_NT) void k_km_nd(const double* __restrict__ X, 
             if (tid == 0) { double m = 0; for (int q = 0; q < 16; ++q) m = fmax(m, sc[q]); s_dmax = m; }
             __syncthreads();
             if (s_dmax > 0) {
+                // the list of empty clusters is FIXED before anything moves (sklearn's _relocate_empty_clusters_dense takes
+                // np.where(weight_in_clusters == 0) first): a cluster that a relocation empties -- its only point was the farthest one --
+                // is not relocated in this pass (round 3 re-tested the count while walking and relocated it too)
+                if (tid < k) s_emp[tid] = Cw[(size_t)tid * BW + DIM] == 0.0;
+                __syncthreads();
                 for (int j = 0; j < k; ++j) {
-                    if (Cw[(size_t)j * BW + DIM] != 0.0) continue;      // block-uniform (LDS value)
+                    if (!s_emp[j]) continue;                            // block-uniform (LDS value)
                     double bv = -1; int bi = 0x7fffffff;
                     for (int i = tid; i < n; i += KND_NT) if (far_d[i] > bv) { bv = far_d[i]; bi = i; }
                     for (int off = 32; off >= 1; off >>= 1) {

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_l1(Dims D, Ws W0, int par, size_t bstri
     const float b = W.P[D.ob1 + o];
     for (int r = 0; r < D.K; ++r) {
         const float v = wave_sum_fast(lane < D.IN ? w * W.enc[(size_t)r * D.IN + lane] : 0.f) + b;
-        if (lane == 0) W.x1[par][(size_t)r * D.H + o] = act_f(v, D.slope);
+        if (lane == 0) (par ? W.x1[1] : W.x1[0])[(size_t)r * D.H + o] = act_f(v, D.slope);      // (a runtime index into the shifted struct put all of it -- 312 bytes a lane -- into scratch)
     }
 }
 
@@ -651,8 +651,13 @@ __device__ __forceinline__ TrainState advance_state(const TrainState& S, float l
     const bool improved = loss < S.min_loss;
     N.last_loss = loss;
     N.epochs_run = S.epochs_run + 1;
-    if (improved) { N.min_loss = loss; N.count = 0; N.best_epoch = S.epochs_run; }
-    else { N.count = S.count + 1; if (N.count > hy.stop) N.stopped = 1; }            // mlp_reg.py:107-111
+    // (selects of values, not conditional stores into N: hipcc turned those into ONE store through a computed address into a stack
+    //  copy of the struct -- 16 bytes of scratch per lane and a scratch round trip in the middle of the kernel)
+    const int count = improved ? 0 : S.count + 1;
+    N.min_loss = improved ? loss : S.min_loss;
+    N.best_epoch = improved ? S.epochs_run : S.best_epoch;
+    N.count = count;
+    N.stopped = (!improved && count > hy.stop) ? 1 : S.stopped;                      // mlp_reg.py:107-111
     if (!N.stopped) {
         // optimizer.step() of this epoch uses S.lr (torch.optim.Adam, betas (0.9, 0.999), eps 1e-8)
         N.step = S.step + 1;
@@ -795,8 +800,10 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
             const float nrm = sv[4];
             if (nrm > 1e-12f) {
                 const float dot = sv[0] * gu[0] + sv[1] * gu[1] + sv[2] * gu[2] + sv[3] * gu[3];
+#pragma unroll
                 for (int i = 0; i < 4; ++i) go[4 + i] = (gu[i] - sv[i] * dot) / nrm;
             } else {
+#pragma unroll
                 for (int i = 0; i < 4; ++i) go[4 + i] = gu[i] / 1e-12f;
             }
         } else {

@@ -341,6 +341,8 @@ def _shard_for_rank(dirs):
 
 
 def main(argv=None):
+    from . import prefer_device_kernargs
+    prefer_device_kernargs()                    # (the command-line entry point: before the first device call)
     global DEVICE, ROBOT, NUM_SEG, DOF, STEP_SZIE, NUM_CAMERAS, MLP_ICP, VIS, ROT, LOSS, NORMAL, RAW_PATH_LIST
     if not torch.cuda.is_available():
         raise RuntimeError("autourdf_amd.mlp_reg needs an MI355X: no GPU is visible and there is no CPU path")

@@ -27,9 +27,9 @@ def estimate_normals(points, radius=0.1, max_nn=30):
 
 
 def _tree_order(n, rows, cols, w, start):
-    """Minimum spanning forest of the weighted graph, then (order, parent) of a breadth-first walk from `start` followed by
-    the other components' highest points (open3d walks one component; a cloud whose Riemannian graph is disconnected keeps
-    the solver's signs elsewhere -- here every further component is rooted at its own first vertex, unflipped)."""
+    """Minimum spanning forest of the weighted graph, then (order, parent) of a breadth-first walk from `start` over ITS component
+    (open3d walks one component too: where the Riemannian graph of a cloud is disconnected, the other components keep the signs the
+    eigen-solver gave them -- they do not appear in `order`)."""
     from scipy.sparse import coo_matrix
     from scipy.sparse.csgraph import breadth_first_order, minimum_spanning_tree
     g = coo_matrix((w + 1.0, (rows, cols)), shape=(n, n)).tocsr()       # + 1: an MST is invariant under it, and a zero weight

@@ -147,6 +147,10 @@ def kmeans_lloyd_nd(X: torch.Tensor, init: torch.Tensor, max_iter: int = 300, to
     n, d, k = X.shape[0], X.shape[1], init.shape[0]
     if init.shape[1] != d:
         raise ValueError("kmeans_lloyd_nd: X and init disagree on the feature count")
+    if n > KMEANS_ND_MAX_N or k > KMEANS_ND_MAX_K:
+        raise ValueError(f"the --normal re-segmentation (k-means over [xyz | 0.5 normal]) runs in one workgroup: frames of at most "
+                         f"{KMEANS_ND_MAX_N} points and {KMEANS_ND_MAX_K} clusters, got {n} points / {k} clusters (the reference's sklearn "
+                         "k_means has no such limit: down-sample the frames -- Segments(sample_size=...) -- or run without --normal)")
     ws_bytes = L.creg_kmeans_nd_workspace_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
     centers = torch.empty(k, d, dtype=torch.float64, device=X.device)
@@ -173,6 +177,7 @@ def knn_normals(X: torch.Tensor, radius: float, max_nn: int, want_normals: bool 
     return normals, idx, cnt
 
 
+KMEANS_ND_MAX_N, KMEANS_ND_MAX_K = 16384, 128      # creg_kmeans_lloyd_nd_f64: labels + centres of one frame in one CU's LDS
 KMEANS_BATCH_MAX_N = 16384         # labels + centres in one CU's LDS; the frame too up to 5120 points, from L2 above
 
 

@@ -28,6 +28,7 @@ import time
 
 # kernel arguments in device memory: this image's HIP runtime does so by default; with HIP_FORCE_DEV_KERNARG=0 every launch reads its
 # arguments from host memory and the headline measured 123 instead of 149 frames/s.  Only a default -- an explicit setting is respected.
+# (An entry point sets it, before the HIP runtime starts; importing autourdf_amd does not touch the environment.)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import numpy as np  # noqa: E402
@@ -82,13 +83,37 @@ def cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters, budget_frames=2, 
     per_epoch = (elapsed - t_km) / max(epochs_done, 1)
     frame_s = elapsed / frames_done if frames_done else float("nan")
     # the same port on ONE host thread (SURVEY 8(d) asks for both), a few epochs only
+    from oracle import _clib
     os.environ["OMP_NUM_THREADS"] = "1"
     torch.set_num_threads(1)
+    _clib.lib().oracle_set_threads(1)
     t1 = time.perf_counter()
     registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=6)
     per_epoch_1 = (time.perf_counter() - t1) / 6
+    # ... and on ALL hardware threads of the box ("all host cores and 1"): two epochs, the first one untimed.  This is
+    # the slow configuration -- the work of an epoch (a 4096 x 4096 nearest-neighbour search, a 20-row MLP) is far too small for a
+    # 256-thread fork-join -- and it is why `value` is taken at 16 threads; the figure is reported, not used.
+    all_cores = None
+    ncpu = os.cpu_count() or 1
+    if ncpu > threads:
+        os.environ["OMP_NUM_THREADS"] = str(ncpu)
+        torch.set_num_threads(ncpu)
+        _clib.lib().oracle_set_threads(ncpu)
+        t2 = time.perf_counter()
+        registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=1)
+        t_first = time.perf_counter() - t2
+        if t_first < 5.0:
+            t2 = time.perf_counter()
+            registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=2)
+            per_epoch_all = (time.perf_counter() - t2) / 2
+        else:
+            per_epoch_all = t_first
+        all_cores = {"threads": ncpu, "ms_per_epoch": round(per_epoch_all * 1e3, 2),
+                     "value": 1.0 / (2 * EPOCHS * per_epoch_all + t_km / max(frames_done, 1)),
+                     "sample": "1-2 epochs after one untimed, extrapolated to 600 + the measured resample"}
     torch.set_num_threads(threads)
     os.environ["OMP_NUM_THREADS"] = str(threads)
+    _clib.lib().oracle_set_threads(threads)
     cpu_model = ""
     try:
         cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
@@ -97,6 +122,9 @@ def cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters, budget_frames=2, 
     return {"value": 1.0 / frame_s, "unit": "frames/s", "cores": threads, "kind": "port",
             "one_thread": {"value": 1.0 / (2 * EPOCHS * per_epoch_1 + t_km / max(frames_done, 1)), "ms_per_epoch": round(per_epoch_1 * 1e3, 2),
                            "sample": "6 epochs, extrapolated to 600 + the measured resample"},
+            "all_cores": all_cores,
+            "cores_note": f"{threads} threads is the FASTEST team on this host for a latency-sized epoch (measured: see all_cores and one_thread); "
+                          "the port's OpenMP C search is also faster than pytorch3d's single-threaded knn_cpu, so the GPU / CPU ratio is conservative",
             "host": {"cpu_model": cpu_model, "os_cpu_count": os.cpu_count()},
             "sample": f"{frames_done} full registered frame(s) of sequence 0 (N={n_points}, K={k_clusters}, hidden {HIDDEN}): {epochs_done} Adam "
                       f"epochs at {per_epoch * 1e3:.2f} ms/epoch + {frames_done} resample_cluster at {t_km / max(frames_done, 1) * 1e3:.1f} ms, "

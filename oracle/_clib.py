@@ -32,5 +32,7 @@ def lib() -> ctypes.CDLL:
         L.oracle_kmeans_lloyd_f64.restype = ctypes.c_int
         L.oracle_fps_f64.argtypes = [vp, i64, i64, vp]
         L.oracle_fps_f64.restype = None
+        L.oracle_set_threads.argtypes = [i32]
+        L.oracle_set_threads.restype = None
         _lib = L
     return _lib

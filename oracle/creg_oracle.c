@@ -23,6 +23,11 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
+
+/* team size of the parallel loops below (bench.py's cpu_baseline times the port at 16, 1 and all host threads: the environment
+ * variable is only read when the OpenMP runtime starts) */
+void oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 /* ---------------------------------------------------------------- NN, L1, K=1 */
 void oracle_nn_l1_f32(const float* x, int64_t nx, const float* y, int64_t ny,

@@ -35,7 +35,7 @@ def _correspond(src_w: np.ndarray, tgt: np.ndarray, th: float):
     d2 = ((src_w[:, None, :] - tgt[None, :, :]) ** 2).sum(-1)
     j = d2.argmin(1)
     dmin = d2[np.arange(len(src_w)), j]
-    ok = dmin <= th * th
+    ok = dmin < th * th                      # strict: open3d KDTreeFlann::SearchHybrid keeps d^2 < r^2 (lower_bound on the sorted distances)
     i = np.nonzero(ok)[0]
     n = len(i)
     fitness = n / len(src_w)

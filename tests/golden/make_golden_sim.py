@@ -1,10 +1,13 @@
-"""Mint tests/golden/sim_angle_list.npz (run in the BUILD CONTAINER only).
+"""Mint tests/golden/sim_angle_list.npz and tests/golden/sim_cameras.npz (run in the BUILD CONTAINER only).
 
     python tests/golden/make_golden_sim.py
 
 Source of truth: the reference's own ``angle_list`` (Sim/sim_data.py:372-430) imported with empty stubs for
 pybullet / pybullet_data (module-top imports it never touches) and the open3d shim.  Fixture = inputs +
-expected outputs only.
+expected outputs only.  sim_cameras.npz: the reference's own ``SimEnv._setup_cameras`` (Sim/sim_data.py:85-116), called unbound on
+an empty object (it only writes ``self.cameras``) for rings of fewer than 20 cameras (evenly spaced, 20 degrees elevation) and of
+20 or more (drawn from numpy's global RandomState, seeded here) -- the part of the reference's data generation that IS plain numpy;
+the depth rendering behind it (PyBullet + OpenGL) is not.
 """
 import os
 import sys
@@ -36,6 +39,20 @@ def main():
     path = os.path.join(HERE, "sim_angle_list.npz")
     np.savez_compressed(path, **out)
     print(f"sim_angle_list.npz {os.path.getsize(path) / 1024:.1f} KB")
+    cams = {}
+    for tag, (radius, n, seed) in {"r3": (1.5, 3, 0), "r8": (1.0, 8, 0), "r19": (2.0, 19, 0), "r20": (2.5, 20, 4), "r24": (1.2, 24, 2024)}.items():
+        holder = types.SimpleNamespace()
+        np.random.seed(seed)
+        ref_sim.SimEnv._setup_cameras(holder, radius, n)
+        c = holder.cameras
+        cams[f"{tag}.args"] = np.array([radius, n, seed], np.float64)
+        cams[f"{tag}.pos"] = np.array([x["camera_pos"] for x in c], np.float64)
+        cams[f"{tag}.target"] = np.array([x["target_pos"] for x in c], np.float64)
+        cams[f"{tag}.up"] = np.array([x["up_vector"] for x in c], np.float64)
+        cams[f"{tag}.intrinsics"] = np.array([[x["fov"], x["aspect"], x["near_val"], x["far_val"]] for x in c], np.float64)
+    path = os.path.join(HERE, "sim_cameras.npz")
+    np.savez_compressed(path, **cams)
+    print(f"sim_cameras.npz {os.path.getsize(path) / 1024:.1f} KB")
 
 
 if __name__ == "__main__":

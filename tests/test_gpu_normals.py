@@ -67,6 +67,35 @@ def test_kmeans_6d_labels_vs_live_sklearn(k):
     assert abs(float(inertia) - sin_) <= 1e-10 * sin_
 
 
+@pytest.mark.parametrize("case", ["far_seeds", "duplicate_seeds", "emptied_by_relocation"])
+def test_kmeans_6d_empty_cluster_relocation_vs_live_sklearn(case):
+    """sklearn's _relocate_empty_clusters_dense in 6-D (untested): seeds that own no point are moved to the points
+    farthest from their centres, in the order sklearn does it and with the list of empty clusters fixed BEFORE anything moves --
+    'emptied_by_relocation' has a one-point cluster whose point is the farthest one: it is emptied by the pass and must not be
+    refilled in the same pass.  Labels, centres, inertia against live scikit-learn."""
+    from sklearn.cluster import k_means
+    from autourdf_amd import ops
+    rng = np.random.default_rng(11)
+    X = rng.normal(size=(700, 6)) * [1, 1, 1, 0.5, 0.5, 0.5]
+    if case == "far_seeds":
+        init = np.vstack([X[:6], 1e3 + rng.normal(size=(3, 6))])
+    elif case == "duplicate_seeds":
+        init = np.vstack([X[:5], X[:1], X[:1], X[2:3]])
+    else:
+        X[0] = [40, 0, 0, 0, 0, 0]                                   # an outlier: its own one-point cluster, and the farthest point of all
+        init = np.vstack([X[0:1], X[1:6], 1e3 + rng.normal(size=(2, 6))])
+        init[0] = [38, 0, 0, 0, 0, 0]
+    k = len(init)
+    c, lab, inertia, n_it = ops.kmeans_lloyd_nd(torch.as_tensor(X, device="cuda"), torch.as_tensor(init, device="cuda"))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sc, slab, sin_ = k_means(X.copy(), init=init.copy(), n_clusters=k, n_init=1)
+    assert (lab.cpu().numpy() == slab).all()
+    np.testing.assert_allclose(c.cpu().numpy(), sc, atol=1e-11)
+    assert abs(float(inertia) - sin_) <= 1e-10 * sin_
+
+
 def test_kmeans_nd_at_dim3_equals_the_3d_kernel():
     from autourdf_amd import ops
     P = _cloud(3000, 7)[0]

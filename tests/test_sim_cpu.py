@@ -119,6 +119,35 @@ def test_camera_ring_matches_the_reference_formula(tmp_path):
     np.testing.assert_allclose(env20.cam_frames[:, :3], np.stack([2.5 * np.cos(th) * np.cos(ph), 2.5 * np.sin(th) * np.cos(ph), 2.5 * np.sin(ph)], 1))
 
 
+def test_camera_ring_vs_reference_minted_golden(tmp_path, golden):
+    """tests/golden/sim_cameras.npz holds what the REFERENCE's own SimEnv._setup_cameras (Sim/sim_data.py:85-116) produced for rings
+    of 3 / 8 / 19 cameras and -- under numpy's seeded global RandomState -- of 20 / 24: the drop-in's camera dictionaries and the
+    oracle's ring (whose frames the visibility kernel is checked against) reproduce positions, targets, up vectors and intrinsics."""
+    from autourdf_amd.sim_data import SimEnv
+    from oracle import sim_data as osim
+    path, _, _ = write_toy_robot(str(tmp_path))
+    g = golden("sim_cameras.npz")
+    for tag in ("r3", "r8", "r19", "r20", "r24"):
+        radius, n, seed = g[f"{tag}.args"]
+        n, seed = int(n), int(seed)
+        np.random.seed(seed)
+        env = SimEnv(path, dof=2, radius=float(radius), num_cameras=n)
+        pos = np.array([c["camera_pos"] for c in env.cameras])
+        np.testing.assert_array_equal(pos, g[f"{tag}.pos"])                      # the same numpy expressions on the same draws
+        np.testing.assert_array_equal(np.array([c["target_pos"] for c in env.cameras], np.float64), g[f"{tag}.target"])
+        np.testing.assert_array_equal(np.array([c["up_vector"] for c in env.cameras], np.float64), g[f"{tag}.up"])
+        np.testing.assert_array_equal(np.array([[c["fov"], c["aspect"], c["near_val"], c["far_val"]] for c in env.cameras], np.float64),
+                                      g[f"{tag}.intrinsics"])
+        np.testing.assert_array_equal(env.cam_frames[:, :3], g[f"{tag}.pos"])
+        # the oracle's ring: its own Generator for >= 20 cameras, so hand it the reference's draws through a RandomState adapter
+        class _Adapter:
+            def __init__(self, s): self.r = np.random.RandomState(s)
+            def random(self, k): return self.r.rand(k)
+        ring = osim.camera_ring(float(radius), n, rng=_Adapter(seed))
+        np.testing.assert_allclose(ring[:, :3], g[f"{tag}.pos"], atol=1e-15)
+        np.testing.assert_allclose(ring, env.cam_frames, atol=1e-15)
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/Robot"), reason="reference assets only exist in the build container")
 def test_reference_franka_collada_visuals_parse_when_present():
     from autourdf_amd.sim_data import SimEnv
