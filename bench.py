@@ -276,9 +276,11 @@ def epoch_kernel_model(k_clusters, n_points, info):
         # (24 B each), current activations, gradients.  B: W2 read once (its columns), the encoder rows + moments read and written,
         # g_h2, current / next encoder activation
         "bd": {"name": f"k_bd<{HIDDEN // 64}, {12 * (HIDDEN // 64)}>", "bound": "hbm",
-               "bytes": 24 * w23 + 4 * (K * H + 2 * K * H2 + 16 * K) + 4 * H2 * H + 24 * w1 + 4 * (K * H2 + 2 * K * H + K * IN)},
+               "bytes": 24 * w23 + 4 * (K * H + 2 * K * H2 + 16 * K) + 4 * H2 * H + 24 * w1 + 4 * (K * H2 + 2 * K * H + K * IN),
+               # the K-row GEMMs on the matrix cores (v_mfma_f32_16x16x4_f32): g_h2 . W2 (B role) and the weight gradients g^T . act (D role)
+               "mfma_flops": 2 * K * H2 * H + 2 * K * (H2 * H + 3 * (H // 2) + 4 * H)},
         # the next hidden activation: W2 + biases read again (from the freshly written buffer), next encoder activation read, h2 written
-        "l2": {"name": "k_l2<8>", "bound": "hbm", "bytes": 4 * (H2 * H + H2) + 4 * (K * H + K * H2)},
+        "l2": {"name": "k_l2<8>", "bound": "hbm", "bytes": 4 * (H2 * H + H2) + 4 * (K * H + K * H2), "mfma_flops": 2 * K * H2 * H},
         # both clouds (16 B points, block-sorted copies) read once, sign bits + integer scatter counters written
         "nn_l1": {"name": nn_name, "bound": "valu", "bytes": 2 * 16 * N + 4 * N + 16 * N, "pruned": pruned},
         # points, counters, signs and predictions of the clusters read, best cloud written when the loss improved, g_h2 rows
@@ -293,7 +295,7 @@ def roofline_block(reg, frames32, n_points, k_clusters, workload, y_index=0):
     kernel + ~1 us launch gap): algorithmic bytes / launch time against the GUIDE's HBM peak.  The top-level block is the
     kernel with the LONGEST launch in THIS run (it was hard-wired to k_dw, wrong for the franka shape).  What
     cannot be read inside this process -- HBM-side traffic and SQ counters need rocprofv3's own --pmc passes -- is replayed
-    from the committed summary of this workload (profiles/r03_pmc.json) and tagged with its source; `frac` of a VALU-bound
+    from the committed summary of this workload (profiles/r04_pmc.json) and tagged with its source; `frac` of a VALU-bound
     kernel is a measured utilisation (wave-cycles the VALUs were issuing / SIMD-cycles of the launch), never an
     exhaustive-search-equivalent rate."""
     r = reg.seqs[0]
@@ -308,11 +310,11 @@ def roofline_block(reg, frames32, n_points, k_clusters, workload, y_index=0):
     model = epoch_kernel_model(k_clusters, n_points, reg.plan.info)
     here = os.path.dirname(os.path.abspath(__file__))
     pmc, pmc_src = {}, None
-    path = os.path.join(here, "profiles", "r03_pmc.json")
+    path = os.path.join(here, "profiles", "r04_pmc.json")
     if os.path.exists(path):
         allp = json.load(open(path))
         if workload in allp:
-            pmc, pmc_src = allp[workload], f"profiles/r03_pmc.json[{workload!r}]"
+            pmc, pmc_src = allp[workload], f"profiles/r04_pmc.json[{workload!r}]"
     kernels = {}
     for key, m in model.items():
         us = b2b[key]
@@ -321,6 +323,12 @@ def roofline_block(reg, frames32, n_points, k_clusters, workload, y_index=0):
         e = {"kernel": m["name"], "bound": m["bound"], "avg_launch_us": round(us, 3), "problems_per_launch": nz,
              "algorithmic_bytes": m["bytes"] * nz, "achieved_GBps": round(m["bytes"] * nz / (us * 1e-6) / 1e9, 1),
              "hbm_frac": round(m["bytes"] * nz / (us * 1e-6) / (HBM_PEAK_GBPS * 1e9), 4)}
+        if "mfma_flops" in m:
+            # algorithmic flops of the kernel's GEMMs (without the padding of the 20 pose rows to MFMA tiles) against the DENSE f32 matrix peak
+            e.update({"mfma_algorithmic_TFLOPs": round(m["mfma_flops"] * nz / (us * 1e-6) / 1e12, 2), "mfma_f32_peak_TFLOPs": 157.3,
+                      "mfma_frac": round(m["mfma_flops"] * nz / (us * 1e-6) / 157.3e12, 4)})
+            if "matrix_pipe_utilisation" in pk:
+                e.update({"matrix_pipe_utilisation": round(pk["matrix_pipe_utilisation"], 4), "mfma_insts_per_wave": round(pk["mfma_insts_per_wave"], 1)})
         if pk:
             traffic = (2 * pk["FETCH_SIZE_KB"] + pk["WRITE_SIZE_KB"]) * 1024 / per * nz
             e.update({"traffic": round(traffic), "traffic_source": pmc_src,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repository root: bench lines + rocprofv3 evidence into gpurun_out/final/.
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
-# then here:  cp gpurun_out/r03_profiles/* profiles/
+# then here:  cp gpurun_out/r04_profiles/* profiles/
 set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
@@ -18,10 +18,12 @@ for wl in wx200_5 franka allegro; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O -o pmc_${wl}_$c -- $W > $O/pmc_${wl}_$c.log 2>&1
   done
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O -o pmc_${wl}_sq -- $W > $O/pmc_${wl}_sq.log 2>&1
+  # round 4: the K-row GEMMs of k_bd / k_l2 run on the matrix cores -- their instruction count, MOPS and busy cycles (own pass)
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES --output-format csv -d $O -o pmc_${wl}_mfma -- $W > $O/pmc_${wl}_mfma.log 2>&1
 done
 # the ICP-style configs[4] frame: the SQ set for its kernels (k_icp_nn, k_km_persist, ...)
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O -o pmc_c5_sq -- python $R/bench.py --workload c5 --steps 3 --warmup 1 > $O/pmc_c5_sq.log 2>&1
-python - <<PYEOF > $R/gpurun_out/r03_c5_pmc_summary.txt
+python - <<PYEOF > $R/gpurun_out/r04_c5_pmc_summary.txt
 import csv, glob, collections
 f = glob.glob("$O/**/pmc_c5_sq*counter_collection.csv", recursive=True)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -35,9 +37,9 @@ for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[
           f"wait any {d.get('SQ_WAIT_ANY', 0) / wc:.3f}  wait inst {d.get('SQ_WAIT_INST_ANY', 0) / wc:.3f}")
 PYEOF
 rm -f $O/*_kernel_trace.csv $O/*_agent_info.csv $O/*_domain_stats.csv
-# counters first, bench lines after: `roofline.traffic` / the measured VALU utilisation of a bench line come from profiles/r03_pmc.json,
+# counters first, bench lines after: `roofline.traffic` / the measured VALU utilisation of a bench line come from profiles/r04_pmc.json,
 # which must describe the kernels that line runs (a line benched before its counters were re-collected divides old cycles by new times)
-cd $R && python tools/summarize_profiles.py $O r03 $R/gpurun_out/r03_profiles > /dev/null 2>&1 && cp $R/gpurun_out/r03_profiles/r03_pmc.json $R/profiles/r03_pmc.json
+cd $R && python tools/summarize_profiles.py $O r04 $R/gpurun_out/r04_profiles > /dev/null 2>&1 && cp $R/gpurun_out/r04_profiles/r04_pmc.json $R/profiles/r04_pmc.json
 cd /tmp
 python $R/bench.py > $O/bench.log 2>$O/bench.err
 python $R/bench.py --sequences 1 --steps 8 --warmup 2 --no-cpu-baseline --no-icp-variant > $O/bench_b1.log 2>/dev/null
@@ -47,13 +49,17 @@ python $R/bench.py --workload allegro --steps 20 --warmup 5 --no-cpu-baseline --
 # BASELINE configs[3] / [4] in replay (independent-frame) mode, one GPU: the items an 8-GPU job would deal out
 python $R/bench.py --mode replay --workload allegro --steps 50 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_replay_allegro.log 2>/dev/null
 python $R/bench.py --workload c5 --steps 12 --warmup 2 > $O/bench_c5.log 2>/dev/null
+# six back-to-back headline runs (one process each) and the same with three graph chains: run-to-run spread, and what a third chain does now
+(for r in 1 2 3 4 5 6; do for g in 2 3; do echo -n "graph chains $g, run $r: "; python $R/bench.py --steps 20 --warmup 5 --graph-branches $g --no-cpu-baseline --no-icp-variant --no-roofline 2>/dev/null | python -c 'import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][0]); print(d["value"], "frames/s", d["ms_per_step"], "ms per frame")'; done; done) > $O/headline_repeats.log
+(for so in 0 10 20 30; do echo -n "seed offset $so: "; python $R/bench.py --steps 20 --warmup 5 --seed-offset $so --no-cpu-baseline --no-icp-variant --no-roofline 2>/dev/null | python -c 'import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][0]); print(d["value"], "frames/s")'; done) >> $O/headline_repeats.log
+python $R/tests/measure/divergence_envelope.py gpu $O/divergence.json 2>/dev/null | grep -v amdgpu.ids > $O/divergence_envelope_gpu.log
 python $R/tests/measure/bench_c5_resegment.py > $O/c5_resegment.log 2>/dev/null
 python $R/tests/measure/profile_icp_frame.py both 2>/dev/null | grep -v amdgpu.ids > $O/icp_frame_phases.log
 python $R/tests/measure/stress_handoffs.py 2>/dev/null | grep -v amdgpu.ids > $O/handoff_stress.log
 (for pe in 1 0; do for pr in 1 0; do [ $pe = 1 ] && [ $pr = 0 ] && continue; echo "# CREG_KM_PRUNE=$pr CREG_KM_PERSIST=$pe"; CREG_KM_PRUNE=$pr CREG_KM_PERSIST=$pe python $R/tests/measure/km_quick.py 2>/dev/null | grep Lloyd; done; done) > $O/km_quick.log
 # summaries on the box (gpurun brings back at most 64 MiB; the raw counter CSVs are ~18 MB each), raw files dropped
-cd $R && python tools/summarize_profiles.py $O r03 $R/gpurun_out/r03_profiles > $R/gpurun_out/r03_profiles_summary.log 2>&1
+cd $R && python tools/summarize_profiles.py $O r04 $R/gpurun_out/r04_profiles > $R/gpurun_out/r04_profiles_summary.log 2>&1
 rm -f $O/*_counter_collection.csv
-cp $R/gpurun_out/r03_c5_pmc_summary.txt $R/gpurun_out/r03_profiles/ 2>/dev/null
-ls -la $R/gpurun_out/r03_profiles | head -40
+cp $R/gpurun_out/r04_c5_pmc_summary.txt $R/gpurun_out/r04_profiles/ 2>/dev/null
+ls -la $R/gpurun_out/r04_profiles | head -40
 tail -c 600 $O/bench.log

@@ -1,8 +1,8 @@
 """Turn the rocprofv3 outputs of a gpurun (gpurun_out/final/) into the tracked summaries under profiles/.
 
-    python tools/summarize_profiles.py gpurun_out/final r03 [output directory, default profiles/]
+    python tools/summarize_profiles.py gpurun_out/final r04 [output directory, default profiles/]
 
-tools/collect_profiles.sh runs it ON THE GPU BOX into gpurun_out/r03_profiles/ (the raw counter CSVs are tens of MB each and
+tools/collect_profiles.sh runs it ON THE GPU BOX into gpurun_out/r04_profiles/ (the raw counter CSVs are tens of MB each and
 stay there); copy that directory's files into profiles/ afterwards.
 """
 import collections
@@ -43,6 +43,7 @@ def main(src, tag, dst="profiles"):
         f, _ = agg(f"{src}/pmc_{wl}_FETCH_SIZE_counter_collection.csv")
         w, _ = agg(f"{src}/pmc_{wl}_WRITE_SIZE_counter_collection.csv")
         sq, names = agg(f"{src}/pmc_{wl}_sq_counter_collection.csv")
+        mf, _ = agg(f"{src}/pmc_{wl}_mfma_counter_collection.csv")
         if not sq:
             continue
         lines.append(f"--- {wl}: bench.py --workload {wl} --steps 5 --warmup 5 (5 sequences as two graph branches: launches carry 3 or 2 problems)")
@@ -62,6 +63,14 @@ def main(src, tag, dst="profiles"):
                            "valu_insts_per_wave": m["SQ_INSTS_VALU"] / wv, "active_valu_cycles_per_wave": 4 * m["SQ_ACTIVE_INST_VALU"] / wv,
                            "wave_cycles_per_wave": 4 * m["SQ_WAVE_CYCLES"] / wv, "wait_any_cycles_per_wave": 4 * m["SQ_WAIT_ANY"] / wv,
                            "dur_us_profiled": m["dur"] / 1e3}
+                if key in mf and mean(mf[key].get("SQ_INSTS_MFMA", [0])) > 0:
+                    mm = {c: mean(v) for c, v in mf[key].items()}
+                    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD (MI355X_MICROARCH.md); v_mfma_f32_16x16x4_f32 = 2048 flops, MOPS = 512-flop units
+                    ks[key].update({"mfma_insts_per_wave": mm["SQ_INSTS_MFMA"] / mm["SQ_WAVES"], "mfma_mops_f32": mm.get("SQ_INSTS_VALU_MFMA_MOPS_F32", float("nan")),
+                                    "mfma_busy_cycles": mm["SQ_VALU_MFMA_BUSY_CYCLES"],
+                                    "matrix_pipe_utilisation": mm["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * mm["dur"] * 2.4)})
+                    lines.append(f"{'':22s} matrix cores: {mm['SQ_INSTS_MFMA'] / mm['SQ_WAVES']:.1f} MFMA per wave, MOPS_F32 {mm.get('SQ_INSTS_VALU_MFMA_MOPS_F32', float('nan')):.0f} per launch, "
+                                 f"busy cycles {mm['SQ_VALU_MFMA_BUSY_CYCLES']:.0f} = {mm['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * mm['dur'] * 2.4):.4f} of the launch's 1024 SIMD x cycles")
         out[wl] = {"problems_per_launch_avg": per, "kernels": ks}
     header = ("rocprofv3 PMC per workload (tools/collect_profiles.sh); one counter set per pass (FETCH_SIZE | WRITE_SIZE | SQ_*), every pass with "
               "--kernel-trace only; averages over all launches of a kernel (5 sequences as two graph branches: 3 or 2 problems per launch, 2.5 "
@@ -85,6 +94,8 @@ def main(src, tag, dst="profiles"):
     cp("icp_frame_phases.log", f"{tag}_icp_frame_phases.log")
     cp("handoff_stress.log", f"{tag}_handoff_stress.log")
     cp("km_quick.log", f"{tag}_kmeans_lloyd_iteration.log")
+    cp("headline_repeats.log", f"{tag}_headline_repeats.log")
+    cp("divergence_envelope_gpu.log", f"{tag}_divergence_envelope_gpu.log")
     print("\n".join(lines))
     if os.path.exists(f"{src}/stats_kernel_stats.csv"):
         for r in list(csv.DictReader(open(f"{src}/stats_kernel_stats.csv")))[:8]:
