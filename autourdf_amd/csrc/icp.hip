@@ -1270,6 +1270,9 @@ __global__ __launch_bounds__(64 * ICP_NNW, 3) void k_icp_nn(IcpLarge P, int n, i
     float* tyf = txf + ICP_NNW * ICP_G * SR; float* tzf = tyf + ICP_NNW * ICP_G * SR;
     __shared__ double sc[ICP_NNW * ICP_NM];
     const int tid = threadIdx.x, lane = tid & 63;
+    // (the host sizes the grid from the live-chunk count it knew one batch of launches ago -- an upper bound, the list only shrinks --
+    //  so workgroups past the CURRENT count leave: what lies behind it in `live` are leftovers of longer lists, possibly duplicates)
+    if (P.use_live && (int)blockIdx.x >= P.running[1]) return;
     const int blk = P.use_live ? P.live[blockIdx.x] : (int)blockIdx.x;     // the chunk this workgroup takes
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef CREG_STAMPS
@@ -1766,7 +1769,8 @@ extern "C" size_t creg_icp_batch_workspace_bytes(int64_t n, int64_t nf, int32_t 
     return icp_ws_one(n, nf, k) * (size_t)batch;
 }
 
-// One problem through the multi-launch path.  Synchronises the stream between batches of iterations.
+// One problem through the multi-launch path.  The host follows the device one batch of iterations behind (no stream synchronisation;
+// it returns when the convergence it has read back says so, with the last launches and k_icp_finish still in the queue).
 static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_t nf, double scale, double th,
                          int32_t max_iteration, int32_t keep_translation, char* ws, hipStream_t s) {
     const IcpLargeLayout L = icp_large_layout(n, nf, k);
@@ -1790,24 +1794,45 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
     hipLaunchKernelGGL(k_icp_pool, dim3(k, 8), dim3(256), 0, s, P, (int)nf);
     if (P.screen) hipLaunchKernelGGL(k_icp_seed, dim3(k, 8), dim3(256), 0, s, P, (int)nf);
     const int nblk = cdiv(n, ICP_CH) + k;                // an upper bound of sum_c ceil(ns_c / ICP_CH); the surplus blocks exit
-    int running[2] = {k, nblk};                                      // clusters still iterating, their chunks
     // every launch is one search + (last chunk of each cluster) one fit = one convergence test and, unless converged, one
-    // update; max_iteration updates need one launch more.  After every batch the live chunks are compacted and the next
-    // batch launches only those.
-    for (int64_t done = 0; running[0] > 0 && done <= (int64_t)max_iteration; ) {
+    // update; max_iteration updates need one launch more.  After every batch of 16 launches the live chunks are compacted on the
+    // device and the two counters (clusters still iterating, their chunks) come back through pinned memory -- but the host no
+    // longer waits for a batch before it enqueues the next one (round 3 synchronised the stream every 16 iterations: the queue ran
+    // dry for a host round trip each time): it reads the counters of batch b - 1 after batch b is in the queue, so the device
+    // always has a batch ahead; the price is at most one surplus batch of launches whose workgroups all leave at once.
+    static thread_local int* h_run = nullptr;                        // pinned: ICP_LAG_RING x {clusters running, live chunks}
+    constexpr int ICP_LAG_RING = 4;
+    if (!h_run) CREG_HIP(hipHostMalloc((void**)&h_run, sizeof(int) * 2 * ICP_LAG_RING, hipHostMallocDefault));
+    hipEvent_t ev[ICP_LAG_RING];
+    for (auto& e : ev) CREG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    int grid = nblk, rc_loop = CREG_OK;                              // live chunks as of the last batch whose counters were read
+    bool converged = false;
+    int64_t done = 0;
+    for (int b = 0; !converged && done <= (int64_t)max_iteration; ++b) {
         const int batch = 16;
-        for (int b = 0; b < batch; ++b, ++done) {
-            hipLaunchKernelGGL(k_icp_nn, dim3(running[1]), dim3(64 * ICP_NNW), nn_smem, s, P, (int)n, k, (int)nf, th * th, max_iteration);
+        for (int q = 0; q < batch; ++q, ++done) {
+            hipLaunchKernelGGL(k_icp_nn, dim3(grid), dim3(64 * ICP_NNW), nn_smem, s, P, (int)n, k, (int)nf, th * th, max_iteration);
 #ifdef CREG_STAMPS
             hipLaunchKernelGGL(k_icp_wall_fold, dim3(1), dim3(1), 0, s);
 #endif
         }
         hipLaunchKernelGGL(k_icp_compact, dim3(1), dim3(1024), 0, s, P, k);
-        CREG_LAUNCH_CHECK();
-        CREG_HIP(hipMemcpyAsync(running, P.running, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-        CREG_HIP(hipStreamSynchronize(s));
+        if (hipGetLastError() != hipSuccess) { rc_loop = CREG_EHIP; break; }
+        if (hipMemcpyAsync(h_run + 2 * (b % ICP_LAG_RING), P.running, 2 * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipEventRecord(ev[b % ICP_LAG_RING], s) != hipSuccess) { rc_loop = CREG_EHIP; break; }
         P.use_live = 1;
+        if (b >= 1) {                                                // the counters of the batch BEFORE the one just enqueued
+            if (hipEventSynchronize(ev[(b - 1) % ICP_LAG_RING]) != hipSuccess) { rc_loop = CREG_EHIP; break; }
+            const int* r = h_run + 2 * ((b - 1) % ICP_LAG_RING);
+            converged = r[0] <= 0;
+            grid = r[1] > 0 ? r[1] : 1;
+        }
     }
+    if (rc_loop == CREG_OK && !converged) {                          // the last batch's counters (max_iteration reached, or one batch only)
+        // nothing to decide any more: k_icp_finish reads the device state
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (rc_loop != CREG_OK) { set_error("creg_masked_icp: HIP error in the iteration loop: %s", hipGetErrorString(hipGetLastError())); return rc_loop; }
     hipLaunchKernelGGL(k_icp_finish, dim3(k), dim3(256), 0, s, P, keep_translation);
     CREG_LAUNCH_CHECK();
     return CREG_OK;

@@ -173,9 +173,11 @@ int creg_quat_to_matrix_f32(const float* q, int32_t k, float* R, creg_stream_t s
  * candidates) over binned lists pruned by the distance to the previous iteration's match.
  * Two regimes, same algorithm: clusters a CU can hold (<= 1024 points on average, frames <= 65536 points) run the whole
  * loop in ONE asynchronous launch; larger ones (BASELINE configs[4]: 2048-point clusters, 262144-point frames) run it
- * one launch per iteration over many workgroups and synchronise the stream every 16 iterations to read the number of
- * clusters (and source chunks) still iterating.  The results of the two regimes agree to rounding (different summation
- * trees), not bit for bit.
+ * one launch per iteration over many workgroups: the host enqueues batches of 16 launches and reads the number of clusters
+ * (and source chunks) still iterating through pinned memory ONE BATCH BEHIND the device (round 4: no stream synchronisation in
+ * the loop; the call returns when the counters it has read say "converged", with at most one surplus batch of empty launches
+ * and the final copy-out still in the queue -- outputs are ready when the stream is).  The results of the two regimes agree to
+ * rounding (different summation trees), not bit for bit.
  * workspace: creg_icp_workspace_bytes(n, nf, k). */
 size_t creg_icp_workspace_bytes(int64_t n, int64_t nf, int32_t k);
 int creg_masked_icp_f64(const double* local, const float* world, const int32_t* world_offsets, int64_t n,
