@@ -267,6 +267,81 @@ __device__ __forceinline__ void dq_to_se3_vjp(const T dq[8], const T G[9], const
     gdq[3] += T(2) * (-dy * a + dx * b - dw * c);
 }
 
+// ---- the two optional pose representations of mlp_reg.py:72-76 / 86-90 (--r 6d, --r rpy), pytorch3d.transforms conventions ----
+// rotation_6d_to_matrix: rows b1 = normalize(a1), b2 = normalize(a2 - (b1 . a2) b1), b3 = b1 x b2  (F.normalize: v / max(|v|, 1e-12))
+template <typename T>
+__device__ __forceinline__ void rot6d_to_matrix(const T d6[6], T R[9]) {
+    const T n1 = sqrt(d6[0] * d6[0] + d6[1] * d6[1] + d6[2] * d6[2]), i1 = T(1) / (n1 > T(1e-12) ? n1 : T(1e-12));
+    const T b1[3] = {d6[0] * i1, d6[1] * i1, d6[2] * i1};
+    const T dot = b1[0] * d6[3] + b1[1] * d6[4] + b1[2] * d6[5];
+    const T u[3] = {d6[3] - dot * b1[0], d6[4] - dot * b1[1], d6[5] - dot * b1[2]};
+    const T n2 = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), i2 = T(1) / (n2 > T(1e-12) ? n2 : T(1e-12));
+    const T b2[3] = {u[0] * i2, u[1] * i2, u[2] * i2};
+    R[0] = b1[0]; R[1] = b1[1]; R[2] = b1[2]; R[3] = b2[0]; R[4] = b2[1]; R[5] = b2[2];
+    R[6] = b1[1] * b2[2] - b1[2] * b2[1]; R[7] = b1[2] * b2[0] - b1[0] * b2[2]; R[8] = b1[0] * b2[1] - b1[1] * b2[0];
+}
+
+// vector-Jacobian product of rot6d_to_matrix: G = dL/dR (row-major) -> g6 = dL/d(d6)
+template <typename T>
+__device__ __forceinline__ void rot6d_to_matrix_vjp(const T d6[6], const T G[9], T g6[6]) {
+    const T n1 = sqrt(d6[0] * d6[0] + d6[1] * d6[1] + d6[2] * d6[2]), c1 = n1 > T(1e-12) ? n1 : T(1e-12);
+    const T b1[3] = {d6[0] / c1, d6[1] / c1, d6[2] / c1};
+    const T dot = b1[0] * d6[3] + b1[1] * d6[4] + b1[2] * d6[5];
+    const T u[3] = {d6[3] - dot * b1[0], d6[4] - dot * b1[1], d6[5] - dot * b1[2]};
+    const T n2 = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), c2 = n2 > T(1e-12) ? n2 : T(1e-12);
+    const T b2[3] = {u[0] / c2, u[1] / c2, u[2] / c2};
+    const T* g3 = G + 6;
+    // b3 = b1 x b2:  dL/db1 += b2 x g3,  dL/db2 += g3 x b1
+    T gb1[3] = {G[0] + (b2[1] * g3[2] - b2[2] * g3[1]), G[1] + (b2[2] * g3[0] - b2[0] * g3[2]), G[2] + (b2[0] * g3[1] - b2[1] * g3[0])};
+    const T gb2[3] = {G[3] + (g3[1] * b1[2] - g3[2] * b1[1]), G[4] + (g3[2] * b1[0] - g3[0] * b1[2]), G[5] + (g3[0] * b1[1] - g3[1] * b1[0])};
+    // b2 = u / max(|u|, eps)
+    T gu[3];
+    if (n2 > T(1e-12)) {
+        const T d = b2[0] * gb2[0] + b2[1] * gb2[1] + b2[2] * gb2[2];
+        for (int i = 0; i < 3; ++i) gu[i] = (gb2[i] - b2[i] * d) / n2;
+    } else {
+        for (int i = 0; i < 3; ++i) gu[i] = gb2[i] / T(1e-12);
+    }
+    // u = a2 - (b1 . a2) b1
+    const T gdot = -(gu[0] * b1[0] + gu[1] * b1[1] + gu[2] * b1[2]);
+    for (int i = 0; i < 3; ++i) { gb1[i] += gdot * d6[3 + i] - dot * gu[i]; g6[3 + i] = gu[i] + gdot * b1[i]; }
+    // b1 = a1 / max(|a1|, eps)
+    if (n1 > T(1e-12)) {
+        const T d = b1[0] * gb1[0] + b1[1] * gb1[1] + b1[2] * gb1[2];
+        for (int i = 0; i < 3; ++i) g6[i] = (gb1[i] - b1[i] * d) / n1;
+    } else {
+        for (int i = 0; i < 3; ++i) g6[i] = gb1[i] / T(1e-12);
+    }
+}
+
+// euler_angles_to_matrix(e, "XYZ") = Rx(a) Ry(b) Rz(c)
+template <typename T>
+__device__ __forceinline__ void euler_xyz_to_matrix(const T e[3], T R[9]) {
+    const T sa = sin(e[0]), ca = cos(e[0]), sb = sin(e[1]), cb = cos(e[1]), sc = sin(e[2]), cc = cos(e[2]);
+    R[0] = cb * cc; R[1] = -cb * sc; R[2] = sb;
+    R[3] = ca * sc + sa * sb * cc; R[4] = ca * cc - sa * sb * sc; R[5] = -sa * cb;
+    R[6] = sa * sc - ca * sb * cc; R[7] = sa * cc + ca * sb * sc; R[8] = ca * cb;
+}
+
+template <typename T>
+__device__ __forceinline__ void euler_xyz_to_matrix_vjp(const T e[3], const T G[9], T ge[3]) {
+    const T sa = sin(e[0]), ca = cos(e[0]), sb = sin(e[1]), cb = cos(e[1]), sc = sin(e[2]), cc = cos(e[2]);
+    T R[9];
+    euler_xyz_to_matrix(e, R);
+    // d/da: row 1 -> -row 2, row 2 -> row 1
+    ge[0] = -(G[3] * R[6] + G[4] * R[7] + G[5] * R[8]) + (G[6] * R[3] + G[7] * R[4] + G[8] * R[5]);
+    ge[1] = G[0] * (-sb * cc) + G[1] * (sb * sc) + G[2] * cb + G[3] * (sa * cb * cc) + G[4] * (-sa * cb * sc) + G[5] * (sa * sb) +
+            G[6] * (-ca * cb * cc) + G[7] * (ca * cb * sc) + G[8] * (-ca * sb);
+    ge[2] = G[0] * (-cb * sc) + G[1] * (-cb * cc) + G[3] * (ca * cc - sa * sb * sc) + G[4] * (-ca * sc - sa * sb * cc) +
+            G[6] * (sa * cc + ca * sb * sc) + G[7] * (-sa * sc + ca * sb * cc);
+}
+
+// matrix_to_euler_angles(R, "XYZ"): R02 = sin b, R12 = -sin a cos b, R22 = cos a cos b, R01 = -cos b sin c, R00 = cos b cos c
+template <typename T>
+__device__ __forceinline__ void matrix_to_euler_xyz(const T R[9], T e[3]) {
+    e[0] = atan2(-R[5], R[8]); e[1] = asin(R[2]); e[2] = atan2(-R[1], R[0]);
+}
+
 // 16 bytes written through (sc1): the line goes to the memory side while the kernel is still running instead of waiting,
 // dirty, for the write-back the end of the kernel performs -- a kernel that rewrites tens of MB (the Adam state) otherwise
 // pays that drain at its boundary (MI355X_MICROARCH.md, "boundary": + B / 6 TB/s behind B dirty bytes).

@@ -89,6 +89,9 @@ __host__ __device__ __forceinline__ Ws ws_shift(Ws W, size_t bytes) {
     return W;
 }
 
+// pose representations of train() (mlp_reg.py:64-90; creg_train_shape.rot)
+constexpr int ROT_Q = 0, ROT_DQ = 1, ROT_6D = 2, ROT_RPY = 3;
+constexpr int POSE_IN = 12;            // floats per pose row of the model input (q: 7, dq: 8, 6d: 9, rpy: 6)
 __device__ __forceinline__ float act_f(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float act_grad(float post, float slope) { return post > 0.f ? 1.f : slope; }
 
@@ -128,18 +131,27 @@ __global__ __launch_bounds__(256) void k_prep(Dims D, Ws W0, size_t bstride, Pre
             const float* M = m + 16 * r;
             const float R[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
             const float tr[3] = {M[3], M[7], M[11]};
-            float in[8];
+            float in[POSE_IN];
+            for (int i = 0; i < POSE_IN; ++i) in[i] = 0.f;
             int nin;
-            if (D.rot == 0) {                     // cat([t, matrix_to_quaternion(R)])  mlp_reg.py:65-66
+            if (D.rot == ROT_Q) {                 // cat([t, matrix_to_quaternion(R)])  mlp_reg.py:65-66
                 float q[4];
                 matrix_to_quat(R, q);
-                in[0] = tr[0]; in[1] = tr[1]; in[2] = tr[2]; in[3] = q[0]; in[4] = q[1]; in[5] = q[2]; in[6] = q[3]; in[7] = 0.f;
+                in[0] = tr[0]; in[1] = tr[1]; in[2] = tr[2]; in[3] = q[0]; in[4] = q[1]; in[5] = q[2]; in[6] = q[3];
                 nin = 7;
-            } else {                              // transform_to_dualquat  mlp_reg.py:80
+            } else if (D.rot == ROT_DQ) {         // transform_to_dualquat  mlp_reg.py:80
                 se3_to_dq(R, tr, in, FLT_EPSILON);
                 nin = 8;
+            } else if (D.rot == ROT_6D) {         // cat([t, matrix_to_rotation_6d(R)]): the first two rows  mlp_reg.py:87-88
+                in[0] = tr[0]; in[1] = tr[1]; in[2] = tr[2];
+                for (int i = 0; i < 6; ++i) in[3 + i] = R[i];
+                nin = 9;
+            } else {                              // cat([t, matrix_to_euler_angles(R, "XYZ")])  mlp_reg.py:73-74
+                in[0] = tr[0]; in[1] = tr[1]; in[2] = tr[2];
+                matrix_to_euler_xyz(R, in + 3);
+                nin = 6;
             }
-            for (int i = 0; i < 8; ++i) W.pose_in[8 * r + i] = in[i];
+            for (int i = 0; i < POSE_IN; ++i) W.pose_in[POSE_IN * r + i] = in[i];
             // [sin x, cos x, sin 2x, cos 2x, sin 4x, cos 4x, sin 8x, cos 8x]  model_utils.py:141-150
             float* e = W.enc + (size_t)r * D.IN;
             for (int f = 0; f < 4; ++f) {
@@ -169,9 +181,12 @@ __global__ __launch_bounds__(256) void k_l1(Dims D, Ws W0, int par, size_t bstri
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o >= D.H) return;
     const float w = lane < D.IN ? W.P[D.oW1 + (size_t)o * D.IN + lane] : 0.f;
+    const float w2 = 64 + lane < D.IN ? W.P[D.oW1 + (size_t)o * D.IN + 64 + lane] : 0.f;      // ('6d': 72 features)
     const float b = W.P[D.ob1 + o];
     for (int r = 0; r < D.K; ++r) {
-        const float v = wave_sum_fast(lane < D.IN ? w * W.enc[(size_t)r * D.IN + lane] : 0.f) + b;
+        float t = lane < D.IN ? w * W.enc[(size_t)r * D.IN + lane] : 0.f;
+        if (64 + lane < D.IN) t = fmaf(w2, W.enc[(size_t)r * D.IN + 64 + lane], t);
+        const float v = wave_sum_fast(t) + b;
         if (lane == 0) (par ? W.x1[1] : W.x1[0])[(size_t)r * D.H + o] = act_f(v, D.slope);      // (a runtime index into the shifted struct put all of it -- 312 bytes a lane -- into scratch)
     }
 }
@@ -261,7 +276,8 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2(Dims D, Ws W0, int par, size_
 // Block r: output layer for pose row r (one wave per output unit), pose assembly, then the rigid
 // transform of cluster r's points (clusters are stored back to back) -- calculate_pc needs no
 // launch of its own and nothing is recomputed.
-template <int NC>
+// X: nine output units ('6d': 3 + 6) -- wave 0 takes the ninth as a second dot product.
+template <int NC, bool X = false>
 __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bstride) {
     // every kernel argument in the entry block, one wait (see k_bd)
     asm volatile("" :: "s"(W0.P), "s"(W0.P1), "s"(W0.h2[0]), "s"(W0.h2[1]), "s"(W0.pose_in), "s"(W0.head_save), "s"(W0.m2), "s"(W0.pts4), "s"(W0.pred4),
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bst
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
     const float* h2cur = par ? W.h2[1] : W.h2[0];
     const float* Pc = par ? W.P1 : W.P;
-    __shared__ float outs[8];
+    __shared__ float outs[12];
     __shared__ float m2s[12];
     const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NO = D.OA + D.OB;
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bst
     // the block index) and only then the operands of the dot products -- hipcc turned the wave-uniform ones into scalar loads and
     // waited for them one after the other: FOUR dependent memory round trips in front of the dot products' loads.  Now the dot
     // products' operands go out first (every wave: waves past the output units mirror the last one), then everything scalar.
-    const int o = min(wave, NO - 1);
+    const int o = min(wave, (X ? 8 : NO) - 1);
     const float *w, *a; int n;
     if (o < D.OA) { w = Pc + D.oW3A + (size_t)o * D.HA; a = h2cur + (size_t)r * D.H2; n = D.HA; }
     else { w = Pc + D.oW3B + (size_t)(o - D.OA) * D.HB; a = h2cur + (size_t)r * D.H2 + D.HA; n = D.HB; }
@@ -287,12 +303,20 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bst
 #pragma unroll
     for (int c = 0; c < NC; ++c) { const int i = min(c * 64 + lane, n - 1); wv[c] = w[i]; av[c] = a[i]; }
     const float bias = o < D.OA ? Pc[D.ob3A + o] : Pc[D.ob3B + o - D.OA];
+    float wv9[NC], av9[NC], bias9 = 0.f;           // X: output unit 8 (branch B's last), every wave requests it, wave 0 uses it
+    if constexpr (X) {
+        const float* w9 = Pc + D.oW3B + (size_t)(8 - D.OA) * D.HB;
+        const float* a9 = h2cur + (size_t)r * D.H2 + D.HA;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { const int i = min(c * 64 + lane, D.HB - 1); wv9[c] = w9[i]; av9[c] = a9[i]; }
+        bias9 = Pc[D.ob3B + 8 - D.OA];
+    }
     __builtin_amdgcn_sched_barrier(0);
     const int stopped = W.state[par].stopped;      // early stop (mlp_reg.py:107-111): the remaining epochs of a captured graph
                                                    // return at their first barrier
-    float pin[8];
+    float pin[POSE_IN];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) pin[i] = W.pose_in[8 * r + i];
+    for (int i = 0; i < POSE_IN; ++i) pin[i] = W.pose_in[POSE_IN * r + i];
     const int b = W.off[r], e = W.off[r + 1];
     // block-sorted walk (D.npb): cluster r owns the slots of blocks [sb[r], sb[r + 1])
     const int BS = 64 * D.ppl;
@@ -305,6 +329,13 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bst
         for (int c = 0; c < NC; ++c) s = fmaf(c * 64 + lane < n ? wv[c] : 0.f, av[c], s);
         s = wave_sum_fast(s) + bias;
         if (lane == 0 && wave < NO) outs[o] = s;
+        if constexpr (X) {
+            float s9 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) s9 = fmaf(c * 64 + lane < D.HB ? wv9[c] : 0.f, av9[c], s9);
+            s9 = wave_sum_fast(s9) + bias9;
+            if (lane == 0 && wave == 0) outs[8] = s9;
+        }
     }
     __syncthreads();
     if (stopped) return;
@@ -312,7 +343,19 @@ __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bst
         const float* in = pin;
         float R[9], t[3], save[16];
         for (int i = 0; i < 16; ++i) save[i] = 0.f;
-        if (D.rot == 0) {
+        if (D.rot == ROT_6D) {
+            // xyz + orig[:, :3], r6d + orig[:, 3:]  model_utils.py:214 ; rotation_6d_to_matrix  mlp_reg.py:89
+            for (int i = 0; i < 3; ++i) t[i] = outs[i] + in[i];
+            float d6[6];
+            for (int i = 0; i < 6; ++i) { d6[i] = outs[3 + i] + in[3 + i]; save[i] = d6[i]; }
+            rot6d_to_matrix(d6, R);
+        } else if (D.rot == ROT_RPY) {
+            // xyz + orig[:, :3], tanh(.) + orig[:, 3:]  model_utils.py:237-242,274 ; euler_angles_to_matrix(r, "XYZ")  mlp_reg.py:75
+            for (int i = 0; i < 3; ++i) t[i] = outs[i] + in[i];
+            float e3[3];
+            for (int i = 0; i < 3; ++i) { const float th = tanhf(outs[3 + i]); e3[i] = th + in[3 + i]; save[i] = e3[i]; save[4 + i] = th; }
+            euler_xyz_to_matrix(e3, R);
+        } else if (D.rot == ROT_Q) {
             // xyz + orig[:, :3] ; normalize(q + orig[:, 3:])   model_utils.py:159
             for (int i = 0; i < 3; ++i) t[i] = outs[i] + in[i];
             float v[4], n2 = 0.f;
@@ -793,7 +836,15 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
         const float gt[3] = {G12[3], G12[7], G12[11]};
         float go[16];                          // [0..2] branch A, [4..11] branch B
         for (int i = 0; i < 16; ++i) go[i] = 0.f;
-        if (D.rot == 0) {
+        if (D.rot == ROT_6D) {
+            go[0] = gt[0]; go[1] = gt[1]; go[2] = gt[2];
+            rot6d_to_matrix_vjp(sv, G, go + 4);
+        } else if (D.rot == ROT_RPY) {
+            go[0] = gt[0]; go[1] = gt[1]; go[2] = gt[2];
+            float ge[3];
+            euler_xyz_to_matrix_vjp(sv, G, ge);
+            for (int i = 0; i < 3; ++i) go[4 + i] = ge[i] * (1.f - sv[4 + i] * sv[4 + i]);      // through the Tanh that ends decoder_2
+        } else if (D.rot == ROT_Q) {
             go[0] = gt[0]; go[1] = gt[1]; go[2] = gt[2];
             float gu[4];
             quat_to_matrix_vjp(sv, G, gu);
@@ -914,7 +965,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 // first FMA): every load is in flight at once and the MFMAs start on the first operands that land.  The per-wave partial tiles are
 // summed over the waves in wave order through LDS as before.  Then, unchanged: activation gradient, the 16 encoder rows' weight
 // gradients + Adam, and the NEXT epoch's encoder activation of the block's 16 units from the registers that hold the updated rows.
-template <int KW>                      // W2 rows per wave: H2 = 8 KW
+template <int KW, bool X>              // W2 rows per wave: H2 = 8 KW; X: more than 64 input features ('6d': 72) -- lanes i4 < 2 of a row take a second float4
 __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch, int blk, float* sh, unsigned long long bd_entry) {
     constexpr int NS = KW / 4;                 // k-steps of a wave
     constexpr bool V4 = KW % 16 == 0;          // A operand as 16-byte loads
@@ -967,6 +1018,11 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
     const int ei = min(4 * i4, D.IN - 4);
     const size_t wi = (size_t)D.oW1 + (size_t)hu * D.IN + ei;
     float4 pw = *(const float4*)(Pc + wi), pm = *(const float4*)(W.AM + wi), pv = *(const float4*)(W.AV + wi);
+    const bool ain2 = X && 64 + 4 * i4 < D.IN;         // the features past 64
+    const int ei2 = min(64 + 4 * i4, D.IN - 4);
+    const size_t wi2 = (size_t)D.oW1 + (size_t)hu * D.IN + ei2;
+    float4 pw2, pm2, pv2;
+    if constexpr (X) { pw2 = *(const float4*)(Pc + wi2); pm2 = *(const float4*)(W.AM + wi2); pv2 = *(const float4*)(W.AV + wi2); }
     float pb = Pc[D.ob1 + hu], mb = W.AM[D.ob1 + hu], vb = W.AV[D.ob1 + hu];
     float xv0 = x1cur[(size_t)min(tid >> 4, D.K - 1) * D.H + c0 + (tid & 15)];      // post-activation of this thread's (pose row, column) output of pass 0
     {   // the features [K][IN] by LDS-DMA, straight-line (K <= 160: at most five 16-byte pieces per thread) and AFTER the other requests:
@@ -1034,12 +1090,16 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
     __syncthreads();
     BD_T                                               // B3: cross-wave reduction, activation gradient, g_x1 into LDS (+ further passes at K > 32)
     // ---- encoder rows: dW1 = g_x1^T enc, Adam, next x1
-    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ag2 = make_float4(0.f, 0.f, 0.f, 0.f);
     float gsum = 0.f;
     for (int r = 0; r < D.K; ++r) {
         const float g = gxs[r * B2_CB + row];
         const float4 e = *(const float4*)(encs + r * D.IN + ei);
         ag.x = fmaf(g, e.x, ag.x); ag.y = fmaf(g, e.y, ag.y); ag.z = fmaf(g, e.z, ag.z); ag.w = fmaf(g, e.w, ag.w);
+        if constexpr (X) {
+            const float4 e2 = *(const float4*)(encs + r * D.IN + ei2);
+            ag2.x = fmaf(g, e2.x, ag2.x); ag2.y = fmaf(g, e2.y, ag2.y); ag2.z = fmaf(g, e2.z, ag2.z); ag2.w = fmaf(g, e2.w, ag2.w);
+        }
         gsum += g;
     }
     float4 nw;
@@ -1047,15 +1107,27 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
     nw.y = adam_value(pw.y, pm.y, pv.y, ag.y, S.step_size, S.bc2_sqrt);
     nw.z = adam_value(pw.z, pm.z, pv.z, ag.z, S.step_size, S.bc2_sqrt);
     nw.w = adam_value(pw.w, pm.w, pv.w, ag.w, S.step_size, S.bc2_sqrt);
+    float4 nw2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (X) {
+        nw2.x = adam_value(pw2.x, pm2.x, pv2.x, ag2.x, S.step_size, S.bc2_sqrt);
+        nw2.y = adam_value(pw2.y, pm2.y, pv2.y, ag2.y, S.step_size, S.bc2_sqrt);
+        nw2.z = adam_value(pw2.z, pm2.z, pv2.z, ag2.z, S.step_size, S.bc2_sqrt);
+        nw2.w = adam_value(pw2.w, pm2.w, pv2.w, ag2.w, S.step_size, S.bc2_sqrt);
+    }
     pb = adam_value(pb, mb, vb, gsum, S.step_size, S.bc2_sqrt);        // every lane of the row (same operands, same result)
     if (live && half == 0) {
         if (ain) { st4_wt(Pn, wi, nw); st4_wt(W.AM, wi, pm); st4_wt(W.AV, wi, pv); }
+        if constexpr (X) if (ain2) { st4_wt(Pn, wi2, nw2); st4_wt(W.AM, wi2, pm2); st4_wt(W.AV, wi2, pv2); }
         if (i4 == 0) { Pn[D.ob1 + hu] = pb; W.AM[D.ob1 + hu] = mb; W.AV[D.ob1 + hu] = vb; }
     }
     BD_T                                               // B4: dW1 over the pose rows, Adam, the encoder rows' stores issued
     for (int r = half; r < D.K; r += 2) {
         const float4 e = *(const float4*)(encs + r * D.IN + ei);
         float v = ain ? fmaf(nw.w, e.w, fmaf(nw.z, e.z, fmaf(nw.y, e.y, nw.x * e.x))) : 0.f;
+        if constexpr (X) {
+            const float4 e2 = *(const float4*)(encs + r * D.IN + ei2);
+            if (ain2) v = fmaf(nw2.w, e2.w, fmaf(nw2.z, e2.z, fmaf(nw2.y, e2.y, fmaf(nw2.x, e2.x, v))));
+        }
         v = row_sum16(v) + pb;
         if (i4 == 0) xt[r * B2_CB + row] = act_f(v, D.slope);
     }
@@ -1208,7 +1280,7 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
 // side the launch takes what the longer role takes, and the next hidden activation, the one thing that needs BOTH results (the
 // next encoder activation from B, the updated hidden rows from D), is k_l2 again, a launch boundary later.
 // grid.x = (H / 16 + H2 / 8 + 1) * problems: the B blocks of ALL problems first (the longer chain of dependent phases).
-template <int NC, int KW>
+template <int NC, int KW, bool X = false>
 __global__ __launch_bounds__(BD_THREADS, 4) void k_bd(Dims D, Ws W0, int epoch, size_t bstride, int nz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef CREG_BD_STAMPS
@@ -1234,7 +1306,7 @@ __global__ __launch_bounds__(BD_THREADS, 4) void k_bd(Dims D, Ws W0, int epoch, 
 #ifdef CREG_BD_ONLY                                   // measurement build: one role alone (1: backward to the encoder, 2: dW + Adam)
     if ((CREG_BD_ONLY == 1) != roleB) return;
 #endif
-    if (roleB) bwd2_role<KW>(D, W, epoch, blk, (float*)smem, bd_entry);
+    if (roleB) bwd2_role<KW, X>(D, W, epoch, blk, (float*)smem, bd_entry);
     else dw_role(D, W, epoch, blk, bd_entry);
 }
 
@@ -1264,13 +1336,17 @@ struct Plan {
 };
 
 static bool make_dims(const creg_train_shape* s, Dims* D) {
-    if (!s || (s->rot != 0 && s->rot != 1) || s->k < 1 || s->k > 160 || (s->hidden != 64 && s->hidden != 128 && s->hidden != 256 && s->hidden != 512) || s->epochs < 1 || s->n_pred < 1 || s->n_tgt < 1 || s->n_pred >= (1ll << 31) ||
+    if (!s || s->rot < 0 || s->rot > 3 || s->k < 1 || s->k > 160 || (s->hidden != 64 && s->hidden != 128 && s->hidden != 256 && s->hidden != 512) || s->epochs < 1 || s->n_pred < 1 || s->n_tgt < 1 || s->n_pred >= (1ll << 31) ||
         s->n_tgt >= (1ll << 31))
         return false;
     memset(D, 0, sizeof(*D));
     D->rot = s->rot; D->K = s->k; D->KP = (s->k + 19) / 20 * 20; D->H = s->hidden; D->NP = (int)s->n_pred; D->NT = (int)s->n_tgt; D->epochs = s->epochs;
-    if (s->rot == 0) { D->IN = 56; D->HA = D->H / 2; D->HB = D->H; D->OA = 3; D->OB = 4; D->slope = 0.01f; }
-    else { D->IN = 64; D->HA = 0; D->HB = D->H; D->OA = 0; D->OB = 8; D->slope = 0.f; }
+    // model_utils.py: QRegMLP :103-168 (7 inputs x 8 sin / cos features), DQRegMLP :65-101 (ReLU, one decoder), RRegMLP :170-214, RegMLP :216-281
+    if (s->rot == ROT_Q) { D->IN = 56; D->HA = D->H / 2; D->HB = D->H; D->OA = 3; D->OB = 4; D->slope = 0.01f; }
+    else if (s->rot == ROT_DQ) { D->IN = 64; D->HA = 0; D->HB = D->H; D->OA = 0; D->OB = 8; D->slope = 0.f; }
+    else if (s->rot == ROT_6D) { D->IN = 72; D->HA = D->H / 2; D->HB = D->H; D->OA = 3; D->OB = 6; D->slope = 0.01f; }
+    else { D->IN = 48; D->HA = D->H / 2; D->HB = D->H; D->OA = 3; D->OB = 3; D->slope = 0.01f; }
+    if (D->K * D->IN / 4 > 5 * 512) return false;            // k_bd stages the [K][IN] features with five 16-byte pieces per thread ('6d': K <= 142)
     D->H2 = D->HA + D->HB;
     int o = 0;
     D->oW1 = o; o += D->H * D->IN; D->ob1 = o; o += D->H;
@@ -1305,7 +1381,7 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     const size_t f = sizeof(float);
     Ws w;
     w.P = (float*)take(f * D.NPAR); w.P1 = (float*)take(f * D.NPAR); w.AM = (float*)take(f * D.NPAR); w.AV = (float*)take(f * D.NPAR);
-    w.pose_in = (float*)take(f * 8 * D.K); w.enc = (float*)take(f * D.K * D.IN);
+    w.pose_in = (float*)take(f * POSE_IN * D.K); w.enc = (float*)take(f * D.K * D.IN);
     w.x1[0] = (float*)take(f * D.KP * D.H); w.x1[1] = (float*)take(f * D.KP * D.H);
     w.h2[0] = (float*)take(f * D.KP * D.H2); w.h2[1] = (float*)take(f * D.KP * D.H2); w.head_save = (float*)take(f * 16 * D.K);
     w.m2 = (float*)take(f * 16 * D.K); w.gm2 = (float*)take(f * 16 * D.K);
@@ -1344,14 +1420,18 @@ static void launch_l2(Plan* P, int par, hipStream_t s) {
 }
 static void launch_head(Plan* P, int par, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
-    by_nc(D.H, [&](auto nc) { hipLaunchKernelGGL((k_head<decltype(nc)::value>), dim3(D.K, 1, P->nz), dim3(512), 0, s, D, W, par, P->bstride); });
+    by_nc(D.H, [&](auto nc) {
+        if (D.OA + D.OB > 8) hipLaunchKernelGGL((k_head<decltype(nc)::value, true>), dim3(D.K, 1, P->nz), dim3(512), 0, s, D, W, par, P->bstride);
+        else hipLaunchKernelGGL((k_head<decltype(nc)::value>), dim3(D.K, 1, P->nz), dim3(512), 0, s, D, W, par, P->bstride);
+    });
 }
 // the k_bd instance of a shape: NC = H / 64; the B role's 8 waves own KW = H2 / 8 rows of W2 each ('q': H2 = 96 NC, 'dq': 64 NC)
 template <typename F>
 static void by_bd(const Dims& D, F f) {
     by_nc(D.H, [&](auto nc) {
         constexpr int NC = decltype(nc)::value;
-        if (D.rot == 0) f(k_bd<NC, 12 * NC>);
+        if (D.IN > 64) f(k_bd<NC, 12 * NC, true>);             // '6d': 72 input features
+        else if (D.HA) f(k_bd<NC, 12 * NC>);                   // two decoders ('q', 'rpy'): H2 = H / 2 + H
         else f(k_bd<NC, 8 * NC>);
     });
 }
@@ -1432,7 +1512,7 @@ static void copy_table_add(CopyTable& T, const void* src, void* dst, size_t byte
 
 struct ParamMap { int off, count; };
 static int param_map(const Dims& D, ParamMap* pm) {
-    if (D.rot == 0) {
+    if (D.rot != ROT_DQ) {                 // QRegMLP / RRegMLP / RegMLP: encoder, decoder_1 (two layers), decoder_2 (two layers)
         const ParamMap m[10] = {{D.oW1, D.H * D.IN}, {D.ob1, D.H}, {D.oW2, D.HA * D.H}, {D.ob2, D.HA},
                                 {D.oW3A, D.OA * D.HA}, {D.ob3A, D.OA}, {D.oW2 + D.HA * D.H, D.HB * D.H},
                                 {D.ob2 + D.HA, D.HB}, {D.oW3B, D.OB * D.HB}, {D.ob3B, D.OB}};

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import mlp_reg, ops
-from .model_utils import DQRegMLP, QRegMLP
+from .model_utils import DQRegMLP, QRegMLP, RegMLP, RRegMLP
 
 
 class _HostInverse:
@@ -49,10 +49,11 @@ class SequenceRegistrar:
         else:
             gen_state = torch.random.get_rng_state()
             torch.manual_seed(seed)                  # the reference leaves the MLP init unseeded
-            ctor = (lambda: QRegMLP(True, hidden_dim=hidden)) if rot == "q" else (lambda: DQRegMLP(hidden_dim=hidden))
+            ctor = {"q": lambda: QRegMLP(True, hidden_dim=hidden), "dq": lambda: DQRegMLP(hidden_dim=hidden),
+                    "6d": lambda: RRegMLP(hidden_dim=hidden), "rpy": lambda: RegMLP(True, hidden_dim=hidden)}[rot]
             self.model, self.model_rf = ctor().to(self.device), ctor().to(self.device)
             torch.random.set_rng_state(gen_state)
-        order = ops.Q_PARAM_ORDER if rot == "q" else ops.DQ_PARAM_ORDER
+        order = ops.DQ_PARAM_ORDER if rot == "dq" else ops.Q_PARAM_ORDER
         self.p_step = [dict(self.model.named_parameters())[n].data for n in order]
         self.p_anchor = [dict(self.model_rf.named_parameters())[n].data for n in order]
         self.m = torch.as_tensor(mats0, dtype=torch.float32).to(self.device).contiguous()

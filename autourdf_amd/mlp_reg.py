@@ -47,52 +47,19 @@ def _plan(rot, k, hidden, n_pred, n_tgt, device):
     return _PLANS[key]
 
 
-def _train_compat(m, y, model, clusters, stop, learning_rate, scheduler_patience, scheduler_factor):
-    """--r rpy / --r 6d (mlp_reg.py:72-76, 86-90): the reference's loop with its MLP, representation maps
-    and Adam in PyTorch-ROCm, and the two point-cloud ops -- calculate_pc and the L1 Chamfer distance
-    with its backward -- on the HIP kernels (K3, K1).  These optional modes have no fused plan."""
-    from . import rot_repr as RR
-    pts, off = ops.pack_clusters(clusters, m.device)
-    sizes = [int(c.shape[0]) for c in clusters]
-    opt = torch.optim.Adam(model.parameters(), lr=learning_rate)
-    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=scheduler_factor, patience=scheduler_patience)
-    min_loss, best_pred, best_m, count = 1000, None, None, 0
-    for epoch in range(EPOCHS):
-        m2 = m.clone()
-        if ROT == "rpy":
-            t, r = model(torch.cat([m2[:, :3, 3], RR.matrix_to_euler_angles(m2[:, :3, :3], "XYZ")], dim=1))
-            rot = RR.euler_angles_to_matrix(r, "XYZ")
-        else:
-            t, r = model(torch.cat([m2[:, :3, 3], RR.matrix_to_rotation_6d(m2[:, :3, :3])], dim=1))
-            rot = RR.rotation_6d_to_matrix(r)
-        m2[:, :3, :3] = rot
-        m2[:, :3, 3] = t
-        pred = ops.cluster_transform(pts, off, m2.contiguous())
-        loss, _ = ops.chamfer_distance(pred.unsqueeze(0), y.unsqueeze(0), norm=1)
-        lv = loss.item()
-        if lv < min_loss:
-            min_loss, best_pred, best_m, count = lv, pred.detach(), m2, 0
-        else:
-            count += 1
-            if count > stop:
-                print(f"Early stopping triggered after {epoch} epochs")
-                break
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        sched.step(loss.detach())
-    pred_np = [p.cpu().numpy() for p in torch.split(best_pred, sizes, dim=0)]
-    print("Best Loss:", min_loss)
-    return pred_np, [PointCloud(p) for p in pred_np], best_m, min_loss
-
-
 def _model_params(model):
     if isinstance(model, QRegMLP):
         rot, order = "q", ops.Q_PARAM_ORDER
     elif isinstance(model, DQRegMLP):
         rot, order = "dq", ops.DQ_PARAM_ORDER
+    elif isinstance(model, RRegMLP):
+        rot, order = "6d", ops.Q_PARAM_ORDER
+    elif isinstance(model, RegMLP):
+        if not model.multi_decoder:
+            raise NotImplementedError("train(): the single-decoder RegMLP is never constructed on the reference path (mlp_reg.py:285)")
+        rot, order = "rpy", ops.Q_PARAM_ORDER
     else:
-        raise NotImplementedError(f"train(): no HIP plan for {type(model).__name__}; use QRegMLP (--r q) or DQRegMLP (--r dq)")
+        raise NotImplementedError(f"train(): no HIP plan for {type(model).__name__}")
     named = dict(model.named_parameters())
     params = [named[n].data for n in order]
     return rot, params, model.encoder[0].out_features
@@ -101,12 +68,10 @@ def _model_params(model):
 def train(m, y, model, clusters, stop=200, learning_rate=0.0002, scheduler_patience=5, scheduler_factor=0.7):
     """The reference's Adam loop (mlp_reg.py:17-152) as one asynchronous device plan.
 
-    Args as in the reference: m (K,4,4) fp32 poses, y (N,3) fp32 target cloud, model (QRegMLP /
-    DQRegMLP, updated in place), clusters (list of K (M_k,3) fp32 local clouds).
+    Args as in the reference: m (K,4,4) fp32 poses, y (N,3) fp32 target cloud, model (QRegMLP / DQRegMLP / RRegMLP /
+    RegMLP for --r q / dq / 6d / rpy, updated in place), clusters (list of K (M_k,3) fp32 local clouds).
     Returns (pred_pcd_np, pred_pcd, best_m, min_loss) like the reference.
     """
-    if ROT in ("rpy", "6d"):
-        return _train_compat(m, y, model, clusters, stop, learning_rate, scheduler_patience, scheduler_factor)
     rot, params, hidden = _model_params(model)
     if rot != ROT:
         raise ValueError(f"model {type(model).__name__} does not match ROT={ROT!r}")
@@ -269,13 +234,13 @@ def match_all(data_dirs):
     sequences are independent once sequence 0 has produced the shared frame-0 state (mlp_reg.py:242-253), so the
     S default-path (MLP + MLP) registrations advance as ONE batched train plan per step -- the same kernels and
     arithmetic as S match() calls, the same files, ~3x the throughput.  Falls back to match() per sequence when
-    the sequences differ in length or size, or for --r rpy|6d.  --mlp_icp takes the same route with one batched
+    the sequences differ in length or size.  --mlp_icp takes the same route with one batched
     masked-ICP launch per step (mlp_reg.py:296-332)."""
     from .engine import BatchRegistrar
     segs = [Segments(d) for d in data_dirs]
     same = len({(sg.data_size, len(sg.pc_list[0].points)) for sg in segs}) == 1 and \
         all(len(p.points) == len(segs[0].pc_list[0].points) for sg in segs for p in sg.pc_list)
-    if ROT not in ("q", "dq") or not same or len(segs) < 2 or NORMAL:      # (--normal: the 6-D re-segmentation has no batched form)
+    if not same or len(segs) < 2 or NORMAL:      # (--normal: the 6-D re-segmentation has no batched form)
         for i, d in enumerate(data_dirs):
             match(d, i)
         return
@@ -300,8 +265,10 @@ def match_all(data_dirs):
         os.makedirs(sd + "matrix", exist_ok=True)
         np.save(sd + "matrix/0000.npy", step_matrices)
         save_pc_npz(step_cluster_np, sd + "cluster/0000.npz")
+    models = [_make_models() for _ in segs]
+    hidden = models[0][0].encoder[0].out_features        # 512, but 3 for --r rpy (RegMLP(6, 3), mlp_reg.py:285)
     reg = BatchRegistrar(np.asarray(step_matrices, np.float32), [np.asarray(c, np.float64) for c in step_cluster_np], n,
-                         len(segs), ROT, 512, EPOCHS, USE_GRAPH, DEVICE, models=[_make_models() for _ in segs])
+                         len(segs), ROT, hidden, EPOCHS, USE_GRAPH, DEVICE, models=models)
     losses = [[] for _ in segs]
     for i in range(segs[0].data_size - 1):
         frames = [torch.as_tensor(np.asarray(sg.pc_list[i + 1].points), dtype=torch.float64, device=DEVICE) for sg in segs]

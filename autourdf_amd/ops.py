@@ -528,6 +528,11 @@ Q_PARAM_ORDER = ["encoder.0.weight", "encoder.0.bias", "decoder_1.0.weight", "de
                  "decoder_2.2.weight", "decoder_2.2.bias"]
 DQ_PARAM_ORDER = ["encoder.0.weight", "encoder.0.bias", "decoder.0.weight", "decoder.0.bias",
                   "decoder.2.weight", "decoder.2.bias"]
+#: creg_train_shape.rot: the reference's four --r choices (mlp_reg.py:64-90).  RRegMLP ('6d') and RegMLP ('rpy') name their
+#: tensors like QRegMLP (model_utils.py:170-281): Q_PARAM_ORDER serves the three.
+TRAIN_ROT = {"q": 0, "dq": 1, "6d": 2, "rpy": 3}
+#: per rot: (input features of the encoder = 8 x the pose row's width, outputs of decoder_2)
+_TWO_DECODER = {0: (56, 4), 2: (72, 6), 3: (48, 3)}
 
 
 TRAIN_HIDDEN_TILES = (64, 128, 256, 512)      # widths the train kernels are instantiated for
@@ -546,7 +551,7 @@ class TrainPlan:
                  use_graph: bool = True, device=None, batch: int = 1, graph_branches: int = 0,
                  nn_search: int = 0):
         self.L = _lib.load()
-        self.rot = {"q": 0, "dq": 1}[rot]
+        self.rot = TRAIN_ROT[rot]
         self.device = torch.device(device if device is not None else "cuda")
         self.batch = int(batch)
         self.hidden_model = int(hidden)                                     # the caller's width
@@ -586,7 +591,7 @@ class TrainPlan:
             self.plan = None
 
     def _args(self, m, y, pts, offsets, params, lr, factor, patience, stop, outs):
-        n = 10 if self.rot == 0 else 6
+        n = 6 if self.rot == 1 else 10
         if len(params) != n:
             raise ValueError(f"expected {n} parameter tensors, got {len(params)}")
         keep = [_need(m, torch.float32, "m"), _need(y, torch.float32, "y"), _need(pts, torch.float32, "pts"),
@@ -626,8 +631,9 @@ class TrainPlan:
 
     def _param_shapes(self, H):
         """Shapes of the model's tensors in Q_PARAM_ORDER / DQ_PARAM_ORDER at width H (model_utils.py:65-168)."""
-        if self.rot == 0:      # QRegMLP: enc 56->H, dec1 H->H/2->3, dec2 H->H->4
-            return [(H, 56), (H,), (H // 2, H), (H // 2,), (3, H // 2), (3,), (H, H), (H,), (4, H), (4,)]
+        if self.rot != 1:      # QRegMLP: enc 56->H, dec1 H->H/2->3, dec2 H->H->4; RRegMLP: 72 features, 6 outputs; RegMLP: 48, 3 (+ Tanh)
+            nin, nout = _TWO_DECODER[self.rot]
+            return [(H, nin), (H,), (H // 2, H), (H // 2,), (3, H // 2), (3,), (H, H), (H,), (nout, H), (nout,)]
         return [(H, 64), (H,), (H, H), (H,), (8, H), (8,)]        # DQRegMLP: enc 64->H, H->H, H->8
 
     def _param_numels(self):

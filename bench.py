@@ -546,6 +546,7 @@ def main(argv=None):
     ap.add_argument("--no-icp-variant", action="store_true", help="skip the ICP-style second line (SURVEY 8(d))")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="eager launches instead of the captured epoch graph")
+    ap.add_argument("--epochs-per-graph", type=int, default=0, help="epochs captured per hipGraph (0 = the library's 50; 300 = one replay per train)")
     ap.add_argument("--graph-branches", type=int, default=0, help="parallel chains in the captured graph (0 = the library's default)")
     ap.add_argument("--stop", type=int, default=200,
                     help="early-stopping patience of train() (mlp_reg.py:17: stop=200, the default and the headline's); a small value "
@@ -622,7 +623,8 @@ def main(argv=None):
     seqs = [make_sequence(robot, sid, max(n_frames, FRAMES_PER_SEQ), n_points) for sid in seq_ids]
     frames64 = [[torch.as_tensor(f, dtype=torch.float64, device=dev) for f in s[1:n_frames]] for s in seqs]
     frames32 = [[f.to(torch.float32) for f in s] for s in frames64]
-    reg = Registrar(mats0, clusters0, n_points, S, "q", HIDDEN, EPOCHS, not args.eager, dev,
+    use_graph = False if args.eager else (args.epochs_per_graph if args.epochs_per_graph > 1 else True)
+    reg = Registrar(mats0, clusters0, n_points, S, "q", HIDDEN, EPOCHS, use_graph, dev,
                     seeds=seq_ids, graph_branches=args.graph_branches)
     reg.stop = args.stop
     epochs_log = []
@@ -645,7 +647,7 @@ def main(argv=None):
 
         def reg_for(b):
             if b not in regs:
-                regs[b] = Registrar(mats0, clusters0, n_points, b, "q", HIDDEN, EPOCHS, not args.eager, dev,
+                regs[b] = Registrar(mats0, clusters0, n_points, b, "q", HIDDEN, EPOCHS, use_graph, dev,
                                     seeds=list(range(b)), graph_branches=args.graph_branches)
                 regs[b].stop = args.stop
             return regs[b]

@@ -300,15 +300,20 @@ int creg_visibility_f64(const double* tri, const int32_t* tri_link, int32_t n_tr
  * ReduceLROnPlateau, best-loss tracking and early stop, with no host round trip per epoch
  * (the reference syncs on loss.item() every epoch, mlp_reg.py:102).
  *
- * rot = 0: ROT == 'q'  with QRegMLP(True, hidden)  (model_utils.py:101-159)
- * rot = 1: ROT == 'dq' with DQRegMLP(hidden)       (model_utils.py:65-99)
+ * The reference's four --r choices (mlp_reg.py:64-90, models built at :276-291):
+ * rot = 0: ROT == 'q'   with QRegMLP(True, hidden)  (model_utils.py:101-159)   pose row [t | quaternion], 7 -> 56 features
+ * rot = 1: ROT == 'dq'  with DQRegMLP(hidden)       (model_utils.py:65-99)     dual quaternion, 8 -> 64 features, one decoder, ReLU
+ * rot = 2: ROT == '6d'  with RRegMLP(hidden)        (model_utils.py:170-214)   [t | first two rows of R], 9 -> 72 features; k <= 142
+ * rot = 3: ROT == 'rpy' with RegMLP(True, hidden)   (model_utils.py:216-281)   [t | XYZ Euler angles], 6 -> 48 features, Tanh after
+ *                                                                              decoder_2 (the reference builds RegMLP(6, 3):
+ *                                                                              hidden 3 -- run zero-padded at 64, see `hidden`)
  * Parameter order in `params` (torch nn.Linear layout, weight (out,in) row-major):
- *   rot 0: encoder.0.{weight,bias}, decoder_1.0.{w,b}, decoder_1.2.{w,b}, decoder_2.0.{w,b},
+ *   rot 0, 2, 3: encoder.0.{weight,bias}, decoder_1.0.{w,b}, decoder_1.2.{w,b}, decoder_2.0.{w,b},
  *          decoder_2.2.{w,b}                                        (10 tensors)
  *   rot 1: encoder.0.{w,b}, decoder.0.{w,b}, decoder.2.{w,b}        (6 tensors)
  */
 typedef struct creg_train_shape {
-    int32_t rot;          /* 0 'q', 1 'dq' */
+    int32_t rot;          /* 0 'q', 1 'dq', 2 '6d', 3 'rpy' */
     int32_t k;            /* clusters (poses), <= 160 */
     int32_t hidden;       /* hidden_dim in {64, 128, 256, 512} (512 in the reference); any other width <= 512: pass the next of these
                              and the parameters zero-padded to it -- exactly equivalent, see autourdf_amd/ops.py::TrainPlan */
@@ -334,7 +339,7 @@ typedef struct creg_train_args {
     const float* y;             /* (n_tgt,3) target frame */
     const float* local_pts;     /* (n_pred,3) clusters in local frames, back to back */
     const int32_t* seg_offsets; /* (k+1) int32, DEVICE */
-    float* const* params;       /* HOST array of 10 (rot 0) / 6 (rot 1) device pointers; updated in place */
+    float* const* params;       /* HOST array of 10 (rot 0, 2, 3) / 6 (rot 1) device pointers; updated in place */
     float lr;                   /* 2e-4 (Step) / 1e-4 (Anchor), mlp_reg.py:17,354 */
     float sched_factor;         /* 0.7 */
     int32_t sched_patience;     /* 5 */

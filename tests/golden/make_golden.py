@@ -8,6 +8,7 @@ Sources of truth, per fixture:
   calculate_pc.npz        reference mlp_reg.calculate_pc
   train_reference.npz     reference mlp_reg.train (full 300-epoch loop, tiny problem, ROT q and dq)
   train_reference_h64.npz reference mlp_reg.train at hidden 64 (6 epochs with the loss of each, and 300), ROT q and dq
+  train_reference_rot.npz the same two runs for ROT 6d (RRegMLP, hidden 64) and rpy (RegMLP(6, 3): hidden 3, mlp_reg.py:285)
   resample_reference.npz  reference mlp_reg.resample_cluster with LIVE scikit-learn k_means
   masked_icp_reference.npz reference cluster_icp.masked_icp (mask + bookkeeping; ICP via oracle stub)
   kmeans_sklearn.npz      live sklearn.cluster.k_means (labels, centres, inertia)
@@ -153,10 +154,21 @@ def g_train_h64():
     plan with the reference DIRECTLY (A1 was pinned two hops away, through the oracle at hidden 32).  Two
     runs per rotation: the first six epochs with every epoch's loss (the reference function, its `range` shadowed in its
     module so the loop stops after 6, chamfer_distance wrapped to record what it returns), and the full 300 epochs."""
+    _train_runs("train_reference_h64.npz", (("q", lambda: ref_models.QRegMLP(True, hidden_dim=64), 31),
+                                            ("dq", lambda: ref_models.DQRegMLP(hidden_dim=64), 32)))
+
+
+def g_train_rot():
+    """The two optional representations (mlp_reg.py:72-76, 86-90) through the reference's own train(): --r 6d with RRegMLP at
+    hidden 64, --r rpy with RegMLP(6, 3) exactly as the reference constructs it (mlp_reg.py:285: hidden_dim = 3)."""
+    _train_runs("train_reference_rot.npz", (("6d", lambda: ref_models.RRegMLP(hidden_dim=64), 33),
+                                            ("rpy", lambda: ref_models.RegMLP(6, 3), 34)))
+
+
+def _train_runs(name, cases):
     import builtins
     out = {}
-    for rot, ctor, seed in (("q", lambda: ref_models.QRegMLP(True, hidden_dim=64), 31),
-                            ("dq", lambda: ref_models.DQRegMLP(hidden_dim=64), 32)):
+    for rot, ctor, seed in cases:
         seq, mats, clusters = tiny_problem(2, n=512, k=5)
         y = torch.from_numpy(seq[1].astype(np.float32))
         ref_reg.ROT = rot
@@ -189,7 +201,7 @@ def g_train_h64():
         out.update({f"{rot}.sd." + k: v for k, v in sd0.items()})
         out.update({f"{rot}_m": mats, f"{rot}_y": y.numpy(), f"{rot}_local": np.concatenate(clusters),
                     f"{rot}_offsets": np.cumsum([0] + [len(c) for c in clusters])})
-    save("train_reference_h64.npz", **out)
+    save(name, **out)
 
 
 class _Seg:
@@ -298,4 +310,8 @@ def g_chamfer():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    g_dq(); g_models(); g_calc_pc(); g_train(); g_train_h64(); g_resample(); g_segments(); g_masked_icp(); g_kmeans(); g_chamfer()
+    if len(sys.argv) > 1:                                  # e.g. `make_golden.py g_train_rot`: one fixture, the others untouched
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+    else:
+        g_dq(); g_models(); g_calc_pc(); g_train(); g_train_h64(); g_train_rot(); g_resample(); g_segments(); g_masked_icp(); g_kmeans(); g_chamfer()

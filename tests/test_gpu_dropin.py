@@ -179,8 +179,9 @@ def test_larger_configs_two_epochs_vs_oracle(robot, n, k):
 
 
 @pytest.mark.parametrize("rot", ["6d", "rpy"])
-def test_compat_modes_short_trajectory_vs_oracle(rot):
-    """--r 6d / --r rpy: PyTorch MLP + HIP Chamfer / calculate_pc against the all-CPU oracle, 5 epochs."""
+def test_optional_representations_short_trajectory_vs_oracle(rot):
+    """--r 6d / --r rpy through the drop-in train(): the fused plan (RegMLP(6, 3) zero-padded to the kernels' width) against the
+    all-CPU oracle, 5 epochs; the model's tensors come back trained, in their own shapes."""
     from autourdf_amd import mlp_reg, model_utils
     from autourdf_amd.synthetic import initial_segmentation, make_sequence
     from oracle import models, registration
@@ -203,3 +204,6 @@ def test_compat_modes_short_trajectory_vs_oracle(rot):
         mlp_reg.ROT, mlp_reg.EPOCHS = old
     assert abs(min_loss - o_min) <= 2e-5 * abs(o_min)
     np.testing.assert_allclose(best_m.detach().cpu().numpy(), o_best.detach().numpy(), atol=2e-5)
+    for (name, p), q in zip(g_model.state_dict().items(), o_model.state_dict().values()):
+        assert p.shape == q.shape
+        np.testing.assert_allclose(p.cpu().numpy(), q.numpy(), atol=5e-5, err_msg=name)

@@ -586,22 +586,34 @@ def _train_case(golden, rot):
     return g, model, sd
 
 
-@pytest.mark.parametrize("rot", ["q", "dq"])
+def _oracle_model(rot, hidden):
+    """The oracle's model of a --r choice (mlp_reg.py:276-291): QRegMLP / DQRegMLP / RRegMLP / RegMLP."""
+    from oracle import models
+    return {"q": lambda: models.QRegMLP(True, hidden), "dq": lambda: models.DQRegMLP(hidden), "6d": lambda: models.RRegMLP(hidden),
+            "rpy": lambda: models.RegMLP(True, hidden)}[rot]()
+
+
+def _order(rot):
+    from autourdf_amd import ops
+    return ops.DQ_PARAM_ORDER if rot == "dq" else ops.Q_PARAM_ORDER
+
+
+@pytest.mark.parametrize("rot", ["q", "dq", "6d", "rpy"])
 def test_train_probe_forward_and_pose_gradient_vs_oracle(dev, golden, rot):
     """One epoch's forward (pose, cloud, loss) and dL/d[R|t] against torch autograd on the oracle."""
     from autourdf_amd import ops
     from oracle import registration
     from oracle.chamfer import chamfer_distance
-    g, model, sd = _train_case(golden, rot)
+    data = rot if rot in ("q", "dq") else "q"                   # (the optional representations: on the 'q' fixture's problem)
+    g, model, sd = _train_case(golden, data)
     hidden = 64                                                  # engine needs hidden % 64 == 0
-    from oracle import models
     torch.manual_seed(3)
-    model = models.QRegMLP(True, hidden) if rot == "q" else models.DQRegMLP(hidden)
+    model = _oracle_model(rot, hidden)
     for p in model.parameters():
         p.data.mul_(0.2)
-    order = ops.Q_PARAM_ORDER if rot == "q" else ops.DQ_PARAM_ORDER
-    m, y = torch.from_numpy(g[f"{rot}_m"]), torch.from_numpy(g[f"{rot}_y"])
-    clusters = [torch.from_numpy(c) for c in _split(g[f"{rot}_local"], g[f"{rot}_offsets"])]
+    order = _order(rot)
+    m, y = torch.from_numpy(g[f"{data}_m"]), torch.from_numpy(g[f"{data}_y"])
+    clusters = [torch.from_numpy(c) for c in _split(g[f"{data}_local"], g[f"{data}_offsets"])]
     m2 = registration.pose_forward(m, model, rot)
     m2.retain_grad()
     pred = torch.cat(registration.calculate_pc(clusters, m2))
@@ -641,6 +653,36 @@ def test_train_vs_reference_train_directly_hidden64(dev, golden, rot):
             np.testing.assert_allclose(bm.cpu().numpy(), g[f"{rot}_e6_best_m"], atol=1e-5)
             np.testing.assert_allclose(bp.cpu().numpy(), g[f"{rot}_e6_best_pred"], atol=1e-5)
             for k, p in zip(order, params):
+                np.testing.assert_allclose(p.cpu().numpy(), g[f"{rot}_e6.final.{k}"], atol=2e-5, err_msg=k)
+        else:
+            assert int(res[1]) == 300
+            assert abs(res[0] - float(g[f"{rot}_e300_min_loss"])) <= 1e-3 * float(g[f"{rot}_e300_min_loss"])
+            np.testing.assert_allclose(bm.cpu().numpy(), g[f"{rot}_e300_best_m"], atol=2e-3)
+
+
+@pytest.mark.parametrize("rot,hidden", [("6d", 64), ("rpy", 3)])
+def test_train_optional_representations_vs_reference_train_directly(dev, golden, rot, hidden):
+    """--r 6d / --r rpy (mlp_reg.py:72-76, 86-90) on the fused plan against the REFERENCE's own train()
+    (tests/golden/train_reference_rot.npz: RRegMLP at hidden 64; RegMLP(6, 3) as mlp_reg.py:285 constructs it -- hidden 3, which
+    the plan runs zero-padded at width 64): every loss of six epochs 1e-5 relative, best pose and cloud 1e-5, parameters after six
+    Adam steps 2e-5; the 300-epoch run to the envelope two float32 implementations keep."""
+    from autourdf_amd import ops
+    g = golden("train_reference_rot.npz")
+    order = ops.Q_PARAM_ORDER
+    m, y = torch.from_numpy(g[f"{rot}_m"]).to(dev), torch.from_numpy(g[f"{rot}_y"]).to(dev)
+    clusters = [torch.from_numpy(c) for c in _split(g[f"{rot}_local"], g[f"{rot}_offsets"])]
+    pts, off = ops.pack_clusters(clusters, dev)
+    for tag, epochs in (("e6", 6), ("e300", 300)):
+        params = [torch.from_numpy(g[f"{rot}.sd.{k}"]).clone().to(dev) for k in order]
+        plan = ops.TrainPlan(rot, len(clusters), hidden, pts.shape[0], y.shape[0], epochs=epochs, use_graph=True, device=dev)
+        bm, bp, res, lh, _ = plan.run(m, y, pts, off, params)
+        res = res.cpu().numpy()
+        if epochs == 6:
+            np.testing.assert_allclose(lh.cpu().numpy().astype(np.float64), g[f"{rot}_e6_loss_hist"], rtol=1e-5)
+            np.testing.assert_allclose(bm.cpu().numpy(), g[f"{rot}_e6_best_m"], atol=1e-5)
+            np.testing.assert_allclose(bp.cpu().numpy(), g[f"{rot}_e6_best_pred"], atol=1e-5)
+            for k, p in zip(order, params):
+                assert tuple(p.shape) == tuple(g[f"{rot}_e6.final.{k}"].shape)
                 np.testing.assert_allclose(p.cpu().numpy(), g[f"{rot}_e6.final.{k}"], atol=2e-5, err_msg=k)
         else:
             assert int(res[1]) == 300
@@ -789,7 +831,7 @@ def test_train_hidden32_reference_golden_runs_on_the_plan(dev, golden, rot):
         assert np.median(d) < 3e-6 and (d < 3e-5).mean() >= 0.99 and d.max() < 1.2e-3, (name, np.median(d), d.max())
 
 
-@pytest.mark.parametrize("rot,hidden", [("q", 48), ("dq", 100), ("q", 200), ("dq", 300)])
+@pytest.mark.parametrize("rot,hidden", [("q", 48), ("dq", 100), ("q", 200), ("dq", 300), ("6d", 100), ("rpy", 3), ("rpy", 48)])
 def test_train_any_hidden_width_three_steps_vs_oracle(dev, rot, hidden):
     """Widths between the instantiated tiles (odd halves included: decoder_1 is hidden // 2 wide): three Adam steps against the
     oracle's model of the SAME width -- loss history 2e-5 relative, best pose 1e-5."""
@@ -801,8 +843,8 @@ def test_train_any_hidden_width_three_steps_vs_oracle(dev, rot, hidden):
     m, y = torch.tensor(mats, dtype=torch.float32), torch.tensor(seq[1], dtype=torch.float32)
     clusters = [torch.tensor(c, dtype=torch.float32) for c in cl]
     torch.manual_seed(13)
-    model = models.QRegMLP(True, hidden) if rot == "q" else models.DQRegMLP(hidden)
-    order = ops.Q_PARAM_ORDER if rot == "q" else ops.DQ_PARAM_ORDER
+    model = _oracle_model(rot, hidden)
+    order = _order(rot)
     params = [model.state_dict()[n].clone().to(dev) for n in order]
     pts, off = ops.pack_clusters(clusters, dev)
     plan = ops.TrainPlan(rot, len(clusters), hidden, pts.shape[0], y.shape[0], epochs=3, use_graph=True, device=dev)
@@ -813,7 +855,8 @@ def test_train_any_hidden_width_three_steps_vs_oracle(dev, rot, hidden):
     assert all(tuple(p.shape) == tuple(model.state_dict()[n].shape) for p, n in zip(params, order))
 
 
-@pytest.mark.parametrize("rot,hidden,k", [("q", 64, 7), ("q", 128, 5), ("dq", 64, 3), ("dq", 128, 9), ("q", 256, 21), ("dq", 512, 33)])
+@pytest.mark.parametrize("rot,hidden,k", [("q", 64, 7), ("q", 128, 5), ("dq", 64, 3), ("dq", 128, 9), ("q", 256, 21), ("dq", 512, 33),
+                                          ("6d", 512, 20), ("6d", 64, 33), ("rpy", 128, 7), ("6d", 256, 142)])
 def test_train_three_steps_odd_shapes_vs_oracle(dev, rot, hidden, k):
     """Hidden sizes and cluster counts whose staged activation blocks do NOT end on a 64 x 16-byte boundary (the
     LDS-DMA tail case): three full Adam steps against the oracle, loss history and poses."""
@@ -826,8 +869,8 @@ def test_train_three_steps_odd_shapes_vs_oracle(dev, rot, hidden, k):
     y = torch.tensor(seq[1], dtype=torch.float32)
     clusters = [torch.tensor(c, dtype=torch.float32) for c in cl]
     torch.manual_seed(9)
-    model = models.QRegMLP(True, hidden) if rot == "q" else models.DQRegMLP(hidden)
-    order = ops.Q_PARAM_ORDER if rot == "q" else ops.DQ_PARAM_ORDER
+    model = _oracle_model(rot, hidden)
+    order = _order(rot)
     params = [model.state_dict()[n].clone().to(dev) for n in order]
     pts, off = ops.pack_clusters(clusters, dev)
     plan = ops.TrainPlan(rot, k, hidden, pts.shape[0], y.shape[0], epochs=3, use_graph=True, device=dev)

@@ -129,6 +129,27 @@ def test_train_hidden64_matches_reference_six_epochs_and_300(golden, rot, ctor):
     np.testing.assert_allclose(best_m.detach().numpy(), g[f"{rot}_e300_best_m"], atol=2e-5)
 
 
+@pytest.mark.parametrize("rot,ctor", [("6d", lambda: models.RRegMLP(64)), ("rpy", lambda: models.RegMLP(6, 3))])
+def test_train_optional_representations_match_reference(golden, rot, ctor):
+    """train_reference_rot.npz: the reference's own train() with --r 6d (RRegMLP, hidden 64) and --r rpy (RegMLP(6, 3), the
+    reference's construction: hidden 3), mlp_reg.py:72-76,86-90,285-290: six epochs pinned per epoch, and the 300-epoch run."""
+    g = golden("train_reference_rot.npz")
+    clusters = [torch.from_numpy(c) for c in _split(g[f"{rot}_local"], g[f"{rot}_offsets"])]
+    m, y = torch.from_numpy(g[f"{rot}_m"]), torch.from_numpy(g[f"{rot}_y"])
+    model = ctor()
+    model.load_state_dict(_load_sd(g, f"{rot}.sd."))
+    _, best_m, min_loss, hist = registration.train(m, y, model, clusters, rot=rot, epochs=6)
+    np.testing.assert_allclose(np.array(hist["loss"]), g[f"{rot}_e6_loss_hist"], rtol=1e-6)
+    np.testing.assert_allclose(best_m.detach().numpy(), g[f"{rot}_e6_best_m"], atol=1e-6)
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), g[f"{rot}_e6.final.{k}"], atol=2e-6)
+    model = ctor()
+    model.load_state_dict(_load_sd(g, f"{rot}.sd."))
+    _, best_m, min_loss, hist = registration.train(m, y, model, clusters, rot=rot)
+    assert abs(min_loss - float(g[f"{rot}_e300_min_loss"])) < 1e-6
+    np.testing.assert_allclose(best_m.detach().numpy(), g[f"{rot}_e300_best_m"], atol=2e-5)
+
+
 def test_train_c1_headline_shape_oracle_reproduces_the_reference(golden):
     """train_reference_c1.npz: the reference's own train() with its default model (QRegMLP(True, hidden_dim=512), mlp_reg.py:281-282)
     at the BASELINE configs[1] shape (N = 4096, K = 20).  The oracle is the same op sequence on the same torch build: six epochs of
