@@ -35,6 +35,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HIDDEN, EPOCHS, FRAMES_PER_SEQ = 512, 300, 10
+MODEL_NAMES = {"q": "QRegMLP hidden 512", "dq": "--r dq: DQRegMLP hidden 512", "6d": "--r 6d: RRegMLP hidden 512",
+               "rpy": "--r rpy: RegMLP(6, 3), hidden 3 as mlp_reg.py:285 builds it"}
 # QRegMLP(multi_decoder=True, hidden 512) parameters: 56->512, 512->256->3, 512->512->4 with biases
 N_PARAMS = (56 * HIDDEN + HIDDEN) + (HIDDEN * (HIDDEN // 2) + HIDDEN // 2) + (3 * (HIDDEN // 2) + 3) + (HIDDEN * HIDDEN + HIDDEN) + (4 * HIDDEN + 4)
 # BASELINE.json configs: [1] is the headline (default); the others are selectable for extra evidence lines
@@ -545,6 +547,8 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-icp-variant", action="store_true", help="skip the ICP-style second line (SURVEY 8(d))")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--r", choices=["q", "dq", "6d", "rpy"], default="q",
+                    help="pose representation (mlp_reg.py:360 --r); 'q' is the reference's default and the metric's; the others skip the roofline / cpu_baseline legs")
     ap.add_argument("--eager", action="store_true", help="eager launches instead of the captured epoch graph")
     ap.add_argument("--epochs-per-graph", type=int, default=0, help="epochs captured per hipGraph (0 = the library's 50; 300 = one replay per train)")
     ap.add_argument("--graph-branches", type=int, default=0, help="parallel chains in the captured graph (0 = the library's default)")
@@ -623,8 +627,11 @@ def main(argv=None):
     seqs = [make_sequence(robot, sid, max(n_frames, FRAMES_PER_SEQ), n_points) for sid in seq_ids]
     frames64 = [[torch.as_tensor(f, dtype=torch.float64, device=dev) for f in s[1:n_frames]] for s in seqs]
     frames32 = [[f.to(torch.float32) for f in s] for s in frames64]
+    hidden = 3 if args.r == "rpy" else HIDDEN            # (the reference builds RegMLP(6, 3), mlp_reg.py:285)
+    if args.r != "q":
+        args.no_roofline = args.no_cpu_baseline = True   # both legs are stated for the default model
     use_graph = False if args.eager else (args.epochs_per_graph if args.epochs_per_graph > 1 else True)
-    reg = Registrar(mats0, clusters0, n_points, S, "q", HIDDEN, EPOCHS, use_graph, dev,
+    reg = Registrar(mats0, clusters0, n_points, S, args.r, hidden, EPOCHS, use_graph, dev,
                     seeds=seq_ids, graph_branches=args.graph_branches)
     reg.stop = args.stop
     epochs_log = []
@@ -647,7 +654,7 @@ def main(argv=None):
 
         def reg_for(b):
             if b not in regs:
-                regs[b] = Registrar(mats0, clusters0, n_points, b, "q", HIDDEN, EPOCHS, use_graph, dev,
+                regs[b] = Registrar(mats0, clusters0, n_points, b, args.r, hidden, EPOCHS, use_graph, dev,
                                     seeds=list(range(b)), graph_branches=args.graph_branches)
                 regs[b].stop = args.stop
             return regs[b]
@@ -733,7 +740,7 @@ def main(argv=None):
                "scaling": "strong" if replay else "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{robot}-shaped, {S} sequences x 10 frames per GPU, N={n_points}, K={k_clusters} ({wl_tag}); "
-                                      "1 step = 1 registered frame = 2 x 300 Adam epochs (QRegMLP hidden 512, L1 Chamfer) "
+                                      f"1 step = 1 registered frame = 2 x 300 Adam epochs ({MODEL_NAMES[args.r]}, L1 Chamfer) "
                                       "+ Lloyd k-means resample", "n_points": n_points, "k_clusters": k_clusters,
                           "mode": ("replay / independent-frame mode: --steps work items in TOTAL, captured from a sequential pass, dealt "
                                    "round-robin to the ranks (SURVEY 8(e); frames of a sequence cannot be sharded otherwise)") if replay else
