@@ -1332,6 +1332,13 @@ struct Plan {
     size_t bstride;           // bytes between consecutive problems' workspaces
     int smem_bd;
     int branches;             // parallel chains in the captured graph (groups of problems)
+    // chain-stream mode (creg_train_shape.graph_branches < 0): every chain is its OWN linear graph on its OWN stream, forked from /
+    // joined to the caller's stream once per train by events -- the chains' hardware queues are then the streams', not what the
+    // runtime picks for the branches of one graph at every launch
+    bool chain_streams;
+    hipStream_t cst[8];
+    hipGraphExec_t cexec[8];
+    hipEvent_t cfork, cjoin[8];
     bool target_blocks_valid; // ys4 / ybox hold the k-d leaves of every problem's last run_batch frame (probe / profile overwrite them)
 };
 
@@ -1647,6 +1654,41 @@ static int capture_epochs(Plan* P, int epg) {
     return CREG_OK;
 }
 
+// chain-stream mode: chain gi's EPG epochs as a linear graph, captured on (and later launched on) the chain's own stream
+static int chain_first(const Plan* P, int gi) { int f = 0; for (int i = 0; i < gi; ++i) f += P->B / P->branches + (i < P->B % P->branches ? 1 : 0); return f; }
+static int chain_count(const Plan* P, int gi) { return P->B / P->branches + (gi < P->B % P->branches ? 1 : 0); }
+static int capture_chains(Plan* P, int epg) {
+    const Ws Wall = P->W;
+    const int nz_all = P->nz;
+    hipError_t err = hipSuccess;
+    const char* what = "";
+#define CAP_TRY(call) do { if (err == hipSuccess) { err = (call); if (err != hipSuccess) what = #call; } } while (0)
+    CAP_TRY(hipEventCreateWithFlags(&P->cfork, hipEventDisableTiming));
+    for (int gi = 0; gi < P->branches && err == hipSuccess; ++gi) {
+        hipGraph_t g = nullptr;
+        CAP_TRY(hipStreamCreateWithFlags(&P->cst[gi], hipStreamNonBlocking));
+        CAP_TRY(hipEventCreateWithFlags(&P->cjoin[gi], hipEventDisableTiming));
+        CAP_TRY(hipStreamBeginCapture(P->cst[gi], hipStreamCaptureModeThreadLocal));
+        if (err != hipSuccess) break;
+        P->W = ws_shift(Wall, (size_t)chain_first(P, gi) * P->bstride); P->nz = chain_count(P, gi);
+        for (int i = 0; i < epg; ++i) enqueue_epoch(P, i, P->cst[gi]);
+        P->W = Wall; P->nz = nz_all;
+        const hipError_t e2 = hipStreamEndCapture(P->cst[gi], &g);
+        if (e2 != hipSuccess) { err = e2; what = "hipStreamEndCapture"; }
+        CAP_TRY(hipGraphInstantiate(&P->cexec[gi], g, nullptr, nullptr, 0));
+        if (g) (void)hipGraphDestroy(g);
+    }
+#undef CAP_TRY
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        creg::set_error("creg_train_plan_run_batch: chain graph capture failed: %s: %s", what, hipGetErrorString(err));
+        return CREG_EHIP;
+    }
+    P->graph_ready = true;
+    P->graph_epochs = epg;
+    return CREG_OK;
+}
+
 static int batch_of(const creg_train_shape* s) { return s->batch >= 1 ? s->batch : 1; }
 
 extern "C" size_t creg_train_workspace_bytes(const creg_train_shape* shape) {
@@ -1668,17 +1710,26 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     P->shape = *shape; P->D = D; P->base = (char*)workspace; P->bytes = workspace_bytes;
     carve(D, P->base, &P->W);
     P->B = batch_of(shape); P->nz = P->B; P->bstride = one;
-    // Default branch count, measured on MI355X (bench.py --graph-branches, three runs each on one box):
-    // frames above 4096 points (several points per lane in the NN kernels) spend most of a step in the
-    // two NN searches, which leave CUs idle near their tails, and a third branch fills them: the
-    // 16384-point shape runs at 71.1 / 76.0 / 67.4 frames/s with 2 / 3 / 4 branches.  At 4096 points
-    // and below the step is a chain of short kernels and a third branch only adds interleaving:
-    // 149 frames/s with 2 branches, 117-124 with 3.
-    const int auto_branches = (D.ppl > 1 && P->B >= 3) ? 3 : (P->B >= 2 ? 2 : 1);
-    P->branches = shape->graph_branches > 0 ? shape->graph_branches : auto_branches;
+    // How the problems of a batch share the GPU (round 4, profiles/r04_chains_by_batch.log; bench.py --graph-branches):
+    //   graph_branches < 0: -n CHAIN STREAMS -- the batch is cut into n contiguous groups, every group's epochs are a LINEAR graph
+    //     (replayed from pre-built packets: 0.6-1.2 ms of host time per 300-epoch train) on its own stream; chain 0 uses the
+    //     caller's stream, the others fork from / join it once per train.
+    //   graph_branches > 0: n parallel branches inside ONE graph (rounds 2-3).  The runtime enqueues every node of a multi-branch
+    //     graph from the host at each replay -- 9 ms per train with two branches, 14 of the train's 15 ms with three, which is why
+    //     three branches ran "bimodal" (host-bound: any hiccup of the enqueuing thread stalls a queue).
+    //   0 = auto: chain streams; one chain up to 4 problems (47.9 / 92.9 / 127 / 153 frames/s for 1-4 sequences against
+    //     - / 84 / 119 / 152 with two), two for 5-7 (182 / 201 / 219 against 175 / 188 / 189 with one and 172 / 198 / 209 with
+    //     three), three from 8 (230 against 226); frames above 4096 points (several points per lane in the NN kernels, whose tails
+    //     leave CUs idle) take three from 3 problems on (franka shape 79.4 against 74.8 / 74.0 with two / one).  Four chains need a
+    //     fifth hardware queue and collapse (112 at 6 sequences).  Results never depend on any of this.
+    const int auto_chains = (D.ppl > 1 && P->B >= 3) ? 3 : (P->B >= 8 ? 3 : (P->B >= 5 ? 2 : 1));
+    P->chain_streams = shape->graph_branches <= 0;
+    P->branches = shape->graph_branches > 0 ? shape->graph_branches : (shape->graph_branches < 0 ? -shape->graph_branches : auto_chains);
     if (P->branches > P->B) P->branches = P->B;
     if (P->branches > 8) P->branches = 8;
     P->gexec = nullptr; P->graph_ready = false; P->target_blocks_valid = false;
+    P->cfork = nullptr;
+    for (int i = 0; i < 8; ++i) { P->cst[i] = nullptr; P->cexec[i] = nullptr; P->cjoin[i] = nullptr; }
     {   // the dynamic LDS of k_bd is the B role's (71 KB at K = 20, hidden 512: its 48 KB slab of W2 + 23 KB; the D role uses none)
         P->smem_bd = (int)(sizeof(float) * b2_smem_floats(D.K, D.IN, D.H2));
     }
@@ -1729,10 +1780,33 @@ extern "C" int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train
         if (epg > D.epochs) epg = D.epochs;
         epg &= ~1;
         if (!P->graph_ready) {
-            const int rc = capture_epochs(P, epg);
+            const int rc = P->chain_streams ? capture_chains(P, epg) : capture_epochs(P, epg);
             if (rc) return rc;
         }
-        for (; e + P->graph_epochs <= D.epochs; e += P->graph_epochs) CREG_HIP(hipGraphLaunch(P->gexec, s));
+        if (P->chain_streams) {
+            // fork once, every chain runs the whole train on its own stream (graph replays, then the epochs that do not fill a
+            // graph), join once.  Chain 0 runs on the CALLER's stream: a stream that only waits for the others would hold a barrier
+            // packet in its hardware queue for the whole train, and a parked barrier slows the chains in the other queues by ~10 %
+            // (measured, tests/measure/frame_phases_by_chains.py).
+            const Ws Wall = P->W;
+            auto st_of = [&](int gi) { return gi == 0 ? s : P->cst[gi]; };
+            CREG_HIP(hipEventRecord(P->cfork, s));
+            for (int gi = 1; gi < P->branches; ++gi) CREG_HIP(hipStreamWaitEvent(P->cst[gi], P->cfork, 0));
+            for (; e + P->graph_epochs <= D.epochs; e += P->graph_epochs)
+                for (int gi = 0; gi < P->branches; ++gi) CREG_HIP(hipGraphLaunch(P->cexec[gi], st_of(gi)));
+            for (int gi = 0; gi < P->branches; ++gi) {
+                P->W = ws_shift(Wall, (size_t)chain_first(P, gi) * P->bstride); P->nz = chain_count(P, gi);
+                for (int e2 = e; e2 < D.epochs; ++e2) enqueue_epoch(P, e2, st_of(gi));
+                P->W = Wall; P->nz = P->B;
+            }
+            for (int gi = 1; gi < P->branches; ++gi) {
+                CREG_HIP(hipEventRecord(P->cjoin[gi], P->cst[gi]));
+                CREG_HIP(hipStreamWaitEvent(s, P->cjoin[gi], 0));
+            }
+            e = D.epochs;
+        } else {
+            for (; e + P->graph_epochs <= D.epochs; e += P->graph_epochs) CREG_HIP(hipGraphLaunch(P->gexec, s));
+        }
     }
     for (; e < D.epochs; ++e) enqueue_epoch(P, e, s);
     hipLaunchKernelGGL(k_params_home, dim3(64, 1, P->B), dim3(256), 0, s, D, P->W, P->bstride);
@@ -1899,6 +1973,13 @@ extern "C" int creg_train_plan_destroy(creg_train_plan* plan) {
     Plan* P = (Plan*)plan;
     if (!P) return CREG_OK;
     if (P->gexec) (void)hipGraphExecDestroy(P->gexec);
+    for (int i = 0; i < 8; ++i) {
+        if (P->cst[i]) (void)hipStreamSynchronize(P->cst[i]);
+        if (P->cexec[i]) (void)hipGraphExecDestroy(P->cexec[i]);
+        if (P->cjoin[i]) (void)hipEventDestroy(P->cjoin[i]);
+        if (P->cst[i]) (void)hipStreamDestroy(P->cst[i]);
+    }
+    if (P->cfork) (void)hipEventDestroy(P->cfork);
     delete P;
     return CREG_OK;
 }

@@ -14,8 +14,13 @@ class _HostInverse:
     """inv(M_k) the way resample_cluster gets it (mlp_reg.py:211): ``np.linalg.inv`` on the HOST in the poses' own
     dtype (float32 after train, float64 after masked_icp) -- LAPACK's rounding is what the reference's
     cluster/NNNN.npz carries and it is not reproducible on the device.  The (K,4,4) poses are fetched on a side
-    stream that waits only for the event recorded right after the launch that produced them, so work enqueued in
-    between (the k-means of the same frames) overlaps the round trip; returns the inverses as float64 on the device."""
+    stream once the event recorded right after the launch that produced them has completed, so work enqueued in
+    between (the k-means of the same frames) overlaps the round trip; returns the inverses as float64 on the device.
+
+    The HOST waits for that event (hipEventSynchronize), not the side stream: `side.wait_event(ev)` parks a barrier packet in
+    the side stream's hardware queue for as long as the trains run, and the command processor's polling of it slows the
+    latency-bound epoch chains in the other queue by 3-10 % (round 4, tests/measure/frame_phases_by_chains.py: a train of
+    5 problems 14.27 -> 13.82 ms with two graph chains, 15.64 -> 14.07 ms as one linear graph)."""
 
     def __init__(self, device):
         self.side = torch.cuda.Stream(device=device)
@@ -26,8 +31,8 @@ class _HostInverse:
         return ev
 
     def __call__(self, M, ev):
+        ev.synchronize()
         with torch.cuda.stream(self.side):
-            self.side.wait_event(ev)
             host = M.to("cpu", non_blocking=True)
             self.side.synchronize()
         inv = np.linalg.inv(host.numpy()).astype(np.float64)

@@ -322,11 +322,14 @@ typedef struct creg_train_shape {
     int64_t n_tgt;        /* points in the target frame */
     int32_t use_graph;    /* 0: eager launches; 1: hipGraph of 50 epochs per launch; n > 1: n epochs per graph */
     int32_t batch;        /* independent problems (sequences) advanced per launch; 0 or 1 = one */
-    int32_t graph_branches; /* parallel chains in the captured graph: the batch is split into this many contiguous
-                               groups whose epochs are captured as independent branches (different hardware queues,
-                               so one group's small kernels overlap the other's NN launch).  0 = auto (2 when
-                               batch >= 2; 3 when batch >= 3 and n_tgt > 4096, where the NN searches dominate),
-                               1 = single chain.  Results do not depend on it. */
+    int32_t graph_branches; /* how the problems of a batch share the GPU: the batch is cut into contiguous groups ("chains") whose
+                               epochs run concurrently in different hardware queues, so that one group's latency-bound kernels
+                               overlap another's.  0 = auto: chain streams (below), 1 chain up to 4 problems, 2 for 5-7, 3 from 8;
+                               3 from 3 problems on when n_tgt > 4096.  -n: n CHAIN STREAMS -- every chain a linear graph on its own
+                               stream (chain 0 on the caller's), forked / joined once per train by events; under 1.5 ms of host
+                               time per train.  +n: n parallel branches inside ONE graph (rounds 2-3; the runtime enqueues every
+                               node of such a graph from the host at each replay: 9-14 ms per train).  At most 3 chains are
+                               useful (a fourth needs a fifth hardware queue).  Results do not depend on it. */
     int32_t nn_search;    /* 0 = auto: the nearest-neighbour searches run over k-d leaf blocks with boxes (exact
                              pruning) when n_tgt <= 65536 (four chunks of 16384 sorted per workgroup) and, for the
                              target -> predicted direction, when the predicted cloud fits 512 blocks (n_pred / 64 + k,

@@ -1062,7 +1062,7 @@ def test_graph_branches_stress_bit_identical_to_single_runs(dev, rot):
     mk = lambda: [model.state_dict()[k].clone().to(dev) for k in order]
     single = ops.TrainPlan(rot, 8, 512, pts.shape[0], ys[0].shape[0], epochs=40, use_graph=True, device=dev)
     ref = [[t.cpu() for t in single.run(m, ys[b], pts, off, mk())] for b in range(5)]
-    for batch, branches, reps in ((5, 2, 12), (4, 2, 6), (5, 3, 4)):
+    for batch, branches, reps in ((5, 2, 12), (4, 2, 6), (5, 3, 4), (5, -2, 6), (5, -3, 4)):      # (negative: chain-stream mode, every chain its own graph on its own stream)
         for _ in range(reps):
             plan = ops.TrainPlan(rot, 8, 512, pts.shape[0], ys[0].shape[0], epochs=40, use_graph=True, device=dev,
                                  batch=batch, graph_branches=branches)
@@ -1088,7 +1088,7 @@ def test_graph_branches_bench_shape_bit_identical_to_single_runs(dev):
     single = ops.TrainPlan("q", 20, 512, 4096, 4096, epochs=60, use_graph=True, device=dev)
     ref = [[t.cpu() for t in single.run(m, ys[b], pts, off, mk())] for b in range(5)]
     for _ in range(5):
-        plan = ops.TrainPlan("q", 20, 512, 4096, 4096, epochs=60, use_graph=True, device=dev, batch=5)       # default: 2 branches
+        plan = ops.TrainPlan("q", 20, 512, 4096, 4096, epochs=60, use_graph=True, device=dev, batch=5)       # default: 2 chain streams
         outs = plan.run_batch([(m, ys[b], pts, off, mk()) for b in range(5)])
         for b in range(5):
             for got, want in zip(outs[b], ref[b]):
@@ -1096,7 +1096,8 @@ def test_graph_branches_bench_shape_bit_identical_to_single_runs(dev):
 
 
 def test_graph_branches_big_frame_default_is_three_chains_and_bit_identical_to_single_runs(dev):
-    """Frames above 4096 points default to three chains (2 + 2 + 1 of 5 problems); the 4096-point shape keeps two."""
+    """Frames above 4096 points default to three chains (2 + 2 + 1 of 5 problems) from three problems on; the 4096-point shape runs
+    one chain up to 4 problems, two for 5-7, three from 8 (chain streams: train_engine.hip, creg_train_plan_create)."""
     from autourdf_amd import ops
     from autourdf_amd.synthetic import initial_segmentation, make_sequence
     from oracle import models
@@ -1112,7 +1113,9 @@ def test_graph_branches_big_frame_default_is_three_chains_and_bit_identical_to_s
     single = ops.TrainPlan("q", 12, 64, n, n, epochs=40, use_graph=True, device=dev)
     assert single.info["graph_branches"] == 1
     assert ops.TrainPlan("q", 12, 64, 4096, 4096, epochs=40, use_graph=True, device=dev, batch=5).info["graph_branches"] == 2
-    assert ops.TrainPlan("q", 12, 64, n, n, epochs=40, use_graph=True, device=dev, batch=2).info["graph_branches"] == 2
+    assert ops.TrainPlan("q", 12, 64, n, n, epochs=40, use_graph=True, device=dev, batch=2).info["graph_branches"] == 1
+    assert ops.TrainPlan("q", 12, 64, 4096, 4096, epochs=40, use_graph=True, device=dev, batch=4).info["graph_branches"] == 1
+    assert ops.TrainPlan("q", 12, 64, 4096, 4096, epochs=40, use_graph=True, device=dev, batch=8).info["graph_branches"] == 3
     ref = [[t.cpu() for t in single.run(m, ys[b], pts, off, mk())] for b in range(5)]
     for _ in range(3):
         plan = ops.TrainPlan("q", 12, 64, n, n, epochs=40, use_graph=True, device=dev, batch=5)
