@@ -277,7 +277,7 @@ def epoch_kernel_model(k_clusters, n_points, info):
         # k_bd = two independent roles in one launch.  D: hidden + output rows, parameters + both Adam moments read and written
         # (24 B each), current activations, gradients.  B: W2 read once (its columns), the encoder rows + moments read and written,
         # g_h2, current / next encoder activation
-        "bd": {"name": f"k_bd<{HIDDEN // 64}, {12 * (HIDDEN // 64)}>", "bound": "hbm",
+        "bd": {"name": f"k_bd<{HIDDEN // 64}, {12 * (HIDDEN // 64)}, false>", "bound": "hbm",
                "bytes": 24 * w23 + 4 * (K * H + 2 * K * H2 + 16 * K) + 4 * H2 * H + 24 * w1 + 4 * (K * H2 + 2 * K * H + K * IN),
                # the K-row GEMMs on the matrix cores (v_mfma_f32_16x16x4_f32): g_h2 . W2 (B role) and the weight gradients g^T . act (D role)
                "mfma_flops": 2 * K * H2 * H + 2 * K * (H2 * H + 3 * (H // 2) + 4 * H)},
@@ -288,7 +288,7 @@ def epoch_kernel_model(k_clusters, n_points, info):
         # points, counters, signs and predictions of the clusters read, best cloud written when the loss improved, g_h2 rows
         "gradc": {"name": "k_gradc", "bound": "latency", "bytes": (16 + 16 + 4 + 16 + 12) * N + 4 * K * H2 + 4 * 8 * H2},
         # hidden activation + output rows read, predicted cloud (16 B), sorted copy (16 B) and zeroed counters (16 B) written
-        "head": {"name": "k_head<8>", "bound": "latency", "bytes": 4 * K * H2 + 4 * 7 * H2 + (16 + 16 + 16 + 16) * N},
+        "head": {"name": "k_head<8, false>", "bound": "latency", "bytes": 4 * K * H2 + 4 * 7 * H2 + (16 + 16 + 16 + 16) * N},
     }
 
 
@@ -354,7 +354,7 @@ def roofline_block(reg, frames32, n_points, k_clusters, workload, y_index=0):
                  "algorithmic_bytes": top["algorithmic_bytes"], "wasted_traffic_ratio": top.get("wasted_traffic_ratio"),
                  "dominant_by": "longest back-to-back launch of the five epoch kernels in this run",
                  "timing_source": "HIP events around 200 back-to-back launches of each kernel on the plan's stream, in this run (kernel + ~1 us "
-                                  "launch gap); launches carry the problems of the larger graph branch, as in the timed region, every one staged from the "
+                                  "launch gap); launches carry the problems of the larger chain, as in the timed region, every one staged from the "
                                   "same inputs and advanced 150 epochs (mid-train) before the launches are timed",
                  "kernels": kernels,
                  "epoch_kernels_event_bracketed_us": {k: round(v, 2) if isinstance(v, float) else v for k, v in prof.items()},

@@ -46,11 +46,14 @@ python $R/bench.py --sequences 1 --steps 8 --warmup 2 --no-cpu-baseline --no-icp
 python $R/bench.py --sequences 8 --steps 40 --warmup 8 --no-cpu-baseline --no-icp-variant > $O/bench_b8.log 2>/dev/null
 python $R/bench.py --workload franka --steps 10 --warmup 5 --no-cpu-baseline --no-icp-variant > $O/bench_franka.log 2>/dev/null
 python $R/bench.py --workload allegro --steps 20 --warmup 5 --no-cpu-baseline --no-icp-variant > $O/bench_allegro.log 2>/dev/null
+# the reference's other --r choices on the fused plan (rpy: RegMLP(6, 3), hidden 3, as mlp_reg.py:285 builds it -- it does not converge)
+(for r in dq 6d rpy; do timeout 300 python $R/bench.py --r $r --steps 20 --warmup 5 --no-icp-variant 2>/dev/null < /dev/null | grep '^{'; done) > $O/bench_rot_modes.log
 # BASELINE configs[3] / [4] in replay (independent-frame) mode, one GPU: the items an 8-GPU job would deal out
 python $R/bench.py --mode replay --workload allegro --steps 50 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_replay_allegro.log 2>/dev/null
 python $R/bench.py --workload c5 --steps 12 --warmup 2 > $O/bench_c5.log 2>/dev/null
-# six back-to-back headline runs (one process each) and the same with three graph chains: run-to-run spread, and what a third chain does now
-(for r in 1 2 3 4 5 6; do for g in 2 3; do echo -n "graph chains $g, run $r: "; python $R/bench.py --steps 20 --warmup 5 --graph-branches $g --no-cpu-baseline --no-icp-variant --no-roofline 2>/dev/null | python -c 'import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][0]); print(d["value"], "frames/s", d["ms_per_step"], "ms per frame")'; done; done) > $O/headline_repeats.log
+# six back-to-back headline runs (one process each): the default (chain streams, two chains at five sequences), the two-branch graph of
+# rounds 2-4 and three chain streams -- run-to-run spread of each
+(for r in 1 2 3 4 5 6; do for g in 0 2 -3; do echo -n "--graph-branches $g (0 = default: 2 chain streams; 2 = one graph, two branches; -3 = 3 chain streams), run $r: "; timeout 300 python $R/bench.py --steps 20 --warmup 5 --graph-branches $g --no-cpu-baseline --no-icp-variant --no-roofline 2>/dev/null < /dev/null | python -c 'import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][0]); print(d["value"], "frames/s", d["ms_per_step"], "ms per frame")'; done; done) > $O/headline_repeats.log
 (for so in 0 10 20 30; do echo -n "seed offset $so: "; python $R/bench.py --steps 20 --warmup 5 --seed-offset $so --no-cpu-baseline --no-icp-variant --no-roofline 2>/dev/null | python -c 'import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][0]); print(d["value"], "frames/s")'; done) >> $O/headline_repeats.log
 python $R/tests/measure/divergence_envelope.py gpu $O/divergence.json 2>/dev/null | grep -v amdgpu.ids > $O/divergence_envelope_gpu.log
 python $R/tests/measure/bench_c5_resegment.py > $O/c5_resegment.log 2>/dev/null
