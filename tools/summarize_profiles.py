@@ -46,7 +46,7 @@ def main(src, tag, dst="profiles"):
         mf, _ = agg(f"{src}/pmc_{wl}_mfma_counter_collection.csv")
         if not sq:
             continue
-        lines.append(f"--- {wl}: bench.py --workload {wl} --steps 5 --warmup 5 (5 sequences as two graph branches: launches carry 3 or 2 problems)")
+        lines.append(f"--- {wl}: bench.py --workload {wl} --steps 5 --warmup 5 (5 sequences as two chains: launches carry 3 or 2 problems)")
         ks = {}
         for key in [r for r, _ in ROLES] + list(EXTRA):
             if key not in sq:
@@ -73,7 +73,7 @@ def main(src, tag, dst="profiles"):
                                  f"busy cycles {mm['SQ_VALU_MFMA_BUSY_CYCLES']:.0f} = {mm['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * mm['dur'] * 2.4):.4f} of the launch's 1024 SIMD x cycles")
         out[wl] = {"problems_per_launch_avg": per, "kernels": ks}
     header = ("rocprofv3 PMC per workload (tools/collect_profiles.sh); one counter set per pass (FETCH_SIZE | WRITE_SIZE | SQ_*), every pass with "
-              "--kernel-trace only; averages over all launches of a kernel (5 sequences as two graph branches: 3 or 2 problems per launch, 2.5 "
+              "--kernel-trace only; averages over all launches of a kernel (5 sequences as two chains: 3 or 2 problems per launch, 2.5 "
               "on average); per-wave values are cycles (quad-cycle counters x4); FETCH_SIZE / WRITE_SIZE are the raw rocprofv3 values in KB.  "
               "MI355X_MICROARCH.md: FETCH_SIZE counts 128-B requests of wide (16 B/lane) coalesced reads as 64 B -> bench.py doubles it "
               "before comparing with a byte count; narrower reads are uncalibrated, so `traffic` of the latency-bound kernels is an upper bound.\n")
@@ -90,6 +90,7 @@ def main(src, tag, dst="profiles"):
     cat(["bench_b1.log", "bench_b8.log"], f"{tag}_final_bench_b1_b8.log")
     cat(["bench_franka.log", "bench_allegro.log"], f"{tag}_final_bench_other_workloads.log")
     cat(["bench_replay_allegro.log", "bench_c5.log"], f"{tag}_final_bench_replay_and_c5.log")
+    cp("bench_rot_modes.log", f"{tag}_final_bench_rot_modes.log")
     cp("c5_resegment.log", f"{tag}_c5_resegment_bench.log")
     cp("icp_frame_phases.log", f"{tag}_icp_frame_phases.log")
     cp("handoff_stress.log", f"{tag}_handoff_stress.log")
