@@ -545,7 +545,10 @@ class TrainPlan:
     instantiated for runs on the next one that is, with the extra units' weights and biases zero.  Such a unit's activation is
     exactly 0 (LeakyReLU / ReLU of 0), it adds exactly 0 to every sum it enters, and every gradient of its parameters is a
     product with that 0 or with the zero column that leads out of it -- so Adam leaves them at 0 and the trained model, losses
-    and poses are those of the unpadded model; the caller's tensors keep their own shapes."""
+    and poses are those of the unpadded model; the caller's tensors keep their own shapes.
+
+    `rot`: 'q' / 'dq' / '6d' / 'rpy' -- the reference's four --r choices (mlp_reg.py:64-90); `params` in Q_PARAM_ORDER (DQ_PARAM_ORDER
+    for 'dq').  `graph_branches`: creg_train_shape.graph_branches (include/creg.h) -- 0 = chain streams, the library's count."""
 
     def __init__(self, rot: str, k: int, hidden: int, n_pred: int, n_tgt: int, epochs: int = 300,
                  use_graph: bool = True, device=None, batch: int = 1, graph_branches: int = 0,

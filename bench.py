@@ -551,7 +551,8 @@ def main(argv=None):
                     help="pose representation (mlp_reg.py:360 --r); 'q' is the reference's default and the metric's; the others skip the roofline / cpu_baseline legs")
     ap.add_argument("--eager", action="store_true", help="eager launches instead of the captured epoch graph")
     ap.add_argument("--epochs-per-graph", type=int, default=0, help="epochs captured per hipGraph (0 = the library's 50; 300 = one replay per train)")
-    ap.add_argument("--graph-branches", type=int, default=0, help="parallel chains in the captured graph (0 = the library's default)")
+    ap.add_argument("--graph-branches", type=int, default=0, help="how a batch shares the GPU: 0 = the library's default (chain streams: 1 / 2 / 3 chains by batch size); -n = n chain streams "
+                         "(every chain a linear graph on its own stream); +n = n parallel branches inside one graph (rounds 2-3)")
     ap.add_argument("--stop", type=int, default=200,
                     help="early-stopping patience of train() (mlp_reg.py:17: stop=200, the default and the headline's); a small value "
                          "forces early stops to show what a stopped train costs")
@@ -746,6 +747,9 @@ def main(argv=None):
                                    "round-robin to the ranks (SURVEY 8(e); frames of a sequence cannot be sharded otherwise)") if replay else
                                   "sequences: every rank registers its own sequences frame by frame (weak scaling)",
                           "epochs_per_frame": 2 * EPOCHS, **ep, "launch": "eager" if args.eager else "hipGraph",
+                          "chains": (lambda pl: None if pl is None else {"count": pl.info["graph_branches"],
+                                                                         "form": "parallel branches of one graph" if args.graph_branches > 0 else
+                                                                         "chain streams: every chain a linear graph on its own stream, chain 0 on the caller's"})(getattr(reg, "plan", None)),
                           "sequences_in_flight_per_gpu": max(rank_rounds[0]) if (replay and rank_rounds[0]) else S,
                           "padded_steps_timed_not_counted": padded,
                           # what every rank ran inside the timed region: its rounds and the problems each carried
