@@ -94,6 +94,28 @@ def test_models_forward_match_reference_golden(golden):
         np.testing.assert_allclose(rr.detach().numpy(), g["rpy_out_r"], atol=1e-7)
 
 
+def test_train_plan_parameter_layout_matches_every_reference_model():
+    """The four --r choices (mlp_reg.py:276-291) on the fused plan: the tensor shapes ops.TrainPlan expects (in Q_PARAM_ORDER /
+    DQ_PARAM_ORDER) are the models' own, at the reference's widths -- 512, and 3 for RegMLP(6, 3) -- and at the padded width."""
+    import types
+    from autourdf_amd import mlp_reg, model_utils, ops
+    cases = [("q", model_utils.QRegMLP(True, 512)), ("dq", model_utils.DQRegMLP(512)), ("6d", model_utils.RRegMLP(512)),
+             ("rpy", model_utils.RegMLP(6, 3)), ("6d", model_utils.RRegMLP(100)), ("rpy", model_utils.RegMLP(True, 64))]
+    for rot, model in cases:
+        got_rot, params, hidden = mlp_reg._model_params(model)
+        assert got_rot == rot and hidden == model.encoder[0].out_features
+        order = ops.DQ_PARAM_ORDER if rot == "dq" else ops.Q_PARAM_ORDER
+        shapes = ops.TrainPlan._param_shapes(types.SimpleNamespace(rot=ops.TRAIN_ROT[rot]), hidden)
+        assert len(params) == len(order) == len(shapes)
+        for name, p, want in zip(order, params, shapes):
+            assert tuple(p.shape) == tuple(want), (rot, name, tuple(p.shape), want)
+        padded = ops.TrainPlan._param_shapes(types.SimpleNamespace(rot=ops.TRAIN_ROT[rot]), next(t for t in ops.TRAIN_HIDDEN_TILES if t >= hidden))
+        assert all(all(a <= b for a, b in zip(sm, sp)) for sm, sp in zip(shapes, padded))
+    with pytest.raises(NotImplementedError):
+        import torch
+        mlp_reg._model_params(torch.nn.Linear(3, 3))
+
+
 def test_rotation_maps_match_oracle_conventions():
     import torch
     from scipy.spatial.transform import Rotation
