@@ -1122,8 +1122,8 @@ __global__ __launch_bounds__(256) void k_icp_pool(IcpLarge P, int nf) {
 }
 
 // Before the first iteration of a frame no source has a previous match, and a search without one scans its cluster's whole grid
-// (one launch of 350-1100 us at configs[4]).  This gives every source SOME target to start from: the first one listed in its own grid
-// cell, or in the nearest ring of cells (up to 3) that holds any.  Any target of the list is a valid start -- k_icp_nn's result is the
+// (one launch of 350-1100 us at configs[4]).  This gives every source SOME target to start from: the nearest one of its own grid
+// cell, or of the nearest ring of cells (up to 3) that holds any.  Any target of the list is a valid start -- k_icp_nn's result is the
 // lexicographic minimum over a square that contains the nearest target, whatever it starts from -- and a near one makes that square small.
 __global__ __launch_bounds__(256) void k_icp_seed(IcpLarge P, int nf) {
     const int c = blockIdx.x;
@@ -1136,11 +1136,22 @@ __global__ __launch_bounds__(256) void k_icp_seed(IcpLarge P, int nf) {
     for (int i = P.off[c] + blockIdx.y * 256 + threadIdx.x; i < P.off[c + 1]; i += gridDim.y * 256) {
         const double s[3] = {P.srcw[3 * (size_t)i], P.srcw[3 * (size_t)i + 1], P.srcw[3 * (size_t)i + 2]};
         const int ia = icp_bin(s[axa], x0a, inv_a, gd), ib = icp_bin(s[axb], x0b, inv_b, gd);
+        // (round 4: the NEAREST target of the first ring that holds any, not the first one listed -- a cell is a column along the
+        //  box's shortest edge, and its first entry can be the cluster's whole thickness away: the first search of a frame scanned
+        //  1.1 ms worth of cells around such seeds)
         int t = -1;
+        double td = INFINITY;
         for (int e = 0; e <= 3 && t < 0; ++e)
-            for (int r = max(ia - e, 0); r <= min(ia + e, gd - 1) && t < 0; ++r) {
+            for (int r = max(ia - e, 0); r <= min(ia + e, gd - 1); ++r) {
                 const int q0 = tst[r * gd + max(ib - e, 0)], q1 = tst[r * gd + min(ib + e, gd - 1) + 1];
-                if (q1 > q0) t = q0;
+                for (int q = q0; q < q1; ++q) {
+                    double x, y, z;
+                    if (tb >= 0) { x = P.tcx[tb + q]; y = P.tcy[tb + q]; z = P.tcz[tb + q]; }
+                    else { const size_t j = (size_t)tidx[q]; x = P.frame[3 * j]; y = P.frame[3 * j + 1]; z = P.frame[3 * j + 2]; }
+                    const double dx = s[0] - x, dy = s[1] - y, dz = s[2] - z;
+                    const double d = (dx * dx + dy * dy) + dz * dz;
+                    if (d < td) { td = d; t = q; }
+                }
             }
         if (t >= 0) {
             const int j = tidx[t];
