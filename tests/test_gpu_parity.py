@@ -1095,6 +1095,40 @@ def test_graph_branches_bench_shape_bit_identical_to_single_runs(dev):
                 assert torch.equal(got.cpu().nan_to_num(), want.nan_to_num())
 
 
+def test_chain_streams_on_a_side_stream_and_plan_destroyed_while_busy(dev):
+    """Chain streams fork from / join the CALLER's stream, whatever it is: a batch of 5 (two chains) and of 8 (three) enqueued on a
+    torch side stream give the single runs' bits; the plan is dropped right after the enqueue (its destroy waits for its chains),
+    and the results are read only after the side stream has been synchronised."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    from oracle import models
+    seq = make_sequence("wx200_5", 7, 2, 2048)
+    mats, cl, _ = initial_segmentation(seq[0], 10, seed=3)
+    m = torch.tensor(mats, dtype=torch.float32, device=dev)
+    ys = [torch.tensor(seq[1] + 0.0007 * b, dtype=torch.float32, device=dev) for b in range(8)]
+    pts, off = ops.pack_clusters([torch.tensor(c, dtype=torch.float32) for c in cl], dev)
+    torch.manual_seed(4)
+    model = models.QRegMLP(True, 128)
+    mk = lambda: [model.state_dict()[k].clone().to(dev) for k in ops.Q_PARAM_ORDER]
+    single = ops.TrainPlan("q", 10, 128, pts.shape[0], 2048, epochs=110, use_graph=True, device=dev)       # 2 graphs of 50 + 10 eager epochs
+    ref = [[t.cpu() for t in single.run(m, ys[b], pts, off, mk())] for b in range(8)]
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for batch, chains in ((5, 2), (8, 3)):
+        with torch.cuda.stream(side):
+            plan = ops.TrainPlan("q", 10, 128, pts.shape[0], 2048, epochs=110, use_graph=True, device=dev, batch=batch)
+            assert plan.info["graph_branches"] == chains
+            params = [mk() for _ in range(batch)]
+            outs = plan.run_batch([(m, ys[b], pts, off, params[b]) for b in range(batch)])
+            ws = plan.ws                                  # (the workspace outlives the plan object: the enqueued work still uses it)
+            del plan
+        side.synchronize()
+        for b in range(batch):
+            for got, want in zip(outs[b], ref[b]):
+                assert torch.equal(got.cpu().nan_to_num(), want.nan_to_num())
+        del ws
+
+
 def test_graph_branches_big_frame_default_is_three_chains_and_bit_identical_to_single_runs(dev):
     """Frames above 4096 points default to three chains (2 + 2 + 1 of 5 problems) from three problems on; the 4096-point shape runs
     one chain up to 4 problems, two for 5-7, three from 8 (chain streams: train_engine.hip, creg_train_plan_create)."""
