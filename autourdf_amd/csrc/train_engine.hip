@@ -1666,17 +1666,22 @@ static int capture_chains(Plan* P, int epg) {
     CAP_TRY(hipEventCreateWithFlags(&P->cfork, hipEventDisableTiming));
     for (int gi = 0; gi < P->branches && err == hipSuccess; ++gi) {
         hipGraph_t g = nullptr;
-        CAP_TRY(hipStreamCreateWithFlags(&P->cst[gi], hipStreamNonBlocking));
-        CAP_TRY(hipEventCreateWithFlags(&P->cjoin[gi], hipEventDisableTiming));
-        CAP_TRY(hipStreamBeginCapture(P->cst[gi], hipStreamCaptureModeThreadLocal));
-        if (err != hipSuccess) break;
-        P->W = ws_shift(Wall, (size_t)chain_first(P, gi) * P->bstride); P->nz = chain_count(P, gi);
-        for (int i = 0; i < epg; ++i) enqueue_epoch(P, i, P->cst[gi]);
-        P->W = Wall; P->nz = nz_all;
-        const hipError_t e2 = hipStreamEndCapture(P->cst[gi], &g);
-        if (e2 != hipSuccess) { err = e2; what = "hipStreamEndCapture"; }
+        // chain 0 RUNS on the caller's stream: the stream it is captured on is a temporary (torch's current stream is usually the
+        // null stream, which cannot be captured); the others are captured on the stream they will run on
+        hipStream_t cs = nullptr;
+        CAP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        if (gi > 0) { P->cst[gi] = cs; CAP_TRY(hipEventCreateWithFlags(&P->cjoin[gi], hipEventDisableTiming)); }
+        CAP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        if (err == hipSuccess) {
+            P->W = ws_shift(Wall, (size_t)chain_first(P, gi) * P->bstride); P->nz = chain_count(P, gi);
+            for (int i = 0; i < epg; ++i) enqueue_epoch(P, i, cs);
+            P->W = Wall; P->nz = nz_all;
+            const hipError_t e2 = hipStreamEndCapture(cs, &g);
+            if (e2 != hipSuccess) { err = e2; what = "hipStreamEndCapture"; }
+        }
         CAP_TRY(hipGraphInstantiate(&P->cexec[gi], g, nullptr, nullptr, 0));
         if (g) (void)hipGraphDestroy(g);
+        if (gi == 0 && cs) (void)hipStreamDestroy(cs);
     }
 #undef CAP_TRY
     if (err != hipSuccess) {
