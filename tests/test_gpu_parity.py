@@ -919,19 +919,22 @@ def test_train_short_trajectory_vs_oracle(dev, golden, rot, graph):
         np.testing.assert_allclose(p.cpu().numpy(), model.state_dict()[k].numpy(), rtol=1e-3, atol=2e-6)
 
 
-def test_train_is_bit_reproducible_and_graph_equals_eager(dev, golden):
+@pytest.mark.parametrize("rot,hidden", [("q", 64), ("dq", 64), ("6d", 128), ("rpy", 3)])
+def test_train_is_bit_reproducible_and_graph_equals_eager(dev, golden, rot, hidden):
+    """Eager launches, the captured graph, and the captured graph again: the same bits, for every pose representation
+    (rpy at the reference's hidden 3: the zero-padded run)."""
     from autourdf_amd import ops
-    from oracle import models
     g, _, _ = _train_case(golden, "q")
     torch.manual_seed(5)
-    model = models.QRegMLP(True, 64)
+    model = _oracle_model(rot, hidden)
+    order = _order(rot)
     m, y = torch.from_numpy(g["q_m"]).to(dev), torch.from_numpy(g["q_y"]).to(dev)
     clusters = [torch.from_numpy(c) for c in _split(g["q_local"], g["q_offsets"])]
     pts, off = ops.pack_clusters(clusters, dev)
     outs = []
     for graph in (False, True, True):
-        params = [model.state_dict()[k].clone().to(dev) for k in ops.Q_PARAM_ORDER]
-        plan = ops.TrainPlan("q", len(clusters), 64, pts.shape[0], y.shape[0], epochs=40, use_graph=graph, device=dev)
+        params = [model.state_dict()[k].clone().to(dev) for k in order]
+        plan = ops.TrainPlan(rot, len(clusters), hidden, pts.shape[0], y.shape[0], epochs=40, use_graph=graph, device=dev)
         bm, bp, res, lh, _ = plan.run(m, y, pts, off, params)
         outs.append((bm.cpu(), lh.cpu(), torch.cat([p.flatten() for p in params]).cpu()))
     for o in outs[1:]:
@@ -1010,11 +1013,11 @@ def test_segments_sample_size_uses_fps(dev, tmp_path):
     np.testing.assert_array_equal(out.points, X[kmeans.farthest_point_sample(X, 256)])
 
 
-def test_batched_plan_is_bit_identical_to_separate_runs(dev, golden):
+@pytest.mark.parametrize("rot", ["q", "6d"])
+def test_batched_plan_is_bit_identical_to_separate_runs(dev, golden, rot):
     """creg_train_plan_run_batch: 3 independent problems (different weights, targets and cluster sizes)
     advanced per launch give exactly the results of 3 separate plans."""
     from autourdf_amd import ops
-    from oracle import models
     g, _, _ = _train_case(golden, "q")
     base = [torch.from_numpy(c) for c in _split(g["q_local"], g["q_offsets"])]
     y0, m0 = torch.from_numpy(g["q_y"]), torch.from_numpy(g["q_m"])
@@ -1022,7 +1025,7 @@ def test_batched_plan_is_bit_identical_to_separate_runs(dev, golden):
     problems, singles = [], []
     for b in range(3):
         torch.manual_seed(20 + b)
-        model = models.QRegMLP(True, 64)
+        model = _oracle_model(rot, 64)
         flat = torch.cat(base)
         cuts = sorted(torch.randperm(n - 1)[: len(base) - 1].add(1).tolist())          # different cluster sizes
         cl = [flat[a:z] for a, z in zip([0] + cuts, cuts + [n])]
@@ -1031,9 +1034,9 @@ def test_batched_plan_is_bit_identical_to_separate_runs(dev, golden):
         mk = lambda: [model.state_dict()[k].clone().to(dev) for k in ops.Q_PARAM_ORDER]
         problems.append((m0.to(dev), y, pts, off, mk()))
         singles.append((m0.to(dev), y, pts, off, mk()))
-    plan_b = ops.TrainPlan("q", len(base), 64, n, y0.shape[0], epochs=30, use_graph=True, device=dev, batch=3)
+    plan_b = ops.TrainPlan(rot, len(base), 64, n, y0.shape[0], epochs=30, use_graph=True, device=dev, batch=3)
     outs_b = plan_b.run_batch(problems)
-    plan_1 = ops.TrainPlan("q", len(base), 64, n, y0.shape[0], epochs=30, use_graph=True, device=dev)
+    plan_1 = ops.TrainPlan(rot, len(base), 64, n, y0.shape[0], epochs=30, use_graph=True, device=dev)
     for b in range(3):
         o1 = plan_1.run(*singles[b])
         for tb, t1 in zip(outs_b[b], o1):
