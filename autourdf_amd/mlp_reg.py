@@ -20,6 +20,8 @@ import argparse
 import glob
 import json
 import os
+import queue
+import threading
 
 import numpy as np
 import torch
@@ -151,6 +153,53 @@ def _make_models():
     return RRegMLP(hidden_dim=512).to(DEVICE), RRegMLP(hidden_dim=512).to(DEVICE)
 
 
+class _FileWriter:
+    """``matrix/NNNN.npy`` / ``cluster/NNNN.npz`` (mlp_reg.py:376-378) written by a worker thread, in submission order, while the
+    next frame registers: ``np.savez`` of a frame's 20 clusters is ~1.2 ms of host time, and written in line it left the GPU idle
+    for a fifth of a lock-step round (5 sequences x 200 frames, files and start-up included: 6.9 -> 6.1 ms per frame end to end
+    with this and the batched device-to-host copies of match_all, profiles/r04_cli_end_to_end.log; the registration alone is 5.5).
+    Same functions, same bytes; an error in the worker is re-raised by the next ``submit`` or by ``close``."""
+
+    def __init__(self):
+        self._q = queue.Queue(maxsize=256)
+        self._err = None
+        self._t = threading.Thread(target=self._run, name="creg-file-writer", daemon=True)
+        self._t.start()
+
+    def _run(self):
+        try:
+            if getattr(DEVICE, "index", None) is not None:      # (one process per GPU: the worker's copies go to the rank's device)
+                torch.cuda.set_device(DEVICE)
+        except BaseException as e:                  # noqa: BLE001
+            self._err = e
+        while True:                                 # keeps draining after an error, so that submit / close never block on a dead worker
+            job = self._q.get()
+            if job is None:
+                return
+            if self._err is None:
+                try:
+                    job[0](*job[1])
+                except BaseException as e:          # noqa: BLE001  (handed to the submitting thread)
+                    self._err = e
+
+    def submit(self, fn, *args):
+        if self._err is not None:
+            raise self._err
+        while True:
+            try:
+                self._q.put((fn, args), timeout=5.0)
+                return
+            except queue.Full:
+                if not self._t.is_alive():
+                    raise RuntimeError("the file-writer thread died") from self._err
+
+    def close(self):
+        self._q.put(None)
+        self._t.join()
+        if self._err is not None:
+            raise self._err
+
+
 def register_sequence(seg, step_matrices, step_cluster_np, save_dir=None, mlp_icp=False, models=None, loss_log=None):
     """Frames 1..T-1 of one sequence (the loop body of ``match``, mlp_reg.py:293-378), on arrays.
     Returns (list of (K,4,4) poses per frame incl. frame 0, best losses)."""
@@ -161,6 +210,16 @@ def register_sequence(seg, step_matrices, step_cluster_np, save_dir=None, mlp_ic
     icp_src = step_cluster_np            # mlp_reg.py:248/253: assigned once; masked_icp's source for EVERY frame (:325)
     model, model_rf = models if models is not None else _make_models()
     poses, best_losses = [np.asarray(step_matrices)], []
+    writer = _FileWriter() if save_dir is not None else None
+    try:
+        _register_frames(seg, K, m_t, cl_t, cl_init, icp_src, model, model_rf, mlp_icp, save_dir, writer, poses, best_losses)
+    finally:
+        if writer is not None:
+            writer.close()
+    return poses, best_losses
+
+
+def _register_frames(seg, K, m_t, cl_t, cl_init, icp_src, model, model_rf, mlp_icp, save_dir, writer, poses, best_losses):
     for i in range(0, seg.data_size - 1):
         target_np = np.array(seg.pc_list[i + 1].points)
         target = torch.tensor(target_np, dtype=torch.float32).to(DEVICE)
@@ -184,9 +243,8 @@ def register_sequence(seg, step_matrices, step_cluster_np, save_dir=None, mlp_ic
         cl_t = [torch.tensor(new_seg_np[j], dtype=torch.float32).to(DEVICE) for j in range(K)]
         poses.append(out_m)
         if save_dir is not None:
-            np.save(save_dir + f"matrix/{(i + 1):04}.npy", out_m)
-            save_pc_npz(new_seg_np, save_dir + f"cluster/{(i + 1):04}.npz")
-    return poses, best_losses
+            writer.submit(np.save, save_dir + f"matrix/{(i + 1):04}.npy", out_m)
+            writer.submit(save_pc_npz, new_seg_np, save_dir + f"cluster/{(i + 1):04}.npz")
 
 
 def match(data_dir, idx):
@@ -240,7 +298,7 @@ def match_all(data_dirs):
     segs = [Segments(d) for d in data_dirs]
     same = len({(sg.data_size, len(sg.pc_list[0].points)) for sg in segs}) == 1 and \
         all(len(p.points) == len(segs[0].pc_list[0].points) for sg in segs for p in sg.pc_list)
-    if not same or len(segs) < 2 or NORMAL:      # (--normal: the 6-D re-segmentation has no batched form)
+    if not same or len(segs) < 1 or NORMAL:      # (--normal: the 6-D re-segmentation has no batched form)
         for i, d in enumerate(data_dirs):
             match(d, i)
         return
@@ -270,14 +328,24 @@ def match_all(data_dirs):
     reg = BatchRegistrar(np.asarray(step_matrices, np.float32), [np.asarray(c, np.float64) for c in step_cluster_np], n,
                          len(segs), ROT, hidden, EPOCHS, USE_GRAPH, DEVICE, models=models)
     losses = [[] for _ in segs]
-    for i in range(segs[0].data_size - 1):
-        frames = [torch.as_tensor(np.asarray(sg.pc_list[i + 1].points), dtype=torch.float64, device=DEVICE) for sg in segs]
-        out = reg.step_mlp_icp(frames) if MLP_ICP else reg.step(frames)
-        for s, (r, (m2, res)) in enumerate(zip(reg.seqs, out)):
-            off, local = r.off.cpu().numpy(), r.local64.cpu().numpy()
-            np.save(save_dirs[s] + f"matrix/{(i + 1):04}.npy", m2.cpu().numpy())
-            save_pc_npz([local[off[j]:off[j + 1]] for j in range(len(off) - 1)], save_dirs[s] + f"cluster/{(i + 1):04}.npz")
-            losses[s].append(float(res[0]))
+    writer = _FileWriter()
+    try:
+        for i in range(segs[0].data_size - 1):
+            frames = [torch.as_tensor(np.asarray(sg.pc_list[i + 1].points), dtype=torch.float64, device=DEVICE) for sg in segs]
+            out = reg.step_mlp_icp(frames) if MLP_ICP else reg.step(frames)
+            # one device-to-host copy per kind for all sequences (20 small copies cost the main thread ~1 ms of every round, with
+            # the GPU idle), the files on the worker
+            offs = torch.stack([r.off for r in reg.seqs]).cpu().numpy()
+            locs = torch.stack([r.local64 for r in reg.seqs]).cpu().numpy()
+            ms = torch.stack([o[0] for o in out]).cpu().numpy()
+            rs = torch.stack([o[1] for o in out]).cpu().numpy()
+            for s in range(len(segs)):
+                off, local = offs[s], locs[s]
+                writer.submit(np.save, save_dirs[s] + f"matrix/{(i + 1):04}.npy", ms[s])
+                writer.submit(save_pc_npz, [local[off[j]:off[j + 1]] for j in range(len(off) - 1)], save_dirs[s] + f"cluster/{(i + 1):04}.npz")
+                losses[s].append(float(rs[s][0]))
+    finally:
+        writer.close()
     if LOSS:
         for sd, l in zip(save_dirs, losses):
             np.savetxt(sd + "loss.txt", l)

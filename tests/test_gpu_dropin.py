@@ -84,24 +84,25 @@ def test_torchrun_world_size_one_of_the_dropin_module(workdir):
     np.testing.assert_array_equal(np.load(base / "V0000/matrix/0000.npy"), np.load(base / "V0001/matrix/0000.npy"))
 
 
-@pytest.mark.parametrize("rot,extra", [("q", []), ("dq", []), ("q", ["--mlp_icp"])])
-def test_lock_step_run_equals_one_match_per_sequence(workdir, rot, extra, monkeypatch):
+@pytest.mark.parametrize("rot,extra,nv", [("q", [], 2), ("dq", [], 2), ("q", ["--mlp_icp"], 2), ("6d", [], 2), ("q", [], 1), ("rpy", [], 1)])
+def test_lock_step_run_equals_one_match_per_sequence(workdir, rot, extra, nv, monkeypatch):
     """main() registers all sequences in lock-step (match_all); --sequential is the reference's loop of match()
-    calls.  Same frame-0 state + same model initialisation => identical files, bit for bit."""
+    calls.  Same frame-0 state + same model initialisation => identical files, bit for bit -- also for a single sequence
+    (--num_video 1 takes the device-resident engine too: no host round trip per train) and for the optional pose representations."""
     import shutil
     from autourdf_amd import mlp_reg
     monkeypatch.setattr(mlp_reg, "EPOCHS", 12)
     base = workdir / "data/part/wx200_5_8_seg/4_deg_20_cams"
     mlp_reg._PLANS.clear()
     torch.manual_seed(0)
-    mlp_reg.main(["--robot", "wx200_5", "--num_video", "2", "--loss", "--sequential", "--r", rot] + extra)
+    mlp_reg.main(["--robot", "wx200_5", "--num_video", str(nv), "--loss", "--sequential", "--r", rot] + extra)
     shutil.copytree(base, workdir / "sequential")
-    for v in range(2):                                   # keep only the shared frame-0 state, as a finished first run leaves it
+    for v in range(nv):                                  # keep only the shared frame-0 state, as a finished first run leaves it
         for t in (1, 2):
             os.remove(base / f"V{v:04}/matrix/{t:04}.npy"); os.remove(base / f"V{v:04}/cluster/{t:04}.npz")
     torch.manual_seed(0)
-    mlp_reg.main(["--robot", "wx200_5", "--num_video", "2", "--loss", "--r", rot] + extra)
-    for v in range(2):
+    mlp_reg.main(["--robot", "wx200_5", "--num_video", str(nv), "--loss", "--r", rot] + extra)
+    for v in range(nv):
         for t in range(3):
             np.testing.assert_array_equal(np.load(base / f"V{v:04}/matrix/{t:04}.npy"),
                                           np.load(workdir / f"sequential/V{v:04}/matrix/{t:04}.npy"))
