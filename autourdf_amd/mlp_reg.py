@@ -156,8 +156,8 @@ def _make_models():
 class _FileWriter:
     """``matrix/NNNN.npy`` / ``cluster/NNNN.npz`` (mlp_reg.py:376-378) written by a worker thread, in submission order, while the
     next frame registers: ``np.savez`` of a frame's 20 clusters is ~1.2 ms of host time, and written in line it left the GPU idle
-    for a fifth of a lock-step round (5 sequences x 200 frames, files and start-up included: 6.9 -> 6.1 ms per frame end to end
-    with this and the batched device-to-host copies of match_all, profiles/r04_cli_end_to_end.log; the registration alone is 5.5).
+    for a fifth of a lock-step round (5 sequences x 200 frames, files and start-up included: 6.9 -> 6.0 ms per frame end to end
+    with this and the worker-side fetch of match_all, profiles/r04_cli_end_to_end.log; the registration alone is 5.5).
     Same functions, same bytes; an error in the worker is re-raised by the next ``submit`` or by ``close``."""
 
     def __init__(self):
@@ -198,6 +198,26 @@ class _FileWriter:
         self._t.join()
         if self._err is not None:
             raise self._err
+
+
+_FETCH_STREAM = {}
+
+
+def _fetch_and_save(save_dirs, t, stacked, ev, losses):
+    """Worker-side half of a lock-step frame: the stacked device results -> matrix/TTTT.npy, cluster/TTTT.npz per sequence, the
+    best losses (appended in frame order: one worker, jobs in submission order)."""
+    ev.synchronize()
+    dev = stacked[0].device
+    side = _FETCH_STREAM.get(dev)
+    if side is None:
+        side = _FETCH_STREAM[dev] = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        offs, locs, ms, rs = [x.cpu().numpy() for x in stacked]
+    for s, sd in enumerate(save_dirs):
+        off, local = offs[s], locs[s]
+        np.save(sd + f"matrix/{t:04}.npy", ms[s])
+        save_pc_npz([local[off[j]:off[j + 1]] for j in range(len(off) - 1)], sd + f"cluster/{t:04}.npz")
+        losses[s].append(float(rs[s][0]))
 
 
 def register_sequence(seg, step_matrices, step_cluster_np, save_dir=None, mlp_icp=False, models=None, loss_log=None):
@@ -333,17 +353,14 @@ def match_all(data_dirs):
         for i in range(segs[0].data_size - 1):
             frames = [torch.as_tensor(np.asarray(sg.pc_list[i + 1].points), dtype=torch.float64, device=DEVICE) for sg in segs]
             out = reg.step_mlp_icp(frames) if MLP_ICP else reg.step(frames)
-            # one device-to-host copy per kind for all sequences (20 small copies cost the main thread ~1 ms of every round, with
-            # the GPU idle), the files on the worker
-            offs = torch.stack([r.off for r in reg.seqs]).cpu().numpy()
-            locs = torch.stack([r.local64 for r in reg.seqs]).cpu().numpy()
-            ms = torch.stack([o[0] for o in out]).cpu().numpy()
-            rs = torch.stack([o[1] for o in out]).cpu().numpy()
-            for s in range(len(segs)):
-                off, local = offs[s], locs[s]
-                writer.submit(np.save, save_dirs[s] + f"matrix/{(i + 1):04}.npy", ms[s])
-                writer.submit(save_pc_npz, [local[off[j]:off[j + 1]] for j in range(len(off) - 1)], save_dirs[s] + f"cluster/{(i + 1):04}.npz")
-                losses[s].append(float(rs[s][0]))
+            # One stacked tensor per kind for all sequences (device side), an event behind them, and the rest on the worker: it
+            # waits for the event ON THE HOST, copies on its own stream (a copy on the main stream would queue behind the next
+            # frame's trains), slices and writes -- the main thread goes straight on to the next frame.
+            stacked = (torch.stack([r.off for r in reg.seqs]), torch.stack([r.local64 for r in reg.seqs]),
+                       torch.stack([o[0] for o in out]), torch.stack([o[1] for o in out]))
+            ev = torch.cuda.Event()
+            ev.record()
+            writer.submit(_fetch_and_save, save_dirs, i + 1, stacked, ev, losses)
     finally:
         writer.close()
     if LOSS:
