@@ -1706,7 +1706,7 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
                                       creg_train_plan** plan) {
     Dims D;
     CREG_REQUIRE(plan && workspace, "creg_train_plan_create: null pointer");
-    CREG_REQUIRE(make_dims(shape, &D), "creg_train_plan_create: unsupported shape (rot in {0,1}, 64 <= hidden <= 1024 multiple of 64, sizes >= 1)");
+    CREG_REQUIRE(make_dims(shape, &D), "creg_train_plan_create: unsupported shape (rot in 0..3, hidden in {64, 128, 256, 512}, 1 <= k <= 160 (rot 2: <= 142), sizes >= 1)");
     CREG_REQUIRE(((uintptr_t)workspace & 255) == 0, "creg_train_plan_create: workspace must be 256-byte aligned");
     CREG_REQUIRE(shape->batch >= 0 && shape->batch <= 64, "creg_train_plan_create: batch must be in [0, 64]");
     const size_t one = align_up(carve(D, nullptr, nullptr), 256), need = one * batch_of(shape);
