@@ -303,7 +303,7 @@ int creg_visibility_f64(const double* tri, const int32_t* tri_link, int32_t n_tr
  * The reference's four --r choices (mlp_reg.py:64-90, models built at :276-291):
  * rot = 0: ROT == 'q'   with QRegMLP(True, hidden)  (model_utils.py:101-159)   pose row [t | quaternion], 7 -> 56 features
  * rot = 1: ROT == 'dq'  with DQRegMLP(hidden)       (model_utils.py:65-99)     dual quaternion, 8 -> 64 features, one decoder, ReLU
- * rot = 2: ROT == '6d'  with RRegMLP(hidden)        (model_utils.py:170-214)   [t | first two rows of R], 9 -> 72 features; k <= 142
+ * rot = 2: ROT == '6d'  with RRegMLP(hidden)        (model_utils.py:170-214)   [t | first two rows of R], 9 -> 72 features
  * rot = 3: ROT == 'rpy' with RegMLP(True, hidden)   (model_utils.py:216-281)   [t | XYZ Euler angles], 6 -> 48 features, Tanh after
  *                                                                              decoder_2 (the reference builds RegMLP(6, 3):
  *                                                                              hidden 3 -- run zero-padded at 64, see `hidden`)
