@@ -114,3 +114,15 @@ def load(check_device: bool = True) -> ctypes.CDLL:
 def check(rc: int, what: str = "libcreg call"):
     if rc != 0:
         raise RuntimeError(f"{what} failed ({rc}): {_lib.creg_last_error().decode()}")
+
+
+def device(*refs) -> torch.device:
+    """The device a host-side entry point works on: the device of the first CUDA tensor among ``refs`` (or a
+    ``torch.device`` handed in), otherwise the CURRENT device with its index spelled out -- never a bare "cuda"
+    string, so a host that embeds the package on GPU != 0 keeps inputs, outputs and launches on one device."""
+    for r in refs:
+        if isinstance(r, torch.Tensor) and r.is_cuda:
+            return r.device
+        if isinstance(r, torch.device) and r.type == "cuda":
+            return r if r.index is not None else torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cuda", torch.cuda.current_device())

@@ -188,7 +188,7 @@ class Segments:
         (cluster_icp.py:86-99).  Like the reference, the draw comes from numpy's GLOBAL RandomState unless
         ``seed`` is given (``np.random.seed(s)`` pins both implementations to the same segmentation)."""
         _lib.load()
-        dev = torch.device("cuda")
+        dev = _lib.device()
         pc_np = np.asarray(self.pc_list[pc_id].points)
         rs = np.random.RandomState(seed) if seed is not None else np.random.mtrand._rand
         X = torch.as_tensor(pc_np, dtype=torch.float64, device=dev)
@@ -235,7 +235,7 @@ def masked_icp(clusters_local, clusters_world, step_pc_np, matrices, visual=Fals
     Returns (list of world-frame clusters (M_k,3) f64, new matrices (K,4,4) f64) like the reference."""
     if visual:
         raise NotImplementedError("visual=True needs Open3D's GUI (out of scope)")
-    dev = torch.device("cuda")
+    dev = _lib.device(step_pc_np, matrices, *clusters_local[:1])
     k = len(clusters_local)
     local, off = ops.pack_clusters(clusters_local, dev, torch.float64)
     # the two lists may be segmented differently: match() --mlp_icp hands the frame-0 clusters as sources and the

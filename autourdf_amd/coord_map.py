@@ -18,7 +18,7 @@ import glob
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .cluster_icp import read_point_cloud
 
 
@@ -41,7 +41,7 @@ class CoordMap:
         """Poses already in memory ((T,K,4,4) array or device tensor): no file round trip."""
         self = cls.__new__(cls)
         self.data_path, self.gt_data, self.start_steps, self.end_steps = None, False, 0, 0
-        self._M = torch.as_tensor(matrices, dtype=torch.float64).to("cuda").contiguous()
+        self._M = torch.as_tensor(matrices, dtype=torch.float64).to(_lib.device(matrices)).contiguous()
         self.matrices = self._M.cpu().numpy()
         self.coords = ops.pose_coords(self._M).cpu().numpy()
         self.clusters = clusters if clusters is not None else []
@@ -56,7 +56,7 @@ class CoordMap:
         if not files:
             raise FileNotFoundError(f"no matrix/*.npy under {self.data_path} in [{start_steps}:{end_steps}]")
         matrices = np.array([np.load(f) for f in files])           # (T,K,4,4); float64 as soon as one file is
-        self._M = torch.as_tensor(matrices, dtype=torch.float64).to("cuda").contiguous()
+        self._M = torch.as_tensor(matrices, dtype=torch.float64).to(_lib.device()).contiguous()
         coords = ops.pose_coords(self._M).cpu().numpy().astype(matrices.dtype, copy=False)
         return coords, matrices
 
@@ -87,7 +87,7 @@ class CoordMap:
     def coord_dist_map_legacy(self, diff=True):
         """xyz relative to step 0 + remaining pose coordinates, Euclidean distance matrices per step
         (coord_map.py:309-332); `diff` is ignored there too.  Two cdist calls per step on the device."""
-        c = torch.as_tensor(np.asarray(self.coords, np.float64), device="cuda")
+        c = torch.as_tensor(np.asarray(self.coords, np.float64), device=_lib.device(getattr(self, "_M", None)))
         xyz = c[:, :, :3] - c[:1, :, :3]
         mode = "donot_use_mm_for_euclid_dist"          # exact differences, not the |a|^2 + |b|^2 - 2ab expansion
         rest = c[:, :, 3:].contiguous()

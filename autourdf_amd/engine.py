@@ -6,7 +6,7 @@ the same train plans (A1) and the same k-means / grouping kernels (K2) run in th
 import numpy as np
 import torch
 
-from . import mlp_reg, ops
+from . import _lib, mlp_reg, ops
 from .model_utils import DQRegMLP, QRegMLP, RegMLP, RRegMLP
 
 
@@ -40,9 +40,9 @@ class _HostInverse:
 
 
 class SequenceRegistrar:
-    def __init__(self, mats0, clusters0, n_tgt, rot="q", hidden=512, epochs=300, use_graph=True, device="cuda",
+    def __init__(self, mats0, clusters0, n_tgt, rot="q", hidden=512, epochs=300, use_graph=True, device=None,
                  seed=0):
-        self._init_state(mats0, clusters0, rot, hidden, torch.device(device), seed)
+        self._init_state(mats0, clusters0, rot, hidden, _lib.device(torch.device(device) if device is not None else None), seed)
         self.plan = ops.TrainPlan(rot, self.K, hidden, self.pts.shape[0], n_tgt, epochs=epochs, use_graph=use_graph,
                                   device=self.device)
 
@@ -89,8 +89,8 @@ class BatchRegistrar:
     problems and the latency-bound kernels of one sequence hide behind the others'."""
 
     def __init__(self, mats0, clusters0, n_tgt, n_sequences, rot="q", hidden=512, epochs=300, use_graph=True,
-                 device="cuda", seeds=None, models=None, graph_branches=0, nn_search=0):
-        self.device = torch.device(device)
+                 device=None, seeds=None, models=None, graph_branches=0, nn_search=0):
+        self.device = _lib.device(torch.device(device) if device is not None else None)
         self.S = n_sequences
         self.host_inverse = _HostInverse(self.device)
         seeds = list(seeds) if seeds is not None else list(range(n_sequences))
@@ -189,8 +189,8 @@ class IcpRegistrar:
     (resample_cluster, mlp_reg.py:172-237).  The same kernels the `--mlp_icp` branch of match() runs
     (mlp_reg.py:325-326), minus train."""
 
-    def __init__(self, mats0, clusters0, device="cuda"):
-        self.device = torch.device(device)
+    def __init__(self, mats0, clusters0, device=None):
+        self.device = _lib.device(torch.device(device) if device is not None else None)
         self.M = torch.as_tensor(mats0, dtype=torch.float64).to(self.device).contiguous()
         self.local, self.off = ops.pack_clusters(clusters0, self.device, torch.float64)
 
@@ -211,7 +211,7 @@ class BatchIcpRegistrar:
     round).  Results equal S separate IcpRegistrars (the batched k-means is bit-identical to the
     multi-launch one)."""
 
-    def __init__(self, mats0, clusters0, n_sequences, device="cuda"):
+    def __init__(self, mats0, clusters0, n_sequences, device=None):
         self.regs = [IcpRegistrar(mats0, clusters0, device) for _ in range(n_sequences)]
 
     def step(self, frames64):

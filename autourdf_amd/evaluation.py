@@ -5,7 +5,7 @@ point-to-point, threshold 0.01, identity start, max 20000 iterations) and ``torc
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .cluster_icp import PointCloud
 
 
@@ -15,8 +15,9 @@ def _points(p):
 
 def torch_chamfer_distance(p1, p2):
     """p1, p2: point clouds (objects with ``.points`` or arrays).  L1 Chamfer distance in float32 (K1)."""
-    a = torch.as_tensor(_points(p1), dtype=torch.float32, device="cuda")
-    b = torch.as_tensor(_points(p2), dtype=torch.float32, device="cuda")
+    dev = _lib.device()
+    a = torch.as_tensor(_points(p1), dtype=torch.float32, device=dev)
+    b = torch.as_tensor(_points(p2), dtype=torch.float32, device=dev)
     return ops.chamfer_distance(a[None], b[None], norm=1)[0].item()
 
 
@@ -24,7 +25,7 @@ def icp_filter(pred_pcd, gt_pcd, threshold=0.01, max_iteration=20000):
     """registration_icp(pred, gt, threshold, I, point-to-point) and pred moved by the result.
     Returns (transformation (4,4) float64, moved PointCloud).  The whole cloud is ONE workgroup's job here
     (the K4 kernel is built for many small clusters): fine for link-sized clouds, slow beyond ~1e4 points."""
-    dev = torch.device("cuda")
+    dev = _lib.device()
     src = torch.as_tensor(_points(pred_pcd), device=dev)
     tgt = torch.as_tensor(_points(gt_pcd), device=dev)
     soff = torch.tensor([0, src.shape[0]], dtype=torch.int32, device=dev)

@@ -14,7 +14,7 @@ def farthest_point_sample(points, num_samples: int) -> np.ndarray:
     if isinstance(points, torch.Tensor) and points.is_cuda:
         X = points.to(torch.float64).contiguous()
     else:
-        X = torch.as_tensor(np.asarray(points, np.float64), device="cuda").contiguous()
+        X = torch.as_tensor(np.asarray(points, np.float64), device=_lib.device()).contiguous()
     n = X.shape[0]
     if not (1 <= num_samples <= n):
         raise ValueError("need 1 <= num_samples <= number of points")

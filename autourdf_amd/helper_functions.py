@@ -15,15 +15,15 @@ def load_pc_npz(path):
 
 def matrix2xyzquant_torch(matrix):
     """4x4 -> (x, y, z, qw, qx, qy, qz) (real-first quaternion, like the reference's output)."""
-    from . import ops
-    M = torch.as_tensor(matrix, dtype=torch.float32, device="cuda")
+    from . import _lib, ops
+    M = torch.as_tensor(matrix, dtype=torch.float32, device=_lib.device(matrix))
     q = ops.matrix_to_quat(M[:3, :3].reshape(1, 3, 3).contiguous())[0]
     return torch.cat([M[:3, 3], q])
 
 
 def xyzquant2matrix_torch(xyzquat):
-    from . import ops
-    v = torch.as_tensor(xyzquat, dtype=torch.float32, device="cuda")
+    from . import _lib, ops
+    v = torch.as_tensor(xyzquat, dtype=torch.float32, device=_lib.device(xyzquat))
     out = torch.eye(4, device=v.device)
     out[:3, :3] = ops.quat_to_matrix(v[3:].reshape(1, 4).contiguous())[0]
     out[:3, 3] = v[:3]

@@ -13,7 +13,7 @@ import os
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .helper_functions import load_pc_npz, save_pc_npz
 
 
@@ -26,7 +26,7 @@ def _pack(clouds, device):
 
 def refine_links_clusters(path_list, start_steps, end_steps, dof):
     """match clusters_i to clusters_0, in local frame (same signature and files as link.py:85)."""
-    dev = torch.device("cuda")
+    dev = _lib.device()
     for link_dir in path_list:
         link_c_files = sorted(glob.glob(link_dir + 'cluster/*.npz'))
         os.makedirs(link_dir + 'cluster_rf', exist_ok=True)

@@ -26,7 +26,7 @@ import threading
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .cluster_icp import PointCloud, Segments, masked_icp
 from .helper_functions import load_pc_npz, save_pc_npz
 from .model_utils import DQRegMLP, QRegMLP, RegMLP, RRegMLP
@@ -108,7 +108,7 @@ def resample_cluster(segments, idx, n_clusters, matrices, normal=False, visual=F
     (mlp_reg.py:172-237): k_means(init = pose translations, n_init=1) -> labels -> inv(M_k).[p;1]."""
     if visual:
         raise NotImplementedError("visual=True needs Open3D's GUI (out of scope)")
-    dev = torch.device("cuda")
+    dev = _lib.device(globals().get("DEVICE"))
     pc_np = np.asarray(segments.pc_list[idx].points)
     X = torch.as_tensor(pc_np, dtype=torch.float64, device=dev).contiguous()
     matrices = np.asarray(matrices)
@@ -398,7 +398,7 @@ def main(argv=None):
     global DEVICE, ROBOT, NUM_SEG, DOF, STEP_SZIE, NUM_CAMERAS, MLP_ICP, VIS, ROT, LOSS, NORMAL, RAW_PATH_LIST
     if not torch.cuda.is_available():
         raise RuntimeError("autourdf_amd.mlp_reg needs an MI355X: no GPU is visible and there is no CPU path")
-    DEVICE = torch.device("cuda")
+    DEVICE = _lib.device()                      # the current device, index spelled out
     print("Using device:", DEVICE)
     parser = argparse.ArgumentParser()
     parser.add_argument("--robot", type=str, default="nao")

@@ -15,13 +15,13 @@ neighbours it needs come from the same GPU search.  Parity with open3d is UNPINN
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 def estimate_normals(points, radius=0.1, max_nn=30):
     """open3d PointCloud.estimate_normals with KDTreeSearchParamHybrid(radius, max_nn): (n,3) float64 unit normals, signs
     as the eigen-solver leaves them."""
-    X = torch.as_tensor(np.asarray(points), dtype=torch.float64, device="cuda").contiguous()
+    X = torch.as_tensor(np.asarray(points), dtype=torch.float64, device=_lib.device()).contiguous()
     n, _, _ = ops.knn_normals(X, radius, max_nn)
     return n.cpu().numpy()
 
@@ -57,7 +57,7 @@ def orient_normals_consistent_tangent_plane(points, normals, k=30):
     emst = minimum_spanning_tree(coo_matrix((d2 + 1.0, (e[:, 0], e[:, 1])), shape=(n, n)).tocsr()).tocoo()
     edges = np.stack([emst.row, emst.col], 1)
     # + the k nearest neighbours of every point (GPU search; the first entry is the point itself)
-    X = torch.as_tensor(P, device="cuda").contiguous()
+    X = torch.as_tensor(P, device=_lib.device()).contiguous()
     _, idx, _ = ops.knn_normals(X, -1.0, min(k, 32), want_normals=False, want_idx=True)
     idx = idx.cpu().numpy()
     src = np.repeat(np.arange(n), idx.shape[1])

@@ -555,7 +555,7 @@ class TrainPlan:
                  nn_search: int = 0):
         self.L = _lib.load()
         self.rot = TRAIN_ROT[rot]
-        self.device = torch.device(device if device is not None else "cuda")
+        self.device = _lib.device(torch.device(device) if device is not None else None)
         self.batch = int(batch)
         self.hidden_model = int(hidden)                                     # the caller's width
         if hidden < 2 or hidden > TRAIN_HIDDEN_TILES[-1]:

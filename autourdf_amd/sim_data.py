@@ -21,7 +21,7 @@ import xml.etree.ElementTree as ET
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .cluster_icp import PointCloud
 from .fps import farthest_point_sample
 
@@ -417,7 +417,7 @@ class SimEnv:
 
     def _device_mesh(self):
         if self._dev is None:
-            d = torch.device("cuda")
+            d = _lib.device()
             r = self.robot
             self._dev = (torch.as_tensor(r.tri, device=d).contiguous(), torch.as_tensor(r.cum_area, device=d),
                          torch.as_tensor(r.tri_link, device=d))

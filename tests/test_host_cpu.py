@@ -116,19 +116,6 @@ def test_train_plan_parameter_layout_matches_every_reference_model():
         mlp_reg._model_params(torch.nn.Linear(3, 3))
 
 
-def test_rotation_maps_match_oracle_conventions():
-    import torch
-    from scipy.spatial.transform import Rotation
-    from autourdf_amd import rot_repr as RR
-    from oracle import transforms as T
-    R = torch.from_numpy(Rotation.random(50, random_state=2).as_matrix())
-    for a, b in ((RR.matrix_to_euler_angles(R, "XYZ"), T.matrix_to_euler_angles(R, "XYZ")),
-                 (RR.matrix_to_rotation_6d(R), T.matrix_to_rotation_6d(R))):
-        np.testing.assert_allclose(a.numpy(), b.numpy(), atol=1e-14)
-    np.testing.assert_allclose(RR.euler_angles_to_matrix(RR.matrix_to_euler_angles(R)).numpy(), R.numpy(), atol=1e-12)
-    np.testing.assert_allclose(RR.rotation_6d_to_matrix(RR.matrix_to_rotation_6d(R)).numpy(), R.numpy(), atol=1e-12)
-
-
 def test_npz_roundtrip_keeps_order_and_dtype(tmp_path):
     from autourdf_amd.helper_functions import load_pc_npz, save_pc_npz
     rng = np.random.default_rng(0)
