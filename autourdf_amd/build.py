@@ -19,6 +19,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
+def kernel_source_sha256() -> str:
+    """Fingerprint of the train plan's kernel sources: tools/summarize_profiles.py stores it beside the rocprofv3 counters it
+    summarises, bench.py compares it with the tree it runs from and marks counters of another build `stale`."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("train_engine.hip", "nn_l1.h", "creg_dev.h", "creg_common.h"):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):

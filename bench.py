@@ -30,6 +30,9 @@ import time
 # arguments from host memory and the headline measured 123 instead of 149 frames/s.  Only a default -- an explicit setting is respected.
 # (An entry point sets it, before the HIP runtime starts; importing autourdf_amd does not touch the environment.)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# dmabuf IPC only on this host driver (RCCL / cross-process device memory needs it): set here as well as by the self-launcher, so that a
+# launcher the DRIVER supplies (torch.distributed.run started by someone else) gets it too
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -92,11 +95,24 @@ def cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters, budget_frames=2, 
     t1 = time.perf_counter()
     registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=6)
     per_epoch_1 = (time.perf_counter() - t1) / 6
-    # ... and on ALL hardware threads of the box ("all host cores and 1"): two epochs, the first one untimed.  This is
-    # the slow configuration -- the work of an epoch (a 4096 x 4096 nearest-neighbour search, a 20-row MLP) is far too small for a
-    # 256-thread fork-join -- and it is why `value` is taken at 16 threads; the figure is reported, not used.
-    all_cores = None
+    # the team sizes around the one `value` is taken at: ms per epoch at 8 / 32 / 64 threads (one untimed epoch, then three timed), so that
+    # "16 is the fastest team" is bracketed by neighbours and not only by 1 and all
     ncpu = os.cpu_count() or 1
+    team_points = {1: round(per_epoch_1 * 1e3, 2), threads: round(per_epoch * 1e3, 2)}
+    for nt in (8, 32, 64):
+        if nt > ncpu or nt in team_points:
+            continue
+        os.environ["OMP_NUM_THREADS"] = str(nt)
+        torch.set_num_threads(nt)
+        _clib.lib().oracle_set_threads(nt)
+        registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=1)
+        tt = time.perf_counter()
+        registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=3)
+        team_points[nt] = round((time.perf_counter() - tt) / 3 * 1e3, 2)
+    # ... and on ALL hardware threads of the box ("all host cores and 1").  This is the slow configuration -- the work of an
+    # epoch (a 4096 x 4096 nearest-neighbour search, a 20-row MLP) is far too small for a 256-thread fork-join -- and it is why `value`
+    # is taken at 16 threads; the figure is reported, not used.  ONE epoch is run first; only if it took under 5 s are two more timed.
+    all_cores = None
     if ncpu > threads:
         os.environ["OMP_NUM_THREADS"] = str(ncpu)
         torch.set_num_threads(ncpu)
@@ -108,11 +124,15 @@ def cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters, budget_frames=2, 
             t2 = time.perf_counter()
             registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=2)
             per_epoch_all = (time.perf_counter() - t2) / 2
+            what = "two epochs after one untimed epoch"
         else:
             per_epoch_all = t_first
+            what = (f"ONE cold epoch of {t_first:.1f} s, the team's spin-up included (nothing was run before it at this team size and nothing "
+                    "after it: a second epoch would double the bench's run time)")
         all_cores = {"threads": ncpu, "ms_per_epoch": round(per_epoch_all * 1e3, 2),
                      "value": 1.0 / (2 * EPOCHS * per_epoch_all + t_km / max(frames_done, 1)),
-                     "sample": "1-2 epochs after one untimed, extrapolated to 600 + the measured resample"}
+                     "sample": what + ", extrapolated to 600 epochs + the measured resample"}
+        team_points[ncpu] = round(per_epoch_all * 1e3, 2)
     torch.set_num_threads(threads)
     os.environ["OMP_NUM_THREADS"] = str(threads)
     _clib.lib().oracle_set_threads(threads)
@@ -125,7 +145,9 @@ def cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters, budget_frames=2, 
             "one_thread": {"value": 1.0 / (2 * EPOCHS * per_epoch_1 + t_km / max(frames_done, 1)), "ms_per_epoch": round(per_epoch_1 * 1e3, 2),
                            "sample": "6 epochs, extrapolated to 600 + the measured resample"},
             "all_cores": all_cores,
-            "cores_note": f"{threads} threads is the FASTEST team on this host for a latency-sized epoch (measured: see all_cores and one_thread); "
+            "ms_per_epoch_by_threads": {str(k): v for k, v in sorted(team_points.items())},
+            "cores_note": f"`value` is taken at {threads} threads; ms_per_epoch_by_threads holds what this host measured at 1 / 8 / {threads} / 32 / 64 / all "
+                          f"threads in this run (fastest team here: {min(team_points, key=team_points.get)}); "
                           "the port's OpenMP C search is also faster than pytorch3d's single-threaded knn_cpu, so the GPU / CPU ratio is conservative",
             "host": {"cpu_model": cpu_model, "os_cpu_count": os.cpu_count()},
             "sample": f"{frames_done} full registered frame(s) of sequence 0 (N={n_points}, K={k_clusters}, hidden {HIDDEN}): {epochs_done} Adam "
@@ -297,7 +319,8 @@ def roofline_block(reg, frames32, n_points, k_clusters, workload, y_index=0):
     kernel + ~1 us launch gap): algorithmic bytes / launch time against the GUIDE's HBM peak.  The top-level block is the
     kernel with the LONGEST launch in THIS run (it was hard-wired to k_dw, wrong for the franka shape).  What
     cannot be read inside this process -- HBM-side traffic and SQ counters need rocprofv3's own --pmc passes -- is replayed
-    from the committed summary of this workload (profiles/r04_pmc.json) and tagged with its source; `frac` of a VALU-bound
+    from the committed summary of this workload (the newest profiles/rNN_pmc.json) and tagged with its source and with `traffic_stale`
+    (the summary stores a fingerprint of the kernel sources it was collected from); `frac` of a VALU-bound
     kernel is a measured utilisation (wave-cycles the VALUs were issuing / SIMD-cycles of the launch), never an
     exhaustive-search-equivalent rate."""
     r = reg.seqs[0]
@@ -311,12 +334,17 @@ def roofline_block(reg, frames32, n_points, k_clusters, workload, y_index=0):
     nz = prof.pop("nn_l1_problems_per_launch")
     model = epoch_kernel_model(k_clusters, n_points, reg.plan.info)
     here = os.path.dirname(os.path.abspath(__file__))
-    pmc, pmc_src = {}, None
-    path = os.path.join(here, "profiles", "r04_pmc.json")
-    if os.path.exists(path):
+    pmc, pmc_src, pmc_stale = {}, None, None
+    import glob
+    cands = sorted(glob.glob(os.path.join(here, "profiles", "r[0-9][0-9]_pmc.json")))
+    if cands:
+        path = cands[-1]                                   # the newest round's collection
         allp = json.load(open(path))
         if workload in allp:
-            pmc, pmc_src = allp[workload], f"profiles/r04_pmc.json[{workload!r}]"
+            pmc, pmc_src = allp[workload], f"profiles/{os.path.basename(path)}[{workload!r}]"
+            from autourdf_amd.build import kernel_source_sha256
+            # counters of ANOTHER build of the kernels describe other code: say so instead of dividing old cycles by new times silently
+            pmc_stale = allp.get("kernel_source_sha256") != kernel_source_sha256()
     kernels = {}
     for key, m in model.items():
         us = b2b[key]
@@ -350,7 +378,11 @@ def roofline_block(reg, frames32, n_points, k_clusters, workload, y_index=0):
     else:
         roof = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": top["hbm_frac"], "traffic": top.get("traffic")}
-    roof.update({"traffic_source": top.get("traffic_source"), "avg_launch_us": top["avg_launch_us"], "problems_per_launch": nz,
+    roof.update({"traffic_stale": pmc_stale,
+                 "traffic_stale_note": None if not pmc_stale else "the counters were collected from a tree whose train-plan kernel sources (train_engine.hip, nn_l1.h, "
+                                       "creg_dev.h, creg_common.h) differ from this one, or carry no fingerprint: traffic / utilisation figures describe THAT build "
+                                       "(re-run tools/collect_profiles.sh)",
+                 "traffic_source": top.get("traffic_source"), "avg_launch_us": top["avg_launch_us"], "problems_per_launch": nz,
                  "algorithmic_bytes": top["algorithmic_bytes"], "wasted_traffic_ratio": top.get("wasted_traffic_ratio"),
                  "dominant_by": "longest back-to-back launch of the five epoch kernels in this run",
                  "timing_source": "HIP events around 200 back-to-back launches of each kernel on the plan's stream, in this run (kernel + ~1 us "
@@ -363,8 +395,22 @@ def roofline_block(reg, frames32, n_points, k_clusters, workload, y_index=0):
     return roof
 
 
+def frame_level(roof, frames_per_s_per_gpu, n_points, k_clusters):
+    """SURVEY 8(d) "Frame-level": the algorithmic HBM bytes of ONE registered frame (600 epochs x the five epoch kernels' bytes per
+    problem, + the frame's k-means / change of frame: the fp64 frame read per Lloyd iteration is L2-resident and counted once) x the
+    frames per second one GPU registered, against the HBM peak."""
+    per_problem = sum(k["algorithmic_bytes"] / max(k["problems_per_launch"], 1) for k in roof["kernels"].values())
+    resample = (24 + 4 + 24 + 12) * n_points + 2 * 128 * k_clusters          # frame read, labels, local clusters written (f64 + f32), poses
+    per_frame = 2 * EPOCHS * per_problem + resample
+    gbps = per_frame * frames_per_s_per_gpu / 1e9
+    return {"bytes_per_frame": int(per_frame), "bytes_per_epoch_per_problem": int(per_problem), "GBps": round(gbps, 1), "peak": HBM_PEAK_GBPS,
+            "frac": round(gbps / HBM_PEAK_GBPS, 4),
+            "note": "sum of the five epoch kernels' algorithmic bytes per problem x 600 epochs + the resample's one pass, x frames/s of one GPU; the "
+                    "epoch chain is latency-bound (five dependent launches per epoch), so this fraction moves with the chain's length, not with any one kernel"}
+
+
 # ------------------------------------------------------------------------------------------ configs[4]: N=262144, K=128
-def run_c5(args, robot, n_points, k_clusters, wl_tag):
+def run_c5(args, ctx, robot, n_points, k_clusters, wl_tag):
     """BASELINE configs[4] (synthetic N=262144, K=128, independent frames sharded over the GPUs): SURVEY 8(d) defines this
     line over the assign / fit kernels only -- the ICP-style frame: K4 masked per-cluster ICP from the current poses
     (mask boxes of the current clusters), K5 dual quaternions, K2 Lloyd re-segmentation seeded at the new translations +
@@ -375,19 +421,7 @@ def run_c5(args, robot, n_points, k_clusters, wl_tag):
     from autourdf_amd.distributed import gather_poses
     from autourdf_amd.engine import IcpRegistrar
     from autourdf_amd.synthetic import initial_segmentation, make_sequence
-    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no GPU visible; there is no CPU path to time)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    if args.gpus != world:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it as `python bench.py --gpus N`, which launches "
-                         "the ranks itself, or under torch.distributed.run with --nproc-per-node equal to --gpus)")
+    world, rank, dev, dist = ctx.world, ctx.rank, ctx.dev, ctx.dist
     total = args.steps + args.warmup
     t_gen = time.perf_counter()
     seq = make_sequence(robot, 0, total + 1, n_points)
@@ -436,6 +470,7 @@ def run_c5(args, robot, n_points, k_clusters, wl_tag):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(gathered).all() and gathered.shape[0] == args.steps
+    out = None
     if rank == 0:
         # the assign kernel (K2 E-step) alone, event-timed on torch's stream (ops launch there): N x K fp64 distances
         it = job[0]
@@ -493,9 +528,7 @@ def run_c5(args, robot, n_points, k_clusters, wl_tag):
                             "note": "N x K assignment at K = 128 sits at the fp64 ridge (64 flop/B against 78.6 TF / 8 TB/s ~ 10): the E-step is "
                                     "fp64-FMA-bound, so both roofs are given; timing = HIP events around 50 back-to-back launches in this run"},
                "pose_checksum": round(float(gathered.abs().sum()), 6)}
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    return out
 
 
 
@@ -536,8 +569,78 @@ def replay_batches(n_items, max_batch=REPLAY_MAX_BATCH):
     return [lo + 1] * extra + [lo] * (rounds - extra)
 
 
+# ------------------------------------------------------------------------------------------ the world (ranks, device, RCCL)
+class _World:
+    """world / rank / device / `torch.distributed` module (None without a process group) of this process."""
+
+    def __init__(self, world, rank, dev, dist, note=None):
+        self.world, self.rank, self.dev, self.dist, self.note = world, rank, dev, dist, note
+
+
+def init_world(args):
+    """One process per GPU.  Under a launcher (RANK set): the launcher's world over RCCL (gloo for the CPU plumbing test).  Started
+    plainly with --gpus 1: STILL a process group -- world size 1, backend nccl -- so that the one collective of the job, the final
+    all_gather of the poses (distributed.gather_poses), goes through RCCL on hardware in every single-GPU run too.
+    If RCCL cannot be initialised on this box, the run continues without a group and says so."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if STUB:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no GPU visible; there is no CPU path to time)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it as `python bench.py --gpus N`, which launches "
+                         "the ranks itself, or under torch.distributed.run with --nproc-per-node equal to --gpus)")
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one process per GPU over RCCL
+        if STUB:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        return _World(world, rank, dev, dist, "launcher-provided process group")
+    if STUB or args.no_rccl_world1:
+        return _World(1, 0, dev, None, "no process group (single process)")
+    try:
+        dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+        t = torch.zeros(1, device=dev)
+        dist.all_reduce(t)                          # builds the communicator now, not inside a timed region
+        torch.cuda.synchronize()
+        return _World(1, 0, dev, dist, "world-1 RCCL group created by bench.py itself (no launcher)")
+    except Exception as e:                          # pragma: no cover -- a box without a usable RCCL
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
+        return _World(1, 0, dev, None, f"world-1 RCCL group could NOT be created ({type(e).__name__}: {str(e)[:200]}); ran without a process group")
+
+
+def rccl_gather_probe(ctx, poses, reps=20):
+    """The job's one collective on its own: `distributed.gather_poses` (RCCL all_gather_into_tensor) of this rank's pose block, timed with
+    events on torch's current stream (where RCCL enqueues its kernel) over `reps` back-to-back calls after two untimed ones."""
+    from autourdf_amd.distributed import gather_poses
+    if ctx.dist is None or STUB:
+        return None
+    for _ in range(2):
+        g = gather_poses(poses)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g = gather_poses(poses)
+    e1.record()
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(g[ctx.rank * poses.shape[0]:(ctx.rank + 1) * poses.shape[0]], poses))
+    return {"us": round(e0.elapsed_time(e1) * 1e3 / reps, 2), "payload_bytes": poses.numel() * poses.element_size(), "world": ctx.world,
+            "backend": ctx.dist.get_backend(), "collective": "all_gather_into_tensor", "own_block_returned_intact": ok, "group": ctx.note}
+
+
 # ------------------------------------------------------------------------------------------ main
-def main(argv=None):
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
@@ -547,6 +650,12 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-icp-variant", action="store_true", help="skip the ICP-style second line (SURVEY 8(d))")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the extra legs of the default single-GPU run: BASELINE configs[2] (franka shape) and configs[4] (N=262144, K=128)")
+    ap.add_argument("--no-rccl-world1", action="store_true", help="single process without a launcher: do not create the world-1 RCCL group")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="sequences mode: the timed region (the same --steps frames from the same state) is run this many times in all; "
+                         "`value` is the FIRST run (exactly --steps steps after --warmup), `repeats` reports median / min / max")
     ap.add_argument("--r", choices=["q", "dq", "6d", "rpy"], default="q",
                     help="pose representation (mlp_reg.py:360 --r); 'q' is the reference's default and the metric's; the others skip the roofline / cpu_baseline legs")
     ap.add_argument("--eager", action="store_true", help="eager launches instead of the captured epoch graph")
@@ -561,36 +670,73 @@ def main(argv=None):
                          "trajectories the trains take -- a numerically different build is compared over several offsets")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="wx200_5",
                     help="default = the configuration BASELINE.json's metric is quoted on")
+    return ap
+
+
+def main(argv=None):
+    import sys
+    ap = build_parser()
     args = ap.parse_args(argv)
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
-        import sys
         raise SystemExit(self_launch(args.gpus, sys.argv[1:] if argv is None else argv))
+    ctx = init_world(args)
     robot, n_points, k_clusters, wl_tag = WORKLOADS[args.workload]
     if args.workload == "c5":
         args.mode = "replay"
-        return run_c5(args, robot, n_points, k_clusters, wl_tag)
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if STUB:
-        dev = torch.device("cpu")
+        out = run_c5(args, ctx, robot, n_points, k_clusters, wl_tag)
     else:
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs an MI355X (no GPU visible; there is no CPU path to time)")
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one process per GPU over RCCL
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if STUB:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    if args.gpus != world:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it as `python bench.py --gpus N`, which launches "
-                         "the ranks itself, or under torch.distributed.run with --nproc-per-node equal to --gpus)")
+        out = run_registration(args, ctx)
+        # The default single-GPU invocation (what the driver runs) also carries the other single-GPU BASELINE configs, each a full run of
+        # its own workload in this process AFTER the headline was measured: configs[2] (franka shape) and configs[4] (N=262144, K=128).
+        headline = (args.workload == "wx200_5" and args.mode == "sequences" and args.r == "q" and ctx.world == 1 and not STUB
+                    and not args.no_other_workloads and not args.eager and args.graph_branches == 0 and args.sequences == 5)
+        if headline and out is not None:
+            out["other_workloads"] = other_workloads(ap, ctx)
+    if ctx.rank == 0 and out is not None:
+        print(json.dumps(out))
+    if ctx.dist is not None:
+        ctx.dist.destroy_process_group()
+
+
+def other_workloads(ap, ctx):
+    """BASELINE configs[2] and configs[4] on the driver's one line: the same code paths as `--workload franka` / `--workload c5`, trimmed
+    to what a reader needs (value, ms per step, checksum, the run's own roofline block).  A leg that fails reports its error instead of
+    taking the headline with it."""
+    legs = {"franka": ["--workload", "franka", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-icp-variant", "--repeats", "1"],
+            "c5": ["--workload", "c5", "--steps", "8", "--warmup", "2"]}
+    res = {}
+    for name, argv in legs.items():
+        t0 = time.perf_counter()
+        try:
+            a = ap.parse_args(argv)
+            robot, n_points, k_clusters, wl_tag = WORKLOADS[a.workload]
+            if name == "c5":
+                a.mode = "replay"
+                d = run_c5(a, ctx, robot, n_points, k_clusters, wl_tag)
+            else:
+                d = run_registration(a, ctx)
+            keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "dtype", "pose_checksum", "roofline")
+            e = {k: d[k] for k in keep if k in d}
+            e["config"] = {k: d["config"][k] for k in ("workload", "mode", "epochs_per_frame", "chains", "sequences_in_flight_per_gpu",
+                                                       "mean_icp_iterations_per_cluster", "frame_ms_rank0") if k in d["config"]}
+            if "rccl_gather" in d:
+                e["rccl_gather"] = d["rccl_gather"]
+            e["argv"] = " ".join(argv)
+        except Exception as ex:                      # pragma: no cover
+            import traceback
+            e = {"error": f"{type(ex).__name__}: {ex}", "traceback_tail": traceback.format_exc()[-600:]}
+        e["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+        res[name] = e
+        if not STUB:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    return res
+
+
+def run_registration(args, ctx):
+    """One run of the default path (train Step + train Anchor + resample per frame) for `args.workload`; returns the JSON dict on rank 0."""
+    robot, n_points, k_clusters, wl_tag = WORKLOADS[args.workload]
+    world, rank, dev, dist = ctx.world, ctx.rank, ctx.dev, ctx.dist
 
     from autourdf_amd.distributed import gather_poses
     from autourdf_amd.synthetic import initial_segmentation, make_sequence
@@ -705,25 +851,67 @@ def main(argv=None):
                 for s, (m, res) in enumerate(out):
                     poses[f * S + s].copy_(m)
 
+        def snapshot():
+            """The state entering the timed region: poses / clusters by reference (a step replaces them, never writes them), the two
+            models' parameters -- which the plan trains in place -- as copies."""
+            return [(r.m, getattr(r, "pts", None), getattr(r, "off", None), getattr(r, "local64", None), [q.clone() for q in getattr(r, "p_step", [])],
+                     [q.clone() for q in getattr(r, "p_anchor", [])]) for r in reg.seqs]
+
+        def restore(snap):
+            for r, (m_, pts_, off_, l64, ps, pa) in zip(reg.seqs, snap):
+                r.m = m_
+                if pts_ is not None:
+                    r.pts, r.off = pts_, off_
+                if l64 is not None:
+                    r.local64 = l64
+                for dst, src in zip(getattr(r, "p_step", []), ps):
+                    dst.copy_(src)
+                for dst, src in zip(getattr(r, "p_anchor", []), pa):
+                    dst.copy_(src)
+
         sync()
         run_rounds(0, warm_rounds)
+        n_rep = max(1, args.repeats)
+        snap = snapshot() if n_rep > 1 else None
         fence()
         epochs_log.clear()
         t0 = time.perf_counter()
         run_rounds(warm_rounds, warm_rounds + timed_rounds)
         timed = poses[warm_rounds * S: warm_rounds * S + args.steps]
-        gathered = gather_poses(timed)                     # the one exchange of the job (RCCL all_gather; no-op at N=1)
+        gathered = gather_poses(timed)                     # the one exchange of the job (RCCL all_gather; world 1 included when a group exists)
         fence()
         elapsed = time.perf_counter() - t0
         n_counted = world * args.steps
         padded = timed_rounds * S - args.steps
         rank_rounds = [[S] * timed_rounds for _ in range(world)]
+        # --repeats: the SAME timed region again (same state, same frames, same gather) -- `value` stays the first run; identical checksums
+        # are a run-to-run determinism check of the whole frame loop on the side
+        rep_elapsed, rep_same = [elapsed], True
+        for _ in range(n_rep - 1):
+            first = gathered.clone()
+            restore(snap)
+            keep_log = list(epochs_log)
+            fence()
+            tr = time.perf_counter()
+            run_rounds(warm_rounds, warm_rounds + timed_rounds)
+            g2 = gather_poses(poses[warm_rounds * S: warm_rounds * S + args.steps])
+            fence()
+            rep_elapsed.append(time.perf_counter() - tr)
+            rep_same = rep_same and bool(torch.equal(g2, first))
+            epochs_log[:] = keep_log
+    if replay:
+        rep_elapsed, rep_same = [elapsed], True
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor(rep_elapsed, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        rep_elapsed = [float(v) for v in t.tolist()]
+        elapsed = rep_elapsed[0]
     assert torch.isfinite(gathered).all() and gathered.shape[0] == n_counted, (gathered.shape, n_counted)
+    # the job's one collective, on its own (every rank takes part)
+    mine_block = poses[:max(n_mine, 1)] if replay else poses[warm_rounds * S: warm_rounds * S + args.steps]
+    rccl = rccl_gather_probe(ctx, mine_block.contiguous()) if (not replay or len({len(job[r::world]) for r in range(world)}) == 1) else None
 
+    out = None
     if rank == 0:
         ep = {}
         if epochs_log:
@@ -758,17 +946,27 @@ def main(argv=None):
                           "sharding": ("items round-robin over ranks" if replay else "sequences per rank") + ", final all_gather of poses"
                                       if world > 1 else "single GPU"},
                "pose_checksum": round(float(gathered.double().abs().sum()), 6)}
+        if len(rep_elapsed) > 1:
+            vals = sorted(n_counted / e for e in rep_elapsed)
+            out["repeats"] = {"n": len(rep_elapsed), "values": [round(n_counted / e, 2) for e in rep_elapsed],
+                              "median": round(vals[len(vals) // 2], 2), "min": round(vals[0], 2), "max": round(vals[-1], 2),
+                              "poses_identical_across_repeats": rep_same,
+                              "note": "the timed region run n times from the same state (parameters restored, same frames, same final gather); "
+                                      "`value` is the first of them -- exactly --steps steps after --warmup -- the others only show the spread on this box"}
+        if rccl is not None:
+            out["rccl_gather"] = rccl
+            if world == 1:
+                out["rccl_world1_gather_us"] = rccl["us"]
         if not STUB and not args.no_roofline:
             out["roofline"] = roofline_block(reg, frames32, n_points, k_clusters, args.workload,
                                              y_index=0 if replay else max(warm_rounds + timed_rounds - 2, 0))
+            out["roofline"]["frame_level"] = frame_level(out["roofline"], out["value"] / world, n_points, k_clusters)
         if not STUB and world == 1 and not args.no_icp_variant and not replay:      # a one-GPU secondary line: not while other ranks wait
             out["icp_variant"] = icp_variant(frames64, mats0, clusters0, dev, warm_rounds, timed_rounds)
         if not STUB and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters)
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

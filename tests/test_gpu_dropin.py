@@ -208,3 +208,49 @@ def test_optional_representations_short_trajectory_vs_oracle(rot):
     for (name, p), q in zip(g_model.state_dict().items(), o_model.state_dict().values()):
         assert p.shape == q.shape
         np.testing.assert_allclose(p.cpu().numpy(), q.numpy(), atol=5e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("mode", ["sequences", "replay"])
+def test_bench_under_torchrun_world_one_runs_the_rccl_gather(mode):
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 ...` (the driver's launcher shape at N > 1, here with one
+    rank): the process group is RCCL, the final `gather_poses` is a real all_gather_into_tensor on the GPU, and the line reports it."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "5", "--mode", mode,
+                        "--no-cpu-baseline", "--no-icp-variant", "--no-roofline", "--no-other-workloads", "--repeats", "2"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["value"] > 0
+    g = d["rccl_gather"]
+    assert g["backend"] == "nccl" and g["world"] == 1 and g["own_block_returned_intact"] is True and g["us"] > 0
+    assert g["payload_bytes"] == 5 * 20 * 64
+    if mode == "sequences":
+        assert d["repeats"]["n"] == 2 and d["repeats"]["poses_identical_across_repeats"] is True
+
+
+def test_bench_plain_single_process_creates_its_own_world_one_rccl_group():
+    """`python bench.py --gpus 1` without a launcher (the driver's N = 1 command): bench.py creates the world-1 RCCL group itself so the
+    job's one collective runs on hardware in every round's BENCH line (`rccl_world1_gather_us`)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "5",
+                        "--no-cpu-baseline", "--no-icp-variant", "--no-roofline", "--no-other-workloads", "--repeats", "1"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["rccl_world1_gather_us"] > 0 and d["rccl_gather"]["backend"] == "nccl", d.get("rccl_gather")
+    assert "created by bench.py" in d["rccl_gather"]["group"]

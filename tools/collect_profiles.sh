@@ -1,19 +1,19 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repository root: bench lines + rocprofv3 evidence into gpurun_out/final/.
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
-# then here:  cp gpurun_out/r04_profiles/* profiles/
+# then here:  cp gpurun_out/r05_profiles/* profiles/
 set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline"
+CMD="python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline --no-other-workloads --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats -- $CMD > $O/prof_run.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o c5 -- python $R/bench.py --workload c5 --steps 4 --warmup 1 > $O/prof_c5.log 2>&1
 # counters: one set per pass (FETCH_SIZE | WRITE_SIZE | the SQ set), per workload, never together with a trace domain other than --kernel-trace
 for wl in wx200_5 franka allegro; do
   steps=5; [ $wl = franka ] && steps=5
-  W="python $R/bench.py --workload $wl --steps $steps --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline"
+  W="python $R/bench.py --workload $wl --steps $steps --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline --no-other-workloads --repeats 1"
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O -o pmc_${wl}_$c -- $W > $O/pmc_${wl}_$c.log 2>&1
   done
@@ -23,7 +23,7 @@ for wl in wx200_5 franka allegro; do
 done
 # the ICP-style configs[4] frame: the SQ set for its kernels (k_icp_nn, k_km_persist, ...)
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O -o pmc_c5_sq -- python $R/bench.py --workload c5 --steps 3 --warmup 1 > $O/pmc_c5_sq.log 2>&1
-python - <<PYEOF > $R/gpurun_out/r04_c5_pmc_summary.txt
+python - <<PYEOF > $R/gpurun_out/r05_c5_pmc_summary.txt
 import csv, glob, collections
 f = glob.glob("$O/**/pmc_c5_sq*counter_collection.csv", recursive=True)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -37,9 +37,9 @@ for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[
           f"wait any {d.get('SQ_WAIT_ANY', 0) / wc:.3f}  wait inst {d.get('SQ_WAIT_INST_ANY', 0) / wc:.3f}")
 PYEOF
 rm -f $O/*_kernel_trace.csv $O/*_agent_info.csv $O/*_domain_stats.csv
-# counters first, bench lines after: `roofline.traffic` / the measured VALU utilisation of a bench line come from profiles/r04_pmc.json,
+# counters first, bench lines after: `roofline.traffic` / the measured VALU utilisation of a bench line come from profiles/r05_pmc.json,
 # which must describe the kernels that line runs (a line benched before its counters were re-collected divides old cycles by new times)
-cd $R && python tools/summarize_profiles.py $O r04 $R/gpurun_out/r04_profiles > /dev/null 2>&1 && cp $R/gpurun_out/r04_profiles/r04_pmc.json $R/profiles/r04_pmc.json
+cd $R && python tools/summarize_profiles.py $O r05 $R/gpurun_out/r05_profiles > /dev/null 2>&1 && cp $R/gpurun_out/r05_profiles/r05_pmc.json $R/profiles/r05_pmc.json
 cd /tmp
 python $R/bench.py > $O/bench.log 2>$O/bench.err
 python $R/bench.py --sequences 1 --steps 8 --warmup 2 --no-cpu-baseline --no-icp-variant > $O/bench_b1.log 2>/dev/null
@@ -61,8 +61,8 @@ python $R/tests/measure/profile_icp_frame.py both 2>/dev/null | grep -v amdgpu.i
 python $R/tests/measure/stress_handoffs.py 2>/dev/null | grep -v amdgpu.ids > $O/handoff_stress.log
 (for pe in 1 0; do for pr in 1 0; do [ $pe = 1 ] && [ $pr = 0 ] && continue; echo "# CREG_KM_PRUNE=$pr CREG_KM_PERSIST=$pe"; CREG_KM_PRUNE=$pr CREG_KM_PERSIST=$pe python $R/tests/measure/km_quick.py 2>/dev/null | grep Lloyd; done; done) > $O/km_quick.log
 # summaries on the box (gpurun brings back at most 64 MiB; the raw counter CSVs are ~18 MB each), raw files dropped
-cd $R && python tools/summarize_profiles.py $O r04 $R/gpurun_out/r04_profiles > $R/gpurun_out/r04_profiles_summary.log 2>&1
+cd $R && python tools/summarize_profiles.py $O r05 $R/gpurun_out/r05_profiles > $R/gpurun_out/r05_profiles_summary.log 2>&1
 rm -f $O/*_counter_collection.csv
-cp $R/gpurun_out/r04_c5_pmc_summary.txt $R/gpurun_out/r04_profiles/ 2>/dev/null
-ls -la $R/gpurun_out/r04_profiles | head -40
+cp $R/gpurun_out/r05_c5_pmc_summary.txt $R/gpurun_out/r05_profiles/ 2>/dev/null
+ls -la $R/gpurun_out/r05_profiles | head -40
 tail -c 600 $O/bench.log

@@ -80,6 +80,13 @@ def main(src, tag, dst="profiles"):
     open(f"{dst}/{tag}_pmc_summary.txt", "w").write(header + "\n".join(lines) + "\n")
     out["source"] = ("rocprofv3 --kernel-trace --pmc, separate passes for FETCH_SIZE / WRITE_SIZE / the SQ set per workload, `bench.py --workload W "
                      "--steps 5 --warmup 5 --no-cpu-baseline --no-icp-variant --no-roofline` (tools/collect_profiles.sh)")
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from autourdf_amd.build import kernel_source_sha256
+        out["kernel_source_sha256"] = kernel_source_sha256()       # of the tree the counters were collected from (bench.py: `stale`)
+    except Exception as e:
+        out["kernel_source_sha256"] = None
+        print("no source fingerprint:", e)
     json.dump(out, open(f"{dst}/{tag}_pmc.json", "w"), indent=1)
     cp = lambda a, b: os.path.exists(f"{src}/{a}") and shutil.copy(f"{src}/{a}", f"{dst}/{b}")
     cp("stats_kernel_stats.csv", f"{tag}_final_kernel_stats.csv")
