@@ -21,7 +21,9 @@
 // run to run).  State that the reference keeps in Python (min_loss, count, scheduler, lr) lives in
 // a double-buffered device struct indexed by epoch parity.
 #include <cfloat>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -1340,6 +1342,8 @@ struct Plan {
     hipStream_t cst[8];
     hipGraphExec_t cexec[8];
     hipEvent_t cfork, cjoin[8];
+    hipStream_t cal_stream;   // the caller's stream the chain streams were picked against (pick_chain_streams)
+    bool cal_done;
     bool target_blocks_valid; // ys4 / ybox hold the k-d leaves of every problem's last run_batch frame (probe / profile overwrite them)
 };
 
@@ -1655,7 +1659,73 @@ static int capture_epochs(Plan* P, int epg) {
     return CREG_OK;
 }
 
-// chain-stream mode: chain gi's EPG epochs as a linear graph, captured on (and later launched on) the chain's own stream
+// ---- chain streams must sit in DIFFERENT hardware queues (round 5) -------------------------------------------------------------
+// The runtime multiplexes streams onto GPU_MAX_HW_QUEUES (4) hardware queues: the first four streams of a process get a queue each,
+// every later one SHARES the queue with the fewest users -- possibly the caller's.  Two chains in one queue run one after the other
+// (75 us per epoch instead of 45.8: the default bench line fell 182 -> 112 frames/s the moment a world-1 RCCL group, which owns
+// streams of its own, was created before the plan; profiles/r05_rccl_vs_chains.log).  HIP does not say which queue a stream got, so
+// it is measured: a stream is accepted as a chain's when a 150 us spin kernel on it runs CONCURRENTLY with one on the caller's stream
+// and on the chains picked before it; rejected candidates stay alive until the pick is over (so that the next one lands elsewhere).
+__global__ void k_spin(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+static double spin_together_us(hipStream_t* st, int n, unsigned long long ticks) {
+    for (int i = 0; i < n; ++i) if (hipStreamSynchronize(st[i]) != hipSuccess) return -1.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st[i], ticks);
+    if (hipGetLastError() != hipSuccess) return -1.0;
+    for (int i = 0; i < n; ++i) if (hipStreamSynchronize(st[i]) != hipSuccess) return -1.0;
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// (Re)creates P->cst[1 .. branches-1] so that they overlap with `s` and with each other; keeps what it has when no better stream exists.
+static int pick_chain_streams(Plan* P, hipStream_t s) {
+    static const bool probe = !(getenv("CREG_NO_QUEUE_PROBE") && getenv("CREG_NO_QUEUE_PROBE")[0] == '1');
+    const unsigned long long ticks = 15000;                 // wall_clock64 runs at 100 MHz: 150 us
+    for (int gi = 1; gi < P->branches; ++gi) {
+        hipStream_t set[9], rejected[8];
+        int ns = 0, nr = 0;
+        set[ns++] = s;
+        for (int j = 1; j < gi; ++j) set[ns++] = P->cst[j];
+        hipStream_t chosen = nullptr;
+        if (P->cst[gi]) {                                    // the stream of an earlier pick (another caller stream): keep it if it still fits
+            set[ns] = P->cst[gi];
+            double t = spin_together_us(set, ns + 1, ticks);
+            const double t2 = t < 0 || t >= 250.0 ? spin_together_us(set, ns + 1, ticks) : t;
+            if (t2 >= 0 && (t < 0 || t2 < t)) t = t2;
+            if (!probe || (t >= 0 && t < 250.0)) chosen = P->cst[gi];
+            else { (void)hipStreamSynchronize(P->cst[gi]); rejected[nr++] = P->cst[gi]; P->cst[gi] = nullptr; }
+        }
+        for (int attempt = 0; !chosen && attempt < 7; ++attempt) {
+            hipStream_t cs = nullptr;
+            if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) break;
+            if (!probe) { chosen = cs; break; }
+            set[ns] = cs;
+            double t = spin_together_us(set, ns + 1, ticks);
+            if (t < 0 || t >= 250.0) {                       // a late host thread looks like a shared queue: ask twice
+                const double t2 = spin_together_us(set, ns + 1, ticks);
+                if (t2 >= 0 && (t < 0 || t2 < t)) t = t2;
+            }
+            if (t >= 0 && t < 250.0) chosen = cs;
+            else if (nr < 8) rejected[nr++] = cs;
+            else (void)hipStreamDestroy(cs);
+        }
+        if (!chosen && nr) chosen = rejected[--nr];          // every queue is shared with somebody: any stream is as good as another
+        for (int i = 0; i < nr; ++i) (void)hipStreamDestroy(rejected[i]);
+        if (!chosen) {
+            (void)hipGetLastError();
+            creg::set_error("creg_train_plan_run_batch: cannot create a stream for chain %d", gi);
+            return CREG_EHIP;
+        }
+        P->cst[gi] = chosen;
+    }
+    P->cal_stream = s; P->cal_done = true;
+    return CREG_OK;
+}
+
+// chain-stream mode: chain gi's EPG epochs as a linear graph (captured on a temporary stream: an instantiated graph runs on any)
 static int chain_first(const Plan* P, int gi) { int f = 0; for (int i = 0; i < gi; ++i) f += P->B / P->branches + (i < P->B % P->branches ? 1 : 0); return f; }
 static int chain_count(const Plan* P, int gi) { return P->B / P->branches + (gi < P->B % P->branches ? 1 : 0); }
 static int capture_chains(Plan* P, int epg) {
@@ -1664,14 +1734,13 @@ static int capture_chains(Plan* P, int epg) {
     hipError_t err = hipSuccess;
     const char* what = "";
 #define CAP_TRY(call) do { if (err == hipSuccess) { err = (call); if (err != hipSuccess) what = #call; } } while (0)
-    CAP_TRY(hipEventCreateWithFlags(&P->cfork, hipEventDisableTiming));
+    if (!P->cfork) CAP_TRY(hipEventCreateWithFlags(&P->cfork, hipEventDisableTiming));
+    hipStream_t cs = nullptr;
+    CAP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     for (int gi = 0; gi < P->branches && err == hipSuccess; ++gi) {
         hipGraph_t g = nullptr;
-        // chain 0 RUNS on the caller's stream: the stream it is captured on is a temporary (torch's current stream is usually the
-        // null stream, which cannot be captured); the others are captured on the stream they will run on
-        hipStream_t cs = nullptr;
-        CAP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        if (gi > 0) { P->cst[gi] = cs; CAP_TRY(hipEventCreateWithFlags(&P->cjoin[gi], hipEventDisableTiming)); }
+        if (gi > 0 && !P->cjoin[gi]) CAP_TRY(hipEventCreateWithFlags(&P->cjoin[gi], hipEventDisableTiming));
+        if (P->cexec[gi]) { (void)hipGraphExecDestroy(P->cexec[gi]); P->cexec[gi] = nullptr; }      // (a retry after a failed capture)
         CAP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         if (err == hipSuccess) {
             P->W = ws_shift(Wall, (size_t)chain_first(P, gi) * P->bstride); P->nz = chain_count(P, gi);
@@ -1682,11 +1751,12 @@ static int capture_chains(Plan* P, int epg) {
         }
         CAP_TRY(hipGraphInstantiate(&P->cexec[gi], g, nullptr, nullptr, 0));
         if (g) (void)hipGraphDestroy(g);
-        if (gi == 0 && cs) (void)hipStreamDestroy(cs);
     }
+    if (cs) (void)hipStreamDestroy(cs);
 #undef CAP_TRY
     if (err != hipSuccess) {
         (void)hipGetLastError();
+        for (int gi = 0; gi < 8; ++gi) if (P->cexec[gi]) { (void)hipGraphExecDestroy(P->cexec[gi]); P->cexec[gi] = nullptr; }
         creg::set_error("creg_train_plan_run_batch: chain graph capture failed: %s: %s", what, hipGetErrorString(err));
         return CREG_EHIP;
     }
@@ -1734,7 +1804,7 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     if (P->branches > P->B) P->branches = P->B;
     if (P->branches > 8) P->branches = 8;
     P->gexec = nullptr; P->graph_ready = false; P->target_blocks_valid = false;
-    P->cfork = nullptr;
+    P->cfork = nullptr; P->cal_stream = nullptr; P->cal_done = false;
     for (int i = 0; i < 8; ++i) { P->cst[i] = nullptr; P->cexec[i] = nullptr; P->cjoin[i] = nullptr; }
     {   // the dynamic LDS of k_bd is the B role's (71 KB at K = 20, hidden 512: its 48 KB slab of W2 + 23 KB; the D role uses none)
         P->smem_bd = (int)(sizeof(float) * b2_smem_floats(D.K, D.IN, D.H2));
@@ -1794,20 +1864,38 @@ extern "C" int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train
             // graph), join once.  Chain 0 runs on the CALLER's stream: a stream that only waits for the others would hold a barrier
             // packet in its hardware queue for the whole train, and a parked barrier slows the chains in the other queues by ~10 %
             // (measured, tests/measure/frame_phases_by_chains.py).
+            if (P->branches > 1 && (!P->cal_done || P->cal_stream != s)) {
+                const int rc = pick_chain_streams(P, s);           // streams in hardware queues of their own (measured, see there)
+                if (rc) { P->target_blocks_valid = false; return rc; }
+            }
             const Ws Wall = P->W;
             auto st_of = [&](int gi) { return gi == 0 ? s : P->cst[gi]; };
-            CREG_HIP(hipEventRecord(P->cfork, s));
-            for (int gi = 1; gi < P->branches; ++gi) CREG_HIP(hipStreamWaitEvent(P->cst[gi], P->cfork, 0));
-            for (; e + P->graph_epochs <= D.epochs; e += P->graph_epochs)
-                for (int gi = 0; gi < P->branches; ++gi) CREG_HIP(hipGraphLaunch(P->cexec[gi], st_of(gi)));
-            for (int gi = 0; gi < P->branches; ++gi) {
+            hipError_t cerr = hipSuccess;
+            const char* cwhat = "";
+#define CH_TRY(call) do { if (cerr == hipSuccess) { cerr = (call); if (cerr != hipSuccess) cwhat = #call; } } while (0)
+            CH_TRY(hipEventRecord(P->cfork, s));
+            for (int gi = 1; gi < P->branches; ++gi) CH_TRY(hipStreamWaitEvent(P->cst[gi], P->cfork, 0));
+            for (; cerr == hipSuccess && e + P->graph_epochs <= D.epochs; e += P->graph_epochs)
+                for (int gi = 0; gi < P->branches; ++gi) CH_TRY(hipGraphLaunch(P->cexec[gi], st_of(gi)));
+            for (int gi = 0; cerr == hipSuccess && gi < P->branches; ++gi) {
                 P->W = ws_shift(Wall, (size_t)chain_first(P, gi) * P->bstride); P->nz = chain_count(P, gi);
                 for (int e2 = e; e2 < D.epochs; ++e2) enqueue_epoch(P, e2, st_of(gi));
                 P->W = Wall; P->nz = P->B;
             }
+            // the join is enqueued ALSO after a failure: chains that did start must not be left running on the workspace, un-joined,
+            // beside whatever the caller does next (a retry would stage inputs under them)
             for (int gi = 1; gi < P->branches; ++gi) {
-                CREG_HIP(hipEventRecord(P->cjoin[gi], P->cst[gi]));
-                CREG_HIP(hipStreamWaitEvent(s, P->cjoin[gi], 0));
+                if (hipEventRecord(P->cjoin[gi], P->cst[gi]) != hipSuccess || hipStreamWaitEvent(s, P->cjoin[gi], 0) != hipSuccess) {
+                    (void)hipStreamSynchronize(P->cst[gi]);
+                    if (cerr == hipSuccess) { cerr = hipErrorUnknown; cwhat = "joining a chain stream"; }
+                }
+            }
+#undef CH_TRY
+            if (cerr != hipSuccess) {
+                (void)hipGetLastError();
+                P->target_blocks_valid = false;                    // nothing of this run may be vouched for by the next one
+                creg::set_error("creg_train_plan_run_batch: %s: %s", cwhat, hipGetErrorString(cerr));
+                return CREG_EHIP;
             }
             e = D.epochs;
         } else {
