@@ -7,7 +7,9 @@ import torch  # noqa: F401  -- FIRST: brings torch's bundled libamdhip64 (SONAME
 #                 process so libcreg.so binds to the same HIP runtime instead of a second copy from /opt/rocm
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcreg.so")
+# CREG_LIB_VARIANT=asan: the sanitizer build of the same sources (python -m autourdf_amd.build --asan), for tools/run_sanitizer_suite.sh
+_VARIANT = os.environ.get("CREG_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, "libcreg" + ("_" + _VARIANT if _VARIANT else "") + ".so")
 
 vp, i64, i32, f32, f64, sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
                               ctypes.c_double, ctypes.c_size_t)

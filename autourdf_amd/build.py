@@ -1,6 +1,16 @@
 """Build libcreg.so (hipcc, gfx950 only) in-tree so it travels with the repo snapshot.
 
-    python -m autourdf_amd.build [--force]
+    python -m autourdf_amd.build [--force] [--asan]
+
+`--asan` / `--ubsan` build a SECOND library, libcreg_asan.so / libcreg_ubsan.so (objects under csrc/_obj_<variant>): the host side of
+every entry point -- plans, chain streams, pinned rings, events, argument checks -- under AddressSanitizer or UBSan
+(`-fno-gpu-sanitize`: device code is compiled as always).  ROCm's own ASan runtime (libclang_rt.asan) intercepts the HSA allocator and
+aborts inside `hipInit` unless the whole ROCm stack is its -asan build ("out of memory ... hsa_amd_memory_pool_allocate", measured on
+the GPU box), so the ASan objects are linked WITHOUT a runtime and take gcc's libasan (same interface, no HSA interceptors) from
+LD_PRELOAD:
+    CREG_LIB_VARIANT=asan LD_PRELOAD=/usr/lib/x86_64-linux-gnu/libasan.so.6 ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -m gpu
+    CREG_LIB_VARIANT=ubsan python -m pytest tests -m gpu
+(tools/run_sanitizer_suite.sh; SURVEY section 5 / VERDICT r4 item 8).
 """
 import os
 import shutil
@@ -44,12 +54,24 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
+VARIANT_FLAGS = {"asan": ["-fsanitize=address", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g"],
+                 "ubsan": ["-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g"]}
+VARIANT_LINK = {"asan": ["-Wl,--allow-shlib-undefined"],                  # the runtime comes from LD_PRELOAD (gcc's libasan)
+                "ubsan": ["-fsanitize=undefined", "-fno-gpu-sanitize"]}
+
+
+def build_lib(force: bool = False, verbose: bool = False, variant: str = "") -> str:
+    OBJ = os.path.join(CSRC, "_obj" + ("_" + variant if variant else ""))
+    LIB = os.path.join(HERE, "libcreg" + ("_" + variant if variant else "") + ".so")
+    if variant not in ("", "asan", "ubsan"):
+        raise ValueError(f"unknown build variant {variant!r}")
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "creg.h"))
     hipcc = _hipcc()
     extra = os.environ.get("CREG_EXTRA_FLAGS", "").split()      # e.g. -DCREG_BACK_STAMPS for tools/back_stamps.py
+    if variant:
+        extra = extra + VARIANT_FLAGS[variant]
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -67,10 +89,10 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         if verbose and out:
             print(out.decode())
     if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + (VARIANT_LINK[variant] if variant else []) + objs
         subprocess.check_call(cmd)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_lib(force="--force" in sys.argv, verbose=True, variant="asan" if "--asan" in sys.argv else ("ubsan" if "--ubsan" in sys.argv else "")))

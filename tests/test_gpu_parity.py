@@ -897,6 +897,90 @@ def test_train_three_steps_odd_shapes_vs_oracle(dev, rot, hidden, k):
         assert d.max() < (7e-3 if wide else 5e-4), (name, d.max())         # (wide: three steps of 2 lr each at most)
 
 
+def _plan_first_moments(plan, order, shapes):
+    """The Adam first moments a plan holds after a run, per parameter tensor, read from the CALLER-OWNED workspace (DESIGN.md section 3:
+    four flat float32 arrays of NPAR values each -- P, P1, m, v -- 256-byte aligned, in the order of ops.Q_PARAM_ORDER / DQ_PARAM_ORDER
+    with decoder_1.0 / decoder_2.0 stacked into one W2).  After ONE optimizer step from zero moments m = (1 - beta1) g exactly, so
+    this is the weight gradient of the first epoch, which nothing the plan returns exposes."""
+    n = {k: int(np.prod(shapes[k])) for k in order}
+    npar = sum(n.values())
+    stride = (4 * npar + 255) // 256 * 256
+    base = (plan.ws.data_ptr() + 255) // 256 * 256 - plan.ws.data_ptr()
+    am = plan.ws[base + 2 * stride: base + 2 * stride + 4 * npar].view(torch.float32).cpu().numpy()
+    if len(order) == 10:        # flat order: W1 b1 | W2 = [dec1.0 ; dec2.0] , b2 = [dec1.0.b ; dec2.0.b] | W3A b3A | W3B b3B
+        flat = [order[0], order[1], order[2], order[6], order[3], order[7], order[4], order[5], order[8], order[9]]
+    else:
+        flat = list(order)
+    out, o = {}, 0
+    for k in flat:
+        out[k] = am[o:o + n[k]].reshape(shapes[k])
+        o += n[k]
+    return out
+
+
+@pytest.mark.parametrize("rot,k", [("6d", 142), ("6d", 144), ("6d", 160), ("q", 160), ("rpy", 160)])
+def test_train_weight_gradients_with_many_clusters_vs_oracle_autograd(dev, rot, k):
+    """the sixth 16-byte feature piece of k_bd's B role exists only for '6d' with K >= 143 (K x 72 / 4 > 2560), and
+    nothing held it to more than a smoke test: Adam's first step is +-lr whatever a gradient's size and its next ones divide by running
+    moments with the same error, so parameters after three steps barely notice a gradient that lost the contribution of pose rows
+    143..159 (measured here: even real-size clusters leave 0.01-0.04 % of the weights a full 2 lr apart after ONE step between two
+    correct float32 implementations -- exact cancellations -- for 'q' and '6d' alike).  So the gradients themselves: after one optimizer
+    step from zero moments the plan's first moments are (1 - beta1) g, and they sit in the caller's workspace.  On a 16384-point
+    frame (56+ points per cluster) every weight gradient of every layer against torch autograd on the oracle's MLP + pose map, both
+    pulled back from the SAME dL/d[R|t] (the plan's own, from `probe`, itself held to the oracle's with the usual tolerance: the Chamfer
+    gradient is a sum of +-1/N signs, and one point whose coordinate sits within an ulp of its neighbour's flips a sign between any two
+    float32 implementations -- at K = 160 on this frame exactly one does, 2 / 16384 in one translation gradient, which a comparison
+    through the loss would have to tolerate in every layer).  An element's error is at most 5e-6 of the tensor's largest gradient
+    (measured 1e-7 .. 3e-7: float32 sums over up to 160 rows / 768 units in another order), the encoder's -- what the sixth piece
+    feeds: dW1 = g_x1^T . features -- included."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    from oracle import registration
+    from oracle.chamfer import chamfer_distance
+    seq = make_sequence("franka", 23, 2, 16384)
+    mats, cl, _ = initial_segmentation(seq[0], k, seed=4)
+    assert min(len(c) for c in cl) >= 20
+    m = torch.tensor(mats, dtype=torch.float32)
+    y = torch.tensor(seq[1], dtype=torch.float32)
+    clusters = [torch.tensor(c, dtype=torch.float32) for c in cl]
+    hidden = 256
+    torch.manual_seed(11)
+    model = _oracle_model(rot, hidden)
+    order = _order(rot)
+    sd = model.state_dict()
+    params = [sd[n].clone().to(dev) for n in order]
+    pts, off = ops.pack_clusters(clusters, dev)
+    plan = ops.TrainPlan(rot, k, hidden, pts.shape[0], y.shape[0], epochs=1, use_graph=False, device=dev)
+    gm2, gpred, gloss, ggrad = plan.probe(m.to(dev), y.to(dev), pts, off, params)
+    bm, bp, res, lh, _ = plan.run(m.to(dev), y.to(dev), pts, off, params, lr=1e-3)
+    torch.cuda.synchronize()
+    moments = _plan_first_moments(plan, order, {n: tuple(sd[n].shape) for n in order})
+    m2 = registration.pose_forward(m, model, rot)
+    m2.retain_grad()
+    pred = torch.cat(registration.calculate_pc(clusters, m2))
+    loss, _ = chamfer_distance(pred.unsqueeze(0), y.unsqueeze(0), norm=1)
+    loss.backward(retain_graph=True)
+    assert abs(float(lh[0]) - float(loss)) <= 2e-5 * float(loss)
+    np.testing.assert_allclose(bm.cpu().numpy(), m2.detach().numpy(), atol=1e-5)
+    # dL/d[R|t]: the plan's against the oracle's; a flipped sign of one point moves one entry by 2 / N (x its coordinate for dL/dR)
+    gp, go = ggrad.cpu().numpy()[:, :3, :], m2.grad.numpy()[:, :3, :]
+    assert int((np.abs(gp - go) > 1e-4 * np.abs(go) + 2e-6).sum()) <= 4, np.abs(gp - go).max()
+    assert float(np.abs(gp - go).max()) <= 3.0 / y.shape[0]
+    # the MLP + pose map's backward from the plan's dL/d[R|t]
+    model.zero_grad()
+    g_in = torch.zeros_like(m2)
+    g_in[:, :3, :] = torch.from_numpy(gp)
+    m2.backward(gradient=g_in)
+    named = dict(model.named_parameters())
+    for name in order:
+        g_ref = named[name].grad.numpy()
+        g_plan = moments[name] / np.float32(1.0 - 0.9)
+        scale = float(np.abs(g_ref).max())
+        assert scale > 0, name
+        err = float(np.abs(g_plan - g_ref).max())
+        assert err <= 5e-6 * scale, (name, err, scale)
+
+
 @pytest.mark.parametrize("rot", ["q", "dq"])
 @pytest.mark.parametrize("graph", [False, True])
 def test_train_short_trajectory_vs_oracle(dev, golden, rot, graph):
