@@ -8,7 +8,7 @@ every entry point -- plans, chain streams, pinned rings, events, argument checks
 aborts inside `hipInit` unless the whole ROCm stack is its -asan build ("out of memory ... hsa_amd_memory_pool_allocate", measured on
 the GPU box), so the ASan objects are linked WITHOUT a runtime and take gcc's libasan (same interface, no HSA interceptors) from
 LD_PRELOAD:
-    CREG_LIB_VARIANT=asan LD_PRELOAD=/usr/lib/x86_64-linux-gnu/libasan.so.6 ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -m gpu
+    CREG_LIB_VARIANT=asan LD_PRELOAD="/usr/lib/x86_64-linux-gnu/libasan.so.6 /usr/lib/x86_64-linux-gnu/libstdc++.so.6" ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -m gpu
     CREG_LIB_VARIANT=ubsan python -m pytest tests -m gpu
 (tools/run_sanitizer_suite.sh; SURVEY section 5 / VERDICT r4 item 8).
 """

@@ -79,6 +79,8 @@ struct Ws {         // device pointers into the caller's workspace
     float *best_m, *best_pred, *loss_hist, *lr_hist, *result;
     int* off;
     Hyper* hyper;
+    int* sync;          // fused backward launch (k_gbd): [0] arrivals of the gradient role's blocks (k_head zeroes it every epoch),
+                        //   [32 .. 35] (its own 128-byte line) the record the consumers need of the advanced state: stopped, step_size, bc2_sqrt
 };
 
 // Problem b of a batch lives in its own copy of the workspace layout, `bytes` = b * stride further on:
@@ -283,10 +285,11 @@ template <int NC, bool X = false>
 __global__ __launch_bounds__(512) void k_head(Dims D, Ws W0, int par, size_t bstride) {
     // every kernel argument in the entry block, one wait (see k_bd)
     asm volatile("" :: "s"(W0.P), "s"(W0.P1), "s"(W0.h2[0]), "s"(W0.h2[1]), "s"(W0.pose_in), "s"(W0.head_save), "s"(W0.m2), "s"(W0.pts4), "s"(W0.pred4),
-                 "s"(W0.psl4), "s"(W0.ps4), "s"(W0.pbox), "s"(W0.sb), "s"(W0.cnt4), "s"(W0.state), "s"(W0.off), "s"(D.rot), "s"(D.K), "s"(D.H2), "s"(D.HA),
+                 "s"(W0.psl4), "s"(W0.ps4), "s"(W0.pbox), "s"(W0.sb), "s"(W0.cnt4), "s"(W0.state), "s"(W0.off), "s"(W0.sync), "s"(D.rot), "s"(D.K), "s"(D.H2), "s"(D.HA),
                  "s"(D.HB), "s"(D.OA), "s"(D.OB), "s"(D.NP), "s"(D.npb), "s"(D.ppl), "s"(D.nbp), "s"(D.oW3A), "s"(D.ob3A), "s"(D.oW3B), "s"(D.ob3B), "s"(par),
                  "s"(bstride));
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
+    if (blockIdx.x == 0 && threadIdx.x == 0) W.sync[0] = 0;      // the fused backward launch of this epoch (k_gbd) counts its gradient blocks from zero
     const float* h2cur = par ? W.h2[1] : W.h2[0];
     const float* Pc = par ? W.P1 : W.P;
     __shared__ float outs[12];
@@ -722,18 +725,21 @@ __device__ __forceinline__ TrainState advance_state(const TrainState& S, float l
 }
 
 constexpr int GC_QMAX = 3;             // hidden units per thread of k_gradc's last phase: H2 <= 768 = 3 x 256
-__global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx, int nby, size_t bstride) {
-    const Ws W = ws_shift(W0, blockIdx.z * bstride);
+// FUSED (the gradient role of k_gbd, 256 live threads of a 512-thread workgroup): what the other roles of the SAME launch consume --
+// g_out, g_h2, the three scalars of the advanced state -- goes out as 16-byte write-through (sc1) stores, and every block, also one
+// that leaves early (a stopped train), drains its stores and counts itself in W.sync[0] on its way out.
+__device__ __forceinline__ void gradc_arrive(const Ws& W) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's write-through stores have been acknowledged ...
+    __syncthreads();                                       // ... every thread's
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(W.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool FUSED>
+__device__ __forceinline__ void gradc_role(const Dims& D, const Ws& W, int epoch, int nbx, int nby, int k) {
     __shared__ float red[4][14];
     __shared__ float s_loss;
     __shared__ float s_go[16];
-    // every kernel argument in the entry block, one wait (see k_bd)
-    asm volatile("" :: "s"(W0.P), "s"(W0.P1), "s"(W0.h2[0]), "s"(W0.h2[1]), "s"(W0.head_save), "s"(W0.m2), "s"(W0.gm2), "s"(W0.pts4), "s"(W0.pred4),
-                 "s"(W0.sgn_x), "s"(W0.cnt4), "s"(W0.lossp_x), "s"(W0.lossp_y), "s"(W0.g_out), "s"(W0.g_h2), "s"(W0.state), "s"(W0.bc1), "s"(W0.bc2s),
-                 "s"(W0.best_m), "s"(W0.best_pred), "s"(W0.loss_hist), "s"(W0.lr_hist), "s"(W0.result), "s"(W0.off), "s"(W0.hyper),
-                 "s"(D.rot), "s"(D.K), "s"(D.H2), "s"(D.HA), "s"(D.HB), "s"(D.OA), "s"(D.OB), "s"(D.NP), "s"(D.NT), "s"(D.epochs), "s"(D.slope),
-                 "s"(D.oW3A), "s"(D.oW3B), "s"(epoch), "s"(nbx), "s"(nby), "s"(bstride));
-    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float s_gh[FUSED ? 256 * GC_QMAX : 4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // ONE round trip for everything that does not depend on another load: the state (with the bias corrections of the
     // coming step), the cluster bounds, the hyper-parameters, the NN launch's loss partials, the pose row, and the
     // operands of the last phase (this thread's hidden units of pose row k and their output-layer weights) -- round 2
@@ -768,7 +774,11 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
         asm volatile("" :: "v"(h2v[q]), "v"(w3v[q][0]), "v"(w3v[q][1]), "v"(w3v[q][2]), "v"(w3v[q][3]), "v"(w3v[q][4]), "v"(w3v[q][5]), "v"(w3v[q][6]),
                      "v"(w3v[q][7]));
     if (S.stopped) {
-        if (k == 0 && tid == 0) W.state[(epoch + 1) & 1] = S;
+        if (k == 0 && tid == 0) {
+            W.state[(epoch + 1) & 1] = S;
+            if constexpr (FUSED) st4_wt((float*)W.sync, 32, make_float4(__int_as_float(1), 0.f, 0.f, 0.f));
+        }
+        if constexpr (FUSED) gradc_arrive(W);
         return;
     }
     // second round trip: this thread's first point of the cluster (the loss reduction runs in its shadow)
@@ -806,8 +816,12 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
         W.loss_hist[S.epochs_run] = loss;
         W.lr_hist[S.epochs_run] = (float)S.lr;
         W.result[0] = N.min_loss; W.result[1] = (float)N.epochs_run; W.result[2] = (float)N.lr; W.result[3] = (float)N.best_epoch;
+        if constexpr (FUSED) st4_wt((float*)W.sync, 32, make_float4(__int_as_float(N.stopped), N.step_size, N.bc2_sqrt, 0.f));
     }
-    if (N.stopped) return;                              // the reference breaks before backward()
+    if (N.stopped) {                                    // the reference breaks before backward()
+        if constexpr (FUSED) gradc_arrive(W);
+        return;
+    }
     // ---- per-cluster reduction of the point gradients
     const float gx = 1.0f / (float)D.NP, gy = 1.0f / (float)D.NT;
     float acc[12];
@@ -864,7 +878,12 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
             dq_to_se3_vjp(sv, G, gt, gdq);
             for (int i = 0; i < 8; ++i) go[4 + i] = gdq[i];
         }
-        for (int i = 0; i < 12; ++i) { W.g_out[16 * k + i] = go[i]; s_go[i] = go[i]; }
+        if constexpr (FUSED) {
+            for (int i = 0; i < 12; ++i) s_go[i] = go[i];
+            for (int i = 0; i < 3; ++i) st4_wt(W.g_out, 16 * k + 4 * i, make_float4(go[4 * i], go[4 * i + 1], go[4 * i + 2], go[4 * i + 3]));
+        } else {
+            for (int i = 0; i < 12; ++i) { W.g_out[16 * k + i] = go[i]; s_go[i] = go[i]; }
+        }
     }
     __syncthreads();
     // ---- pose row k of dL/d(hidden pre-activation): g_h2[k][o] = act'(h2[k][o]) * sum_j g_out[k][j] W3[j][o]
@@ -878,10 +897,29 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
             float sum = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) if (j < nj) sum = fmaf(s_go[gofs + j], w3v[q][j], sum);
-            W.g_h2[(size_t)k * D.H2 + o] = sum * act_grad(h2v[q], D.slope);
+            const float gh = sum * act_grad(h2v[q], D.slope);
+            if constexpr (FUSED) s_gh[o] = gh;           // the row leaves as 16-byte write-through stores below
+            else W.g_h2[(size_t)k * D.H2 + o] = gh;
         }
     }
+    if constexpr (FUSED) {
+        __syncthreads();
+        if (4 * tid < D.H2) st4_wt(W.g_h2, k * D.H2 + 4 * tid, *(const float4*)(s_gh + 4 * tid));
+        gradc_arrive(W);
+    }
 }
+
+__global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx, int nby, size_t bstride) {
+    // every kernel argument in the entry block, one wait (see k_bd)
+    asm volatile("" :: "s"(W0.P), "s"(W0.P1), "s"(W0.h2[0]), "s"(W0.h2[1]), "s"(W0.head_save), "s"(W0.m2), "s"(W0.gm2), "s"(W0.pts4), "s"(W0.pred4),
+                 "s"(W0.sgn_x), "s"(W0.cnt4), "s"(W0.lossp_x), "s"(W0.lossp_y), "s"(W0.g_out), "s"(W0.g_h2), "s"(W0.state), "s"(W0.bc1), "s"(W0.bc2s),
+                 "s"(W0.best_m), "s"(W0.best_pred), "s"(W0.loss_hist), "s"(W0.lr_hist), "s"(W0.result), "s"(W0.off), "s"(W0.hyper),
+                 "s"(D.rot), "s"(D.K), "s"(D.H2), "s"(D.HA), "s"(D.HB), "s"(D.OA), "s"(D.OB), "s"(D.NP), "s"(D.NT), "s"(D.epochs), "s"(D.slope),
+                 "s"(D.oW3A), "s"(D.oW3B), "s"(epoch), "s"(nbx), "s"(nby), "s"(bstride));
+    const Ws W = ws_shift(W0, blockIdx.z * bstride);
+    gradc_role<false>(D, W, epoch, nbx, nby, blockIdx.x);
+}
+
 
 // ------------------------------------------------------------------------------------------ Adam
 __device__ __forceinline__ float adam_value(float p, float& mm, float& vv, float g, float step_size, float bc2_sqrt) {
@@ -967,7 +1005,33 @@ __device__ __forceinline__ float row_sum16(float v) {
 // first FMA): every load is in flight at once and the MFMAs start on the first operands that land.  The per-wave partial tiles are
 // summed over the waves in wave order through LDS as before.  Then, unchanged: activation gradient, the 16 encoder rows' weight
 // gradients + Adam, and the NEXT epoch's encoder activation of the block's 16 units from the registers that hold the updated rows.
-template <int KW, bool X>              // W2 rows per wave: H2 = 8 KW; X: more than 64 input features ('6d': 72) -- lanes i4 < 2 of a row take a second float4
+// ---- fused backward launch (k_gbd): the consumers' side of the hand-off ----------------------------------------------------------
+// A consumer role first requests everything that does NOT depend on this epoch's gradients -- its parameter rows and Adam moments,
+// its slab of W2, the activations: 96-110 KB per workgroup, the part of k_bd that a CU's ~11 B/cycle intake makes slow -- then waits
+// here until the K blocks of the gradient role have counted themselves in, and only then asks for the gradients and the three
+// scalars of the advanced state (sc1 loads: the producers wrote them through with sc1 stores and nothing of this launch has touched
+// those lines before, MI355X_MICROARCH.md "valid forms").  One polling lane per workgroup; the poll is bounded (a few hundred
+// milliseconds): a launch whose producers never arrive -- which cannot happen while workgroups are dispatched in index order, the
+// gradient role owning the lowest indices -- ends as a stopped train instead of hanging the queue.
+struct GbdRecord { int stopped; float step_size, bc2_sqrt; };
+__device__ __forceinline__ bool gbd_wait(const Ws& W, int K) {
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        int it = 0, seen = __hip_atomic_load(W.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (seen < K && ++it < (1 << 19)) { __builtin_amdgcn_s_sleep(16); seen = __hip_atomic_load(W.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        s_ok = seen >= K;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+__device__ __forceinline__ GbdRecord gbd_record(const Ws& W, bool ok) {
+    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(buf_rsrc(W.sync, 64 * 4), 32 * 4, 0, 16);      // sc1
+    GbdRecord r;
+    r.stopped = ok ? (int)v[0] : 1; r.step_size = __uint_as_float(v[1]); r.bc2_sqrt = __uint_as_float(v[2]);
+    return r;
+}
+
+template <int KW, bool X, bool FUSED = false>              // W2 rows per wave: H2 = 8 KW; X: more than 64 input features ('6d': 72) -- lanes i4 < 2 of a row take a second float4
 __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch, int blk, float* sh, unsigned long long bd_entry) {
     constexpr int NS = KW / 4;                 // k-steps of a wave
     constexpr bool V4 = KW % 16 == 0;          // A operand as 16-byte loads
@@ -1001,18 +1065,32 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
                                                  (__attribute__((address_space(3))) void*)(dst + i * B2_CB), 16, 0, 0);
     }
     const float* gbase = W.g_h2 + wv * KW + (V4 ? 4 * kk : kk);        // + row * H2 (+ 16 g | 4 s)
+    const __amdgpu_buffer_rsrc_t rGH = buf_rsrc(W.g_h2, D.KP * D.H2 * 4);
     auto load_a = [&](int row, float* dst) {                           // one tile's A operands of this lane: pose row `row` (clamped)
-        const float* g = gbase + (size_t)min(row, D.K - 1) * D.H2;
+        if constexpr (FUSED) {                                         // written by the gradient role of THIS launch: sc1 loads
+            const int off = (min(row, D.K - 1) * D.H2 + wv * KW + (V4 ? 4 * kk : kk)) * 4;
 #pragma unroll
-        for (int q = 0; q < NA; ++q) {
-            if constexpr (V4) { const float4 v = *(const float4*)(g + 16 * q); dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w; }
-            else dst[q] = g[4 * q];
+            for (int q = 0; q < NA; ++q) {
+                if constexpr (V4) {
+                    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rGH, off + 64 * q, 0, 16);
+                    dst[4 * q] = __uint_as_float(v[0]); dst[4 * q + 1] = __uint_as_float(v[1]); dst[4 * q + 2] = __uint_as_float(v[2]); dst[4 * q + 3] = __uint_as_float(v[3]);
+                } else dst[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rGH, off + 16 * q, 0, 16));
+            }
+        } else {
+            const float* g = gbase + (size_t)min(row, D.K - 1) * D.H2;
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                if constexpr (V4) { const float4 v = *(const float4*)(g + 16 * q); dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w; }
+                else dst[q] = g[4 * q];
+            }
         }
     };
     float a0[NS], a1[NS];
-    load_a(lj, a0);
     const bool two0 = D.K > 16;                        // workgroup-uniform
-    if (two0) load_a(16 + lj, a1);
+    if constexpr (!FUSED) {
+        load_a(lj, a0);
+        if (two0) load_a(16 + lj, a1);
+    }
     // encoder rows: thread = (half, row of the block, float4 of its IN inputs); both halves hold the row (same operands,
     // same Adam result) and share the pose rows of the next-activation loop
     const int half = tid >> 8, t2 = tid & 255, row = t2 >> 4, i4 = t2 & 15, hu = c0 + row;
@@ -1042,7 +1120,17 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
     __builtin_amdgcn_sched_barrier(0);                 // the loads above stay above
     // the state is requested LAST: hipcc makes `stopped` wave-uniform (v_readfirstlane) the moment it can, i.e. it waits for this load
     // right where it is issued -- at the top of the role that put a whole memory round trip in front of every other request
-    const TrainState S = W.state[(epoch + 1) & 1];
+    GbdRecord S;
+    if constexpr (FUSED) {
+        const bool ok = gbd_wait(W, D.K);              // everything above is in flight or has landed; now the gradients exist
+        load_a(lj, a0);
+        if (two0) load_a(16 + lj, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        S = gbd_record(W, ok);
+    } else {
+        const TrainState St = W.state[(epoch + 1) & 1];
+        S.stopped = St.stopped; S.step_size = St.step_size; S.bc2_sqrt = St.bc2_sqrt;
+    }
     const bool live = !S.stopped;
     __builtin_amdgcn_sched_barrier(0);
     BD_T                                               // B1: everything requested
@@ -1162,6 +1250,7 @@ constexpr int DW_TILES = 4;           // 16-input tiles per wave: 8 waves x 64 i
 constexpr int DW_KC = 5;              // k-steps (4 pose rows each) per chunk of operand loads: K = 20 is one chunk
 __host__ __device__ inline int dw_blocks(const Dims& D) { return D.H2 / DW_UNITS + 2; }
 
+template <bool FUSED = false>
 __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, int blk, unsigned long long bd_entry) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lj = lane & 15, q = lane >> 4;
     __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): see bwd2_role
@@ -1180,7 +1269,11 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
     if (blk < nb2) { u0 = blk * DW_UNITS; nu = DW_UNITS; n_in = D.H; oW = D.oW2 + u0 * D.H; ob = D.ob2 + u0; amat = x1cur; astride = D.H; gmat = W.g_h2 + u0; gstride = D.H2; }
     else if (blk == nb2) { u0 = 0; nu = D.OA; n_in = D.HA; oW = D.oW3A; ob = D.ob3A; amat = h2cur; astride = D.H2; gmat = W.g_out; gstride = 16; }
     else { u0 = 0; nu = D.OB; n_in = D.HB; oW = D.oW3B; ob = D.ob3B; amat = h2cur + D.HA; astride = D.H2; gmat = W.g_out + 4; gstride = 16; }
-    if (nu == 0 || 64 * wv >= n_in) return;         // no decoder_1 ('dq'), or a wave past the row's width (wave-uniform)
+    if (nu == 0) return;                            // no decoder_1 ('dq'): block-uniform
+    if (64 * wv >= n_in) {                          // a wave past the row's width (wave-uniform)
+        if constexpr (FUSED) (void)gbd_wait(W, D.K);        // (it still owes the workgroup's barrier inside the wait)
+        return;
+    }
     BD_T0
     const int unit = min(lj, nu - 1);               // lanes past the live units mirror the last one and store nothing
     const bool ulive = lj < nu;
@@ -1214,12 +1307,21 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
     const int aoff = (q * astride + i0 + 16 * (lj & 3) + 4 * (lj >> 2)) * 4, goff = (q * gstride + unit) * 4;
     float bop[DW_KC];
     float4 aop[DW_KC];
+    auto load_b = [&](int s0) {                     // the gradients (FUSED: written by the gradient role of THIS launch -- sc1 loads)
+#pragma unroll
+        for (int s = 0; s < DW_KC; ++s)
+            bop[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rG, goff, 4 * (s0 + s) * gstride * 4, FUSED ? 16 : 0));
+    };
+    auto load_a = [&](int s0) {                     // the activations
+#pragma unroll
+        for (int s = 0; s < DW_KC; ++s) aop[s] = ld_buf4(rA, aoff, 4 * (s0 + s) * astride * 4);   // (inputs past the row's width read the next row or 0: their gradients are not used)
+    };
     auto load_ops = [&](int s0) {
 #pragma unroll
         for (int s = 0; s < DW_KC; ++s) {
             const int r4 = 4 * (s0 + s);             // scalar: rows r4 + q
-            bop[s] = ld_buf(rG, goff, r4 * gstride * 4);
-            aop[s] = ld_buf4(rA, aoff, r4 * astride * 4);             // (inputs past the row's width read the next row or 0: their gradients are not used)
+            bop[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rG, goff, r4 * gstride * 4, FUSED ? 16 : 0));
+            aop[s] = ld_buf4(rA, aoff, r4 * astride * 4);
         }
     };
     auto mfma_ops = [&]() {
@@ -1233,9 +1335,13 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
 #pragma unroll
         for (int s = 0; s < DW_KC; ++s) gb += bop[s];
     };
-    load_ops(0);
+    GbdRecord S;
+    if constexpr (FUSED) load_a(0); else load_ops(0);
     __builtin_amdgcn_sched_barrier(0);              // (the scheduler otherwise interleaves requests with the MFMAs and their waits)
-    const TrainState S = W.state[(epoch + 1) & 1];
+    if constexpr (!FUSED) {
+        const TrainState St = W.state[(epoch + 1) & 1];
+        S.stopped = St.stopped; S.step_size = St.step_size; S.bc2_sqrt = St.bc2_sqrt;
+    }
     float pb = Pc[ob + unit], mb = W.AM[ob + unit], vb = W.AV[ob + unit];
     __builtin_amdgcn_sched_barrier(0);
     float4 pw[DW_TILES], pm[DW_TILES], pv[DW_TILES];
@@ -1244,6 +1350,13 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
     for (int v = 0; v < DW_TILES; ++v) {
         vl[v] = ulive && i0 + 16 * v + 4 * q < n_in;                 // (HA = 32 at hidden 64: half a wave's inputs exist)
         pw[v] = ld_buf4(rP, po + 64 * v, 0); pm[v] = ld_buf4(rM, po + 64 * v, 0); pv[v] = ld_buf4(rV, po + 64 * v, 0);      // (past the arrays: 0)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (FUSED) {
+        const bool ok = gbd_wait(W, D.K);           // the parameter rows and the activations are here; now the gradients exist
+        load_b(0);
+        __builtin_amdgcn_sched_barrier(0);
+        S = gbd_record(W, ok);
         __builtin_amdgcn_sched_barrier(0);
     }
     BD_T                                            // D1: everything requested
@@ -1310,7 +1423,42 @@ __global__ __launch_bounds__(BD_THREADS, 4) void k_bd(Dims D, Ws W0, int epoch, 
     if ((CREG_BD_ONLY == 1) != roleB) return;
 #endif
     if (roleB) bwd2_role<KW, X>(D, W, epoch, blk, (float*)smem, bd_entry);
-    else dw_role(D, W, epoch, blk, bd_entry);
+    else dw_role<false>(D, W, epoch, blk, bd_entry);
+}
+
+// ------------------------------------------------------------------------------------------ the fused backward launch: k_gbd (round 5)
+// k_gradc and k_bd as ONE launch: grid.x = (K + H / 16 + H2 / 16 + 2) * problems, the gradient role's blocks first.  What the
+// boundary between the two launches serialised is not the arithmetic but the INTAKE: a B block pulls 110 KB and a D block 96 KB
+// through a CU that takes ~11 bytes per cycle, and all but the few KB of gradients of it -- parameter rows, Adam moments, W2 slab,
+// activations -- is known before k_gradc has started.  Here the consumers request all of that at once, then wait for the K gradient
+// blocks (gbd_wait), then fetch the gradients.  One hand-off (gradient role -> {B, D} side by side), write-through stores on one side,
+// sc1 loads on the other, no fence; bit-identical to the two launches (same arithmetic in the same order).
+template <int NC, int KW, bool X = false>
+__global__ __launch_bounds__(BD_THREADS, 4) void k_gbd(Dims D, Ws W0, int epoch, int nbx, int nby, size_t bstride, int nz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    asm volatile("" :: "s"(W0.P), "s"(W0.P1), "s"(W0.AM), "s"(W0.AV), "s"(W0.enc), "s"(W0.x1[0]), "s"(W0.x1[1]), "s"(W0.h2[0]), "s"(W0.h2[1]),
+                 "s"(W0.g_out), "s"(W0.g_h2), "s"(W0.state), "s"(W0.sync), "s"(D.K), "s"(D.KP), "s"(D.IN), "s"(D.H), "s"(D.H2), "s"(D.HA), "s"(D.HB), "s"(D.OA),
+                 "s"(D.OB), "s"(D.oW1), "s"(D.ob1), "s"(D.oW2), "s"(D.ob2), "s"(D.oW3A), "s"(D.ob3A), "s"(D.oW3B), "s"(D.ob3B), "s"(D.NPAR),
+                 "s"(D.slope), "s"(epoch), "s"(bstride), "s"(nz));
+    asm volatile("" :: "s"(W0.head_save), "s"(W0.m2), "s"(W0.gm2), "s"(W0.pts4), "s"(W0.pred4), "s"(W0.sgn_x), "s"(W0.cnt4), "s"(W0.lossp_x), "s"(W0.lossp_y),
+                 "s"(W0.bc1), "s"(W0.bc2s), "s"(W0.best_m), "s"(W0.best_pred), "s"(W0.loss_hist), "s"(W0.lr_hist), "s"(W0.result), "s"(W0.off), "s"(W0.hyper),
+                 "s"(D.rot), "s"(D.NP), "s"(D.NT), "s"(D.epochs), "s"(nbx), "s"(nby));
+    const int nG = D.K, nB = D.H / B2_CB, nD = dw_blocks(D);
+    int i = blockIdx.x;
+    if (i < nG * nz) {
+        if (threadIdx.x >= 256) return;             // the gradient role is a 256-thread role
+        const int z = i / nG;
+        const Ws W = ws_shift(W0, (size_t)z * bstride);
+        gradc_role<true>(D, W, epoch, nbx, nby, i - z * nG);
+        return;
+    }
+    i -= nG * nz;
+    const bool roleB = i < nB * nz;
+    if (!roleB) i -= nB * nz;
+    const int n = roleB ? nB : nD, z = i / n, blk = i - z * n;
+    const Ws W = ws_shift(W0, (size_t)z * bstride);
+    if (roleB) bwd2_role<KW, X, true>(D, W, epoch, blk, (float*)smem, 0ull);
+    else dw_role<true>(D, W, epoch, blk, 0ull);
 }
 
 // after the last epoch: the parameters of an odd number of optimizer steps sit in the second buffer; the copy-out reads the first
@@ -1334,6 +1482,7 @@ struct Plan {
     int nz;                   // problems per launch right now (grid.z): B for run, 1 for probe / profile
     size_t bstride;           // bytes between consecutive problems' workspaces
     int smem_bd;
+    bool fused;               // gradient reduction + backward as ONE launch (k_gbd)
     int branches;             // parallel chains in the captured graph (groups of problems)
     // chain-stream mode (creg_train_shape.graph_branches < 0): every chain is its OWN linear graph on its OWN stream, forked from /
     // joined to the caller's stream once per train by events -- the chains' hardware queues are then the streams', not what the
@@ -1412,6 +1561,7 @@ static size_t carve(const Dims& D, char* base, Ws* W) {
     w.best_m = (float*)take(f * 16 * D.K); w.best_pred = (float*)take(f * 3 * D.NP);
     w.loss_hist = (float*)take(f * D.epochs); w.lr_hist = (float*)take(f * D.epochs); w.result = (float*)take(f * 4);
     w.off = (int*)take(sizeof(int) * (D.K + 1)); w.hyper = (Hyper*)take(sizeof(Hyper));
+    w.sync = (int*)take(sizeof(int) * 64);
     if (W) *W = w;
     return o;
 }
@@ -1451,6 +1601,20 @@ static void launch_bd(Plan* P, int epoch, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
     const int per = D.H / B2_CB + dw_blocks(D);
     by_bd(D, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(per * P->nz), dim3(BD_THREADS), P->smem_bd, s, D, W, epoch, P->bstride, P->nz); });
+}
+template <typename F>
+static void by_gbd(const Dims& D, F f) {
+    by_nc(D.H, [&](auto nc) {
+        constexpr int NC = decltype(nc)::value;
+        if (D.IN > 64) f(k_gbd<NC, 12 * NC, true>);
+        else if (D.HA) f(k_gbd<NC, 12 * NC>);
+        else f(k_gbd<NC, 8 * NC>);
+    });
+}
+static void launch_gbd(Plan* P, int epoch, hipStream_t s) {
+    const Dims& D = P->D; const Ws& W = P->W;
+    const int per = D.K + D.H / B2_CB + dw_blocks(D);
+    by_gbd(D, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(per * P->nz), dim3(BD_THREADS), P->smem_bd, s, D, W, epoch, D.nbx, D.nby, P->bstride, P->nz); });
 }
 static void launch_nn(const Dims& D, const Ws& W, size_t bstride, int nz, hipStream_t s, int par = 0) {
     const EngineEpi epi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, bstride, &W.state[par].stopped};
@@ -1499,8 +1663,11 @@ static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nu
     mark(0);
     launch_head(P, par, s); mark(1);
     launch_nn(D, W, P->bstride, P->nz, s, par); mark(2);
-    hipLaunchKernelGGL(k_gradc, dim3(D.K, 1, P->nz), dim3(256), 0, s, D, W, epoch, D.nbx, D.nby, P->bstride); mark(3);
-    launch_bd(P, epoch, s); mark(4);
+    if (P->fused) { launch_gbd(P, epoch, s); mark(3); mark(4); }
+    else {
+        hipLaunchKernelGGL(k_gradc, dim3(D.K, 1, P->nz), dim3(256), 0, s, D, W, epoch, D.nbx, D.nby, P->bstride); mark(3);
+        launch_bd(P, epoch, s); mark(4);
+    }
     launch_l2(P, par ^ 1, s); mark(5);        // the next epoch's hidden activation: next encoder activation (B) x updated hidden rows (D)
 }
 
@@ -1815,6 +1982,17 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
         hipError_t e2 = hipSuccess;
         by_bd(D, [&](auto kern) { e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         CREG_REQUIRE(e2 == hipSuccess, "creg_train_plan_create: cannot raise the dynamic LDS limit of k_bd");
+        // the fused launch carries the gradient role's static LDS (4 KB) beside the B role's dynamic block
+        const char* fe = getenv("CREG_FUSED_GBD");
+        // Measured (profiles/r05_fused_gbd_ab.log): bit-identical, and SLOWER -- 174 against 181.5 frames/s at five sequences, 48.5
+        // against 48.8 at one, franka 77.2 against 80.9: what the consumers do AFTER the gradients exist (B: a 61 KB read of g_h2, the
+        // MFMAs, the cross-wave sum, dW1, Adam, the next activation: ~7 us of dependent phases) is the critical path, not the intake
+        // the prefetch hides, and the hand-off costs what the boundary did.  Off unless CREG_FUSED_GBD=1 (kept as a tested experiment).
+        P->fused = (fe ? fe[0] == '1' : false) && P->smem_bd + 4608 <= 160 * 1024;
+        if (P->fused) {
+            by_gbd(D, [&](auto kern) { e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4608); });
+            if (e2 != hipSuccess) { (void)hipGetLastError(); P->fused = false; }
+        }
     }
     // the limit is per kernel, not per plan: always raise it to the largest any plan can ask for (16384 keys + boxes),
     // so that a small plan created later does not lower it under a large one

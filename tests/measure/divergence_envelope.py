@@ -119,6 +119,9 @@ def run_cpu(out_path, shape="c1"):
     over = np.nonzero(allv > 1e-5)[0]
     n_e = int(over[0] - 1) if len(over) else 299
     print("envelope (max over the permuted runs): " + "  ".join(f"e{e} {env[e]:.2g}" for e in CHECK))
+    over_p = np.nonzero(env > 1e-5)[0]
+    n_e_perm = int(over_p[0] - 1) if len(over_p) else 299
+    print(f"N_e (permuted float32 runs only) = {n_e_perm}")
     print(f"N_e = {n_e}: every variant (permuted float32, float64) is within 1e-5 of the float32 oracle up to the pose evaluated at epoch {n_e}")
     # what train() RETURNS: the best loss and the pose that reached it (mlp_reg.py:102-106), variant against the unpermuted float32 run
     b0 = best["base"]
@@ -128,14 +131,14 @@ def run_cpu(out_path, shape="c1"):
           + "  ".join(f"{k} {v:.2g}" for k, v in min_loss_rel.items()))
     print("best-pose difference of the variants: " + "  ".join(f"{k} {v:.2g}" for k, v in best_pose.items()))
     np.savez_compressed(out_path, min_loss_rel_envelope=np.float64(max(min_loss_rel.values())),
-                        best_pose_envelope=np.float64(max(best_pose.values())), envelope=env, f64=curves["f64"], oracle_vs_reference=d_ref, n_e=np.int64(n_e),
+                        best_pose_envelope=np.float64(max(best_pose.values())), envelope=env, f64=curves["f64"], oracle_vs_reference=d_ref, n_e=np.int64(n_e), n_e_perm=np.int64(n_e_perm),
                         **{k: v for k, v in curves.items() if k.startswith("perm")})
     print("wrote", out_path, f"{os.path.getsize(out_path) / 1024:.1f} KB")
 
 
-def gpu_trajectory(epochs_list, use_graph=True):
+def gpu_trajectory(epochs_list, use_graph=True, shape="c1"):
     from autourdf_amd import ops
-    g, sd, m, y, clusters = load_case()
+    g, sd, m, y, clusters = load_case(shape)
     dev = torch.device("cuda:0")
     order = ops.Q_PARAM_ORDER
     mt, yt = torch.from_numpy(m).to(dev), torch.from_numpy(y).to(dev)
@@ -157,11 +160,17 @@ def gpu_trajectory(epochs_list, use_graph=True):
     return out, losses, g
 
 
-def run_gpu(out_path):
-    epochs_list = list(range(0, 31)) + list(range(40, 300, 10)) + [299]
-    traj, losses, g = gpu_trajectory(epochs_list)
-    ref = g["pose_hist"].astype(np.float64)
-    env = np.load(os.path.join(GOLDEN, "divergence_envelope_c1.npz"))
+def run_gpu(out_path, shape="c1"):
+    if shape == "c1":
+        epochs_list = list(range(0, 31)) + list(range(40, 300, 10)) + [299]
+    else:
+        epochs_list = [int(e) for e in np.load(os.path.join(GOLDEN, f"train_reference_{shape}.npz"))["pose_epochs"]]
+    traj, losses, g = gpu_trajectory(epochs_list, shape=shape)
+    if shape == "c1":
+        ref = g["pose_hist"].astype(np.float64)
+    else:
+        ref = {int(e): g["pose_hist_sel"][i].astype(np.float64) for i, e in enumerate(g["pose_epochs"])}
+    env = np.load(os.path.join(GOLDEN, f"divergence_envelope_{shape}.npz"))
     rows = []
     for e in epochs_list:
         d = float(np.abs(traj[e][:, :3, :] - ref[e][:, :3, :]).max())
@@ -184,4 +193,5 @@ if __name__ == "__main__":
         shape = mode.split(":")[1] if ":" in mode else "c1"
         run_cpu(sys.argv[2] if len(sys.argv) > 2 else os.path.join(GOLDEN, f"divergence_envelope_{shape}.npz"), shape)
     else:
-        run_gpu(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "r04_divergence_envelope.json"))
+        shape = mode.split(":")[1] if ":" in mode else "c1"
+        run_gpu(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", f"r05_divergence_envelope_{shape}.json"), shape)

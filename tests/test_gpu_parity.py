@@ -1032,6 +1032,36 @@ def test_train_is_bit_reproducible_and_graph_equals_eager(dev, golden, rot, hidd
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
 
 
+@pytest.mark.parametrize("rot,hidden,lr,stop", [("q", 512, 2e-4, 200), ("dq", 64, 2e-4, 200), ("6d", 128, 2e-4, 200), ("q", 64, 0.2, 3)])
+def test_train_fused_backward_launch_is_bit_identical(dev, golden, rot, hidden, lr, stop, monkeypatch):
+    """CREG_FUSED_GBD=1 (round 5 experiment, off by default because it measured slower: profiles/r05_fused_gbd_ab.log): the gradient
+    reduction and the backward as ONE launch -- the consumers prefetch their parameter rows, wait for the gradient role's blocks inside
+    the launch, then read the gradients with sc1 loads.  Same arithmetic in the same order: every output bit equals the two-launch
+    plan's, eager and captured, also when the train stops early (the gradient blocks of a stopped train still count themselves in)."""
+    from autourdf_amd import ops
+    g, _, _ = _train_case(golden, "q")
+    torch.manual_seed(5)
+    model = _oracle_model(rot, hidden)
+    if lr > 0.1:
+        for p in model.parameters():
+            p.data.mul_(0.2)
+    order = _order(rot)
+    m, y = torch.from_numpy(g["q_m"]).to(dev), torch.from_numpy(g["q_y"]).to(dev)
+    clusters = [torch.from_numpy(c) for c in _split(g["q_local"], g["q_offsets"])]
+    pts, off = ops.pack_clusters(clusters, dev)
+    outs = []
+    for fused, graph in (("0", True), ("1", False), ("1", True)):
+        monkeypatch.setenv("CREG_FUSED_GBD", fused)
+        params = [model.state_dict()[k].clone().to(dev) for k in order]
+        plan = ops.TrainPlan(rot, len(clusters), hidden, pts.shape[0], y.shape[0], epochs=40, use_graph=graph, device=dev)
+        bm, bp, res, lh, lrh = plan.run(m, y, pts, off, params, lr=lr, patience=1 if lr > 0.1 else 5, stop=stop)
+        outs.append((bm.cpu(), lh.cpu(), torch.cat([p.flatten() for p in params]).cpu(), res.cpu(), lrh.cpu()))
+    if lr > 0.1:
+        assert int(outs[0][3][1]) < 40                      # it did stop early
+    for o in outs[1:]:
+        assert all(torch.equal(a, b, ) or (torch.isnan(a) == torch.isnan(b)).all() and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)) for a, b in zip(o, outs[0]))
+
+
 @pytest.mark.parametrize("lr,stop,expect_stop", [(0.2, 3, True), (5e-2, 4, False)])
 def test_train_early_stop_and_scheduler(dev, golden, lr, stop, expect_stop):
     """Large lr: the loss stops improving, ReduceLROnPlateau(patience=1) cuts lr, and with stop=3 the

@@ -7,13 +7,13 @@
 #     tools/run_sanitizer_suite.sh r05
 tag=${1:-r05}
 mkdir -p gpurun_out
-asan_rt=/usr/lib/x86_64-linux-gnu/libasan.so.6
+asan_rt="/usr/lib/x86_64-linux-gnu/libasan.so.6 /usr/lib/x86_64-linux-gnu/libstdc++.so.6"     # (libstdc++ too: the runtime resolves __cxa_throw when it starts, before python has loaded any C++ library)
 ubsan_rt=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.ubsan_standalone-x86_64.so)
 filter() { grep -v "Warning\|warnings.warn\|^$\|amdgpu.ids"; }
 {
   echo "== pytest -m gpu, CREG_LIB_VARIANT=asan, LD_PRELOAD=$asan_rt"
-  CREG_LIB_VARIANT=asan LD_PRELOAD=$asan_rt ASAN_OPTIONS=detect_leaks=0 python -c 'from autourdf_amd import _lib; _lib.load(); print("loaded:", _lib.LIB_PATH)' 2>&1 | filter
-  CREG_LIB_VARIANT=asan LD_PRELOAD=$asan_rt ASAN_OPTIONS=detect_leaks=0 timeout 1800 python -m pytest tests -m gpu -q -x -p no:cacheprovider 2>&1 | filter | tail -40
+  CREG_LIB_VARIANT=asan LD_PRELOAD="$asan_rt" ASAN_OPTIONS=detect_leaks=0 python -c 'from autourdf_amd import _lib; _lib.load(); print("loaded:", _lib.LIB_PATH)' 2>&1 | filter
+  CREG_LIB_VARIANT=asan LD_PRELOAD="$asan_rt" ASAN_OPTIONS=detect_leaks=0 timeout 1800 python -m pytest tests -m gpu -q -x -p no:cacheprovider 2>&1 | filter | tail -40
 } > gpurun_out/${tag}_asan_gpu_suite.log 2>&1
 {
   echo "== pytest -m gpu, CREG_LIB_VARIANT=ubsan, LD_PRELOAD=$ubsan_rt"
