@@ -63,14 +63,14 @@ VARIANT_LINK = {"asan": ["-Wl,--allow-shlib-undefined"],                  # the 
 def build_lib(force: bool = False, verbose: bool = False, variant: str = "") -> str:
     OBJ = os.path.join(CSRC, "_obj" + ("_" + variant if variant else ""))
     LIB = os.path.join(HERE, "libcreg" + ("_" + variant if variant else "") + ".so")
-    if variant not in ("", "asan", "ubsan"):
-        raise ValueError(f"unknown build variant {variant!r}")
+    # any other variant name: an A/B build of the same sources with CREG_EXTRA_FLAGS, loaded with CREG_LIB_VARIANT=<name> (both builds
+    # travel in one snapshot, so one gpurun call alternates them on one box)
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "creg.h"))
     hipcc = _hipcc()
     extra = os.environ.get("CREG_EXTRA_FLAGS", "").split()      # e.g. -DCREG_BACK_STAMPS for tools/back_stamps.py
-    if variant:
+    if variant in VARIANT_FLAGS:
         extra = extra + VARIANT_FLAGS[variant]
     objs, procs = [], []
     for src in SOURCES:
@@ -89,10 +89,11 @@ def build_lib(force: bool = False, verbose: bool = False, variant: str = "") -> 
         if verbose and out:
             print(out.decode())
     if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + (VARIANT_LINK[variant] if variant else []) + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + VARIANT_LINK.get(variant, []) + objs
         subprocess.check_call(cmd)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True, variant="asan" if "--asan" in sys.argv else ("ubsan" if "--ubsan" in sys.argv else "")))
+    print(build_lib(force="--force" in sys.argv, verbose=True, variant="asan" if "--asan" in sys.argv else ("ubsan" if "--ubsan" in sys.argv else
+                                                                   (sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""))))

@@ -842,6 +842,7 @@ __global__ __launch_bounds__(ICP_NT) void k_masked_icp(IcpBatch P, int nf, float
 typedef float nn_f2 __attribute__((ext_vector_type(2)));          // (v_pk_* float32 pairs: the screen of k_icp_nn)
 struct IcpLarge {                          // per problem
     const double* local; const float* world; const int* off; const int* woff; const double* frame; const double* Min;
+    const int* toff;                           // point-to-point mode: cluster c's targets are frame[toff[c] .. toff[c + 1]), no mask; null = masked mode
     double* Mout; double* world_out; int* n_iter_out;
     double* srcw; int* tidx; int* tcount; float* box; int* nn; double* part; double* state; int* running;
     int* chunk0;                               // [k + 1] first source chunk of every cluster (k_icp_nn's block -> cluster map)
@@ -887,7 +888,11 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = P.off[k], e = P.off[k + 1];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    if (!from_pose) {
+    const int* toff = P.toff;                  // block-uniform
+    if (toff) {                                // point-to-point mode: no mask; the cells need the extent of the cluster's own target segment
+        for (int j = toff[k] + tid; j < toff[k + 1]; j += 1024)           // (any box is correct: the binning clamps and is monotone)
+            for (int d = 0; d < 3; ++d) { const float v = (float)P.frame[3 * (size_t)j + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
+    } else if (!from_pose) {
         const int* woff = P.woff ? P.woff : P.off;
         for (int i = woff[k] + tid; i < woff[k + 1]; i += 1024)
             for (int d = 0; d < 3; ++d) { const float v = P.world[3 * (size_t)i + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
@@ -914,7 +919,7 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
         float l = wl[0][d], h = wh[0][d];
         for (int w = 1; w < 16; ++w) { l = fminf(l, wl[w][d]); h = fmaxf(h, wh[w][d]); }
         const float c = (l + h) / 2.0f, sz = h - l;
-        s_lo[d] = c - half_scale * sz; s_hi[d] = c + half_scale * sz;
+        s_lo[d] = toff ? l : c - half_scale * sz; s_hi[d] = toff ? h : c + half_scale * sz;
         if (P.box) { P.box[6 * k + d] = s_lo[d]; P.box[6 * k + 3 + d] = s_hi[d]; }
     }
     __syncthreads();
@@ -931,12 +936,12 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
         const int gd = icp_grid_dim(e - b), ncell = gd * gd;
         const double x0a = (double)s_lo[axa], inv_a = ext[axa] > 0.f && ext[axa] < INFINITY ? (double)gd / (double)ext[axa] : 0.0;
         const double x0b = (double)s_lo[axb], inv_b = ext[axb] > 0.f && ext[axb] < INFINITY ? (double)gd / (double)ext[axb] : 0.0;
-        const int nfe = e > b ? nf : 0;
+        const int j0 = toff ? toff[k] : 0, nfe = e > b ? (toff ? toff[k + 1] : nf) : j0;
         __shared__ int wsum[16];
         for (int pass = 0; pass < 2; ++pass) {
-            for (int j = tid; j < nfe; j += 1024) {
+            for (int j = j0 + tid; j < nfe; j += 1024) {
                 const double p[3] = {P.frame[3 * (size_t)j], P.frame[3 * (size_t)j + 1], P.frame[3 * (size_t)j + 2]};
-                if (p[0] > blo0 && p[0] < bhi0 && p[1] > blo1 && p[1] < bhi1 && p[2] > blo2 && p[2] < bhi2) {
+                if (toff || (p[0] > blo0 && p[0] < bhi0 && p[1] > blo1 && p[1] < bhi1 && p[2] > blo2 && p[2] < bhi2)) {
                     const double ca = axa == 0 ? p[0] : (axa == 1 ? p[1] : p[2]), cb = axb == 0 ? p[0] : (axb == 1 ? p[1] : p[2]);
                     const int cell = icp_bin(ca, x0a, inv_a, gd) * gd + icp_bin(cb, x0b, inv_b, gd);
                     if (pass == 0) atomicAdd(&cnt[cell], 1);
@@ -1270,7 +1275,10 @@ __device__ void icp_fit_cluster(const IcpLarge& P, int k, int max_iter, int lane
 // rectangle [4] cluster [5] launch grid
 __device__ unsigned long long g_icp_blk[6][8192];
 #endif
-__global__ __launch_bounds__(64 * ICP_NNW, 3) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2, int max_iter) {
+#ifndef ICP_NN_WPS
+#define ICP_NN_WPS 3                       // minimum waves per SIMD the register allocation of k_icp_nn is held to
+#endif
+__global__ __launch_bounds__(64 * ICP_NNW, ICP_NN_WPS) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2, int max_iter) {
     constexpr int SB = ICP_SB, SR = ICP_SB + 2;                       // staged targets per lane group and batch; slice stride
                                                                       // (+2: the four groups' equal slots fall into different LDS banks)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1793,10 +1801,7 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
     P.chunk0 = (int*)(ws + L.chunk0); P.tst = (int*)(ws + L.tst); P.chunk_cl = (int*)(ws + L.chunk_cl); P.prevt = (double*)(ws + L.prevt);
     P.tcx = (double*)(ws + L.tcx); P.tcy = (double*)(ws + L.tcy); P.tcz = (double*)(ws + L.tcz); P.tbase = (int*)(ws + L.tbase); P.arrive = (int*)(ws + L.arrive); P.live = (int*)(ws + L.live); P.use_live = 0; P.pool_cap = L.pool_cap;
     P.tcf = (float4*)(ws + L.tcf); P.tlmax = (unsigned*)(ws + L.tlmax);
-    if (q.tgt_offsets) {
-        set_error("creg_masked_icp: point-to-point mode (tgt_offsets) is not available in the large-cluster regime");
-        return CREG_EINVAL;
-    }
+    P.toff = q.tgt_offsets;                          // point-to-point mode (round 5): the cluster's own target segment, no mask
     const int nn_smem = ICP_NNW * ICP_G * (ICP_SB + 2) * 40;  // k_icp_nn: per wave 4 lane groups x ICP_SB (+2: bank offset) staged targets (x, y, z fp64, frame index, x, y, z float32)
     { static int scr = -1; if (scr < 0) { const char* e = getenv("CREG_ICP_SCREEN"); scr = e ? atoi(e) != 0 : 1; } P.screen = scr; }
     CREG_HIP(hipFuncSetAttribute((const void*)k_icp_nn, hipFuncAttributeMaxDynamicSharedMemorySize, nn_smem));
@@ -1860,7 +1865,10 @@ static int icp_launch(const creg_icp_problem* pr, int batch, int64_t n, int32_t 
     const size_t one = icp_ws_one(n, nf, k);
     CREG_REQUIRE(workspace_bytes >= one * (size_t)batch, "%s: workspace too small (%zu < %zu)", who, workspace_bytes,
                  one * (size_t)batch);
-    if (icp_large_regime(n, nf, k) && !pr[0].tgt_offsets) {
+    // (CREG_ICP_P2P_ONE_WORKGROUP=1: point-to-point problems stay in the one-workgroup kernel whatever their size, as before round 5 --
+    //  a measurement knob for tests/measure/bench_icp_p2p_regimes.py)
+    const char* p2p_small = getenv("CREG_ICP_P2P_ONE_WORKGROUP");
+    if (icp_large_regime(n, nf, k) && !(pr[0].tgt_offsets && p2p_small && p2p_small[0] == '1')) {
         // clusters / frames beyond what one CU's LDS holds: many workgroups per iteration instead of one per cluster
         for (int i = 0; i < batch; ++i) {
             const creg_icp_problem& q = pr[i];
@@ -1912,7 +1920,7 @@ extern "C" int creg_aabb_mask_f64(const float* world, const int32_t* world_offse
     CREG_REQUIRE(world && world_offsets && frame && mask_idx && mask_count && k >= 1 && nf >= 1 && nf < (1ll << 31),
                  "creg_aabb_mask_f64: bad argument");
     IcpLarge P{};
-    P.world = world; P.off = world_offsets; P.woff = world_offsets; P.frame = frame;
+    P.world = world; P.off = world_offsets; P.woff = world_offsets; P.frame = frame; P.toff = nullptr;
     P.tidx = mask_idx; P.tcount = mask_count; P.box = boxes;
     hipLaunchKernelGGL(k_icp_mask, dim3(k), dim3(1024), 0, (hipStream_t)stream, P, (int)nf, (float)(0.5 * scale), 0, 0);
     CREG_LAUNCH_CHECK();

@@ -1380,22 +1380,42 @@ __global__ __launch_bounds__(1024) void k_km_small(KmBatch A, int n, int k, int 
 static size_t kms_stride(int64_t n, int k) { return align_up(sizeof(double) * (14 * (size_t)k + n), 256); }
 
 // ---- grouping by label + inverse-pose change of frame ------------------------------------------
-__device__ void inv4x4(const double* M, double* I) {      // Gauss-Jordan, partial pivoting
+// Every index is a compile-time constant (round 5): the row exchange of the partial pivoting is a conditional swap of the pivot row
+// with each later row in turn -- as a run-time row index it put the 4 x 8 matrix into scratch memory (272 bytes per lane, 93 scratch
+// instructions in k_group_scatter / k_group_scatter_big).  Same operations in the same order: bit-identical.
+__device__ __forceinline__ void inv4x4(const double* M, double* I) {      // Gauss-Jordan, partial pivoting
     double a[4][8];
-    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { a[r][c] = M[4 * r + c]; a[r][4 + c] = (r == c) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { a[r][c] = M[4 * r + c]; a[r][4 + c] = (r == c) ? 1.0 : 0.0; }
+#pragma unroll
     for (int c = 0; c < 4; ++c) {
-        int p = c;
-        for (int r = c + 1; r < 4; ++r) if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
-        if (p != c) for (int q = 0; q < 8; ++q) { const double t = a[c][q]; a[c][q] = a[p][q]; a[p][q] = t; }
+        int p = c;                                        // first row of the largest |entry| in column c, rows c .. 3
+        double best = fabs(a[c][c]);
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) { const double v = fabs(a[r][c]); if (v > best) { best = v; p = r; } }
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {
+            const bool sw = p == r;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const double t = a[c][q], u = a[r][q]; a[c][q] = sw ? u : t; a[r][q] = sw ? t : u; }
+        }
         const double inv = 1.0 / a[c][c];
+#pragma unroll
         for (int q = 0; q < 8; ++q) a[c][q] *= inv;
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (r == c) continue;
             const double fct = a[r][c];
+#pragma unroll
             for (int q = 0; q < 8; ++q) a[r][q] = fma(-fct, a[c][q], a[r][q]);
         }
     }
-    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) I[4 * r + c] = a[r][4 + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) I[4 * r + c] = a[r][4 + c];
 }
 
 // grid.y = problem of a batch (the per-frame pointers come from the table)

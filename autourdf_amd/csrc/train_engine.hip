@@ -1105,10 +1105,10 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
     if constexpr (X) { pw2 = *(const float4*)(Pc + wi2); pm2 = *(const float4*)(W.AM + wi2); pv2 = *(const float4*)(W.AV + wi2); }
     float pb = Pc[D.ob1 + hu], mb = W.AM[D.ob1 + hu], vb = W.AV[D.ob1 + hu];
     float xv0 = x1cur[(size_t)min(tid >> 4, D.K - 1) * D.H + c0 + (tid & 15)];      // post-activation of this thread's (pose row, column) output of pass 0
-    {   // the features [K][IN] by LDS-DMA, straight-line (K <= 160: at most five 16-byte pieces per thread, six with 72 features) and AFTER the other requests:
+    {   // the features [K][IN] by LDS-DMA, straight-line (at most eight 16-byte pieces per thread: K x IN <= 16384 values; K = 20 needs one) and AFTER the other requests:
         // behind stage_issue's loop hipcc puts a full vmcnt(0) -- in front of everything requested after it
         const int n = D.K * D.IN / 4;
-        constexpr int NPC = X ? 6 : 5;                 // 16-byte pieces per thread: K * IN / 4 <= 512 NPC (K <= 160; IN = 72 needs the sixth)
+        constexpr int NPC = 8;                         // 16-byte pieces per thread: K * IN / 4 <= 512 NPC (round 4: 5 / 6 pieces, K <= 160; a piece past the end costs one branch)
 #pragma unroll
         for (int c = 0; c < NPC; ++c) {
             const int i = c * B2_THREADS + tid;
@@ -1497,7 +1497,7 @@ struct Plan {
 };
 
 static bool make_dims(const creg_train_shape* s, Dims* D) {
-    if (!s || s->rot < 0 || s->rot > 3 || s->k < 1 || s->k > 160 || (s->hidden != 64 && s->hidden != 128 && s->hidden != 256 && s->hidden != 512) || s->epochs < 1 || s->n_pred < 1 || s->n_tgt < 1 || s->n_pred >= (1ll << 31) ||
+    if (!s || s->rot < 0 || s->rot > 3 || s->k < 1 || s->k > 256 || (s->hidden != 64 && s->hidden != 128 && s->hidden != 256 && s->hidden != 512) || s->epochs < 1 || s->n_pred < 1 || s->n_tgt < 1 || s->n_pred >= (1ll << 31) ||
         s->n_tgt >= (1ll << 31))
         return false;
     memset(D, 0, sizeof(*D));
@@ -1507,8 +1507,9 @@ static bool make_dims(const creg_train_shape* s, Dims* D) {
     else if (s->rot == ROT_DQ) { D->IN = 64; D->HA = 0; D->HB = D->H; D->OA = 0; D->OB = 8; D->slope = 0.f; }
     else if (s->rot == ROT_6D) { D->IN = 72; D->HA = D->H / 2; D->HB = D->H; D->OA = 3; D->OB = 6; D->slope = 0.01f; }
     else { D->IN = 48; D->HA = D->H / 2; D->HB = D->H; D->OA = 3; D->OB = 3; D->slope = 0.01f; }
-    if (D->K * D->IN / 4 > (D->IN > 64 ? 6 : 5) * 512) return false;      // k_bd stages the [K][IN] features with five (six: '6d') 16-byte pieces per thread
+    if (D->K * D->IN / 4 > 8 * 512) return false;      // k_bd stages the [K][IN] features with at most eight 16-byte pieces per thread ('6d', 72 features: K <= 227)
     D->H2 = D->HA + D->HB;
+    if (sizeof(float) * b2_smem_floats(D->K, D->IN, D->H2) > 160 * 1024) return false;      // ... in one CU's LDS beside its slab of W2 ('6d' at hidden 512: K <= 193)
     int o = 0;
     D->oW1 = o; o += D->H * D->IN; D->ob1 = o; o += D->H;
     D->oW2 = o; o += D->H2 * D->H; D->ob2 = o; o += D->H2;
@@ -1944,7 +1945,7 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
                                       creg_train_plan** plan) {
     Dims D;
     CREG_REQUIRE(plan && workspace, "creg_train_plan_create: null pointer");
-    CREG_REQUIRE(make_dims(shape, &D), "creg_train_plan_create: unsupported shape (rot in 0..3, hidden in {64, 128, 256, 512}, 1 <= k <= 160, sizes >= 1)");
+    CREG_REQUIRE(make_dims(shape, &D), "creg_train_plan_create: unsupported shape (rot in 0..3, hidden in {64, 128, 256, 512}, 1 <= k <= 256 with the K x IN features + the B role's tiles inside 160 KB of LDS, sizes >= 1)");
     CREG_REQUIRE(((uintptr_t)workspace & 255) == 0, "creg_train_plan_create: workspace must be 256-byte aligned");
     CREG_REQUIRE(shape->batch >= 0 && shape->batch <= 64, "creg_train_plan_create: batch must be in [0, 64]");
     const size_t one = align_up(carve(D, nullptr, nullptr), 256), need = one * batch_of(shape);

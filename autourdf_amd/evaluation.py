@@ -23,8 +23,9 @@ def torch_chamfer_distance(p1, p2):
 
 def icp_filter(pred_pcd, gt_pcd, threshold=0.01, max_iteration=20000):
     """registration_icp(pred, gt, threshold, I, point-to-point) and pred moved by the result.
-    Returns (transformation (4,4) float64, moved PointCloud).  The whole cloud is ONE workgroup's job here
-    (the K4 kernel is built for many small clusters): fine for link-sized clouds, slow beyond ~1e4 points."""
+    Returns (transformation (4,4) float64, moved PointCloud).  Clouds above 1024 source points / 65536 targets run in K4's
+    many-workgroup regime (round 5: point-to-point mode there too -- 64 sources per workgroup, cell grid over the target cloud),
+    smaller ones as one workgroup."""
     dev = _lib.device()
     src = torch.as_tensor(_points(pred_pcd), device=dev)
     tgt = torch.as_tensor(_points(gt_pcd), device=dev)

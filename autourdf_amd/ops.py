@@ -565,7 +565,7 @@ class TrainPlan:
                                      int(graph_branches), int(nn_search))
         need = self.L.creg_train_workspace_bytes(ctypes.byref(self.shape))
         if need == 0:
-            raise ValueError(f"unsupported train shape (rot {rot!r}, k = {k}, hidden {hidden}): the plan takes 1 <= k <= 160 clusters "
+            raise ValueError(f"unsupported train shape (rot {rot!r}, k = {k}, hidden {hidden}): the plan takes 1 <= k <= 256 clusters (fewer for --r 6d at hidden 512: the backward's LDS tiles) "
                              "and hidden widths up to 512 (include/creg.h, creg_train_shape)")
         self.ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
         base = (self.ws.data_ptr() + 255) // 256 * 256

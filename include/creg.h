@@ -314,7 +314,7 @@ int creg_visibility_f64(const double* tri, const int32_t* tri_link, int32_t n_tr
  */
 typedef struct creg_train_shape {
     int32_t rot;          /* 0 'q', 1 'dq', 2 '6d', 3 'rpy' */
-    int32_t k;            /* clusters (poses), <= 160 */
+    int32_t k;            /* clusters (poses), <= 256 (k_bd's LDS tiles: '6d' <= 227, <= 193 at hidden 512) */
     int32_t hidden;       /* hidden_dim in {64, 128, 256, 512} (512 in the reference); any other width <= 512: pass the next of these
                              and the parameters zero-padded to it -- exactly equivalent, see autourdf_amd/ops.py::TrainPlan */
     int32_t epochs;       /* 300 in the reference (mlp_reg.py:60) */

@@ -24,6 +24,8 @@ def lib() -> ctypes.CDLL:
                                   ctypes.c_float, ctypes.c_double)
         L.oracle_nn_l1_f32.argtypes = [vp, i64, vp, i64, vp, vp]
         L.oracle_nn_l1_f32.restype = None
+        L.oracle_nn_l2_f64.argtypes = [vp, i64, vp, i64, vp, vp]
+        L.oracle_nn_l2_f64.restype = None
         L.oracle_nn_l1_bwd_f32.argtypes = [vp, i64, vp, i64, vp, vp, f32, f32, vp, vp]
         L.oracle_nn_l1_bwd_f32.restype = None
         L.oracle_kmeans_assign_f64.argtypes = [vp, i64, vp, i32, vp]

@@ -48,6 +48,26 @@ void oracle_nn_l1_f32(const float* x, int64_t nx, const float* y, int64_t ny,
     }
 }
 
+/* ---------------------------------------------------------------- NN, squared L2, K=1, float64 (open3d registration_icp's search)
+ * d2 = ((dx*dx + dy*dy) + dz*dz): numpy's ((a - b) ** 2).sum(-1) of oracle/icp.py:_correspond, first minimum in target order
+ * (np.argmin).  For pairs too large for the dense (n, m, 3) array of the numpy form (Sim/evaluation.py:358-362 registers whole
+ * robot clouds); tests/test_oracle_golden.py holds the two forms to identical indices and distances. */
+void oracle_nn_l2_f64(const double* x, int64_t nx, const double* y, int64_t ny, double* d2, int64_t* idx) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nx; ++i) {
+        const double a0 = x[3 * i], a1 = x[3 * i + 1], a2 = x[3 * i + 2];
+        double best = INFINITY;
+        int64_t bj = -1;
+        for (int64_t j = 0; j < ny; ++j) {
+            const double e0 = a0 - y[3 * j], e1 = a1 - y[3 * j + 1], e2 = a2 - y[3 * j + 2];
+            const double d = (e0 * e0 + e1 * e1) + e2 * e2;
+            if (d < best || bj < 0) { best = d; bj = j; }
+        }
+        d2[i] = best;
+        idx[i] = bj;
+    }
+}
+
 /* grad wrt x of  sum_i gx*|x_i - y[ix_i]|_1 + sum_j gy*|y_j - x[iy_j]|_1  (pytorch3d sign rule).
  * part_x / part_y are returned separately (autograd adds them afterwards). */
 void oracle_nn_l1_bwd_f32(const float* x, int64_t nx, const float* y, int64_t ny,

@@ -29,12 +29,28 @@ def kabsch(src: np.ndarray, dst: np.ndarray, w: np.ndarray = None) -> np.ndarray
     return T
 
 
+_DENSE_PAIRS = 4_000_000                     # above this many (source, target) pairs the C loop replaces the dense numpy form
+
+
+def _nn_l2_c(src_w: np.ndarray, tgt: np.ndarray):
+    from ._clib import lib
+    a = np.ascontiguousarray(src_w, np.float64)
+    b = np.ascontiguousarray(tgt, np.float64)
+    d2 = np.empty(len(a), np.float64)
+    j = np.empty(len(a), np.int64)
+    lib().oracle_nn_l2_f64(a.ctypes.data, len(a), b.ctypes.data, len(b), d2.ctypes.data, j.ctypes.data)
+    return d2, j
+
+
 def _correspond(src_w: np.ndarray, tgt: np.ndarray, th: float):
     if len(tgt) == 0 or len(src_w) == 0:
         return np.zeros(0, int), np.zeros(0, int), 0.0, 0.0
-    d2 = ((src_w[:, None, :] - tgt[None, :, :]) ** 2).sum(-1)
-    j = d2.argmin(1)
-    dmin = d2[np.arange(len(src_w)), j]
+    if len(src_w) * len(tgt) <= _DENSE_PAIRS:
+        d2 = ((src_w[:, None, :] - tgt[None, :, :]) ** 2).sum(-1)
+        j = d2.argmin(1)
+        dmin = d2[np.arange(len(src_w)), j]
+    else:                                    # the same search without the dense (n, m, 3) array (creg_oracle.c: oracle_nn_l2_f64)
+        dmin, j = _nn_l2_c(src_w, tgt)
     ok = dmin < th * th                      # strict: open3d KDTreeFlann::SearchHybrid keeps d^2 < r^2 (lower_bound on the sorted distances)
     i = np.nonzero(ok)[0]
     n = len(i)

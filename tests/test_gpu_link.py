@@ -124,3 +124,52 @@ def test_icp_inlier_threshold_is_strict_like_open3d_search_hybrid():
     T2_ref, _, _, _ = registration_icp(src, tgt, 0.5 + 1e-9, np.eye(4), 1)
     assert np.abs(T2[0].cpu().numpy() - np.eye(4)).max() > 1e-3
     np.testing.assert_allclose(T2[0].cpu().numpy(), T2_ref, atol=1e-8)
+
+
+def test_icp_point_to_point_in_the_many_workgroup_regime_vs_oracle():
+    """Round 5: point-to-point mode of K4's many-workgroup regime.  Sim/evaluation.py:358-362 registers WHOLE
+    robot clouds; above 1024 sources per pair the search now runs 64 sources per workgroup over a cell grid of the pair's own target
+    segment instead of one workgroup per pair.  (a) a 20000 x 20000 `icp_filter` against the oracle (1e-8: pose and moved cloud),
+    (b) three pairs of different sizes in one call, each against the oracle and against the one-workgroup path's own result
+    (CREG_ICP_P2P_ONE_WORKGROUP=1), iteration counts included."""
+    import os
+    from scipy.spatial.transform import Rotation
+    from autourdf_amd import ops
+    from autourdf_amd.cluster_icp import PointCloud
+    from autourdf_amd.evaluation import icp_filter
+    from oracle import icp as oicp, link as olink
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rng = np.random.default_rng(21)
+    # (a) a surface-like cloud (a noisy torus), prediction = a rotated, shifted, noisy subsample
+    u, v = rng.uniform(0, 2 * np.pi, 20000), rng.uniform(0, 2 * np.pi, 20000)
+    gt = np.stack([(0.3 + 0.08 * np.cos(v)) * np.cos(u), (0.3 + 0.08 * np.cos(v)) * np.sin(u), 0.08 * np.sin(v)], 1)
+    R = Rotation.from_rotvec([0.004, -0.003, 0.005]).as_matrix()
+    pred = gt[rng.permutation(20000)] @ R.T + np.array([0.0015, -0.001, 0.002]) + rng.normal(scale=2e-4, size=(20000, 3))
+    T, moved = icp_filter(PointCloud(pred), PointCloud(gt))
+    T_ref, moved_ref = olink.icp_filter(pred, gt)
+    np.testing.assert_allclose(T, T_ref, atol=1e-8)
+    np.testing.assert_allclose(moved.points, moved_ref, atol=1e-8)
+    # (b) three pairs: 3000 / 1500 / 2600 sources against 4000 / 2500 / 3000 targets (1e-8 vs oracle; identical to the one-workgroup path)
+    ns, nt = (3000, 1500, 2600), (4000, 2500, 3000)
+    srcs, tgts = [], []
+    for i, (a, b) in enumerate(zip(ns, nt)):
+        t = rng.uniform(-0.2, 0.2, size=(b, 3)) * np.array([1.0, 0.6, 0.15]) + i
+        Ri = Rotation.from_rotvec(rng.normal(scale=0.01, size=3)).as_matrix()
+        srcs.append(t[rng.permutation(b)[:a]] @ Ri.T + rng.normal(scale=1e-3, size=3))
+        tgts.append(t)
+    so = torch.tensor(np.cumsum((0,) + ns), dtype=torch.int32, device=dev)
+    to = torch.tensor(np.cumsum((0,) + nt), dtype=torch.int32, device=dev)
+    args = (torch.as_tensor(np.concatenate(srcs), device=dev), so, torch.as_tensor(np.concatenate(tgts), device=dev), to,
+            torch.eye(4, dtype=torch.float64, device=dev).repeat(3, 1, 1))
+    T3, m3, it3 = ops.icp_p2p(*args, th=0.05, max_iteration=300)
+    os.environ["CREG_ICP_P2P_ONE_WORKGROUP"] = "1"
+    try:
+        T1, m1, it1 = ops.icp_p2p(*args, th=0.05, max_iteration=300)
+    finally:
+        del os.environ["CREG_ICP_P2P_ONE_WORKGROUP"]
+    for i in range(3):
+        T_ref, _, _, n_ref = oicp.registration_icp(srcs[i], tgts[i], 0.05, np.eye(4), 300)
+        np.testing.assert_allclose(T3[i].cpu().numpy(), T_ref, atol=1e-8)
+        assert int(it3[i]) == n_ref == int(it1[i])
+    np.testing.assert_allclose(T3.cpu().numpy(), T1.cpu().numpy(), atol=1e-12)
+    np.testing.assert_allclose(m3.cpu().numpy(), m1.cpu().numpy(), atol=1e-12)

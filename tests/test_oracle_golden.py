@@ -366,3 +366,26 @@ def test_aabb_mask_indices_match_reference(golden):
     for c, w in enumerate(world):
         idx = np.nonzero(icp.aabb_mask(w, g["frame"], 1.2))[0]
         np.testing.assert_array_equal(idx, g["mask_idx"][g["mask_offsets"][c]:g["mask_offsets"][c + 1]])
+
+
+def test_oracle_icp_search_dense_and_c_forms_agree():
+    """oracle/icp.py:_correspond switches from the dense numpy form to creg_oracle.c's loop above 4e6 pairs (whole-cloud ICP,
+    Sim/evaluation.py:358-362): identical nearest indices (first minimum, ties included: lattice coordinates) and distances."""
+    from oracle import icp
+    rng = np.random.default_rng(3)
+    a = np.round(rng.uniform(-1, 1, (600, 3)) * 8) / 8            # a coarse lattice: many exactly equal distances
+    b = np.round(rng.uniform(-1, 1, (800, 3)) * 8) / 8
+    b[10] = b[500]
+    d2 = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+    j = d2.argmin(1)
+    dc, jc = icp._nn_l2_c(a, b)
+    assert (j == jc).all() and (d2[np.arange(len(a)), j] == dc).all()
+    old = icp._DENSE_PAIRS
+    try:
+        src = b[:300] + 0.01
+        T0, f0, r0, n0 = icp.registration_icp(src, b, 1.0, np.eye(4), 50)
+        icp._DENSE_PAIRS = 0
+        T1, f1, r1, n1 = icp.registration_icp(src, b, 1.0, np.eye(4), 50)
+    finally:
+        icp._DENSE_PAIRS = old
+    assert n0 == n1 and f0 == f1 and r0 == r1 and (T0 == T1).all()
