@@ -330,6 +330,208 @@ __device__ __forceinline__ void nn_l1_block_pruned(const float* Q, int nq, int s
     }
 }
 
+// ---- exact search, sixteen queries per wave (round 5) -------------------------------------------------------------------------
+// nn_l1_block_pruned gives a wave FOUR queries and evaluates one target per lane: every per-query step -- the box bounds, the wave
+// minima, the ballots, the bookkeeping of visited blocks -- is executed by all 64 lanes for one query at a time, and the pair
+// evaluations are a sixth of its ~800 VALU instructions per wave (200 per query; the launch is VALU-issue bound: 6 waves per SIMD at
+// three problems).  Here a wave takes SIXTEEN queries that are neighbours in space -- 16 consecutive slots of a k-d leaf of the
+// QUERY cloud (both clouds are block-sorted: the target frame once per frame, the predicted cloud by k_head every epoch) -- as
+// lane = 16 g + q: query q, target quarter g.  Per wave, once: the box of its queries (row reductions), its L1 box-to-box bound to
+// every target block (lane b <-> block b: a lower bound for every (query, target) pair, in float arithmetic too -- subtraction and
+// addition are monotone), the block with the smallest bound is visited first.  A visit: lane (g, q) evaluates targets 16 g .. 16 g + 15
+// of the block for its query (16-byte loads, one address per row), running minimum as ONE 64-bit key (distance bits : original index),
+// then the four quarters of a query are combined by two row swaps.  After the first visit the remaining blocks are taken in order of
+// their box-to-box bound while that bound is <= the largest running distance among the wave's queries; a block is visited only if
+// some query's own point-to-box bound is <= its running distance (ties included: a smaller original index may win).  Exact: the
+// result is the exhaustive kernel's (smallest distance, then smallest ORIGINAL index).  Per-wave instruction count ~900 for 16
+// queries (~55 per query).  The epilogue runs per lane (row 0), the wave's loss partial is the row sum of its 16 distances in slot
+// order: lossp[16-slot group] -- another summation order than the four-queries-per-wave kernels' (per 32 original indices), i.e. the
+// loss can differ from theirs in the last bit; indices, distances, signs and counters are identical.
+__device__ __forceinline__ float row_min16(float v) {
+    asm("s_nop 4\n\t"
+        "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float row_max16(float v) {
+    asm("s_nop 4\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float row_sum16_f(float v) {
+    CREG_DPP_STEP(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+    CREG_DPP_STEP(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+    CREG_DPP_STEP(v, 0x141, 0xF);   // row_half_mirror
+    CREG_DPP_STEP(v, 0x140, 0xF);   // row_mirror
+    return v;
+}
+// min over the lanes l, l ^ 16, l ^ 32, l ^ 48 of a 64-bit key (gfx950 row / half swaps: one VALU instruction per word and step)
+__device__ __forceinline__ unsigned long long key_min_rows(unsigned long long k) {
+    {   const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(k >> 32), (unsigned)(k >> 32), false, false);
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)k, (unsigned)k, false, false);
+        const unsigned long long a = ((unsigned long long)hi[0] << 32) | lo[0], b = ((unsigned long long)hi[1] << 32) | lo[1];
+        k = a < b ? a : b; }
+    {   const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(k >> 32), (unsigned)(k >> 32), false, false);
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false);
+        const unsigned long long a = ((unsigned long long)hi[0] << 32) | lo[0], b = ((unsigned long long)hi[1] << 32) | lo[1];
+        k = a < b ? a : b; }
+    return k;
+}
+#ifdef CREG_NN_STATS
+__device__ unsigned long long g_nn_stats[8];       // waves, candidates tested, visits, ... (measurement build: tests/measure/nn_rows_stats.py)
+#define NN_STAT(i, v) do { if (lane == 0) atomicAdd(&g_nn_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define NN_STAT(i, v) do { } while (0)
+#endif
+constexpr int NN_ROWQ = 16;                        // queries per wave
+#ifndef NN_ROW_BATCH
+#define NN_ROW_BATCH 3                             // candidate blocks whose loads are in flight together after the first visit
+#endif
+constexpr int NN_ROW_SLOTS = (NN_BLOCK / 64) * NN_ROWQ;      // query slots per workgroup
+
+// qs4: the QUERY cloud in slot order (xyz, bits(original index); padding = index INT_MAX), 64 * nqblk slots in use (nqblk_dev: the
+// device-side count when the host only knows an upper bound); tb: the target blocks of 64 slots with their boxes (NB per lane);
+// T: the targets in ORIGINAL order, 4 floats per point (the winner's coordinates for the epilogue); lossp[group]: the wave's partial.
+template <int NB, typename Epi, bool NBDEV, bool NQDEV>
+__device__ __forceinline__ void nn_l1_rows(const float4* __restrict__ qs4, int nqblk, const int* nqblk_dev, NnBlocks tb, int dir, Epi& epi, int blk,
+                                           const int* stop_flag, const float* __restrict__ T, float* __restrict__ lossp) {
+    const int tid = threadIdx.x, lane = tid & 63, q = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = blk * (NN_BLOCK / 64) + wave;             // this wave's 16-slot group of the query cloud
+    int stop = *stop_flag;
+    int nblk = tb.nblk;
+    if constexpr (NBDEV) nblk = *tb.nblk_dev;
+    if constexpr (NQDEV) nqblk = *nqblk_dev;
+    float lox[NB], loy[NB], loz[NB], hix[NB], hiy[NB], hiz[NB];
+#pragma unroll
+    for (int gi = 0; gi < NB; ++gi) {          // (the box table holds 64 * NB entries: no dependence on the block counts' round trip)
+        const float* bx = tb.tbox + 64 * gi + lane;
+        constexpr int BP = 64 * NB;
+        lox[gi] = bx[0]; loy[gi] = bx[BP]; loz[gi] = bx[2 * BP]; hix[gi] = bx[3 * BP]; hiy[gi] = bx[4 * BP]; hiz[gi] = bx[5 * BP];
+    }
+    const int slot = NN_ROWQ * grp + q;
+    const float4 qv = qs4[slot];               // (the slot arrays are allocated for the host's upper bound of blocks)
+    stop = __builtin_amdgcn_readfirstlane(stop); nblk = __builtin_amdgcn_readfirstlane(nblk); nqblk = __builtin_amdgcn_readfirstlane(nqblk);
+    const int qi = __float_as_int(qv.w);
+    const bool valid = slot < 64 * nqblk && qi != 0x7fffffff;
+    const float qx = qv.x, qy = qv.y, qz = qv.z;
+    if (stop) return;                                            // workgroup-uniform
+    if (!__ballot(valid)) { if (lane == 0) lossp[grp] = 0.f; return; }      // a group of padding / past the cloud: an empty partial
+    // the box of the wave's queries (every row holds the same sixteen)
+    const float qlx = row_min16(valid ? qx : INFINITY), qly = row_min16(valid ? qy : INFINITY), qlz = row_min16(valid ? qz : INFINITY);
+    const float qhx = row_max16(valid ? qx : -INFINITY), qhy = row_max16(valid ? qy : -INFINITY), qhz = row_max16(valid ? qz : -INFINITY);
+    float bnd[NB];                                               // box-to-box bound of block 64 gi + lane; +inf: visited, rejected or none
+    float lm = INFINITY;
+#pragma unroll
+    for (int gi = 0; gi < NB; ++gi) {
+        const float ex = fmaxf(fmaxf(lox[gi] - qhx, qlx - hix[gi]), 0.f);
+        const float ey = fmaxf(fmaxf(loy[gi] - qhy, qly - hiy[gi]), 0.f);
+        const float ez = fmaxf(fmaxf(loz[gi] - qhz, qlz - hiz[gi]), 0.f);
+        const float b = (ex + ey) + ez;                          // same association as l1_dist
+        bnd[gi] = (64 * gi + lane < nblk && b == b) ? b : INFINITY;     // (a NaN box: never a candidate; nothing could be taken from it)
+        lm = __builtin_fminf(lm, bnd[gi]);
+    }
+    unsigned long long key = (0x7f800000ull << 32) | 0x7fffffffu;      // (+inf : INT_MAX): nothing found yet
+    NN_STAT(0 + 4 * dir, 1);
+    // One block's 64 targets against the wave's queries: lane l holds target l (ONE coalesced 16-byte load per lane and visit); lane
+    // (g, q) meets the sixteen targets of ITS row by rotating the row (DPP row_ror: the rotated operand feeds the subtraction
+    // directly) -- every lane sees them in another order, which the key (distance : original index) does not care about.
+    auto visit = [&](const float4 v) {
+#define CREG_NN_PAIR(tx_, ty_, tz_, ti_) {                                                                                   \
+            const float d = l1_dist(qx, qy, qz, tx_, ty_, tz_);                                                               \
+            /* (a NaN distance has the bits of a huge key and is never taken; -0.0 cannot occur: a sum of absolute values) */ \
+            const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(ti_);                   \
+            key = kk < key ? kk : key; }
+#define CREG_NN_ROT(R) CREG_NN_PAIR(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0x120 + R, 0xF, 0xF, true)),   \
+                                    __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0x120 + R, 0xF, 0xF, true)),   \
+                                    __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.z), 0x120 + R, 0xF, 0xF, true)),   \
+                                    __builtin_amdgcn_update_dpp(0, __float_as_int(v.w), 0x120 + R, 0xF, 0xF, true))
+        CREG_NN_PAIR(v.x, v.y, v.z, __float_as_int(v.w))
+        CREG_NN_ROT(1) CREG_NN_ROT(2) CREG_NN_ROT(3) CREG_NN_ROT(4) CREG_NN_ROT(5) CREG_NN_ROT(6) CREG_NN_ROT(7) CREG_NN_ROT(8)
+        CREG_NN_ROT(9) CREG_NN_ROT(10) CREG_NN_ROT(11) CREG_NN_ROT(12) CREG_NN_ROT(13) CREG_NN_ROT(14) CREG_NN_ROT(15)
+#undef CREG_NN_ROT
+#undef CREG_NN_PAIR
+        key = key_min_rows(key);                                 // the four rows of every query
+    };
+    // the remaining block with the smallest box-to-box bound <= r: its index (or -1), its box into (bl, bh), its bound retired
+    auto take_next = [&](float r, float (&bl)[3], float (&bh)[3]) -> int {
+        const float m = wave_min_fast(lm);
+        if (!(m <= r)) return -1;                                // (also when nothing is left: m = +inf, r < +inf -- or both +inf: below)
+        if (!(m < INFINITY)) return -1;
+        int b = 0;
+        bool found = false;
+#pragma unroll
+        for (int gi = 0; gi < NB; ++gi) {
+            const unsigned long long f = __ballot(bnd[gi] == m);
+            if (!found && f) { b = 64 * gi + __builtin_ctzll(f); found = true; }
+        }
+        lm = INFINITY;
+#pragma unroll
+        for (int gi = 0; gi < NB; ++gi) {
+            if ((b >> 6) == gi) {                                // wave-uniform
+                const int src = b & 63;
+                bl[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lox[gi]), src)); bl[1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(loy[gi]), src));
+                bl[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(loz[gi]), src)); bh[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hix[gi]), src));
+                bh[1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hiy[gi]), src)); bh[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hiz[gi]), src));
+                if (lane == src) bnd[gi] = INFINITY;             // taken: never again
+            }
+            lm = __builtin_fminf(lm, bnd[gi]);
+        }
+        NN_STAT(1 + 4 * dir, 1);
+        return b;
+    };
+    auto needed = [&](const float (&bl)[3], const float (&bh)[3]) -> bool {      // does any query's own point-to-box bound reach its running distance?
+        const float ex = fmaxf(fmaxf(bl[0] - qx, qx - bh[0]), 0.f), ey = fmaxf(fmaxf(bl[1] - qy, qy - bh[1]), 0.f), ez = fmaxf(fmaxf(bl[2] - qz, qz - bh[2]), 0.f);
+        const float pb = (ex + ey) + ez;
+        return __ballot(valid && pb <= __uint_as_float((unsigned)(key >> 32))) != 0ull;
+    };
+    {   // the block with the smallest bound: always visited
+        float bl[3], bh[3];
+        const int b = take_next(INFINITY, bl, bh);
+        if (b >= 0) { NN_STAT(2 + 4 * dir, 1); visit(tb.ts4[(size_t)b * 64 + lane]); }
+    }
+    // then batches of up to NN_ROW_BATCH: the next blocks by bound while the bound is <= the largest running distance of the wave's
+    // queries (taken from the distances BEFORE the batch: a superset, r only shrinks), their loads in flight together; a block is
+    // evaluated only if some query still needs it when its turn comes
+    for (;;) {
+        const float r = -wave_min_fast(valid ? -__uint_as_float((unsigned)(key >> 32)) : INFINITY);
+        float bl[NN_ROW_BATCH][3], bh[NN_ROW_BATCH][3];
+        int bb[NN_ROW_BATCH];
+        bool open = true;
+#pragma unroll
+        for (int j = 0; j < NN_ROW_BATCH; ++j) {
+            bb[j] = open ? take_next(r, bl[j], bh[j]) : -1;
+            open = bb[j] >= 0;
+        }
+        if (bb[0] < 0) break;
+        float4 v[NN_ROW_BATCH];
+#pragma unroll
+        for (int j = 0; j < NN_ROW_BATCH; ++j) v[j] = tb.ts4[(size_t)max(bb[j], 0) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < NN_ROW_BATCH; ++j)
+            if (bb[j] >= 0 && needed(bl[j], bh[j])) { NN_STAT(2 + 4 * dir, 1); visit(v[j]); }
+        if (!open) break;                                        // the batch was not full: nothing is left within r
+    }
+    // ---- per query (row 0): outputs, epilogue, the wave's partial
+    const float bd = __uint_as_float((unsigned)(key >> 32));
+    const int bi = (int)(unsigned)key;
+    float acc = 0.f;
+    if (g == 0 && valid) {
+        float tx = 0.f, ty = 0.f, tz = 0.f;
+        if (bi != 0x7fffffff) { const float* p = T + (size_t)bi * 4; tx = p[0]; ty = p[1]; tz = p[2]; }
+        epi(dir, qi, bi, bd, qx, qy, qz, tx, ty, tz, acc);
+    }
+    acc = row_sum16_f(acc);
+    if (lane == 0) lossp[grp] = acc;
+}
+
 template <int QW, typename IdxT, typename Epi>
 __global__ __launch_bounds__(NN_BLOCK) void k_nn_l1(
     const float* A, int na, int sa, const float* B, int nb, int sb,

@@ -42,6 +42,7 @@ struct Dims {
     int npb;       // upper bound of the blocks of the predicted cloud, clusters padded (0: that direction exhaustive)
     int ppl;       // points per lane and block visit: blocks hold 64 * ppl points
     int nbt, nbp;  // boxes per lane of the search over the target frame / the predicted cloud (their box tables hold 64 nbt / 64 nbp)
+    int rows;      // the search takes sixteen queries per wave in slot order (nn_l1_rows, round 5): loss partials per 16-slot group
 };
 
 constexpr int PS_MAXB = 512;                   // most blocks of the predicted cloud (clusters padded): eight boxes per lane in the search
@@ -498,7 +499,9 @@ __global__ __launch_bounds__(1024) void k_sort_y(Dims D, Ws W0, size_t bstride, 
     for (int j = tid; j < npow; j += 1024) key[j] = j < nc ? (unsigned long long)j : ~0ull;
     __syncthreads();
     int level = 0;
-    for (int seg = npow; seg > BS; seg >>= 1, ++level) {
+    // (D.rows: the sixteen-queries-per-wave search takes its QUERIES from these slots too, 16 consecutive ones per wave -- two more
+    //  levels make every aligned group of 16 slots a k-d cell of its leaf: the fewer target blocks the sixteen need between them)
+    for (int seg = npow; seg > (D.rows ? 16 : BS); seg >>= 1, ++level) {
         const int axis = level % 3;
         for (int j = tid; j < npow; j += 1024) {
             const unsigned long long k = key[j];
@@ -589,12 +592,14 @@ __global__ __launch_bounds__(512) void k_sort_p(Dims D, Ws W0, size_t bstride) {
     for (int sl = tid; sl < npow; sl += 512) key[sl] = sl >= ns ? ~0ull : sl < n ? (unsigned long long)(p0 + sl) : 0xFFFFull;
     for (int b = tid; b < m; b += 512) { sf[b] = 0; sm[b] = (unsigned short)m; }
     __syncthreads();
+    int levels = 0;
     for (int level = 0; level < 9; ++level) {
         if (tid == 0) s_more = 0;
         __syncthreads();
         for (int b = tid; b < m; b += 512) if (sm[b] > 1) s_more = 1;
         __syncthreads();
         if (!s_more) break;
+        levels = level + 1;
         const int axis = level % 3;
         for (int sl = tid; sl < ns; sl += 512) {
             const unsigned idx = (unsigned)(key[sl] & 0xFFFFull);
@@ -622,6 +627,22 @@ __global__ __launch_bounds__(512) void k_sort_p(Dims D, Ws W0, size_t bstride) {
         if (mine) { sf[tid] = nf; sm[tid] = nm; }
         __syncthreads();
     }
+    if (D.rows)            // two more levels inside every 64-slot block: aligned groups of 16 slots are k-d cells (see k_sort_y)
+        for (int sub = 0; sub < 2; ++sub) {
+            const int axis = (levels + sub) % 3;
+            __syncthreads();
+            for (int sl = tid; sl < ns; sl += 512) {
+                const unsigned idx = (unsigned)(key[sl] & 0xFFFFull);
+                unsigned u = 0xFFFFFFFFu;                     // padding sorts last inside its segment
+                if (idx != 0xFFFFu) {
+                    const float4 p = W.pts4[idx];
+                    u = ordered_bits(axis == 0 ? p.x : axis == 1 ? p.y : p.z);
+                }
+                key[sl] = ((unsigned long long)u << 16) | idx;
+            }
+            __syncthreads();
+            bitonic_segments(key, npow, 64 >> sub, tid, 512);
+        }
     for (int sl = tid; sl < ns; sl += 512) {
         const unsigned idx = (unsigned)(key[sl] & 0xFFFFull);
         float4 o = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
@@ -687,6 +708,30 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_plan(const float* A, int na, co
         pb.nblk_dev = (const int*)((const char*)pb.nblk_dev + zb);
         nn_l1_block_pruned<NBP, PPL, EngineEpi, true, true>(B, nb, 4, pb, 1, epi, bx - blocksA, epi.stopped, A, 4);
     } else nn_l1_block<4, int, EngineEpi>(A, na, 4, B, nb, 4, nullptr, nullptr, nullptr, nullptr, blocksA, epi, bx);
+}
+
+// Round 5: the same launch with sixteen queries per wave (nn_l1_rows): both directions take their QUERIES in slot order of their own
+// block-sorted copy (ps4 / ys4: neighbours in space share a wave), 64-point blocks on both sides.
+template <int NBT, int NBP>
+__global__ __launch_bounds__(NN_BLOCK) void k_nn_rows(const float* A, const float* B, int blocksA, int blocksB, EngineEpi epi, NnBlocks yb, NnBlocks pb,
+                                                      size_t zstride) {
+    asm volatile("" :: "s"(A), "s"(B), "s"(blocksA), "s"(blocksB), "s"(epi.sgn_x), "s"(epi.cnt4), "s"(epi.lossp_x), "s"(epi.lossp_y),
+                 "s"(epi.bstride), "s"(epi.stopped), "s"(yb.ts4), "s"(yb.tbox), "s"(yb.nblk), "s"(pb.ts4), "s"(pb.tbox), "s"(pb.nblk_dev), "s"(zstride));
+    const int nz = gridDim.x / (blocksA + blocksB);
+    int i = blockIdx.x, z, bx;
+    if (i < blocksB * nz) { z = i / blocksB; bx = blocksA + (i - z * blocksB); }
+    else { i -= blocksB * nz; z = i / blocksA; bx = i - z * blocksA; }
+    const size_t zb = z * zstride;
+    A = (const float*)((const char*)A + zb);
+    B = (const float*)((const char*)B + zb);
+    yb.ts4 = (const float4*)((const char*)yb.ts4 + zb);
+    yb.tbox = (const float*)((const char*)yb.tbox + zb);
+    pb.ts4 = (const float4*)((const char*)pb.ts4 + zb);
+    pb.tbox = (const float*)((const char*)pb.tbox + zb);
+    pb.nblk_dev = (const int*)((const char*)pb.nblk_dev + zb);
+    epi.shift(z);
+    if (bx < blocksA) nn_l1_rows<NBT, EngineEpi, false, true>(pb.ts4, 0, pb.nblk_dev, yb, 0, epi, bx, epi.stopped, B, epi.lossp_x);
+    else nn_l1_rows<NBP, EngineEpi, true, false>(yb.ts4, yb.nblk, nullptr, pb, 1, epi, bx - blocksA, epi.stopped, A, epi.lossp_y);
 }
 
 // ------------------------------------------------------------------------------------------ control + cluster grads
@@ -1527,13 +1572,22 @@ static bool make_dims(const creg_train_shape* s, Dims* D) {
     // finer blocks save.  The target frame is cut into k-d leaves in LDS, 16384 points per workgroup (k_sort_y; up to four
     // chunks), a cluster by one workgroup (k_sort_p): n_tgt <= 65536, n_pred < 65535 (16-bit indices in the sort keys) and
     // clusters of at most 16384 points are this form's limits; outside them the plan runs the exhaustive kernel per direction.
-    D->ppl = D->NT <= 64 * 64 ? 1 : 4;
+    // Round 5: nn_search 0 takes sixteen queries per wave (nn_l1_rows) wherever BOTH clouds fit the 64-point block layouts -- up to 256
+    // target blocks (four boxes per lane: n_tgt <= 16384, one chunk of k-d leaves) and PS_MAXB blocks of the padded predicted cloud;
+    // nn_search 2 = the four-queries-per-wave search of rounds 2-4 (256-point blocks above 4096 targets), nn_search 1 = exhaustive.
+    const bool rows_fit = D->NT <= 16384 && D->NP < 65535 && (D->NP + 63) / 64 + D->K <= PS_MAXB && g.qw == 4;
+    // CREG_NN_ROWS: 0 = never, 1 = wherever it fits, unset = where it measured faster (profiles/r05_nn_rows_ab.log)
+    const char* rows_env = getenv("CREG_NN_ROWS");
+    const bool rows_pays = D->NT > 64 * 64;
+    D->rows = s->nn_search == 0 && rows_fit && (rows_env ? rows_env[0] == '1' : rows_pays);
+    D->ppl = (D->rows || D->NT <= 64 * 64) ? 1 : 4;
     const int BS = 64 * D->ppl;
-    D->nyb = (s->nn_search == 0 && D->NT <= 4 * YS_CHUNK && g.qw == 4) ? (D->NT + BS - 1) / BS : 0;      // (chunks of 16384: k_sort_y)
+    D->nyb = (s->nn_search != 1 && D->NT <= 4 * YS_CHUNK && g.qw == 4) ? (D->NT + BS - 1) / BS : 0;      // (chunks of 16384: k_sort_y)
     D->npb = (D->nyb && D->NP < 65535 && (D->NP + BS - 1) / BS + D->K <= PS_MAXB) ? (D->NP + BS - 1) / BS + D->K : 0;
     const int nt = (D->nyb + 63) / 64, np = (D->npb + 63) / 64;
     D->nbt = nt <= 1 ? 1 : (nt <= 2 ? 2 : 4);
     D->nbp = np <= 2 ? 2 : (np <= 3 ? 3 : (np <= 4 ? 4 : (np <= 5 ? 5 : (np <= 6 ? 6 : 8))));
+    if (D->rows) { D->nbx = 4 * D->npb; D->nby = 4 * D->nyb; }          // loss partials per 16-slot group of the query clouds
     return true;
 }
 
@@ -1619,7 +1673,30 @@ static void launch_gbd(Plan* P, int epoch, hipStream_t s) {
 }
 static void launch_nn(const Dims& D, const Ws& W, size_t bstride, int nz, hipStream_t s, int par = 0) {
     const EngineEpi epi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, bstride, &W.state[par].stopped};
-    if (D.nyb) {
+    if (D.rows) {
+        const NnBlocks yb{W.ys4, W.ybox, D.nyb, nullptr}, pb{W.ps4, W.pbox, 0, W.sb + D.K};
+        const int blocksA = cdiv(64 * D.npb, NN_ROW_SLOTS), blocksB = cdiv(64 * D.nyb, NN_ROW_SLOTS);
+        const dim3 grid((blocksA + blocksB) * nz);
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, grid, dim3(NN_BLOCK), 0, s, (const float*)W.pred4, (const float*)W.y4, blocksA, blocksB, epi, yb, pb, bstride);
+        };
+        auto pick_p = [&](auto nbt) {
+            constexpr int NBT = decltype(nbt)::value;
+            switch (D.nbp) {
+                case 2: go(k_nn_rows<NBT, 2>); break;
+                case 3: go(k_nn_rows<NBT, 3>); break;
+                case 4: go(k_nn_rows<NBT, 4>); break;
+                case 5: go(k_nn_rows<NBT, 5>); break;
+                case 6: go(k_nn_rows<NBT, 6>); break;
+                default: go(k_nn_rows<NBT, 8>); break;
+            }
+        };
+        switch (D.nbt) {
+            case 1: pick_p(std::integral_constant<int, 1>{}); break;
+            case 2: pick_p(std::integral_constant<int, 2>{}); break;
+            default: pick_p(std::integral_constant<int, 4>{}); break;
+        }
+    } else if (D.nyb) {
         const NnGrid g = nn_grid(D.NP, D.NT, true, true, 4);
         const NnBlocks yb{W.ys4, W.ybox, D.nyb, nullptr}, pb{W.ps4, W.pbox, 0, W.sb + D.K};
         const dim3 grid((g.blocksA + g.blocksB) * nz);
@@ -2228,10 +2305,18 @@ extern "C" int creg_debug_bd_stamps(double* out) {
 }
 #endif
 
+#ifdef CREG_NN_STATS
+extern "C" int creg_debug_nn_stats(unsigned long long* out8, int reset) {
+    CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_nn_stats), sizeof(unsigned long long) * 8));
+    if (reset) { unsigned long long z[8] = {0}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_nn_stats), z, sizeof(z))); }
+    return CREG_OK;
+}
+#endif
+
 extern "C" int creg_train_plan_info(const creg_train_plan* plan, creg_train_plan_info_t* info) {
     CREG_REQUIRE(plan && info, "creg_train_plan_info: null pointer");
     const Plan* P = (const Plan*)plan;
-    info->pruned_target_search = P->D.nyb > 0;
+    info->pruned_target_search = P->D.rows ? 2 : (P->D.nyb > 0);
     info->pruned_predicted_search = P->D.npb > 0;
     info->graph_branches = P->branches;
     info->batch = P->B;

@@ -578,7 +578,7 @@ class TrainPlan:
         #: what the plan chose from its shape (never a result): searches, graph branches, problems per launch, epochs per graph
         self.info = {"pruned_target_search": bool(info[0]), "pruned_predicted_search": bool(info[1]), "graph_branches": int(info[2]),
                      "batch": int(info[3]), "epochs_per_graph": int(info[4]), "nn_points_per_lane": int(info[5]),
-                     "nn_boxes_per_lane": (int(info[6]), int(info[7]))}
+                     "nn_boxes_per_lane": (int(info[6]), int(info[7])), "nn_queries_per_wave": 16 if int(info[0]) == 2 else 4}
         if nn_search == 0 and not (self.info["pruned_target_search"] and self.info["pruned_predicted_search"]):
             import warnings
             which = [d for d, on in (("predicted -> target", self.info["pruned_target_search"]),

@@ -334,7 +334,12 @@ typedef struct creg_train_shape {
                              pruning) when n_tgt <= 65536 (four chunks of 16384 sorted per workgroup) and, for the
                              target -> predicted direction, when the predicted cloud fits 512 blocks (n_pred / 64 + k,
                              or n_pred / 256 + k above 4096 targets) with n_pred < 65535; 1 = exhaustive in both
-                             directions.  Results do not depend on it (creg_train_plan_info says what a plan chose). */
+                             directions; 2 = as 0, but always the four-queries-per-wave search of rounds 2-4.  Round 5: under 0,
+                             frames of 4097..16384 target points (and a predicted cloud of at most 512 64-point blocks) take the
+                             sixteen-queries-per-wave search (nn_l1.h: nn_l1_rows; franka shape 80.7 -> 104.2 frames/s).  Matches,
+                             distances, gradients and every trained parameter do not depend on it; the LOSS is summed per 16-slot
+                             group there instead of per 32 original indices and can differ in its last bit
+                             (creg_train_plan_info says what a plan chose). */
 } creg_train_shape;
 
 typedef struct creg_train_args {
@@ -365,7 +370,8 @@ typedef struct creg_train_plan creg_train_plan;
  * how many graph branches and problems per launch it uses.  A caller that sized its clouds beyond the pruned search's
  * limits sees it here instead of only in the timing. */
 typedef struct creg_train_plan_info_t {
-    int32_t pruned_target_search;     /* 1: predicted -> target search over k-d leaf blocks; 0: exhaustive (n_tgt > 16384 or nn_search = 1) */
+    int32_t pruned_target_search;     /* 1: predicted -> target search over k-d leaf blocks, four queries per wave; 2: sixteen queries per wave
+                                         (both directions); 0: exhaustive (n_tgt > 65536 or nn_search = 1) */
     int32_t pruned_predicted_search;  /* 1: target -> predicted search over blocks; 0: exhaustive (more than 128 predicted blocks, ...) */
     int32_t graph_branches;           /* parallel chains in the captured graph */
     int32_t batch;                    /* problems the plan advances per run_batch call */

@@ -4,7 +4,9 @@
 
 Every shape draws its own cluster count, cloud sizes (up to 16384, so both block sizes are exercised), cluster
 sizes (empty and whole-block clusters included), duplicated points (exact distance ties) and model; a short train
-is run under nn_search = 0 and 1 and every output tensor compared bit for bit.
+is run under nn_search = 0 and 1 and every output tensor compared bit for bit -- except, where the plan chose the sixteen-queries-per-
+wave search (round 5: its loss partials are summed in another order), the loss history and min_loss, which are held to 1e-6 relative.
+CREG_NN_ROWS=1 in the environment puts every shape that fits on that search (default: frames above 4096 points only).
 """
 import os
 import sys
@@ -44,13 +46,19 @@ def one(g, dev, max_points=None):
     pts, off = ops.pack_clusters(cl, dev)
     torch.manual_seed(int(torch.randint(0, 1 << 30, (), generator=g)))
     model, order = (models.QRegMLP(True, 64), ops.Q_PARAM_ORDER) if rot == "q" else (models.DQRegMLP(64), ops.DQ_PARAM_ORDER)
-    outs = []
+    outs, rows = [], False
     for mode in (0, 1):
         params = [model.state_dict()[key].clone().to(dev) for key in order]
         plan = ops.TrainPlan(rot, k, 64, n_pred, n_tgt, epochs=8, use_graph=True, device=dev, nn_search=mode)
+        rows = rows or plan.info["nn_queries_per_wave"] == 16
         o = plan.run(m.to(dev), y.to(dev), pts, off, params)
         outs.append([t.cpu() for t in o] + [t.cpu() for t in params])
-    ok = all(torch.equal(a.nan_to_num(), b.nan_to_num()) for a, b in zip(*outs))
+    ok = True
+    for i, (a, b) in enumerate(zip(*outs)):             # outputs: best_m, best_pred, result, loss_hist, lr_hist, then the parameters
+        if rows and i in (2, 3):                         # (result[0] = min_loss; loss_hist) -- another summation order of the same distances
+            ok = ok and bool(torch.allclose(a.nan_to_num(), b.nan_to_num(), rtol=1e-6, atol=0.0)) and bool((a.isnan() == b.isnan()).all())
+        else:
+            ok = ok and torch.equal(a.nan_to_num(), b.nan_to_num())
     return ok, (rot, k, n_pred, n_tgt), bool(torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][2][:1]).all())
 
 

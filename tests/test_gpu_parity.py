@@ -1332,14 +1332,24 @@ def test_train_pruned_search_bit_identical_to_exhaustive(dev, rot, k, hidden, n_
     pts, off = ops.pack_clusters(cl, dev)
     torch.manual_seed(5)
     model, order = (models.QRegMLP(True, hidden), ops.Q_PARAM_ORDER) if rot == "q" else (models.DQRegMLP(hidden), ops.DQ_PARAM_ORDER)
-    outs = []
-    for mode in (0, 1):
+    outs, rows = [], []
+    for mode in (0, 2, 1):
         params = [model.state_dict()[key].clone().to(dev) for key in order]
         plan = ops.TrainPlan(rot, k, hidden, n_pred, n_tgt, epochs=25, use_graph=True, device=dev, nn_search=mode)
+        rows.append(plan.info["nn_queries_per_wave"] == 16)
         o = plan.run(m.to(dev), y.to(dev), pts, off, params)
         outs.append([t.cpu() for t in o] + [t.cpu() for t in params])
-    for a, b in zip(*outs):
+    assert not rows[1] and not rows[2]
+    for a, b in zip(outs[1], outs[2]):                   # four queries per wave against exhaustive: every bit
         assert torch.equal(a.nan_to_num(), b.nan_to_num())
+    # nn_search 0: the same unless the plan took the sixteen-queries-per-wave search (round 5: frames above 4096 points, or everywhere
+    # under CREG_NN_ROWS=1), whose loss partials are summed per 16-slot group -- loss history and min_loss to 1e-6 then, everything
+    # else (poses, best cloud, lr history, every trained parameter) still bit for bit
+    for i, (a, b) in enumerate(zip(outs[0], outs[2])):
+        if rows[0] and i in (2, 3):
+            assert torch.allclose(a.nan_to_num(), b.nan_to_num(), rtol=1e-6, atol=0.0) and bool((a.isnan() == b.isnan()).all())
+        else:
+            assert torch.equal(a.nan_to_num(), b.nan_to_num()), i
     assert torch.isfinite(outs[0][0]).all()
 
 
