@@ -1817,8 +1817,13 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
     // dry for a host round trip each time): it reads the counters of batch b - 1 after batch b is in the queue, so the device
     // always has a batch ahead; the price is at most one surplus batch of launches whose workgroups all leave at once.
     static thread_local int* h_run = nullptr;                        // pinned: ICP_LAG_RING x {clusters running, live chunks}
+    static thread_local hipEvent_t h_last = nullptr;                 // behind the LAST copy into h_run of this thread's previous call
     constexpr int ICP_LAG_RING = 4;
-    if (!h_run) CREG_HIP(hipHostMalloc((void**)&h_run, sizeof(int) * 2 * ICP_LAG_RING, hipHostMallocDefault));
+    // (portable: the ring is used from whichever device is current.  A call returns with its last copy still in flight -- the next one
+    //  on this thread, possibly on another stream or device, must not reuse the slots before that copy has landed: a late copy would
+    //  overwrite the new call's counters, typically with "0 clusters running", and end its iteration loop early)
+    if (!h_run) CREG_HIP(hipHostMalloc((void**)&h_run, sizeof(int) * 2 * ICP_LAG_RING, hipHostMallocPortable));
+    if (h_last) { (void)hipEventSynchronize(h_last); (void)hipEventDestroy(h_last); h_last = nullptr; }
     hipEvent_t ev[ICP_LAG_RING];
     for (auto& e : ev) CREG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     int grid = nblk, rc_loop = CREG_OK;                              // live chunks as of the last batch whose counters were read
@@ -1848,6 +1853,9 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
         // nothing to decide any more: k_icp_finish reads the device state
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
+    if (hipEventCreateWithFlags(&h_last, hipEventDisableTiming) == hipSuccess) {
+        if (hipEventRecord(h_last, s) != hipSuccess) { (void)hipEventDestroy(h_last); h_last = nullptr; (void)hipStreamSynchronize(s); }
+    } else { h_last = nullptr; (void)hipStreamSynchronize(s); }
     if (rc_loop != CREG_OK) { set_error("creg_masked_icp: HIP error in the iteration loop: %s", hipGetErrorString(hipGetLastError())); return rc_loop; }
     hipLaunchKernelGGL(k_icp_finish, dim3(k), dim3(256), 0, s, P, keep_translation);
     CREG_LAUNCH_CHECK();

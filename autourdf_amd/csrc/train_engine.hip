@@ -2043,7 +2043,7 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     //     three), three from 8 (230 against 226); frames above 4096 points (several points per lane in the NN kernels, whose tails
     //     leave CUs idle) take three from 3 problems on (franka shape 79.4 against 74.8 / 74.0 with two / one).  Four chains need a
     //     fifth hardware queue and collapse (112 at 6 sequences).  Results never depend on any of this.
-    const int auto_chains = (D.ppl > 1 && P->B >= 3) ? 3 : (P->B >= 8 ? 3 : (P->B >= 5 ? 2 : 1));
+    const int auto_chains = (D.NT > 64 * 64 && P->B >= 3) ? 3 : (P->B >= 8 ? 3 : (P->B >= 5 ? 2 : 1));
     P->chain_streams = shape->graph_branches <= 0;
     P->branches = shape->graph_branches > 0 ? shape->graph_branches : (shape->graph_branches < 0 ? -shape->graph_branches : auto_chains);
     if (P->branches > P->B) P->branches = P->B;

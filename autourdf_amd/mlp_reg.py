@@ -21,6 +21,7 @@ import glob
 import json
 import os
 import queue
+import sys
 import threading
 
 import numpy as np
@@ -158,10 +159,13 @@ class _FileWriter:
     next frame registers: ``np.savez`` of a frame's 20 clusters is ~1.2 ms of host time, and written in line it left the GPU idle
     for a fifth of a lock-step round (5 sequences x 200 frames, files and start-up included: 6.9 -> 6.0 ms per frame end to end
     with this and the worker-side fetch of match_all, profiles/r04_cli_end_to_end.log; the registration alone is 5.5).
-    Same functions, same bytes; an error in the worker is re-raised by the next ``submit`` or by ``close``."""
+    Same functions, same bytes; an error in the worker is re-raised by the next ``submit`` or by ``close``.
+    At most ``MAX_PENDING`` frames wait behind the worker: a job of the lock-step engine pins a frame's stacked DEVICE tensors
+    (S x N x 3 float64 + poses: ~30 MB at 5 x 262144 points) until it is written, so the queue bounds device memory, not just count."""
+    MAX_PENDING = 8
 
     def __init__(self):
-        self._q = queue.Queue(maxsize=256)
+        self._q = queue.Queue(maxsize=self.MAX_PENDING)
         self._err = None
         self._t = threading.Thread(target=self._run, name="creg-file-writer", daemon=True)
         self._t.start()
@@ -193,10 +197,12 @@ class _FileWriter:
                 if not self._t.is_alive():
                     raise RuntimeError("the file-writer thread died") from self._err
 
-    def close(self):
+    def close(self, propagating: bool = False):
+        """Drain and stop.  ``propagating``: another exception is already on its way out of the frame loop -- the worker's stored
+        error (usually a consequence of it) must not replace it."""
         self._q.put(None)
         self._t.join()
-        if self._err is not None:
+        if self._err is not None and not propagating:
             raise self._err
 
 
@@ -235,7 +241,7 @@ def register_sequence(seg, step_matrices, step_cluster_np, save_dir=None, mlp_ic
         _register_frames(seg, K, m_t, cl_t, cl_init, icp_src, model, model_rf, mlp_icp, save_dir, writer, poses, best_losses)
     finally:
         if writer is not None:
-            writer.close()
+            writer.close(propagating=sys.exc_info()[0] is not None)
     return poses, best_losses
 
 
@@ -362,7 +368,7 @@ def match_all(data_dirs):
             ev.record()
             writer.submit(_fetch_and_save, save_dirs, i + 1, stacked, ev, losses)
     finally:
-        writer.close()
+        writer.close(propagating=sys.exc_info()[0] is not None)
     if LOSS:
         for sd, l in zip(save_dirs, losses):
             np.savetxt(sd + "loss.txt", l)
