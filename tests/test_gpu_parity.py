@@ -758,6 +758,53 @@ def test_train_c1_divergence_stays_inside_the_measured_oracle_envelope(dev, gold
     assert float(np.abs(bm.cpu().numpy()[:, :3, :] - g["e300_best_m"][:, :3, :]).max()) <= 2.0 * float(env["best_pose_envelope"])
 
 
+@pytest.mark.parametrize("shape,k,n", [("allegro", 30, 4096), ("franka", 40, 16384)])
+def test_train_other_shapes_vs_reference_train_and_the_measured_envelope(dev, golden, shape, k, n):
+    """VERDICT r4 ("what's weak" 1): the whole-frame parity claim rested on ONE problem.  tests/golden/train_reference_{allegro,franka}.npz
+    (make_golden_shapes.py: the REFERENCE's own train() at BASELINE configs[3] / configs[2] shapes, from the pinned state of the configs[1]
+    golden) and divergence_envelope_{shape}.npz (divergence_envelope.py cpu:<shape>: the float32 oracle against itself with permuted
+    points and in float64) put the other two registration shapes under the same statements:
+      * the forward is exact: the pose before any step within 2e-6 of the reference's, the first loss within 1e-5 relative;
+      * ONE Adam step later the plan is within 1e-5 -- or, where the envelope says no second implementation is (the allegro shape:
+        the float64 oracle is 4.3e-4 away after one step; a sum of +-1/N signs that is an output bias's gradient sits next to zero and
+        one point within an ulp of its neighbour's coordinate flips its sign), within one full step of that bias in the other direction
+        (2.5 lr);
+      * what train() returns after 300 epochs -- min_loss, best pose -- and the pose at epoch 299 stay inside twice the spread of the
+        oracle variants (allegro: the spread itself is 59 % / a flipped cluster; franka 0.4 % / 1.9e-2: DESIGN.md section 2)."""
+    from autourdf_amd import ops
+    g = golden(f"train_reference_{shape}.npz")
+    env = golden(f"divergence_envelope_{shape}.npz")
+    c1 = golden("train_reference_c1.npz")
+    sd = {key[5:]: torch.from_numpy(c1[key].astype(np.float32)) for key in c1.files if key.startswith("sd16.")}
+    order = ops.Q_PARAM_ORDER
+    m, y = torch.from_numpy(g["m"]).to(dev), torch.from_numpy(g["y"]).to(dev)
+    pts, off = ops.pack_clusters([torch.from_numpy(c) for c in _split(g["local"], g["offsets"])], dev)
+    assert pts.shape[0] == n and len(g["offsets"]) == k + 1
+    ref = {int(e): g["pose_hist_sel"][i] for i, e in enumerate(g["pose_epochs"])}
+    spread = np.maximum(env["envelope"], env["f64"])
+    probe_plan = ops.TrainPlan("q", k, 512, n, n, epochs=2, use_graph=False, device=dev)
+    params = [sd[key].clone().to(dev) for key in order]
+    m0, _, loss0, _ = probe_plan.probe(m, y, pts, off, params)
+    assert float(np.abs(m0.cpu().numpy()[:, :3, :] - ref[0][:, :3, :]).max()) <= 2e-6
+    assert abs(float(loss0) - float(g["loss_hist"][0])) <= 1e-5 * float(g["loss_hist"][0])
+    seen = {}
+    for e in (1, 299):
+        params = [sd[key].clone().to(dev) for key in order]
+        plan = ops.TrainPlan("q", k, 512, n, n, epochs=e, use_graph=e >= 2, device=dev)
+        plan.run(m, y, pts, off, params, stop=10 ** 6)
+        m2, _, _, _ = probe_plan.probe(m, y, pts, off, params)
+        seen[e] = float(np.abs(m2.cpu().numpy()[:, :3, :] - ref[e][:, :3, :]).max())
+    one_step = 1e-5 if float(spread[1]) <= 1e-5 else 2.5 * 2e-4
+    assert seen[1] <= one_step, seen
+    assert seen[299] <= 2.0 * float(spread[299]), seen
+    params = [sd[key].clone().to(dev) for key in order]
+    plan = ops.TrainPlan("q", k, 512, n, n, epochs=300, use_graph=True, device=dev)
+    bm, _, res, _, _ = plan.run(m, y, pts, off, params)
+    ml = float(g["e300_min_loss"])
+    assert abs(float(res[0]) - ml) <= 2.0 * float(env["min_loss_rel_envelope"]) * ml, (float(res[0]), ml)
+    assert float(np.abs(bm.cpu().numpy()[:, :3, :] - g["e300_best_m"][:, :3, :]).max()) <= 2.0 * float(env["best_pose_envelope"])
+
+
 def test_train_same_target_keeps_the_frames_leaves_bit_identical(dev):
     """creg_train_args.y_unchanged (ops: same_target=True): "Anchor" after "Step" on the same frame keeps the target frame's k-d leaf
     blocks instead of sorting the frame again -- every output bit of the second train is what a rebuilding run gives, single and

@@ -389,3 +389,17 @@ def test_oracle_icp_search_dense_and_c_forms_agree():
     finally:
         icp._DENSE_PAIRS = old
     assert n0 == n1 and f0 == f1 and r0 == r1 and (T0 == T1).all()
+
+
+@pytest.mark.parametrize("shape", ["allegro", "franka"])
+def test_divergence_envelope_fixtures_of_the_other_shapes_are_consistent(golden, shape):
+    """tests/golden/divergence_envelope_{allegro,franka}.npz against train_reference_{shape}.npz: the float32 oracle reproduced the
+    reference's trajectory at every pinned epoch (bit for bit: same torch build, same op sequence), the permuted runs start inside
+    1e-5, and the fixture carries what the GPU test reads."""
+    e = golden(f"divergence_envelope_{shape}.npz")
+    g = golden(f"train_reference_{shape}.npz")
+    assert float(e["oracle_vs_reference"].max()) == 0.0
+    assert e["envelope"].shape == (300,) and e["f64"].shape == (300,)
+    assert float(e["envelope"][1]) < 1e-5 and int(e["n_e_perm"]) >= 1
+    assert float(e["min_loss_rel_envelope"]) > 0 and float(e["best_pose_envelope"]) > 0
+    assert len(g["loss_hist"]) == 300 and g["pose_hist_sel"].shape[0] == len(g["pose_epochs"])
