@@ -360,7 +360,10 @@ typedef struct creg_train_args {
     int32_t y_unchanged;        /* != 0: the caller guarantees that `y` holds the values it held in this plan's PREVIOUS run of this problem
                                    slot -- match() registers every frame twice, "Step" then "Anchor" (mlp_reg.py:338-356).  When every
                                    problem of a call says so the plan keeps the target frame's k-d leaf blocks (one bitonic sort per
-                                   frame instead of one per train: 145 us at 4096 points, 673 us at 16384).  0 is always correct. */
+                                   frame instead of one per train: 145 us at 4096 points, 673 us at 16384).  0 is always correct; since
+                                   round 5 a non-zero value is VERIFIED on the device (a 64-bit position-dependent fingerprint of the staged
+                                   frame against the one stored with the leaves): a frame that differs is sorted again, never searched
+                                   through stale leaves. */
     int32_t reserved_;
 } creg_train_args;
 

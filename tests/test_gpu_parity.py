@@ -841,6 +841,40 @@ def test_train_same_target_keeps_the_frames_leaves_bit_identical(dev):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n_pts", [1500, 9000])
+def test_train_same_target_claim_is_verified_on_the_device(dev, n_pts):
+    """y_unchanged used to rest on the caller's word -- a buffer reused for the NEXT frame, or two registrars sharing a plan,
+    and the search ran through the previous frame's k-d leaves: wrong neighbours, no error.  Round 5: the launch that would sort the
+    frame compares a 64-bit position-dependent fingerprint of the staged frame with the one stored with the leaves and sorts again
+    when they differ.  A false claim (another frame; the same points in another order; one coordinate changed in its last bit) must
+    give exactly what an honest run gives, with both searches (1500 / 9000 points)."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    from oracle import models
+    seq = make_sequence("wx200_5", 32, 3, n_pts)
+    mats, cl, _ = initial_segmentation(seq[0], 7, seed=2)
+    m = torch.tensor(mats, dtype=torch.float32, device=dev)
+    pts, off = ops.pack_clusters([torch.tensor(c, dtype=torch.float32) for c in cl], dev)
+    y1 = torch.tensor(seq[1], dtype=torch.float32, device=dev)
+    g = torch.Generator().manual_seed(1)
+    bumped = y1.clone()
+    bumped[n_pts // 2, 1] = torch.nextafter(bumped[n_pts // 2, 1], torch.tensor(10.0, device=dev))
+    others = {"next frame": torch.tensor(seq[2], dtype=torch.float32, device=dev), "permuted": y1[torch.randperm(n_pts, generator=g).to(dev)],
+              "one ulp": bumped}
+    torch.manual_seed(5)
+    sd = models.QRegMLP(True, 64).state_dict()
+    params = lambda: [sd[k].clone().to(dev) for k in ops.Q_PARAM_ORDER]
+    flat = lambda o: torch.cat([t.reshape(-1) for t in o[:4]])
+    for name, y2 in others.items():
+        honest = ops.TrainPlan("q", 7, 64, pts.shape[0], n_pts, epochs=8, use_graph=True, device=dev)
+        honest.run(m, y1, pts, off, params())
+        want = flat(honest.run(m, y2, pts, off, params()))
+        lying = ops.TrainPlan("q", 7, 64, pts.shape[0], n_pts, epochs=8, use_graph=True, device=dev)
+        lying.run(m, y1, pts, off, params())
+        got = flat(lying.run(m, y2, pts, off, params(), same_target=True))
+        assert torch.equal(got.nan_to_num(), want.nan_to_num()), name
+
+
 @pytest.mark.parametrize("rot", ["q", "dq"])
 def test_train_hidden32_reference_golden_runs_on_the_plan(dev, golden, rot):
     """tests/golden/train_reference.npz is the reference's own train() at hidden 32 (300 epochs) -- a width the kernels are not
