@@ -293,8 +293,11 @@ def epoch_kernel_model(k_clusters, n_points, info):
     w23 = N_PARAMS - w1                                 # hidden + output rows (k_dw updates them)
     pruned = info["pruned_target_search"] and info["pruned_predicted_search"]
     nbt, nbp = info["nn_boxes_per_lane"]
-    nn_name = (f"k_nn_plan<{'true' if info['pruned_predicted_search'] else 'false'}, {info['nn_points_per_lane']}, {nbt}, "
-               f"{nbp if info['pruned_predicted_search'] else 2}>" if info["pruned_target_search"] else "k_nn_l1<4>")
+    if info.get("nn_queries_per_wave") == 16:            # round 5: sixteen queries per wave (frames above 4096 points)
+        nn_name = f"k_nn_rows<{nbt}, {nbp}>"
+    else:
+        nn_name = (f"k_nn_plan<{'true' if info['pruned_predicted_search'] else 'false'}, {info['nn_points_per_lane']}, {nbt}, "
+                   f"{nbp if info['pruned_predicted_search'] else 2}>" if info["pruned_target_search"] else "k_nn_l1<4>")
     return {
         # k_bd = two independent roles in one launch.  D: hidden + output rows, parameters + both Adam moments read and written
         # (24 B each), current activations, gradients.  B: W2 read once (its columns), the encoder rows + moments read and written,

@@ -215,3 +215,43 @@ def test_dq_autograd_formulas_match_the_oracle_values_and_gradients():
         sum((y * ww).sum() for y, ww in zip(ob, w)).backward()
         for x, y in zip(a, b):
             assert torch.allclose(x.grad, y.grad, atol=1e-12)
+
+
+def test_file_writer_is_bounded_and_does_not_mask_the_frame_loops_error():
+    """mlp_reg._FileWriter: at most MAX_PENDING frames wait behind the worker (a job pins a frame's device tensors), a
+    submit blocks instead of queueing more, the worker's error surfaces in close() -- unless another exception is already propagating,
+    which it must not replace."""
+    import sys
+    import threading
+    import time
+    from autourdf_amd import mlp_reg
+    w = mlp_reg._FileWriter()
+    gate, done = threading.Event(), []
+    w.submit(lambda: gate.wait(10))                       # the worker is busy with this one
+    for i in range(mlp_reg._FileWriter.MAX_PENDING):
+        w.submit(done.append, i)                         # fills the queue
+    t = threading.Thread(target=lambda: w.submit(done.append, "late"))
+    t.start()
+    time.sleep(0.3)
+    assert t.is_alive()                                  # the submit beyond the bound waits
+    gate.set()
+    t.join(10)
+    w.close()
+    assert done == list(range(mlp_reg._FileWriter.MAX_PENDING)) + ["late"]
+
+    def boom():
+        raise ValueError("disk full")
+
+    w = mlp_reg._FileWriter()
+    w.submit(boom)
+    time.sleep(0.2)
+    with pytest.raises(KeyError):
+        try:
+            raise KeyError("the frame loop's own error")
+        finally:
+            w.close(propagating=sys.exc_info()[0] is not None)
+    w = mlp_reg._FileWriter()
+    w.submit(boom)
+    time.sleep(0.2)
+    with pytest.raises(ValueError):
+        w.close()
