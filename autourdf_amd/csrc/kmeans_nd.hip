@@ -26,7 +26,11 @@ __device__ __forceinline__ double knd_fix_scale(double range, int n) {      // 2
     return ldexp(1.0, 62 - nb - e);
 }
 
-template <int DIM>
+// GL (round 5): the two label buffers live in the caller's workspace instead of LDS -- frames above 16384 points (the reference's
+// sklearn call has no cap; one workgroup still runs the whole k_means(): a 32768-point frame with 45 clusters takes ~0.1 ms per
+// Lloyd iteration, which the `--normal` branch, dominated by its O(N^2) neighbour search, does not notice).  Stores and loads of one
+// workgroup to global memory are ordered by its barriers.
+template <int DIM, bool GL = false>
 __global__ __launch_bounds__(KND_NT) void k_km_nd(const double* __restrict__ X, int n, const double* __restrict__ init, int k,
                                                  int max_iter, double tol_rel, double* __restrict__ centers, int* __restrict__ labels_out,
                                                  double* __restrict__ inertia, int* __restrict__ n_iter, double* __restrict__ far_d) {
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(KND_NT) void k_km_nd(const double* __restrict__ X, 
     double* Cw = C2 + 2 * (size_t)k * DIM;                        // [k][DIM + 1] sums | count
     unsigned long long* accI = (unsigned long long*)(Cw + (size_t)k * BW);   // [k][DIM + 1] exact sums | count
     double* s_sh = (double*)(accI + (size_t)k * BW);              // [k]
-    unsigned short* lab0 = (unsigned short*)(s_sh + k);
+    unsigned short* lab0 = GL ? (unsigned short*)(far_d + n) : (unsigned short*)(s_sh + k);
     unsigned short* lab[2] = {lab0, lab0 + n};
     __shared__ double sc[16], s_mean[DIM], s_tol, s_fscale, s_finv, s_dmax, s_fv[16];
     __shared__ int s_changed, s_done, s_strict, s_it, s_nempty, s_argmax, s_fi[16];
@@ -253,25 +257,30 @@ __global__ __launch_bounds__(KND_NT) void k_km_nd(const double* __restrict__ X, 
 }  // namespace creg
 using namespace creg;
 
-extern "C" size_t creg_kmeans_nd_workspace_bytes(int64_t n) { return align_up(sizeof(double) * (size_t)(n > 0 ? n : 1), 256); }
+constexpr int64_t KND_LDS_N = 16384;       // labels of frames up to this size stay in LDS
+extern "C" size_t creg_kmeans_nd_workspace_bytes(int64_t n) {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    return align_up(sizeof(double) * nn + (n > KND_LDS_N ? 2 * sizeof(unsigned short) * nn : 0), 256);
+}
 
 extern "C" int creg_kmeans_lloyd_nd_f64(const double* X, int64_t n, int32_t dim, const double* init, int32_t k, int32_t max_iter,
                                         double tol_rel, double* centers, int32_t* labels, double* inertia, int32_t* n_iter,
                                         void* workspace, size_t workspace_bytes, creg_stream_t stream) {
     CREG_REQUIRE(X && init && centers && labels && inertia && n_iter && workspace, "creg_kmeans_lloyd_nd_f64: null pointer");
     CREG_REQUIRE(dim == 6 || dim == 3, "creg_kmeans_lloyd_nd_f64: dim must be 6 ([xyz | 0.5 normal], the --normal branch) or 3");
-    CREG_REQUIRE(n >= 1 && n <= 16384 && k >= 1 && k <= KND_MAXK && max_iter >= 1,
-                 "creg_kmeans_lloyd_nd_f64: needs n <= 16384 and k <= %d (one workgroup, labels and centres in LDS)", KND_MAXK);
+    CREG_REQUIRE(n >= 1 && n < (1ll << 24) && k >= 1 && k <= KND_MAXK && max_iter >= 1,
+                 "creg_kmeans_lloyd_nd_f64: needs n < 2^24 and k <= %d (one workgroup, centres in LDS)", KND_MAXK);
     CREG_REQUIRE(workspace_bytes >= creg_kmeans_nd_workspace_bytes(n), "creg_kmeans_lloyd_nd_f64: workspace too small");
     const int bw = dim + 1;
-    const int smem = (int)(sizeof(double) * ((size_t)k * bw + 2 * (size_t)k * dim + (size_t)k * bw + (size_t)k * bw + k) + 2 * sizeof(unsigned short) * (size_t)n);
+    const bool gl = n > KND_LDS_N;
+    const int smem = (int)(sizeof(double) * ((size_t)k * bw + 2 * (size_t)k * dim + (size_t)k * bw + (size_t)k * bw + k) + (gl ? 0 : 2 * sizeof(unsigned short) * (size_t)n));
     auto go = [&](auto kern) -> int {
         CREG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         hipLaunchKernelGGL(kern, dim3(1), dim3(KND_NT), smem, (hipStream_t)stream, X, (int)n, init, k, max_iter, tol_rel, centers, labels,
                            inertia, n_iter, (double*)workspace);
         return CREG_OK;
     };
-    const int rc = dim == 6 ? go(k_km_nd<6>) : go(k_km_nd<3>);
+    const int rc = dim == 6 ? (gl ? go(k_km_nd<6, true>) : go(k_km_nd<6>)) : (gl ? go(k_km_nd<3, true>) : go(k_km_nd<3>));
     if (rc) return rc;
     CREG_LAUNCH_CHECK();
     return CREG_OK;

@@ -111,6 +111,23 @@ class BatchRegistrar:
         after "Step" on the same frames -- the plan keeps the frames' k-d leaf blocks."""
         return self.plan.run_batch(problems, lr=lr, stop=getattr(self, "stop", 200), same_target=same_target)
 
+    normal = False      # --normal (mlp_reg.py:190-203): the re-segmentation clusters [xyz | 0.5 n]
+
+    def _kmeans(self, frames64, inits):
+        """The S re-segmentations of a round (resample_cluster's k_means, mlp_reg.py:187-204): one launch for all sequences where the
+        frames fit, per sequence otherwise; under `normal` the 6-D form per sequence (normals: GPU neighbour search + host orientation)."""
+        if self.normal:
+            from .normals import point_features
+            km = []
+            for f, c in zip(frames64, inits):
+                feat, _ = point_features(f.cpu().numpy())
+                X6 = torch.as_tensor(feat, dtype=torch.float64, device=f.device).contiguous()
+                km.append(ops.kmeans_lloyd_nd(X6, torch.cat([c, torch.zeros_like(c)], 1).contiguous()))
+            return km
+        if frames64[0].shape[0] <= ops.KMEANS_BATCH_MAX_N and self.S <= 16 and inits[0].shape[0] <= 128:      # all S in one launch
+            return ops.kmeans_lloyd_batch(frames64, inits)
+        return [ops.kmeans_lloyd(f, c) for f, c in zip(frames64, inits)]
+
     def step(self, frames64, frames32=None):
         """frames64: list of S (N,3) fp64 device tensors (the next frame of every sequence)."""
         ys = frames32 if frames32 is not None else [f.to(torch.float32) for f in frames64]
@@ -124,10 +141,7 @@ class BatchRegistrar:
         ev = self.host_inverse.mark()
         t_all = M_all[:, :, :3, 3].to(torch.float64).contiguous()                 # one cast and one slice for all sequences
         inits = [t_all[i] for i in range(self.S)]
-        if frames64[0].shape[0] <= ops.KMEANS_BATCH_MAX_N and self.S <= 16 and len(self.seqs[0].off) - 1 <= 128:      # all S re-segmentations in one launch
-            km = ops.kmeans_lloyd_batch(frames64, inits)
-        else:
-            km = [ops.kmeans_lloyd(f, c) for f, c in zip(frames64, inits)]
+        km = self._kmeans(frames64, inits)
         inv_all = self.host_inverse(M_all, ev)                                    # float32 LAPACK inverse, as mlp_reg.py:211
         invs = [inv_all[i] for i in range(self.S)]
         if self.S <= ops.GROUP_BATCH_MAX and len({f.shape[0] for f in frames64}) == 1:
@@ -160,10 +174,7 @@ def _step_mlp_icp(self, frames64, frames32=None):
     M_all = torch.stack(Ms)                                                       # (S,K,4,4) float64: masked_icp's poses
     ev = self.host_inverse.mark()
     inits = [M[:, :3, 3].contiguous() for M in Ms]
-    if frames64[0].shape[0] <= ops.KMEANS_BATCH_MAX_N and self.S <= 16 and inits[0].shape[0] <= 128:
-        km = ops.kmeans_lloyd_batch(frames64, inits)
-    else:
-        km = [ops.kmeans_lloyd(f, c) for f, c in zip(frames64, inits)]
+    km = self._kmeans(frames64, inits)
     out = []
     inv_all = self.host_inverse(M_all, ev)                                        # float64 LAPACK inverse (mlp_reg.py:211,326)
     invs = [inv_all[i] for i in range(self.S)]

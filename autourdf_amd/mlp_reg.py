@@ -324,7 +324,7 @@ def match_all(data_dirs):
     segs = [Segments(d) for d in data_dirs]
     same = len({(sg.data_size, len(sg.pc_list[0].points)) for sg in segs}) == 1 and \
         all(len(p.points) == len(segs[0].pc_list[0].points) for sg in segs for p in sg.pc_list)
-    if not same or len(segs) < 1 or NORMAL:      # (--normal: the 6-D re-segmentation has no batched form)
+    if not same or len(segs) < 1:
         for i, d in enumerate(data_dirs):
             match(d, i)
         return
@@ -353,6 +353,7 @@ def match_all(data_dirs):
     hidden = models[0][0].encoder[0].out_features        # 512, but 3 for --r rpy (RegMLP(6, 3), mlp_reg.py:285)
     reg = BatchRegistrar(np.asarray(step_matrices, np.float32), [np.asarray(c, np.float64) for c in step_cluster_np], n,
                          len(segs), ROT, hidden, EPOCHS, USE_GRAPH, DEVICE, models=models)
+    reg.normal = NORMAL                                  # --normal: the re-segmentation over [xyz | 0.5 n], per sequence, inside the lock-step round
     losses = [[] for _ in segs]
     writer = _FileWriter()
     try:

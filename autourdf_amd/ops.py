@@ -177,7 +177,7 @@ def knn_normals(X: torch.Tensor, radius: float, max_nn: int, want_normals: bool 
     return normals, idx, cnt
 
 
-KMEANS_ND_MAX_N, KMEANS_ND_MAX_K = 16384, 128      # creg_kmeans_lloyd_nd_f64: labels + centres of one frame in one CU's LDS
+KMEANS_ND_MAX_N, KMEANS_ND_MAX_K = (1 << 24) - 1, 128      # creg_kmeans_lloyd_nd_f64: one workgroup, centres in LDS (labels too up to 16384 points, in the workspace above)
 KMEANS_BATCH_MAX_N = 16384         # labels + centres in one CU's LDS; the frame too up to 5120 points, from L2 above
 
 

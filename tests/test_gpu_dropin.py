@@ -84,7 +84,8 @@ def test_torchrun_world_size_one_of_the_dropin_module(workdir):
     np.testing.assert_array_equal(np.load(base / "V0000/matrix/0000.npy"), np.load(base / "V0001/matrix/0000.npy"))
 
 
-@pytest.mark.parametrize("rot,extra,nv", [("q", [], 2), ("dq", [], 2), ("q", ["--mlp_icp"], 2), ("6d", [], 2), ("q", [], 1), ("rpy", [], 1)])
+@pytest.mark.parametrize("rot,extra,nv", [("q", [], 2), ("dq", [], 2), ("q", ["--mlp_icp"], 2), ("6d", [], 2), ("q", [], 1), ("rpy", [], 1),
+                                          ("q", ["--normal"], 2)])
 def test_lock_step_run_equals_one_match_per_sequence(workdir, rot, extra, nv, monkeypatch):
     """main() registers all sequences in lock-step (match_all); --sequential is the reference's loop of match()
     calls.  Same frame-0 state + same model initialisation => identical files, bit for bit -- also for a single sequence

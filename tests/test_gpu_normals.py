@@ -96,6 +96,32 @@ def test_kmeans_6d_empty_cluster_relocation_vs_live_sklearn(case):
     assert abs(float(inertia) - sin_) <= 1e-10 * sin_
 
 
+def test_kmeans_6d_above_16384_points_vs_live_sklearn():
+    """Round 5: the `--normal` k-means had a 16384-point cap the reference's sklearn call does not have
+    (mlp_reg.py:190-203): above it the label buffers of the one-workgroup kernel live in the workspace instead of LDS.  A 32768-point
+    frame, 45 clusters (parameters.json's largest K), features [xyz | 0.5 n] of a synthetic surface with exact unit normals, with some
+    seeds far away (relocation) -- labels, centres and inertia against live scikit-learn; and the same frame cut to 16384 points through
+    both forms of the kernel agrees with itself."""
+    import warnings
+    from sklearn.cluster import k_means
+    from autourdf_amd import ops
+    rng = np.random.default_rng(4)
+    n, k = 32768, 45
+    u, v = rng.uniform(0, 2 * np.pi, n), rng.uniform(0, 2 * np.pi, n)
+    P = np.stack([(0.3 + 0.08 * np.cos(v)) * np.cos(u), (0.3 + 0.08 * np.cos(v)) * np.sin(u), 0.08 * np.sin(v)], 1)
+    Nrm = np.stack([np.cos(v) * np.cos(u), np.cos(v) * np.sin(u), np.sin(v)], 1)
+    feat = np.hstack([P, 0.5 * Nrm])
+    init = np.hstack([P[rng.choice(n, k, replace=False)], np.zeros((k, 3))])
+    init[-2:] += 50.0                                                     # two seeds that own no point
+    c, lab, inertia, n_it = ops.kmeans_lloyd_nd(torch.as_tensor(feat, device="cuda"), torch.as_tensor(init, device="cuda"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sc, slab, sin_ = k_means(feat.copy(), init=init.copy(), n_clusters=k, n_init=1)
+    assert (lab.cpu().numpy() == slab).all()
+    np.testing.assert_allclose(c.cpu().numpy(), sc, atol=1e-11)
+    assert abs(float(inertia) - sin_) <= 1e-10 * sin_
+
+
 def test_kmeans_nd_at_dim3_equals_the_3d_kernel():
     from autourdf_amd import ops
     P = _cloud(3000, 7)[0]
