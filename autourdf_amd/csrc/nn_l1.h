@@ -391,6 +391,9 @@ __device__ unsigned long long g_nn_stats[8];       // waves, candidates tested, 
 #define NN_STAT(i, v) do { } while (0)
 #endif
 constexpr int NN_ROWQ = 16;                        // queries per wave
+#ifndef NN_ROW_FIRST
+#define NN_ROW_FIRST 2                             // blocks loaded in the first trip: the nearest by bound + the next ones, speculatively
+#endif
 #ifndef NN_ROW_BATCH
 #define NN_ROW_BATCH 3                             // candidate blocks whose loads are in flight together after the first visit
 #endif
@@ -492,10 +495,23 @@ __device__ __forceinline__ void nn_l1_rows(const float4* __restrict__ qs4, int n
         const float pb = (ex + ey) + ez;
         return __ballot(valid && pb <= __uint_as_float((unsigned)(key >> 32))) != 0ull;
     };
-    {   // the block with the smallest bound: always visited
-        float bl[3], bh[3];
-        const int b = take_next(INFINITY, bl, bh);
-        if (b >= 0) { NN_STAT(2 + 4 * dir, 1); visit(tb.ts4[(size_t)b * 64 + lane]); }
+    {   // the first trip: the block with the smallest bound (always evaluated) and, their loads in flight with its own, the next
+        // NN_ROW_FIRST - 1 by bound (evaluated if some query still needs them afterwards) -- one dependent round trip instead of two
+        float bl[NN_ROW_FIRST][3], bh[NN_ROW_FIRST][3];
+        int bb[NN_ROW_FIRST];
+        bool open = true;
+#pragma unroll
+        for (int j = 0; j < NN_ROW_FIRST; ++j) {
+            bb[j] = open ? take_next(INFINITY, bl[j], bh[j]) : -1;
+            open = bb[j] >= 0;
+        }
+        float4 v[NN_ROW_FIRST];
+#pragma unroll
+        for (int j = 0; j < NN_ROW_FIRST; ++j) v[j] = tb.ts4[(size_t)max(bb[j], 0) * 64 + lane];
+        if (bb[0] >= 0) { NN_STAT(2 + 4 * dir, 1); visit(v[0]); }
+#pragma unroll
+        for (int j = 1; j < NN_ROW_FIRST; ++j)
+            if (bb[j] >= 0 && needed(bl[j], bh[j])) { NN_STAT(2 + 4 * dir, 1); visit(v[j]); }
     }
     // then batches of up to NN_ROW_BATCH: the next blocks by bound while the bound is <= the largest running distance of the wave's
     // queries (taken from the distances BEFORE the batch: a superset, r only shrinks), their loads in flight together; a block is
