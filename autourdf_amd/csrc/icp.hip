@@ -867,7 +867,10 @@ constexpr int ICP_CH = 64;                 // sources per k_icp_nn workgroup (4 
 constexpr int ICP_G = 1 << ICP_LG;         // lane groups of a wave = lanes per source
 constexpr int ICP_SPW = 64 >> ICP_LG;      // sources per wave
 constexpr int ICP_NNW = ICP_CH / ICP_SPW;  // waves of a k_icp_nn workgroup
-constexpr int ICP_SB = 64;                 // targets a lane group stages per batch (128 measured no better)
+#ifndef ICP_SB_N
+#define ICP_SB_N 64
+#endif
+constexpr int ICP_SB = ICP_SB_N;           // targets a lane group stages per batch (128 measured no better)
 constexpr int ICP_ST = 48;                 // doubles of per-cluster state: T[16] U[16] prev_fit prev_rmse done n_updates | a: x0 inv_w axis | shc[3] | b: x0 inv_w axis | g
 constexpr int ICP_NM = 17;                 // moments per chunk: count, sum d2, sum (s - shc), sum (d - shc), sum (s - shc)(d - shc)^T
 constexpr int ICP_GMAX = 64;               // the grid over the box's longest (a) and second longest (b) edge has g x g cells, g per
