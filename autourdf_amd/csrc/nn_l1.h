@@ -402,12 +402,16 @@ constexpr int NN_ROW_SLOTS = (NN_BLOCK / 64) * NN_ROWQ;      // query slots per 
 // qs4: the QUERY cloud in slot order (xyz, bits(original index); padding = index INT_MAX), 64 * nqblk slots in use (nqblk_dev: the
 // device-side count when the host only knows an upper bound); tb: the target blocks of 64 slots with their boxes (NB per lane);
 // T: the targets in ORIGINAL order, 4 floats per point (the winner's coordinates for the epilogue); lossp[group]: the wave's partial.
+// nqblk_host: the HOST's upper bound of the query cloud's blocks -- what the slot array and lossp are allocated for (4 groups per block).
+// The grid is cut in workgroups of NN_ROW_SLOTS = 128 slots = two blocks: with an odd bound the last workgroup's upper four waves lie past
+// both arrays and leave before any load or store (they used to read qs4 and write lossp[4 nqblk_host ..] into the carve padding).
 template <int NB, typename Epi, bool NBDEV, bool NQDEV>
-__device__ __forceinline__ void nn_l1_rows(const float4* __restrict__ qs4, int nqblk, const int* nqblk_dev, NnBlocks tb, int dir, Epi& epi, int blk,
+__device__ __forceinline__ void nn_l1_rows(const float4* __restrict__ qs4, int nqblk, const int* nqblk_dev, int nqblk_host, NnBlocks tb, int dir, Epi& epi, int blk,
                                            const int* stop_flag, const float* __restrict__ T, float* __restrict__ lossp) {
     const int tid = threadIdx.x, lane = tid & 63, q = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = blk * (NN_BLOCK / 64) + wave;             // this wave's 16-slot group of the query cloud
+    if (grp >= 4 * nqblk_host) return;                        // wave-uniform; nothing below synchronises the workgroup
     int stop = *stop_flag;
     int nblk = tb.nblk;
     if constexpr (NBDEV) nblk = *tb.nblk_dev;
@@ -420,7 +424,7 @@ __device__ __forceinline__ void nn_l1_rows(const float4* __restrict__ qs4, int n
         lox[gi] = bx[0]; loy[gi] = bx[BP]; loz[gi] = bx[2 * BP]; hix[gi] = bx[3 * BP]; hiy[gi] = bx[4 * BP]; hiz[gi] = bx[5 * BP];
     }
     const int slot = NN_ROWQ * grp + q;
-    const float4 qv = qs4[slot];               // (the slot arrays are allocated for the host's upper bound of blocks)
+    const float4 qv = qs4[slot];               // (inside the slot array: grp < 4 nqblk_host, the bound it is allocated for)
     stop = __builtin_amdgcn_readfirstlane(stop); nblk = __builtin_amdgcn_readfirstlane(nblk); nqblk = __builtin_amdgcn_readfirstlane(nqblk);
     const int qi = __float_as_int(qv.w);
     const bool valid = slot < 64 * nqblk && qi != 0x7fffffff;

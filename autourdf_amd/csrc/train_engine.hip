@@ -755,8 +755,8 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_rows(const float* A, const floa
     pb.tbox = (const float*)((const char*)pb.tbox + zb);
     pb.nblk_dev = (const int*)((const char*)pb.nblk_dev + zb);
     epi.shift(z);
-    if (bx < blocksA) nn_l1_rows<NBT, EngineEpi, false, true>(pb.ts4, 0, pb.nblk_dev, yb, 0, epi, bx, epi.stopped, B, epi.lossp_x);
-    else nn_l1_rows<NBP, EngineEpi, true, false>(yb.ts4, yb.nblk, nullptr, pb, 1, epi, bx - blocksA, epi.stopped, A, epi.lossp_y);
+    if (bx < blocksA) nn_l1_rows<NBT, EngineEpi, false, true>(pb.ts4, 0, pb.nblk_dev, pb.nblk, yb, 0, epi, bx, epi.stopped, B, epi.lossp_x);
+    else nn_l1_rows<NBP, EngineEpi, true, false>(yb.ts4, yb.nblk, nullptr, yb.nblk, pb, 1, epi, bx - blocksA, epi.stopped, A, epi.lossp_y);
 }
 
 // ------------------------------------------------------------------------------------------ control + cluster grads
@@ -1700,7 +1700,7 @@ static void launch_gbd(Plan* P, int epoch, hipStream_t s) {
 static void launch_nn(const Dims& D, const Ws& W, size_t bstride, int nz, hipStream_t s, int par = 0) {
     const EngineEpi epi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, bstride, &W.state[par].stopped};
     if (D.rows) {
-        const NnBlocks yb{W.ys4, W.ybox, D.nyb, nullptr}, pb{W.ps4, W.pbox, 0, W.sb + D.K};
+        const NnBlocks yb{W.ys4, W.ybox, D.nyb, nullptr}, pb{W.ps4, W.pbox, D.npb, W.sb + D.K};      // (pb.nblk: the host's bound, what ps4 / lossp_x are carved for)
         const int blocksA = cdiv(64 * D.npb, NN_ROW_SLOTS), blocksB = cdiv(64 * D.nyb, NN_ROW_SLOTS);
         const dim3 grid((blocksA + blocksB) * nz);
         auto go = [&](auto kern) {

@@ -21,7 +21,6 @@ import glob
 import json
 import os
 import queue
-import sys
 import threading
 
 import numpy as np
@@ -237,11 +236,17 @@ def register_sequence(seg, step_matrices, step_cluster_np, save_dir=None, mlp_ic
     model, model_rf = models if models is not None else _make_models()
     poses, best_losses = [np.asarray(step_matrices)], []
     writer = _FileWriter() if save_dir is not None else None
+    # (whether an exception of THIS frame loop is on its way out is tracked here: sys.exc_info() in a `finally` is also set when the
+    #  caller merely runs inside somebody's `except` block, and a genuine writer failure was then swallowed -- ADVICE r5)
+    failed = False
     try:
         _register_frames(seg, K, m_t, cl_t, cl_init, icp_src, model, model_rf, mlp_icp, save_dir, writer, poses, best_losses)
+    except BaseException:
+        failed = True
+        raise
     finally:
         if writer is not None:
-            writer.close(propagating=sys.exc_info()[0] is not None)
+            writer.close(propagating=failed)
     return poses, best_losses
 
 
@@ -356,6 +361,7 @@ def match_all(data_dirs):
     reg.normal = NORMAL                                  # --normal: the re-segmentation over [xyz | 0.5 n], per sequence, inside the lock-step round
     losses = [[] for _ in segs]
     writer = _FileWriter()
+    failed = False
     try:
         for i in range(segs[0].data_size - 1):
             frames = [torch.as_tensor(np.asarray(sg.pc_list[i + 1].points), dtype=torch.float64, device=DEVICE) for sg in segs]
@@ -368,8 +374,11 @@ def match_all(data_dirs):
             ev = torch.cuda.Event()
             ev.record()
             writer.submit(_fetch_and_save, save_dirs, i + 1, stacked, ev, losses)
+    except BaseException:
+        failed = True
+        raise
     finally:
-        writer.close(propagating=sys.exc_info()[0] is not None)
+        writer.close(propagating=failed)
     if LOSS:
         for sd, l in zip(save_dirs, losses):
             np.savetxt(sd + "loss.txt", l)

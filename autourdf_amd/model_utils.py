@@ -52,8 +52,8 @@ class DQRegMLP(nn.Module):
 
 
 class RRegMLP(nn.Module):
-    """[t | 6-D rotation] (K,9) -> (t + dt, r6d + dr); model_utils.py:170-214 (--r 6d).  Trained by the
-    compatibility loop of mlp_reg (PyTorch MLP/Adam + HIP Chamfer and calculate_pc kernels)."""
+    """[t | 6-D rotation] (K,9) -> (t + dt, r6d + dr); model_utils.py:170-214 (--r 6d).  Trained by the same
+    device-resident plan as the other three (rot code 2: `k_head<., true>` takes the ninth output unit, k_bd's X instance the 72 input features)."""
 
     def __init__(self, hidden_dim=512):
         super().__init__()

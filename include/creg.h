@@ -337,9 +337,12 @@ typedef struct creg_train_shape {
                              directions; 2 = as 0, but always the four-queries-per-wave search of rounds 2-4.  Round 5: under 0,
                              frames of 4097..16384 target points (and a predicted cloud of at most 512 64-point blocks) take the
                              sixteen-queries-per-wave search (nn_l1.h: nn_l1_rows; franka shape 80.7 -> 104.2 frames/s).  Matches,
-                             distances, gradients and every trained parameter do not depend on it; the LOSS is summed per 16-slot
-                             group there instead of per 32 original indices and can differ in its last bit
-                             (creg_train_plan_info says what a plan chose). */
+                             distances and the gradients of an epoch do not depend on it; the LOSS is summed per 16-slot group there
+                             instead of per 32 original indices and can differ in its last bit -- and the loss feeds comparisons
+                             (min_loss / best pose, ReduceLROnPlateau, early stop): a last-bit flip AT one of them changes lr or the
+                             returned pose from there on, so trained parameters agree between searches only as far as no such
+                             comparison is that close (none seen in the stress runs, not guaranteed).
+                             creg_train_plan_info says what a plan chose (pruned_target_search is TRI-state: 0, 1, 2). */
 } creg_train_shape;
 
 typedef struct creg_train_args {

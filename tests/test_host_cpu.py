@@ -255,3 +255,36 @@ def test_file_writer_is_bounded_and_does_not_mask_the_frame_loops_error():
     time.sleep(0.2)
     with pytest.raises(ValueError):
         w.close()
+
+
+def test_register_sequence_surfaces_a_writer_failure_inside_a_callers_except_block(monkeypatch, tmp_path):
+    """`finally: writer.close(propagating=sys.exc_info()[0] is not None)` was also true when register_sequence was merely
+    CALLED from inside somebody's `except` block -- a genuine file-writer failure was then swallowed and the frames were lost without a
+    message.  The frame loop now tracks its own failure: the writer's error comes out, the loop's own error is still never replaced."""
+    import time
+    import torch
+    from autourdf_amd import mlp_reg
+
+    def boom():
+        raise ValueError("disk full")
+
+    def frames_ok(seg, K, m_t, cl_t, cl_init, icp_src, model, model_rf, mlp_icp, save_dir, writer, poses, best_losses):
+        writer.submit(boom)
+        time.sleep(0.2)
+
+    def frames_fail(*a):
+        a[10].submit(boom)
+        time.sleep(0.2)
+        raise KeyError("the frame loop's own error")
+
+    monkeypatch.setattr(mlp_reg, "DEVICE", torch.device("cpu"))
+    monkeypatch.setattr(mlp_reg, "_register_frames", frames_ok)
+    args = (None, np.eye(4)[None].repeat(2, 0), [np.zeros((3, 3)), np.zeros((2, 3))])
+    with pytest.raises(ValueError, match="disk full"):
+        try:
+            raise RuntimeError("the caller is handling something else")
+        except RuntimeError:
+            mlp_reg.register_sequence(*args, save_dir=str(tmp_path) + "/", models=(None, None))
+    monkeypatch.setattr(mlp_reg, "_register_frames", frames_fail)
+    with pytest.raises(KeyError):
+        mlp_reg.register_sequence(*args, save_dir=str(tmp_path) + "/", models=(None, None))

@@ -1,12 +1,14 @@
 #!/bin/bash
 # The GPU suite (a) against the AddressSanitizer build and (b) against the UBSan build of libcreg's host side (python -m
-# autourdf_amd.build --asan / --ubsan, built in the build container; the .so files travel with the snapshot), and (c) with the
+# autourdf_amd.build --asan / --ubsan: built HERE, on demand -- hipcc is on the GPU box too; the two libraries are listed in
+# .gpurunignore, so no snapshot carries them), and (c) with the
 # background contention streams (CREG_TEST_CONTENTION=1).  SURVEY section 5 / VERDICT r4 item 8.
 # ASan's runtime is gcc's libasan: ROCm's own intercepts the HSA allocator and aborts in hipInit without the -asan ROCm stack.
 # Logs: gpurun_out/<tag>_{asan,ubsan,contention}_gpu_suite.log
 #     tools/run_sanitizer_suite.sh r05
 tag=${1:-r05}
 mkdir -p gpurun_out
+python -m autourdf_amd.build --asan > gpurun_out/${tag}_sanitizer_build.log 2>&1 && python -m autourdf_amd.build --ubsan >> gpurun_out/${tag}_sanitizer_build.log 2>&1 || { echo "sanitizer build failed"; tail -5 gpurun_out/${tag}_sanitizer_build.log; exit 1; }
 asan_rt="/usr/lib/x86_64-linux-gnu/libasan.so.6 /usr/lib/x86_64-linux-gnu/libstdc++.so.6"     # (libstdc++ too: the runtime resolves __cxa_throw when it starts, before python has loaded any C++ library)
 # (ASan's dlopen interceptor makes libasan the "caller" of every dlopen, so libtorch's RUNPATH no longer finds its own lazily loaded
 #  libraries -- "libcaffe2_nvrtc.so: cannot open shared object file" in torch._C._cuda_init: name the directory)
