@@ -27,6 +27,12 @@ class TrainArgs(ctypes.Structure):
                 ("loss_hist", vp), ("lr_hist", vp), ("result", vp), ("y_unchanged", i32), ("reserved_", i32)]
 
 
+class TrainState(ctypes.Structure):          # creg_train_state: the optimizer / control state creg_train_plan_resume continues from
+    _fields_ = [("exp_avg", ctypes.POINTER(vp)), ("exp_avg_sq", ctypes.POINTER(vp)), ("lr", f64), ("sched_best", f64),
+                ("step", i32), ("epochs_run", i32), ("sched_bad", i32), ("count", i32), ("best_epoch", i32), ("stopped", i32),
+                ("min_loss", f32), ("reserved_", i32)]
+
+
 class IcpProblem(ctypes.Structure):
     _fields_ = [("local", vp), ("world", vp), ("seg_offsets", vp), ("frame", vp), ("M", vp),
                 ("M_out", vp), ("world_out", vp), ("n_iter_out", vp), ("tgt_offsets", vp), ("world_offsets", vp)]
@@ -81,6 +87,7 @@ SIGNATURES = {
     "creg_train_plan_create": (ctypes.c_int, [ctypes.POINTER(TrainShape), vp, sz, ctypes.POINTER(vp)]),
     "creg_train_plan_run": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), vp]),
     "creg_train_plan_run_batch": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), i32, vp]),
+    "creg_train_plan_resume": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), ctypes.POINTER(TrainState), i32, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]),
     "creg_train_plan_probe": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), vp, vp, vp, vp, vp]),
     "creg_train_plan_profile": (ctypes.c_int, [vp, ctypes.POINTER(TrainArgs), i32, ctypes.POINTER(f32), vp]),
     "creg_train_plan_info": (ctypes.c_int, [vp, vp]),

@@ -1532,10 +1532,31 @@ __global__ __launch_bounds__(BD_THREADS, 4) void k_gbd(Dims D, Ws W0, int epoch,
 }
 
 // after the last epoch: the parameters of an odd number of optimizer steps sit in the second buffer; the copy-out reads the first
-__global__ __launch_bounds__(256) void k_params_home(Dims D, Ws W0, size_t bstride) {
+// The parameters change buffer with every optimizer step: after a run that took an odd number of them they sit in P1.  `sidx`: the
+// state the run ended in (epochs enqueued & 1), `step0`: the step count it started from (0 unless resumed from a caller's state).
+__global__ __launch_bounds__(256) void k_params_home(Dims D, Ws W0, size_t bstride, int sidx, int step0) {
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
-    if ((W.state[D.epochs & 1].step & 1) == 0) return;
+    if (((W.state[sidx].step - step0) & 1) == 0) return;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < D.NPAR; i += gridDim.x * 256) W.P[i] = W.P1[i];
+}
+
+// creg_train_plan_resume: the caller's optimizer / control state over what k_prep staged (both copies of the double-buffered struct),
+// and the state a run ended in as twelve doubles (the layout include/creg.h documents).
+struct ResumeState { double lr, sched_best; int step, epochs_run, sched_bad, count, best_epoch, stopped; float min_loss; };
+__global__ void k_set_state(Dims D, Ws W, ResumeState rs) {
+    if (threadIdx.x || blockIdx.x) return;
+    TrainState s = W.state[0];
+    s.lr = rs.lr; s.sched_best = rs.sched_best; s.sched_bad = rs.sched_bad; s.count = rs.count; s.stopped = rs.stopped; s.step = rs.step;
+    s.min_loss = rs.min_loss; s.epochs_run = rs.epochs_run; s.best_epoch = rs.best_epoch;
+    s.next_bc1 = W.bc1[min(rs.step + 1, D.epochs)]; s.next_bc2s = W.bc2s[min(rs.step + 1, D.epochs)];       // (k_prep, the launch before, filled the tables)
+    W.state[0] = s; W.state[1] = s;
+    W.result[0] = s.min_loss; W.result[1] = (float)s.epochs_run; W.result[2] = (float)s.lr; W.result[3] = (float)s.best_epoch;
+}
+__global__ void k_get_state(Ws W, int sidx, double* out) {
+    if (threadIdx.x || blockIdx.x) return;
+    const TrainState s = W.state[sidx];
+    out[0] = s.step; out[1] = s.epochs_run; out[2] = s.lr; out[3] = s.sched_best; out[4] = s.sched_bad; out[5] = s.count;
+    out[6] = (double)s.min_loss; out[7] = s.best_epoch; out[8] = s.stopped; out[9] = (double)s.last_loss; out[10] = 0.0; out[11] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -2186,7 +2207,7 @@ extern "C" int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train
         }
     }
     for (; e < D.epochs; ++e) enqueue_epoch(P, e, s);
-    hipLaunchKernelGGL(k_params_home, dim3(64, 1, P->B), dim3(256), 0, s, D, P->W, P->bstride);
+    hipLaunchKernelGGL(k_params_home, dim3(64, 1, P->B), dim3(256), 0, s, D, P->W, P->bstride, D.epochs & 1, 0);
     CREG_LAUNCH_CHECK();
     // results out, parameters back into the callers' tensors
     ParamMap pm[10];
@@ -2208,6 +2229,65 @@ extern "C" int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train
 
 extern "C" int creg_train_plan_run(creg_train_plan* plan, const creg_train_args* a, creg_stream_t stream) {
     return creg_train_plan_run_batch(plan, a, 1, stream);
+}
+
+// Round 6: a train continued from a caller-supplied optimizer / control state (torch.optim.Adam's exp_avg / exp_avg_sq / step,
+// ReduceLROnPlateau's best / num_bad_epochs / lr, train()'s min_loss / count: mlp_reg.py:41-50,96-119) -- checkpoint / resume of a
+// train, and what the teacher-forced late-epoch parity tests are built on (the oracle's state entering epoch e, ONE epoch of the plan).
+// Problem slot 0, eager launches (the kernels are the graph's; graph == eager is tested elsewhere).
+extern "C" int creg_train_plan_resume(creg_train_plan* plan, const creg_train_args* a, const creg_train_state* from, int32_t n_epochs,
+                                      float* const* exp_avg_out, float* const* exp_avg_sq_out, double* state_out, creg_stream_t stream) {
+    Plan* P = (Plan*)plan;
+    CREG_REQUIRE(P && a && from, "creg_train_plan_resume: null pointer");
+    CREG_REQUIRE(a->m && a->y && a->local_pts && a->seg_offsets && a->params && a->best_m && a->best_pred && a->result, "creg_train_plan_resume: null pointer in the problem");
+    CREG_REQUIRE(from->exp_avg && from->exp_avg_sq, "creg_train_plan_resume: the state needs both Adam moment arrays");
+    const Dims& D = P->D;
+    CREG_REQUIRE(n_epochs >= 1 && from->step >= 0 && from->epochs_run >= 0 && from->step + n_epochs <= D.epochs && from->epochs_run + n_epochs <= D.epochs,
+                 "creg_train_plan_resume: step %d / epochs_run %d + %d epochs exceed the plan's %d", from->step, from->epochs_run, n_epochs, D.epochs);
+    CREG_REQUIRE(from->lr >= 0.0 && from->sched_bad >= 0 && from->count >= 0, "creg_train_plan_resume: negative lr or counter");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = stage_inputs(P, a, 1, s);          // parameters into the parity-0 buffer, the activations of epoch "0" from them, state and moments zeroed
+    if (rc) return rc;
+    P->target_blocks_valid = false;
+    launch_sorts(P, s, 1);
+    ParamMap pm[10];
+    const int np = param_map(D, pm);
+    {
+        CopyTable T; T.count = 0;
+        for (int i = 0; i < np; ++i) {
+            CREG_REQUIRE(from->exp_avg[i] && from->exp_avg_sq[i], "creg_train_plan_resume: moment tensor %d is null", i);
+            copy_table_add(T, from->exp_avg[i], P->W.AM + pm[i].off, sizeof(float) * pm[i].count, s);
+            copy_table_add(T, from->exp_avg_sq[i], P->W.AV + pm[i].off, sizeof(float) * pm[i].count, s);
+        }
+        if (from->best_epoch >= 0) {            // the best so far is the caller's (kept when none of the resumed epochs improves on min_loss)
+            copy_table_add(T, a->best_m, P->W.best_m, sizeof(float) * 16 * D.K, s);
+            copy_table_add(T, a->best_pred, P->W.best_pred, sizeof(float) * 3 * D.NP, s);
+        }
+        copy_table_launch(T, s);
+    }
+    const ResumeState rs{from->lr, from->sched_best, from->step, from->epochs_run, from->sched_bad, from->count, from->best_epoch, from->stopped ? 1 : 0, from->min_loss};
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(64), 0, s, D, P->W, rs);
+    const int nz_keep = P->nz;
+    P->nz = 1;
+    for (int e = 0; e < n_epochs; ++e) enqueue_epoch(P, e, s);
+    P->nz = nz_keep;
+    hipLaunchKernelGGL(k_params_home, dim3(64, 1, 1), dim3(256), 0, s, D, P->W, P->bstride, n_epochs & 1, from->step);
+    if (state_out) hipLaunchKernelGGL(k_get_state, dim3(1), dim3(64), 0, s, P->W, n_epochs & 1, state_out);
+    CREG_LAUNCH_CHECK();
+    CopyTable T; T.count = 0;
+    for (int i = 0; i < np; ++i) {
+        copy_table_add(T, P->W.P + pm[i].off, a->params[i], sizeof(float) * pm[i].count, s);
+        if (exp_avg_out && exp_avg_out[i]) copy_table_add(T, P->W.AM + pm[i].off, exp_avg_out[i], sizeof(float) * pm[i].count, s);
+        if (exp_avg_sq_out && exp_avg_sq_out[i]) copy_table_add(T, P->W.AV + pm[i].off, exp_avg_sq_out[i], sizeof(float) * pm[i].count, s);
+    }
+    copy_table_add(T, P->W.best_m, a->best_m, sizeof(float) * 16 * D.K, s);
+    copy_table_add(T, P->W.best_pred, a->best_pred, sizeof(float) * 3 * D.NP, s);
+    copy_table_add(T, P->W.result, a->result, sizeof(float) * 4, s);
+    if (a->loss_hist) copy_table_add(T, P->W.loss_hist, a->loss_hist, sizeof(float) * D.epochs, s);
+    if (a->lr_hist) copy_table_add(T, P->W.lr_hist, a->lr_hist, sizeof(float) * D.epochs, s);
+    copy_table_launch(T, s);
+    CREG_LAUNCH_CHECK();
+    return CREG_OK;
 }
 
 extern "C" int creg_train_plan_probe(creg_train_plan* plan, const creg_train_args* a, float* m2, float* pred,
@@ -2336,6 +2416,229 @@ extern "C" int creg_debug_bd_stamps(double* out) {
 extern "C" int creg_debug_nn_stats(unsigned long long* out8, int reset) {
     CREG_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(creg::g_nn_stats), sizeof(unsigned long long) * 8));
     if (reset) { unsigned long long z[8] = {0}; CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_nn_stats), z, sizeof(z))); }
+    return CREG_OK;
+}
+#endif
+
+#ifdef CREG_XCD_PROBE
+// ---- Stage 1 of the XCD-resident train: a MEASUREMENT build (python -m autourdf_amd.build --variant xcd with
+// CREG_EXTRA_FLAGS=-DCREG_XCD_PROBE; tests/measure/xcd_stage1.py).  Two questions, two kernels:
+//   (a) what does a barrier among the workgroups of ONE XCD cost, a 4 KB hand-off included (every member writes its share with plain
+//       stores, everybody reads all of it)?  Members find each other at run time: a workgroup reads HW_REG_XCC_ID and takes a ticket
+//       from its XCD's counter -- nothing assumes blockIdx % 8.
+//   (b) what does the plan's nearest-neighbour launch cost when ONE problem's blocks are confined to ONE XCD's 32 CUs (problem =
+//       XCC_ID, the blocks handed out by a per-XCD queue)?
+namespace creg {
+__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u); }      // HW_REG_XCC_ID[3:0]
+__device__ __forceinline__ int ld_sc1(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ctl: 128-byte lines of ints.  line x (0..7): XCD x's arrival counter; line 8 + x: its member count; line 16: all members counted.
+// MODE 0 "XCD-local": plain payload stores, vmcnt(0), an atomic that STAYS in the XCD's L2 (workgroup scope: no sc1), sc1 polls and
+//   sc1 payload loads (L2-served: the vector L1 of the reading CU is bypassed) -- sound only because every member IS on this XCD.
+// MODE 1 the placement-independent recipe: plain stores, agent release, agent counter; relaxed poll, agent acquire, plain loads.
+// MODE 2 write-through: sc1 payload stores, vmcnt(0), agent counter; sc1 polls and loads.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_xcd_barrier(int* ctl, float* payload, int rounds, int skew, unsigned long long* ticks, int* errs) {
+    __shared__ int s_t, s_n;
+    const int tid = threadIdx.x;
+    const int x = xcc_id();
+    if (tid == 0) {
+        s_t = __hip_atomic_fetch_add(ctl + 32 * (8 + x), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(ctl + 32 * 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int it = 0;
+        while (ld_sc1(ctl + 32 * 16) < (int)gridDim.x && ++it < (1 << 22)) __builtin_amdgcn_s_sleep(8);
+        s_n = it < (1 << 22) ? ld_sc1(ctl + 32 * (8 + x)) : 0;
+    }
+    __syncthreads();
+    const int t = s_t, n = s_n;
+    if (n == 0) { if (tid == 0) { ticks[blockIdx.x] = ~0ull; atomicAdd(errs, 1 << 20); } return; }      // not co-resident: no barrier possible
+    const int per = 1024 / n, lo = t * per, hi = t == n - 1 ? 1024 : lo + per;      // this member's floats of the 4 KB
+    int bad = 0;
+    const unsigned long long t0 = wall_clock64();
+    for (int r = 0; r < rounds; ++r) {
+        float* buf = payload + (size_t)(2 * x + (r & 1)) * 1024;
+        if (skew && (t & 3) == 1) for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(32);      // uneven arrival
+        for (int i = lo + tid; i < hi; i += 256) {
+            const float v = (float)(r * 4096 + i + 1);
+            if (MODE == 2) __hip_atomic_store(buf + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else buf[i] = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (MODE == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (MODE == 0) __hip_atomic_fetch_add(ctl + 32 * x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_fetch_add(ctl + 32 * x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int it = 0;
+            while (ld_sc1(ctl + 32 * x) < n * (r + 1) && ++it < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+            if (it >= (1 << 22)) atomicAdd(errs, 1 << 20);
+            if (MODE == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        float4 v;
+        if (MODE == 1) v = ((const float4*)buf)[tid];
+        else { const u32x4v w = __builtin_amdgcn_raw_buffer_load_b128(buf_rsrc(buf, 4096), 16 * tid, 0, 16); v = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])); }
+        const float e = (float)(r * 4096 + 4 * tid + 1);
+        bad += (v.x != e) + (v.y != e + 1.f) + (v.z != e + 2.f) + (v.w != e + 3.f);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = wall_clock64();
+    if (tid == 0) ticks[blockIdx.x] = ((t1 - t0) << 8) | (unsigned)(x << 5) | (unsigned)min(n - 1, 31);
+    if (bad) atomicAdd(errs, bad);
+}
+
+// (b) ctl: line x of half `par`: XCD x's block queue head; line 8 + x: members seen (statistics).  The other half is zeroed for the
+// next launch.  WSCOPE: the queue atomics stay in the XCD's L2.
+template <bool ROWS, int NBT, int NBP, bool WSCOPE>
+__global__ __launch_bounds__(NN_BLOCK) void k_nn_xcd(const float* A, int na, const float* B, int nb, int blocksA, int blocksB, EngineEpi epi, NnBlocks yb,
+                                                     NnBlocks pb, size_t zstride, int nz, int* ctl, int par) {
+    __shared__ int s_bx;
+    const int x = xcc_id();
+    int* mine = ctl + 32 * (16 * par + x);
+    if (threadIdx.x == 0) {
+        ctl[32 * (16 * (par ^ 1) + x)] = 0;
+        ctl[32 * (16 * (par ^ 1) + 8 + x)] = 0;
+        __hip_atomic_fetch_add(mine + 32 * 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (x >= nz) return;
+    const size_t zb = x * zstride;
+    A = (const float*)((const char*)A + zb);
+    B = (const float*)((const char*)B + zb);
+    yb.ts4 = (const float4*)((const char*)yb.ts4 + zb);
+    yb.tbox = (const float*)((const char*)yb.tbox + zb);
+    pb.ts4 = (const float4*)((const char*)pb.ts4 + zb);
+    pb.tbox = (const float*)((const char*)pb.tbox + zb);
+    pb.nblk_dev = (const int*)((const char*)pb.nblk_dev + zb);
+    epi.shift(x);
+    for (;;) {
+        __syncthreads();                                   // the previous block's LDS partials have been read
+        if (threadIdx.x == 0)
+            s_bx = WSCOPE ? __hip_atomic_fetch_add(mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                          : __hip_atomic_fetch_add(mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int bx = s_bx;
+        if (bx >= blocksA + blocksB) return;
+        if constexpr (ROWS) {
+            if (bx < blocksA) nn_l1_rows<NBT, EngineEpi, false, true>(pb.ts4, 0, pb.nblk_dev, pb.nblk, yb, 0, epi, bx, epi.stopped, B, epi.lossp_x);
+            else nn_l1_rows<NBP, EngineEpi, true, false>(yb.ts4, yb.nblk, nullptr, yb.nblk, pb, 1, epi, bx - blocksA, epi.stopped, A, epi.lossp_y);
+        } else {
+            if (bx < blocksA) nn_l1_block_pruned<NBT, 1, EngineEpi, true, false>(A, na, 4, yb, 0, epi, bx, epi.stopped, B, 4);
+            else nn_l1_block_pruned<NBP, 1, EngineEpi, true, true>(B, nb, 4, pb, 1, epi, bx - blocksA, epi.stopped, A, 4);
+        }
+    }
+}
+}  // namespace creg
+
+// out (HOST, 64 doubles):
+//  [0..2]  barrier + 4 KB hand-off per round (us, slowest member), 256 workgroups on an idle chip: MODE 0 / 1 / 2;   [3..5] the same with uneven arrival
+//  [6..8]  payload words that arrived wrong, per MODE (both runs);   [9] members of the smallest XCD group, [10] of the largest
+//  [16] the plan's NN launch, one problem on the whole chip (us, 200 back to back)   [17] the same with `nz` problems in grid.z
+//  [18] XCD-confined, nz problems, agent-scope queue   [19] workgroup-scope queue   [20] 1 problem confined   [21] outputs identical to the plan's launch (1 / 0)
+//  [22] workgroups per XCD used   [24..31] workgroups that landed on XCD 0..7 in the last confined launch
+extern "C" int creg_debug_xcd_stage1(creg_train_plan* plan, const creg_train_args* a, int32_t nz, int32_t wg_per_cu, double* out, creg_stream_t stream) {
+    Plan* P = (Plan*)plan;
+    CREG_REQUIRE(P && a && out && nz >= 1 && nz <= 8 && nz <= P->B && wg_per_cu >= 1 && wg_per_cu <= 8, "creg_debug_xcd_stage1: bad argument");
+    const Dims& D = P->D; const Ws& W = P->W;
+    CREG_REQUIRE(D.nyb && D.npb && D.ppl == 1 && D.nbt == 1 && D.nbp == 2, "creg_debug_xcd_stage1: built for the configs[1] instance (64-point blocks, 1 + 2 boxes per lane)");
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < 64; ++i) out[i] = 0.0;
+    int* ctl = nullptr; float* payload = nullptr; unsigned long long* ticks = nullptr; int* errs = nullptr;
+    CREG_HIP(hipMalloc(&ctl, 4 * 32 * 32)); CREG_HIP(hipMalloc(&payload, 16 * 4096)); CREG_HIP(hipMalloc(&ticks, 8 * 1024)); CREG_HIP(hipMalloc(&errs, 4));
+    hipEvent_t e0, e1;
+    CREG_HIP(hipEventCreate(&e0)); CREG_HIP(hipEventCreate(&e1));
+    // ---- (a)
+    const int rounds = 200;
+    for (int skew = 0; skew < 2; ++skew)
+        for (int mode = 0; mode < 3; ++mode) {
+            CREG_HIP(hipMemsetAsync(ctl, 0, 4 * 32 * 32, s)); CREG_HIP(hipMemsetAsync(errs, 0, 4, s)); CREG_HIP(hipMemsetAsync(payload, 0, 16 * 4096, s));
+            if (mode == 0) hipLaunchKernelGGL(k_xcd_barrier<0>, dim3(256), dim3(256), 0, s, ctl, payload, rounds, skew ? 8 : 0, ticks, errs);
+            else if (mode == 1) hipLaunchKernelGGL(k_xcd_barrier<1>, dim3(256), dim3(256), 0, s, ctl, payload, rounds, skew ? 8 : 0, ticks, errs);
+            else hipLaunchKernelGGL(k_xcd_barrier<2>, dim3(256), dim3(256), 0, s, ctl, payload, rounds, skew ? 8 : 0, ticks, errs);
+            CREG_LAUNCH_CHECK();
+            CREG_HIP(hipStreamSynchronize(s));
+            unsigned long long th[256]; int eh = 0;
+            CREG_HIP(hipMemcpy(th, ticks, sizeof(th), hipMemcpyDeviceToHost)); CREG_HIP(hipMemcpy(&eh, errs, 4, hipMemcpyDeviceToHost));
+            unsigned long long mx = 0; int nmin = 99, nmax = 0;
+            for (int i = 0; i < 256; ++i) { if (th[i] == ~0ull) continue; if ((th[i] >> 8) > mx) mx = th[i] >> 8; const int n = (int)(th[i] & 31) + 1; if (n < nmin) nmin = n; if (n > nmax) nmax = n; }
+            out[3 * skew + mode] = (double)mx / 100.0 / rounds;
+            out[6 + mode] += eh;
+            out[9] = nmin; out[10] = nmax;
+        }
+    // ---- (b)
+    std::vector<creg_train_args> all((size_t)nz, *a);
+    int rc = stage_inputs(P, all.data(), nz, s);
+    if (rc) return rc;
+    P->target_blocks_valid = false;
+    launch_sorts(P, s, nz);
+    const int nz_keep = P->nz;
+    P->nz = nz;
+    for (int e = 0; e < 20; ++e) enqueue_epoch(P, e, s);          // a few epochs in: the clouds as a train sees them
+    launch_head(P, 0, s);
+    CREG_LAUNCH_CHECK();
+    const int REP = 200;
+    float ms = 0.f;
+    auto timed = [&](auto launch, double* o) -> int {
+        launch(0);
+        CREG_HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < REP; ++i) launch(i + 1);
+        CREG_HIP(hipEventRecord(e1, s));
+        CREG_HIP(hipStreamSynchronize(s));
+        CREG_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *o = ms * 1000.0 / REP;
+        return CREG_OK;
+    };
+    if (int r2 = timed([&](int) { launch_nn(D, W, P->bstride, 1, s); }, out + 16)) return r2;
+    if (int r2 = timed([&](int) { launch_nn(D, W, P->bstride, nz, s); }, out + 17)) return r2;
+    const EngineEpi epi{W.sgn_x, W.cnt4, W.lossp_x, W.lossp_y, P->bstride, &W.state[0].stopped};
+    const NnBlocks yb{W.ys4, W.ybox, D.nyb, nullptr}, pb{W.ps4, W.pbox, D.rows ? D.npb : 0, W.sb + D.K};
+    int blocksA, blocksB;
+    if (D.rows) { blocksA = cdiv(64 * D.npb, NN_ROW_SLOTS); blocksB = cdiv(64 * D.nyb, NN_ROW_SLOTS); }
+    else { const NnGrid g = nn_grid(D.NP, D.NT, true, true, 4); blocksA = g.blocksA; blocksB = g.blocksB; }
+    const int grid = 8 * 32 * wg_per_cu;
+    auto xl = [&](int i, int nzz, bool wscope) {
+        const int par = i & 1;
+#define CREG_XCD_GO(R, WS) hipLaunchKernelGGL((k_nn_xcd<R, 1, 2, WS>), dim3(grid), dim3(NN_BLOCK), 0, s, (const float*)W.pred4, D.NP, (const float*)W.y4, D.NT, \
+                                              blocksA, blocksB, epi, yb, pb, P->bstride, nzz, ctl, par)
+        if (D.rows) { if (wscope) CREG_XCD_GO(true, true); else CREG_XCD_GO(true, false); }
+        else { if (wscope) CREG_XCD_GO(false, true); else CREG_XCD_GO(false, false); }
+#undef CREG_XCD_GO
+    };
+    CREG_HIP(hipMemsetAsync(ctl, 0, 4 * 32 * 32, s));
+    if (int r2 = timed([&](int i) { xl(i, nz, false); }, out + 18)) return r2;
+    CREG_HIP(hipMemsetAsync(ctl, 0, 4 * 32 * 32, s));
+    if (int r2 = timed([&](int i) { xl(i, nz, true); }, out + 19)) return r2;
+    CREG_HIP(hipMemsetAsync(ctl, 0, 4 * 32 * 32, s));
+    if (int r2 = timed([&](int i) { xl(i, 1, true); }, out + 20)) return r2;
+    {   // identical outputs: loss partials, sign bits and scatter counters of every problem after ONE launch of either kind
+        const size_t nl = (size_t)D.nbx + D.nby;
+        std::vector<float> l0(nl * nz), l1(nl * nz); std::vector<int> s0((size_t)D.NP * nz), s1((size_t)D.NP * nz), c0((size_t)4 * D.NP * nz), c1((size_t)4 * D.NP * nz);
+        auto grab = [&](std::vector<float>& l, std::vector<int>& sg, std::vector<int>& c) -> int {
+            CREG_HIP(hipStreamSynchronize(s));
+            for (int z = 0; z < nz; ++z) {
+                const Ws Wz = ws_shift(W, (size_t)z * P->bstride);
+                CREG_HIP(hipMemcpy(l.data() + nl * z, Wz.lossp_x, 4 * (size_t)D.nbx, hipMemcpyDeviceToHost));
+                CREG_HIP(hipMemcpy(l.data() + nl * z + D.nbx, Wz.lossp_y, 4 * (size_t)D.nby, hipMemcpyDeviceToHost));
+                CREG_HIP(hipMemcpy(sg.data() + (size_t)D.NP * z, Wz.sgn_x, 4 * (size_t)D.NP, hipMemcpyDeviceToHost));
+                CREG_HIP(hipMemcpy(c.data() + (size_t)4 * D.NP * z, Wz.cnt4, 16 * (size_t)D.NP, hipMemcpyDeviceToHost));
+            }
+            return CREG_OK;
+        };
+        launch_head(P, 0, s); launch_nn(D, W, P->bstride, nz, s);
+        if (int r2 = grab(l0, s0, c0)) return r2;
+        launch_head(P, 0, s);
+        CREG_HIP(hipMemsetAsync(ctl, 0, 4 * 32 * 32, s));
+        xl(0, nz, true);
+        if (int r2 = grab(l1, s1, c1)) return r2;
+        out[21] = (memcmp(l0.data(), l1.data(), 4 * l0.size()) == 0 && s0 == s1 && c0 == c1) ? 1.0 : 0.0;
+        int ch[32 * 32];
+        CREG_HIP(hipMemcpy(ch, ctl, sizeof(ch), hipMemcpyDeviceToHost));
+        for (int x = 0; x < 8; ++x) out[24 + x] = ch[32 * (8 + x)];
+    }
+    out[22] = 32 * wg_per_cu;
+    CREG_LAUNCH_CHECK();
+    P->nz = nz_keep;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(ctl); (void)hipFree(payload); (void)hipFree(ticks); (void)hipFree(errs);
     return CREG_OK;
 }
 #endif

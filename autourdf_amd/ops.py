@@ -683,6 +683,53 @@ class TrainPlan:
             self._unpad(pd)
         return outs
 
+    #: scalar fields of a train's control state (creg_train_state; `state_out` of creg_train_plan_resume holds them in this order + last_loss)
+    STATE_FIELDS = ("step", "epochs_run", "lr", "sched_best", "sched_bad", "count", "min_loss", "best_epoch", "stopped")
+
+    def resume(self, m, y, pts, offsets, params, state, n_epochs=1, factor=0.7, patience=5, stop=200, best=None):
+        """`n_epochs` further epochs of one train from a caller-supplied optimizer / control state (creg_train_plan_resume): checkpoint /
+        resume, and the teacher-forced parity hook.  `state`: dict with `exp_avg`, `exp_avg_sq` (lists of fp32 CUDA tensors shaped like
+        `params`: torch.optim.Adam's moments) and the scalars of STATE_FIELDS (missing ones default to a fresh train's).  `best`:
+        (best_m (k,4,4), best_pred (n_pred,3)) so far, required when state['best_epoch'] >= 0.  `params` are updated in place.
+        Returns (best_m, best_pred, result, loss_hist, lr_hist, state_after) -- state_after like `state`, its scalars read back
+        (synchronises the stream for them)."""
+        if self.hidden_model != self.hidden:
+            raise ValueError("resume needs the model at one of the kernels' widths (64, 128, 256, 512): no zero-padding of the moments")
+        n = 6 if self.rot == 1 else 10
+        ea, es = list(state["exp_avg"]), list(state["exp_avg_sq"])
+        if len(ea) != n or len(es) != n:
+            raise ValueError(f"expected {n} moment tensors of each kind")
+        for q, p in zip(ea + es, list(params) * 2):
+            if not (q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and q.numel() == p.numel()):
+                raise TypeError("Adam moments must be contiguous fp32 CUDA tensors shaped like the parameters")
+        o = self._outs()
+        best_epoch = int(state.get("best_epoch", -1))
+        if best_epoch >= 0:
+            if best is None:
+                raise ValueError("state['best_epoch'] >= 0 needs best=(best_m, best_pred)")
+            o[0].copy_(best[0]); o[1].copy_(best[1])
+        a = self._args(m, y, pts, offsets, params, float(state.get("lr", 2e-4)), factor, patience, stop, o)
+        st = _lib.TrainState()
+        arr_a = (ctypes.c_void_p * n)(*[q.data_ptr() for q in ea])
+        arr_s = (ctypes.c_void_p * n)(*[q.data_ptr() for q in es])
+        st.exp_avg, st.exp_avg_sq = ctypes.cast(arr_a, ctypes.POINTER(ctypes.c_void_p)), ctypes.cast(arr_s, ctypes.POINTER(ctypes.c_void_p))
+        st.lr, st.sched_best = float(state.get("lr", 2e-4)), float(state.get("sched_best", float("inf")))
+        st.step, st.epochs_run = int(state.get("step", 0)), int(state.get("epochs_run", state.get("step", 0)))
+        st.sched_bad, st.count, st.best_epoch, st.stopped = int(state.get("sched_bad", 0)), int(state.get("count", 0)), best_epoch, int(state.get("stopped", 0))
+        st.min_loss = float(state.get("min_loss", 1000.0))
+        ea2, es2 = [torch.empty_like(q) for q in ea], [torch.empty_like(q) for q in es]
+        out_a = (ctypes.c_void_p * n)(*[q.data_ptr() for q in ea2])
+        out_s = (ctypes.c_void_p * n)(*[q.data_ptr() for q in es2])
+        sc = torch.empty(12, dtype=torch.float64, device=self.device)
+        _lib.check(self.L.creg_train_plan_resume(self.plan, ctypes.byref(a), ctypes.byref(st), int(n_epochs),
+                                                 ctypes.cast(out_a, ctypes.POINTER(ctypes.c_void_p)), ctypes.cast(out_s, ctypes.POINTER(ctypes.c_void_p)),
+                                                 _p(sc), _stream()), "creg_train_plan_resume")
+        h = sc.cpu().tolist()
+        after = {"exp_avg": ea2, "exp_avg_sq": es2, "last_loss": h[9]}
+        for i, k in enumerate(self.STATE_FIELDS):
+            after[k] = h[i] if k in ("lr", "sched_best", "min_loss") else int(h[i])
+        return o[0], o[1], o[4], o[2], o[3], after
+
     def probe(self, m, y, pts, offsets, params):
         """One forward + pose-gradient evaluation (test hook): (m2, pred, loss, grad_m2)."""
         dev = self.device

@@ -401,6 +401,33 @@ int creg_train_plan_run_batch(creg_train_plan* plan, const creg_train_args* args
 int creg_train_plan_info(const creg_train_plan* plan, creg_train_plan_info_t* info);
 int creg_train_plan_destroy(creg_train_plan* plan);
 
+/* Round 6: a train continued from a caller-supplied state -- checkpoint / resume of `train`, and the hook the teacher-forced
+ * late-epoch parity tests use (the reference's state entering epoch e, then ONE epoch of the plan).  What the reference keeps in Python
+ * objects between epochs (mlp_reg.py:41-50 optimizer + scheduler, :96-119 the loop): torch.optim.Adam's exp_avg / exp_avg_sq per tensor
+ * and its step count, ReduceLROnPlateau's best / num_bad_epochs / the current lr, train()'s own min_loss / count. */
+typedef struct creg_train_state {
+    float* const* exp_avg;      /* HOST array of device pointers: Adam's first moments, order and shapes of creg_train_args.params */
+    float* const* exp_avg_sq;   /* ... second moments */
+    double lr;                  /* the lr the NEXT optimizer step uses (optimizer.param_groups[0]['lr']) */
+    double sched_best;          /* ReduceLROnPlateau.best (+inf before the first scheduler.step) */
+    int32_t step;               /* optimizer steps taken so far */
+    int32_t epochs_run;         /* epochs completed so far (= step unless stopped): the index the next loss is recorded at */
+    int32_t sched_bad;          /* ReduceLROnPlateau.num_bad_epochs */
+    int32_t count;              /* epochs since the loss last improved (mlp_reg.py:104-111) */
+    int32_t best_epoch;         /* epoch min_loss was seen at; -1: none yet (then best_m / best_pred of the args are outputs only) */
+    int32_t stopped;            /* != 0: the train had stopped early (the resumed epochs then change nothing) */
+    float min_loss;             /* 1000 before the first epoch (mlp_reg.py:53) */
+    int32_t reserved_;
+} creg_train_state;
+/* Runs `n_epochs` further epochs of problem `args` (slot 0 of the plan, eager launches) from `from`; from->step + n_epochs and
+ * from->epochs_run + n_epochs must not exceed shape.epochs.  args->params: in (the parameters entering the resumed epochs) / out;
+ * args->best_m / best_pred: in (when from->best_epoch >= 0) / out; loss_hist / lr_hist: entries [from->epochs_run, + n_epochs) are
+ * written, the others are NaN.  exp_avg_out / exp_avg_sq_out (HOST arrays of device pointers, may be NULL): the moments after the
+ * run; state_out (DEVICE, 12 doubles, may be NULL): [step, epochs_run, lr, sched_best, sched_bad, count, min_loss, best_epoch,
+ * stopped, last_loss, 0, 0].  Asynchronous like creg_train_plan_run.  The next run_batch re-sorts its target frames. */
+int creg_train_plan_resume(creg_train_plan* plan, const creg_train_args* args, const creg_train_state* from, int32_t n_epochs,
+                           float* const* exp_avg_out, float* const* exp_avg_sq_out, double* state_out, creg_stream_t stream);
+
 /* Test / profiling hook: run exactly one epoch's forward and return intermediates.
  * m2 (k,4,4), pred (n_pred,3), loss (1), grad_m2 (k,4,4: [dL/dR | dL/dt]); any may be NULL. */
 int creg_train_plan_probe(creg_train_plan* plan, const creg_train_args* args, float* m2,

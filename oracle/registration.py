@@ -44,14 +44,35 @@ def pose_forward(m, model, rot):
     return m2
 
 
+def _train_snapshot(model, opt, sched, epoch, min_loss, count, best_epoch, best_m, best_pcd):
+    """The state ENTERING `epoch` (after `epoch` completed epochs), as creg_train_state carries it (include/creg.h): parameters, Adam's
+    moments and step count, ReduceLROnPlateau's best / num_bad_epochs / lr, train()'s min_loss / count / best so far."""
+    ps = list(model.parameters())
+    st = [opt.state[p] for p in ps] if len(opt.state) else None
+    return {"params": {n: p.detach().clone() for n, p in model.named_parameters()},
+            "exp_avg": {n: (opt.state[p]["exp_avg"].clone() if st else torch.zeros_like(p)) for n, p in model.named_parameters()},
+            "exp_avg_sq": {n: (opt.state[p]["exp_avg_sq"].clone() if st else torch.zeros_like(p)) for n, p in model.named_parameters()},
+            "step": int(st[0]["step"]) if st else 0, "epochs_run": epoch, "lr": float(opt.param_groups[0]["lr"]),
+            "sched_best": float(sched.best), "sched_bad": int(sched.num_bad_epochs), "count": int(count), "min_loss": float(min_loss),
+            "best_epoch": int(best_epoch), "stopped": 0,
+            "best_m": None if best_m is None else best_m.detach().clone(),
+            "best_pred": None if best_pcd is None else torch.cat([p.detach() for p in best_pcd], 0).clone()}
+
+
 def train(m, y, model, clusters, stop=200, learning_rate=0.0002, scheduler_patience=5,
-          scheduler_factor=0.7, rot="q", epochs=300):
+          scheduler_factor=0.7, rot="q", epochs=300, snapshot_at=(), snapshots=None):
+    """snapshot_at / snapshots (test infrastructure of the teacher-forced parity tests): for every epoch e in `snapshot_at` the dict
+    `snapshots[e]` receives the state entering epoch e (_train_snapshot) and, once the epoch has run, `loss`, `m2` and the parameter
+    gradients of that epoch under "epoch".  Nothing else changes: the trajectory is the plain train()'s."""
     opt = torch.optim.Adam(model.parameters(), lr=learning_rate)
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=scheduler_factor,
                                                        patience=scheduler_patience)
     min_loss, best_pcd, best_m, count = 1000, None, None, 0
+    best_epoch = -1
     losses, lrs = [], []
     for epoch in range(epochs):
+        if epoch in snapshot_at:
+            snapshots[epoch] = _train_snapshot(model, opt, sched, epoch, min_loss, count, best_epoch, best_m, best_pcd)
         m2 = pose_forward(m, model, rot)
         pred_list = calculate_pc(clusters, m2)
         loss, _ = chamfer_distance(torch.cat(pred_list, 0).unsqueeze(0), y.unsqueeze(0), norm=1)
@@ -60,14 +81,20 @@ def train(m, y, model, clusters, stop=200, learning_rate=0.0002, scheduler_patie
         lrs.append(opt.param_groups[0]["lr"])
         if lv < min_loss:
             min_loss, best_pcd, best_m, count = lv, pred_list, m2, 0
+            best_epoch = epoch
         else:
             count += 1
             if count > stop:
                 break
         opt.zero_grad()
         loss.backward()
+        if epoch in snapshot_at:
+            snapshots[epoch]["epoch"] = {"loss": lv, "m2": m2.detach().clone(),
+                                         "grad": {n: p.grad.detach().clone() for n, p in model.named_parameters()}}
         opt.step()
         sched.step(loss)
+    if epochs in snapshot_at:
+        snapshots[epochs] = _train_snapshot(model, opt, sched, epochs, min_loss, count, best_epoch, best_m, best_pcd)
     pred_np = [p.detach().cpu().numpy() for p in best_pcd]
     return pred_np, best_m, min_loss, {"loss": losses, "lr": lrs}
 
