@@ -52,23 +52,101 @@ STUB = os.environ.get("CREG_BENCH_STUB") == "1"      # CPU plumbing test: gloo +
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
+_ALL_THREADS_CHILD = r"""
+import os, sys, time
+n = int(sys.argv[2]); os.environ["OMP_NUM_THREADS"] = str(n)
+sys.path.insert(0, sys.argv[3])
+import numpy as np, torch
+torch.set_num_threads(n)
+from oracle import _clib, models, registration
+_clib.lib().oracle_set_threads(n)
+d = np.load(sys.argv[1])
+torch.manual_seed(0)
+m, y = torch.tensor(d["m"]), torch.tensor(d["y"])
+off = d["off"]; cl = [torch.tensor(d["pts"][off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+print("READY", flush=True)
+for ep in (1, 2):
+    t = time.perf_counter()
+    registration.train(m, y, models.QRegMLP(True, int(sys.argv[4])), cl, rot="q", epochs=ep)
+    print("DONE", ep, time.perf_counter() - t, flush=True)
+"""
+
+
+def _all_threads_probe(m, y, cl0, ncpu, cap_s=3.0):
+    """The port on ALL hardware threads of the box ("all host cores and 1") -- the pathological team size for latency-sized
+    work (a 256-thread fork-join per tensor op: one cold epoch took 17 s of the driver's 42 s run in round 5).  Run in a CHILD process and
+    abandoned `cap_s` seconds after the child has finished importing: a reported data point must not cost more than it is worth."""
+    import subprocess
+    import sys
+    import tempfile
+    import threading
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "p.npz")
+        off = np.cumsum([0] + [len(c) for c in cl0])
+        np.savez(path, m=m.numpy(), y=y.numpy(), pts=np.concatenate([c.numpy() for c in cl0]).astype(np.float32), off=off)
+        p = subprocess.Popen([sys.executable, "-c", _ALL_THREADS_CHILD, path, str(ncpu), os.path.dirname(os.path.abspath(__file__)), str(HIDDEN)],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        lines, ready = [], threading.Event()
+
+        def reader():
+            for ln in p.stdout:
+                lines.append(ln.split())
+                ready.set()
+
+        th = threading.Thread(target=reader, daemon=True)
+        th.start()
+        t_import = time.perf_counter()
+        while not any(l and l[0] == "READY" for l in lines) and p.poll() is None and time.perf_counter() - t_import < 90.0:
+            time.sleep(0.05)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < cap_s and p.poll() is None:
+            time.sleep(0.05)
+        if p.poll() is None:
+            p.kill()
+        p.wait()
+        th.join(timeout=2.0)
+    done = {int(l[1]): float(l[2]) for l in lines if l and l[0] == "DONE"}
+    if 2 in done:
+        return done[2] / 2, "two epochs after one untimed epoch, in a child process"
+    if 1 in done:
+        return done[1], f"ONE cold epoch of {done[1]:.2f} s in a child process (the second did not finish inside the {cap_s:.0f} s cap)"
+    return None, f"abandoned: not even one epoch inside the {cap_s:.0f} s cap (child process killed)"
+
+
 def cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters, budget_frames=2, budget_s=25.0):
-    """The oracle (CPU port of the reference path, `kind: "port"`) on the host cores: TWO full registered frames
-    (2 x 600 Adam epochs + 2 resamples) unless the box is so slow that a 25 s budget runs out first, in
-    which case the rest is extrapolated from the per-epoch time and the sample says so."""
-    from oracle import models, registration
-    from oracle import kmeans as okm
+    """The oracle (CPU port of the reference path, `kind: "port"`) on the host cores.  First the team sizes 1 / 8 / 16 / 32 / 64 are
+    timed (one untimed epoch, then three); `value` is then measured at the FASTEST of them (it used to be a
+    hard-coded 16 although 32 measured faster): TWO full registered frames (2 x 600 Adam epochs + 2 resamples) unless the
+    box is so slow that a 25 s budget runs out first, in which case the rest is extrapolated from the per-epoch time and the sample says
+    so.  The all-threads point runs in a child process under a 3 s cap."""
+    from oracle import _clib, models, registration
     torch.manual_seed(0)
-    # a 600-epoch frame is latency-sized work: more host threads than ~16 only add OpenMP / intra-op
-    # fork-join cost (256 threads ran 1000x slower than 16 on the GPU box), so cap the team size
-    threads = min(16, os.cpu_count() or 1)
-    os.environ["OMP_NUM_THREADS"] = str(threads)
-    torch.set_num_threads(threads)
-    model, model_rf = models.QRegMLP(True, HIDDEN), models.QRegMLP(True, HIDDEN)
+    ncpu = os.cpu_count() or 1
+
+    def team(nt):
+        os.environ["OMP_NUM_THREADS"] = str(nt)
+        torch.set_num_threads(nt)
+        _clib.lib().oracle_set_threads(nt)
+
     m = torch.tensor(mats0, dtype=torch.float32)
     cl = [torch.tensor(c, dtype=torch.float32) for c in clusters0]
     cl0 = [c.clone() for c in cl]
-    registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl, rot="q", epochs=2)   # warm caches / build the C lib
+    y1 = torch.tensor(seq0[1], dtype=torch.float32)
+    team(min(16, ncpu))
+    registration.train(m, y1, models.QRegMLP(True, HIDDEN), cl, rot="q", epochs=2)   # warm caches / build the C lib
+    team_points = {}
+    for nt in (1, 8, 16, 32, 64):
+        if nt > ncpu:
+            continue
+        team(nt)
+        registration.train(m, y1, models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=1)
+        tt = time.perf_counter()
+        n_ep = 3 if nt > 1 else 6
+        registration.train(m, y1, models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=n_ep)
+        team_points[nt] = (time.perf_counter() - tt) / n_ep
+    threads = min(team_points, key=team_points.get)
+    team(threads)
+    model, model_rf = models.QRegMLP(True, HIDDEN), models.QRegMLP(True, HIDDEN)
     t0 = time.perf_counter()
     epochs_done, frames_done, t_km = 0, 0, 0.0
     for f in range(budget_frames):
@@ -87,71 +165,33 @@ def cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters, budget_frames=2, 
     elapsed = time.perf_counter() - t0
     per_epoch = (elapsed - t_km) / max(epochs_done, 1)
     frame_s = elapsed / frames_done if frames_done else float("nan")
-    # the same port on ONE host thread (SURVEY 8(d) asks for both), a few epochs only
-    from oracle import _clib
-    os.environ["OMP_NUM_THREADS"] = "1"
-    torch.set_num_threads(1)
-    _clib.lib().oracle_set_threads(1)
-    t1 = time.perf_counter()
-    registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=6)
-    per_epoch_1 = (time.perf_counter() - t1) / 6
-    # the team sizes around the one `value` is taken at: ms per epoch at 8 / 32 / 64 threads (one untimed epoch, then three timed), so that
-    # "16 is the fastest team" is bracketed by neighbours and not only by 1 and all
-    ncpu = os.cpu_count() or 1
-    team_points = {1: round(per_epoch_1 * 1e3, 2), threads: round(per_epoch * 1e3, 2)}
-    for nt in (8, 32, 64):
-        if nt > ncpu or nt in team_points:
-            continue
-        os.environ["OMP_NUM_THREADS"] = str(nt)
-        torch.set_num_threads(nt)
-        _clib.lib().oracle_set_threads(nt)
-        registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=1)
-        tt = time.perf_counter()
-        registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=3)
-        team_points[nt] = round((time.perf_counter() - tt) / 3 * 1e3, 2)
-    # ... and on ALL hardware threads of the box ("all host cores and 1").  This is the slow configuration -- the work of an
-    # epoch (a 4096 x 4096 nearest-neighbour search, a 20-row MLP) is far too small for a 256-thread fork-join -- and it is why `value`
-    # is taken at 16 threads; the figure is reported, not used.  ONE epoch is run first; only if it took under 5 s are two more timed.
+    km_s = t_km / max(frames_done, 1)
     all_cores = None
-    if ncpu > threads:
-        os.environ["OMP_NUM_THREADS"] = str(ncpu)
-        torch.set_num_threads(ncpu)
-        _clib.lib().oracle_set_threads(ncpu)
-        t2 = time.perf_counter()
-        registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=1)
-        t_first = time.perf_counter() - t2
-        if t_first < 5.0:
-            t2 = time.perf_counter()
-            registration.train(m, torch.tensor(seq0[1], dtype=torch.float32), models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=2)
-            per_epoch_all = (time.perf_counter() - t2) / 2
-            what = "two epochs after one untimed epoch"
-        else:
-            per_epoch_all = t_first
-            what = (f"ONE cold epoch of {t_first:.1f} s, the team's spin-up included (nothing was run before it at this team size and nothing "
-                    "after it: a second epoch would double the bench's run time)")
-        all_cores = {"threads": ncpu, "ms_per_epoch": round(per_epoch_all * 1e3, 2),
-                     "value": 1.0 / (2 * EPOCHS * per_epoch_all + t_km / max(frames_done, 1)),
-                     "sample": what + ", extrapolated to 600 epochs + the measured resample"}
-        team_points[ncpu] = round(per_epoch_all * 1e3, 2)
-    torch.set_num_threads(threads)
-    os.environ["OMP_NUM_THREADS"] = str(threads)
-    _clib.lib().oracle_set_threads(threads)
+    if ncpu > max(team_points):
+        per_all, what = _all_threads_probe(torch.tensor(mats0, dtype=torch.float32), y1, cl0, ncpu)
+        all_cores = {"threads": ncpu, "ms_per_epoch": None if per_all is None else round(per_all * 1e3, 2),
+                     "value": None if per_all is None else 1.0 / (2 * EPOCHS * per_all + km_s),
+                     "sample": what + ("" if per_all is None else ", extrapolated to 600 epochs + the measured resample")}
+        team(threads)
     cpu_model = ""
     try:
         cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except Exception:
         pass
+    by = {str(k): round(v * 1e3, 2) for k, v in sorted(team_points.items())}
+    if all_cores is not None and all_cores["ms_per_epoch"] is not None:
+        by[str(ncpu)] = all_cores["ms_per_epoch"]
     return {"value": 1.0 / frame_s, "unit": "frames/s", "cores": threads, "kind": "port",
-            "one_thread": {"value": 1.0 / (2 * EPOCHS * per_epoch_1 + t_km / max(frames_done, 1)), "ms_per_epoch": round(per_epoch_1 * 1e3, 2),
+            "one_thread": {"value": 1.0 / (2 * EPOCHS * team_points[1] + km_s), "ms_per_epoch": round(team_points[1] * 1e3, 2),
                            "sample": "6 epochs, extrapolated to 600 + the measured resample"},
             "all_cores": all_cores,
-            "ms_per_epoch_by_threads": {str(k): v for k, v in sorted(team_points.items())},
-            "cores_note": f"`value` is taken at {threads} threads; ms_per_epoch_by_threads holds what this host measured at 1 / 8 / {threads} / 32 / 64 / all "
-                          f"threads in this run (fastest team here: {min(team_points, key=team_points.get)}); "
-                          "the port's OpenMP C search is also faster than pytorch3d's single-threaded knn_cpu, so the GPU / CPU ratio is conservative",
+            "ms_per_epoch_by_threads": by,
+            "cores_note": f"`value` is taken at {threads} threads, the FASTEST of the team sizes timed in this run (1 / 8 / 16 / 32 / 64: one untimed epoch, "
+                          "then three); the all-threads point runs in a child process under a 3 s cap; the port's OpenMP C search is also faster than "
+                          "pytorch3d's single-threaded knn_cpu, so the GPU / CPU ratio is conservative",
             "host": {"cpu_model": cpu_model, "os_cpu_count": os.cpu_count()},
             "sample": f"{frames_done} full registered frame(s) of sequence 0 (N={n_points}, K={k_clusters}, hidden {HIDDEN}): {epochs_done} Adam "
-                      f"epochs at {per_epoch * 1e3:.2f} ms/epoch + {frames_done} resample_cluster at {t_km / max(frames_done, 1) * 1e3:.1f} ms, "
+                      f"epochs at {per_epoch * 1e3:.2f} ms/epoch + {frames_done} resample_cluster at {km_s * 1e3:.1f} ms, "
                       f"{elapsed:.1f} s of host time, nothing extrapolated; oracle = torch-CPU MLP/Adam + OpenMP C L1-NN "
                       "(oracle/creg_oracle.c) + sklearn-equivalent Lloyd"}
 
@@ -183,15 +223,19 @@ def icp_variant(frames64, mats0, clusters0, dev, warm_rounds, timed_rounds):
     last = [fr[warm_rounds + timed_rounds - 1] for fr in frames64]
     worlds = [ops.cluster_transform(lo.to(torch.float32), of, M.to(torch.float32)) for lo, of, M in saved]
     probs = [(lo, w, of, f, M) for (lo, of, M), w, f in zip(saved, worlds, last)]
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 10
-    ops.masked_icp_batch(probs)
-    e0.record()
-    for _ in range(reps):
+    # (one bracket around ten launches gave 762 us on one box and 1463 us on another for the same five problems: the
+    #  MEDIAN of 24 individually bracketed launches after three warm-up launches, with the spread beside it)
+    reps = 24
+    for _ in range(3):
         ops.masked_icp_batch(probs)
-    e1.record()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    marks[0].record()
+    for i in range(reps):
+        ops.masked_icp_batch(probs)
+        marks[i + 1].record()
     torch.cuda.synchronize()
-    icp_us = e0.elapsed_time(e1) * 1e3 / reps
+    each = sorted(marks[i].elapsed_time(marks[i + 1]) * 1e3 for i in range(reps))
+    icp_us = each[reps // 2]
     r, fr = regs[0], last[0]
     n, nf, k = r.local.shape[0], fr.shape[0], r.off.shape[0] - 1
     it = float(torch.stack(iters).double().mean())
@@ -202,6 +246,7 @@ def icp_variant(frames64, mats0, clusters0, dev, warm_rounds, timed_rounds):
             "value": round(n_frames / dt, 2), "unit": "frames/s", "ms_per_frame": round(dt / n_frames * 1e3, 3),
             "frames_timed": n_frames, "mean_icp_iterations_per_cluster": round(it, 2),
             "roofline": {"bound": "hbm", "kernel": "k_masked_icp", "avg_launch_us": round(icp_us, 1),
+                         "launch_us_min_median_max": [round(each[0], 1), round(icp_us, 1), round(each[-1], 1)], "launches_timed": reps,
                          "achieved": round(alg / (icp_us * 1e-6) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(alg / (icp_us * 1e-6) / (HBM_PEAK_GBPS * 1e9), 6), "traffic": None,
                          "problems_per_launch": S,
@@ -237,6 +282,37 @@ class _StubRegistrar:
             r.m = m2
             out.append((m2, torch.tensor([float(m2[:, :3, 3].abs().sum()), EPOCHS, 1e-4, 0.0])))
         return out
+
+
+class _StubIcpRegistrar:
+    """CREG_BENCH_STUB=1 stand-in of engine.IcpRegistrar for run_c5's rank / sharding / gather logic (no kernel)."""
+
+    def __init__(self, mats0, clusters0, dev):
+        self.M = torch.as_tensor(np.asarray(mats0), dtype=torch.float64)
+        self.local, self.off = None, None
+
+    def step(self, f):
+        M = self.M.clone()
+        M[:, :3, 3] += 0.5 * (f.mean(0) - M[:, :3, 3].mean(0))
+        self.M = M
+        return M, None, torch.tensor([3])
+
+
+class _Mark:
+    """A timing mark on torch's current stream (an event), or wall clock under the CPU stub."""
+
+    def __init__(self):
+        self.ev = None if STUB else torch.cuda.Event(enable_timing=True)
+        self.t = 0.0
+
+    def record(self):
+        if self.ev is not None:
+            self.ev.record()
+        else:
+            self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return self.ev.elapsed_time(other.ev) if self.ev is not None else (other.t - self.t) * 1e3
 
 
 def _registrar_cls():
@@ -279,6 +355,43 @@ def clone_item(it):
         c["p_step"] = [p.clone() for p in it["p_step"]]
         c["p_anchor"] = [p.clone() for p in it["p_anchor"]]
     return c
+
+
+# ------------------------------------------------------------------------------------------ parity summary (BASELINE.md 2 "Reported")
+def parity_block(state0, frame64, frame32, k_clusters, dev, rot="q", hidden=HIDDEN):
+    """OUTSIDE the timed region, rank 0: the HIP path against the oracle on the first timed frame of sequence 0, from the state the
+    sequence ENTERED that frame with (`state0` = poses, local clusters + offsets, a copy of the "Step" model's parameters):
+      nn_idx_exact             every L1 nearest-neighbour index AND distance of both directions (predicted cloud <-> frame) bit-equal
+      labels_exact_fraction    k-means labels of the frame (seeded at the entering translations) equal to the oracle's
+      max_abs_dpose_8_epochs   largest |entry| difference of the [R|t] blocks train() returns after 8 epochs (inside the measured
+                               divergence horizon: the north star's 1e-5 is a statement about this regime)."""
+    from autourdf_amd import ops
+    from oracle import chamfer, kmeans as okm, models as omodels, registration as oreg
+    m, pts, off, p_step = state0
+    x = ops.cluster_transform(pts, off, m)
+    dx, ix, dy, iy = ops.nn_l1_bidir(x, frame32)
+    xn, yn = x.cpu().numpy(), frame32.cpu().numpy()
+    odx, oix = chamfer.nn_l1(xn, yn)
+    ody, oiy = chamfer.nn_l1(yn, xn)
+    nn_exact = bool((ix.cpu().numpy() == oix).all() and (iy.cpu().numpy() == oiy).all() and (dx.cpu().numpy() == odx).all() and (dy.cpu().numpy() == ody).all())
+    seeds = m[:, :3, 3].to(torch.float64).contiguous()
+    _, lab, _, n_it = ops.kmeans_lloyd(frame64, seeds)
+    _, olab, _, on_it = okm.k_means(frame64.cpu().numpy(), seeds.cpu().numpy())
+    lab_frac = float((lab.cpu().numpy() == olab).mean())
+    order = ops.DQ_PARAM_ORDER if rot == "dq" else ops.Q_PARAM_ORDER
+    params = [q.clone() for q in p_step]
+    plan = ops.TrainPlan(rot, k_clusters, hidden, pts.shape[0], frame32.shape[0], epochs=8, use_graph=True, device=dev)
+    bm, _, res, _, _ = plan.run(m, frame32, pts, off, params, lr=2e-4)
+    omodel = omodels.DQRegMLP(hidden) if rot == "dq" else omodels.QRegMLP(True, hidden)
+    omodel.load_state_dict({name: q.detach().cpu().clone() for name, q in zip(order, p_step)})
+    offh = off.cpu().numpy()
+    cl = [pts[offh[i]:offh[i + 1]].cpu() for i in range(len(offh) - 1)]
+    _, obest, omin, _ = oreg.train(m.cpu(), frame32.cpu(), omodel, cl, rot=rot, epochs=8)
+    dpose = float((bm.cpu() - obest.detach())[:, :3, :].abs().max())
+    return {"nn_idx_exact": nn_exact, "labels_exact_fraction": lab_frac, "kmeans_iterations": [int(n_it), int(on_it)],
+            "max_abs_dpose_8_epochs": dpose, "min_loss_rel_8_epochs": abs(float(res[0]) - omin) / abs(omin),
+            "against": "oracle/ (CPU restatement of the reference path) on the first timed frame of sequence 0, outside the timed region",
+            "bars": {"nn_idx_exact": True, "labels_exact_fraction": 1.0, "max_abs_dpose_8_epochs": 1e-5}}
 
 
 # ------------------------------------------------------------------------------------------ roofline block
@@ -420,10 +533,13 @@ def run_c5(args, ctx, robot, n_points, k_clusters, wl_tag):
     change of frame.  (The default path's 600 epochs of an N^2 Chamfer search are 8e13 pair evaluations per frame at
     this size.)  Work items (poses, local clusters, next frame) come from a sequential pass every rank repeats untimed;
     --steps items in total are dealt round-robin."""
-    from autourdf_amd import ops
     from autourdf_amd.distributed import gather_poses
-    from autourdf_amd.engine import IcpRegistrar
     from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    if STUB:                                            # CPU plumbing test: a stand-in registrar on a small cloud (tests/test_bench_cpu.py)
+        IcpRegistrar, n_points, k_clusters = _StubIcpRegistrar, 1024, 6
+    else:
+        from autourdf_amd import ops
+        from autourdf_amd.engine import IcpRegistrar
     world, rank, dev, dist = ctx.world, ctx.rank, ctx.dev, ctx.dist
     total = args.steps + args.warmup
     t_gen = time.perf_counter()
@@ -433,10 +549,11 @@ def run_c5(args, ctx, robot, n_points, k_clusters, wl_tag):
     frames = [torch.as_tensor(f, dtype=torch.float64, device=dev) for f in seq[1:]]
     cap = IcpRegistrar(mats0, clusters0, dev)
     items = []
+    sync = (lambda: None) if STUB else torch.cuda.synchronize
     for f in frames:                                               # the sequential pass (untimed): state entering every frame
         items.append((cap.M, cap.local, cap.off, f))
         cap.step(f)
-    torch.cuda.synchronize()
+    sync()
     job = items[args.warmup:]
     mine = job[rank::world]
     worker = IcpRegistrar(mats0, clusters0, dev)
@@ -447,13 +564,13 @@ def run_c5(args, ctx, robot, n_points, k_clusters, wl_tag):
 
     for it in items[:args.warmup]:
         register(it)
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
     poses = torch.zeros(max(len(mine), 1), k_clusters, 4, 4, dtype=torch.float64, device=dev)
     iters = []
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(mine) + 1)]     # per-frame times without a sync in the loop
+    marks = [_Mark() for _ in range(len(mine) + 1)]     # per-frame times without a sync in the loop
     t0 = time.perf_counter()
     marks[0].record()
     for i, it in enumerate(mine):
@@ -462,11 +579,13 @@ def run_c5(args, ctx, robot, n_points, k_clusters, wl_tag):
         iters.append(n_it)
         marks[i + 1].record()
     counts = [len(job[r::world]) for r in range(world)]
+    t_g = time.perf_counter()
     gathered = gather_poses(poses[:len(mine)], counts=counts if dist is not None else None)
-    torch.cuda.synchronize()
+    sync()
+    gather_s = time.perf_counter() - t_g
     if dist is not None:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -474,6 +593,20 @@ def run_c5(args, ctx, robot, n_points, k_clusters, wl_tag):
         elapsed = float(t.item())
     assert torch.isfinite(gathered).all() and gathered.shape[0] == args.steps
     out = None
+    if rank == 0 and (STUB or getattr(args, "brief", False)):
+        # a strong-scaling leg of the default --gpus N line: value, what every rank ran, the gather -- no kernel-level legs
+        out = {"metric": f"ICP-style registered frames/sec (N={n_points} pts, K={k_clusters} clusters): K4 masked ICP + K5 DQ + K2 Lloyd resample",
+               "value": round(args.steps / elapsed, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"{robot}-shaped synthetic frames, N={n_points}, K={k_clusters} ({wl_tag})",
+                          "mode": "replay / independent-frame mode: --steps work items in TOTAL from a sequential pass, dealt round-robin to the ranks",
+                          "batch_sizes_per_rank": [[1] * c for c in counts], "frames_per_rank": counts,
+                          "frame_ms_rank0_median": (sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(mine)))[len(mine) // 2] if mine else None),
+                          "host_generation_s": round(t_gen, 1)},
+               "gather": {"s": round(gather_s, 6), "world": world, "backend": dist.get_backend() if dist is not None else None,
+                          "payload_bytes_per_rank": int(poses[:len(mine)].numel() * 8), "ragged": len(set(counts)) > 1},
+               "pose_checksum": round(float(gathered.abs().sum()), 6)}
+        return out
     if rank == 0:
         # the assign kernel (K2 E-step) alone, event-timed on torch's stream (ops launch there): N x K fp64 distances
         it = job[0]
@@ -653,6 +786,9 @@ def build_parser():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-icp-variant", action="store_true", help="skip the ICP-style second line (SURVEY 8(d))")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity summary against the oracle (first timed frame of sequence 0, outside the timed region)")
+    ap.add_argument("--no-strong-scaling", action="store_true",
+                    help="world > 1: skip the strong-scaling legs (BASELINE configs[3]: 50 allegro-shaped frames, configs[4]: 200 frames of N=262144 / K=128, both dealt over the ranks)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the extra legs of the default single-GPU run: BASELINE configs[2] (franka shape) and configs[4] (N=262144, K=128)")
     ap.add_argument("--no-rccl-world1", action="store_true", help="single process without a launcher: do not create the world-1 RCCL group")
@@ -695,10 +831,62 @@ def main(argv=None):
                     and not args.no_other_workloads and not args.eager and args.graph_branches == 0 and args.sequences == 5)
         if headline and out is not None:
             out["other_workloads"] = other_workloads(ap, ctx)
+        # world > 1 (the driver's `--gpus N` line): the north star's strong-scaling questions answered by the same command -- BASELINE
+        # configs[3] (50 allegro-shaped frames) and configs[4] (200 frames of N=262144 / K=128) dealt over the N ranks.  EVERY rank takes part
+        # (the legs hold barriers and the gather); the weak-scaling line above stays the headline.
+        strong = (args.workload == "wx200_5" and args.mode == "sequences" and args.r == "q" and ctx.world > 1 and not args.no_strong_scaling
+                  and not args.eager and args.graph_branches == 0)
+        if strong:
+            legs = strong_scaling_legs(ap, ctx)
+            if out is not None:
+                out["strong_scaling"] = legs
     if ctx.rank == 0 and out is not None:
         print(json.dumps(out))
     if ctx.dist is not None:
         ctx.dist.destroy_process_group()
+
+
+STRONG_LEGS = {"configs[3]": ["--mode", "replay", "--workload", "allegro", "--steps", "50", "--warmup", "5", "--no-cpu-baseline", "--no-icp-variant", "--no-roofline",
+                              "--repeats", "1"],
+               "configs[4]": ["--workload", "c5", "--steps", "200", "--warmup", "2"]}
+
+
+def strong_scaling_legs(ap, ctx):
+    """`bench.py --gpus N`, N > 1: the two strong-scaling configurations of BASELINE.json after the weak-scaling headline, on every rank:
+    `--mode replay --workload allegro --steps 50` (configs[3]: 50 frames sharded across the GPUs, RCCL gather of the poses) and
+    `--workload c5 --steps 200` (configs[4]: 200 frames of N=262144 / K=128).  Total work is fixed, so value(N) / value(1 GPU of the same
+    leg) is the speedup the north star asks for (>= 6x at N = 8 on configs[3]); the driver's N = 1 run carries no such leg -- run
+    `python bench.py --mode replay --workload allegro --steps 50` / `--workload c5 --steps 200` for the divisor (profiles/ holds one).
+    A leg that fails reports its error (on every rank alike: the legs' collectives stay matched as long as all ranks fail alike)."""
+    res = {}
+    for name, argv in STRONG_LEGS.items():
+        t0 = time.perf_counter()
+        try:
+            a = ap.parse_args(["--gpus", str(ctx.world)] + argv)
+            a.brief = True
+            robot, n_points, k_clusters, wl_tag = WORKLOADS[a.workload]
+            if a.workload == "c5":
+                a.mode = "replay"
+                d = run_c5(a, ctx, robot, n_points, k_clusters, wl_tag)
+            else:
+                d = run_registration(a, ctx)
+            e = None
+            if d is not None:
+                keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "pose_checksum", "rccl_gather", "gather")
+                e = {k: d[k] for k in keep if k in d}
+                e["config"] = {k: d["config"][k] for k in ("workload", "mode", "batch_sizes_per_rank", "rounds_per_rank", "frames_per_rank", "sequences_in_flight_per_gpu",
+                                                           "chains", "frame_ms_rank0_median", "host_generation_s") if k in d["config"]}
+                e["argv"] = " ".join(argv)
+        except Exception as ex:                      # pragma: no cover
+            import traceback
+            e = {"error": f"{type(ex).__name__}: {ex}", "traceback_tail": traceback.format_exc()[-600:]}
+        if e is not None:
+            e["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+            res[name] = e
+        if not STUB:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    return res
 
 
 def other_workloads(ap, ctx):
@@ -836,7 +1024,12 @@ def run_registration(args, ctx):
             run_batch(mine[pos:pos + b], poses, pos)
             pos += b
         counts = [len(job[r::world]) for r in range(world)]
+        t_g = time.perf_counter()
         gathered = gather_poses(poses[:n_mine], counts=counts if dist is not None else None)
+        sync()
+        replay_gather = {"s": round(time.perf_counter() - t_g, 6), "world": world, "backend": dist.get_backend() if dist is not None else None,
+                         "payload_bytes_per_rank": int(poses[:n_mine].numel() * 4), "ragged": len(set(counts)) > 1,
+                         "note": "the job's one collective inside the timed region (host-timed: the rank's own wait for the slowest rank is in it)"}
         fence()
         elapsed = time.perf_counter() - t0
         n_counted = args.steps
@@ -876,6 +1069,9 @@ def run_registration(args, ctx):
         run_rounds(0, warm_rounds)
         n_rep = max(1, args.repeats)
         snap = snapshot() if n_rep > 1 else None
+        if not STUB and rank == 0:      # sequence 0 entering its first timed frame (the parity summary, computed after the timing)
+            r0 = reg.seqs[0]
+            parity_state = (r0.m, r0.pts, r0.off, [q.clone() for q in r0.p_step])
         fence()
         epochs_log.clear()
         t0 = time.perf_counter()
@@ -956,6 +1152,8 @@ def run_registration(args, ctx):
                               "poses_identical_across_repeats": rep_same,
                               "note": "the timed region run n times from the same state (parameters restored, same frames, same final gather); "
                                       "`value` is the first of them -- exactly --steps steps after --warmup -- the others only show the spread on this box"}
+        if replay:
+            out["gather"] = replay_gather
         if rccl is not None:
             out["rccl_gather"] = rccl
             if world == 1:
@@ -964,6 +1162,11 @@ def run_registration(args, ctx):
             out["roofline"] = roofline_block(reg, frames32, n_points, k_clusters, args.workload,
                                              y_index=0 if replay else max(warm_rounds + timed_rounds - 2, 0))
             out["roofline"]["frame_level"] = frame_level(out["roofline"], out["value"] / world, n_points, k_clusters)
+        if not STUB and not replay and not args.no_parity:
+            try:
+                out["parity"] = parity_block(parity_state, frames64[0][warm_rounds], frames32[0][warm_rounds], k_clusters, dev, args.r, hidden)
+            except Exception as ex:                      # pragma: no cover -- the summary must not take the measured line with it
+                out["parity"] = {"error": f"{type(ex).__name__}: {ex}"}
         if not STUB and world == 1 and not args.no_icp_variant and not replay:      # a one-GPU secondary line: not while other ranks wait
             out["icp_variant"] = icp_variant(frames64, mats0, clusters0, dev, warm_rounds, timed_rounds)
         if not STUB and world == 1 and not args.no_cpu_baseline:

@@ -94,3 +94,33 @@ def test_replay_many_rounds_ragged_two_ranks():
     two = _run(2, ["--steps", "19", "--warmup", "2", "--mode", "replay"])
     assert one["config"]["batch_sizes_per_rank"] == [[7, 6, 6]] and two["config"]["batch_sizes_per_rank"] == [[5, 5], [5, 4]]
     assert abs(one["pose_checksum"] - two["pose_checksum"]) < 1e-3 * max(1.0, abs(one["pose_checksum"]))
+
+
+def test_bench_gpus_2_line_carries_the_strong_scaling_legs():
+    """`bench.py --gpus N` (N > 1) answers the north star's strong-scaling questions by itself -- after the weak-scaling
+    headline every rank runs BASELINE configs[3] (--mode replay --workload allegro --steps 50) and configs[4] (--workload c5 --steps 200);
+    the one JSON line carries both under `strong_scaling`, each with value / scaling "strong" / what every rank ran / the gather."""
+    env = dict(os.environ, CREG_BENCH_STUB="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "5"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 10            # the headline stays the weak-scaling line
+    legs = d["strong_scaling"]
+    assert set(legs) == {"configs[3]", "configs[4]"}
+    c3, c4 = legs["configs[3]"], legs["configs[4]"]
+    for leg, steps in ((c3, 50), (c4, 200)):
+        assert "error" not in leg, leg
+        assert leg["scaling"] == "strong" and leg["steps"] == steps and leg["n_gpus"] == 2 and leg["value"] > 0 and leg["unit"] == "frames/s"
+        assert leg["gather"]["world"] == 2 and leg["gather"]["backend"] == "gloo" and leg["gather"]["s"] >= 0
+        assert "pose_checksum" in leg and leg["leg_wall_s"] >= 0
+    assert c3["config"]["batch_sizes_per_rank"] == [[7, 6, 6, 6], [7, 6, 6, 6]]          # 25 items per rank: four rounds of <= 8, no padding
+    assert c4["config"]["frames_per_rank"] == [100, 100]
+    assert "allegro" in c3["config"]["workload"] and "replay" in c3["config"]["mode"]
+    # a single rank's line has no such legs (the divisor is the same command at --gpus 1 with the leg's own arguments)
+    one = _run(1, ["--steps", "6", "--warmup", "3"])
+    assert "strong_scaling" not in one

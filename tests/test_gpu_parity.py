@@ -748,7 +748,8 @@ def test_train_c1_divergence_stays_inside_the_measured_oracle_envelope(dev, gold
         m2, _, _, _ = probe_plan.probe(m, y, pts, off, params)
         d = float(np.abs(m2.cpu().numpy()[:, :3, :] - ref[e][:, :3, :]).max())
         seen[e] = d
-        tol = 1e-5 if e <= n_e else 2.0 * float(env["envelope"][e])
+        # (round 6: the envelope also holds runs whose MLP matrix products sum in another order -- what a different BLAS does -- `gemm`)
+        tol = 1e-5 if e <= n_e else 2.0 * float(max(env["envelope"][e], env["gemm"][e]))
         assert d <= tol, (e, d, tol, seen)
     params = [sd[k].clone().to(dev) for k in order]
     plan = ops.TrainPlan("q", 20, 512, pts.shape[0], y.shape[0], epochs=300, use_graph=True, device=dev)
@@ -781,7 +782,7 @@ def test_train_other_shapes_vs_reference_train_and_the_measured_envelope(dev, go
     pts, off = ops.pack_clusters([torch.from_numpy(c) for c in _split(g["local"], g["offsets"])], dev)
     assert pts.shape[0] == n and len(g["offsets"]) == k + 1
     ref = {int(e): g["pose_hist_sel"][i] for i, e in enumerate(g["pose_epochs"])}
-    spread = np.maximum(env["envelope"], env["f64"])
+    spread = np.maximum(np.maximum(env["envelope"], env["f64"]), env["gemm"])      # permuted points, float64, another GEMM summation order
     probe_plan = ops.TrainPlan("q", k, 512, n, n, epochs=2, use_graph=False, device=dev)
     params = [sd[key].clone().to(dev) for key in order]
     m0, _, loss0, _ = probe_plan.probe(m, y, pts, off, params)
@@ -796,13 +797,113 @@ def test_train_other_shapes_vs_reference_train_and_the_measured_envelope(dev, go
         seen[e] = float(np.abs(m2.cpu().numpy()[:, :3, :] - ref[e][:, :3, :]).max())
     one_step = 1e-5 if float(spread[1]) <= 1e-5 else 2.5 * 2e-4
     assert seen[1] <= one_step, seen
-    assert seen[299] <= 2.0 * float(spread[299]), seen
     params = [sd[key].clone().to(dev) for key in order]
     plan = ops.TrainPlan("q", k, 512, n, n, epochs=300, use_graph=True, device=dev)
     bm, _, res, _, _ = plan.run(m, y, pts, off, params)
     ml = float(g["e300_min_loss"])
-    assert abs(float(res[0]) - ml) <= 2.0 * float(env["min_loss_rel_envelope"]) * ml, (float(res[0]), ml)
-    assert float(np.abs(bm.cpu().numpy()[:, :3, :] - g["e300_best_m"][:, :3, :]).max()) <= 2.0 * float(env["best_pose_envelope"])
+    assert np.isfinite(float(res[0])) and torch.isfinite(bm).all()
+    if float(env["best_pose_envelope"]) < 0.5:
+        # an envelope that can bite (franka: 0.43 % / 1.9e-2).  At the allegro shape the oracle variants themselves end a flipped cluster
+        # apart (59 % / 2.0 on entries that cannot exceed ~2): bounds taken from that spread cannot fail and are not
+        # asserted -- the late epochs of that shape are pinned by test_train_teacher_forced_late_epochs below instead
+        assert seen[299] <= 2.0 * float(spread[299]), seen
+        assert abs(float(res[0]) - ml) <= 2.0 * float(env["min_loss_rel_envelope"]) * ml, (float(res[0]), ml)
+        assert float(np.abs(bm.cpu().numpy()[:, :3, :] - g["e300_best_m"][:, :3, :]).max()) <= 2.0 * float(env["best_pose_envelope"])
+
+
+@pytest.mark.parametrize("shape,k,n", [("c1", 20, 4096), ("allegro", 30, 4096), ("franka", 40, 16384)])
+def test_train_teacher_forced_late_epochs(dev, golden, shape, k, n):
+    """exact parity beyond the divergence horizon.  Free-running trains of two float32 implementations part after
+    ~13 epochs, so everything later -- Adam's bias corrections at t = 150..300, ReduceLROnPlateau after several cuts,
+    best tracking late in a train -- was only ever compared against envelopes.  Here the errors cannot accumulate: the oracle (the
+    reference's float32 trajectory: bit for bit in the build container, checked below against the reference-minted loss history) runs
+    e epochs on the host, hands its state ENTERING epoch e to the plan (creg_train_plan_resume: parameters, Adam moments, step count,
+    scheduler best / bad epochs / lr, min_loss, stop counter, best pose so far), the plan runs ONE epoch, at BASELINE configs[1], [3]
+    and [2] shapes, hidden 512, e in {0, 13, 50, 150, 299}:
+      * the epoch's loss 1e-6 relative, its pose 1e-5 (measured <= 3e-7 / 6e-7: profiles/r06_teacher_forced.log);
+      * lr (used and next), step, epochs_run, scheduler bad-epoch count, stop counter, best epoch: EXACT; scheduler best / min_loss 1e-6;
+      * the parameter update of every tensor within 3e-6 (1.5 % of a full 2e-4 step; measured <= 1.9e-6) outside a mask of |grad| < 1e-8.
+        The FIRST Adam step (e = 0) normalises every gradient to +-1, so an element whose gradient is rounding noise around zero moves
+        by a full +-lr whatever the implementation (allegro: 4e-4 on a handful of encoder weights): there >= 99.99 % of the elements
+        are within the bound and none moves by more than one flipped unit step;
+      * Adam's second moments after the epoch 1e-2 of the tensor's largest (they see 0.001 g^2), the best pose / cloud 1e-5."""
+    import _teacher as T
+    from autourdf_amd import ops
+    g = golden(f"train_reference_{shape}.npz")
+    c1 = golden("train_reference_c1.npz")
+    sd = {key[5:]: torch.from_numpy(c1[key].astype(np.float32)) for key in c1.files if key.startswith("sd16.")}
+    order = ops.Q_PARAM_ORDER
+    epochs = (0, 13, 50, 150, 299)
+    snaps, hist = T.oracle_snapshots(g, sd, k, epochs)
+    ref_loss = np.asarray(g["loss_hist"], np.float64)
+    np.testing.assert_allclose(np.asarray(hist["loss"][:6], np.float64), ref_loss[:6], rtol=1e-5)      # the teacher IS on the reference's trajectory
+    m, y = torch.from_numpy(g["m"]).to(dev), torch.from_numpy(g["y"]).to(dev)
+    pts, off = ops.pack_clusters([torch.from_numpy(c) for c in _split(g["local"], g["offsets"])], dev)
+    plan = ops.TrainPlan("q", k, 512, n, y.shape[0], epochs=300, use_graph=False, device=dev)
+    probe_plan = ops.TrainPlan("q", k, 512, n, y.shape[0], epochs=2, use_graph=False, device=dev)
+    for e in epochs:
+        s0, s1 = snaps[e], snaps[e + 1]
+        m2, loss, params, after, extra = T.plan_epoch(plan, probe_plan, dev, order, m, y, pts, off, s0)
+        r = T.compare(order, s0, s1, m2, loss, params, after, extra)
+        assert r["loss_rel"] <= 1e-6 and r["pose"] <= 1e-5, (e, r)
+        assert r["lr_used_exact"] and r["lr"][0] == r["lr"][1], (e, r["lr"])
+        for key, (a, b) in r["exact"].items():
+            assert a == b, (e, key, a, b)
+        for key in ("sched_best", "min_loss"):
+            assert abs(r[key][0] - r[key][1]) <= 1e-6 * abs(r[key][1]), (e, key, r[key])
+        assert r["exp_avg_sq_rel"] <= 1e-2, (e, r)
+        if "best_m" in r:
+            assert r["best_m"] <= 1e-5 and r["best_pred"] <= 1e-5, (e, r)
+        if e > 0:
+            assert r["upd"] <= 3e-6, (e, r["upd"], r["upd_worst_tensor"])
+        else:
+            lr, bad, live_n = s0["lr"], 0, 0
+            for i, key in enumerate(order):
+                live = s0["epoch"]["grad"][key].reshape(-1).abs() >= 1e-8
+                err = ((params[i].cpu() - s0["params"][key]) - (s1["params"][key] - s0["params"][key])).reshape(-1).abs()[live]
+                bad += int((err > 3e-6).sum()); live_n += int(live.sum())
+                assert float(err.max()) <= 2.0 * lr * 1.001, (key, float(err.max()))
+            assert bad <= 1e-4 * live_n, (bad, live_n)
+
+
+def test_train_resume_continues_a_run_bit_for_bit(dev):
+    """creg_train_plan_resume as checkpoint / resume: 12 epochs in one run == 5 epochs, the state read back, 7 more from it -- every
+    parameter, both Adam moments, the control state, the loss history and the best pose bit for bit (the same kernels from the same bits)."""
+    from autourdf_amd import ops
+    from autourdf_amd.synthetic import initial_segmentation, make_sequence
+    from oracle import models
+    seq = make_sequence("wx200_5", 7, 2, 1500)
+    mats, cl, _ = initial_segmentation(seq[0], 7, seed=1)
+    m = torch.tensor(mats, dtype=torch.float32, device=dev)
+    pts, off = ops.pack_clusters([torch.tensor(c, dtype=torch.float32) for c in cl], dev)
+    y = torch.tensor(seq[1], dtype=torch.float32, device=dev)
+    for rot, ctor, order in (("q", lambda: models.QRegMLP(True, 64), ops.Q_PARAM_ORDER), ("dq", lambda: models.DQRegMLP(64), ops.DQ_PARAM_ORDER)):
+        torch.manual_seed(3)
+        sd = ctor().state_dict()
+        fresh = lambda: [sd[kk].clone().to(dev) for kk in order]
+        zeros = lambda ps: [torch.zeros_like(p) for p in ps]
+        plan = ops.TrainPlan(rot, 7, 64, pts.shape[0], y.shape[0], epochs=12, use_graph=False, device=dev)
+        pa = fresh()
+        bm_a, bp_a, res_a, lh_a, lrh_a, st_a = plan.resume(m, y, pts, off, pa, {"exp_avg": zeros(pa), "exp_avg_sq": zeros(pa), "lr": 2e-4}, 12, patience=1)
+        pb = fresh()
+        bm_1, bp_1, _, lh_1, _, st_1 = plan.resume(m, y, pts, off, pb, {"exp_avg": zeros(pb), "exp_avg_sq": zeros(pb), "lr": 2e-4}, 5, patience=1)
+        assert st_1["step"] == 5 and st_1["epochs_run"] == 5
+        bm_b, bp_b, res_b, lh_b, lrh_b, st_b = plan.resume(m, y, pts, off, pb, st_1, 7, patience=1, best=(bm_1, bp_1))
+        for a, b in zip(pa, pb):
+            assert torch.equal(a, b)
+        for key in ("exp_avg", "exp_avg_sq"):
+            for a, b in zip(st_a[key], st_b[key]):
+                assert torch.equal(a, b)
+        for key in ops.TrainPlan.STATE_FIELDS + ("last_loss",):
+            assert st_a[key] == st_b[key], (key, st_a[key], st_b[key])
+        assert st_a["lr"] < 2e-4                                      # (patience 1: the scheduler has cut at least once inside the resumed stretch or before)
+        assert torch.equal(bm_a, bm_b) and torch.equal(bp_a, bp_b) and torch.equal(res_a, res_b)
+        assert torch.equal(lh_a[5:12], lh_b[5:12]) and torch.equal(lh_a[:5], lh_1[:5]) and torch.isnan(lh_b[:5]).all()
+        assert torch.equal(lrh_a[5:12], lrh_b[5:12])
+        # ... and the resumed entry point agrees with the plain one on a fresh train
+        pc = fresh()
+        bm_c, bp_c, res_c, lh_c, _ = ops.TrainPlan(rot, 7, 64, pts.shape[0], y.shape[0], epochs=12, use_graph=True, device=dev).run(m, y, pts, off, pc, patience=1)
+        assert torch.equal(bm_a, bm_c) and torch.equal(lh_a, lh_c) and all(torch.equal(a, c) for a, c in zip(pa, pc))
 
 
 def test_train_same_target_keeps_the_frames_leaves_bit_identical(dev):
