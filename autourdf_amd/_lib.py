@@ -73,6 +73,7 @@ SIGNATURES = {
     "creg_masked_icp_batch_f64": (ctypes.c_int, [ctypes.POINTER(IcpProblem), i32, i64, i32, i64, f64, f64, i32, i32, vp, sz, vp]),
     "creg_aabb_mask_f64": (ctypes.c_int, [vp, vp, i32, vp, i64, f64, vp, vp, vp, vp]),
     "creg_icp_p2p_f64": (ctypes.c_int, [vp, i64, vp, vp, i64, vp, i32, vp, f64, i32, vp, vp, vp, vp, sz, vp]),
+    "creg_icp_nn_counters": (ctypes.c_int, [ctypes.POINTER(f64), i32, i32]),
     "creg_kabsch_f64": (ctypes.c_int, [vp, vp, vp, i64, vp, i32, vp, vp]),
     "creg_knn_normals_f64": (ctypes.c_int, [vp, i64, f64, i32, vp, vp, vp, vp]),
     "creg_kmeans_nd_workspace_bytes": (sz, [i64]),

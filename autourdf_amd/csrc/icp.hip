@@ -9,6 +9,7 @@
 //      compose on the left, move the source incrementally like open3d does
 //   3. stop when |d fitness| < 1e-6 and |d rmse| < 1e-6, or after max_iteration
 #include <type_traits>
+#include <vector>
 #include "creg_common.h"
 #include "creg_dev.h"
 
@@ -1281,6 +1282,10 @@ __device__ unsigned long long g_icp_blk[6][8192];
 #ifndef ICP_NN_WPS
 #define ICP_NN_WPS 3                       // minimum waves per SIMD the register allocation of k_icp_nn is held to
 #endif
+// Always-on work counters of the search (round 6: the roofline of the configs[4] frame names THIS kernel): [0] waves that searched,
+// [1] float32 screen trips (a trip = 8 staged targets x the wave's 64 lanes = 512 pair evaluations), [2] trips that went on to the fp64
+// evaluation, [3] live sources (source-iterations), [4] tie rescans.  Wave-uniform tallies in SGPRs, one atomic per counter and wave.
+__device__ unsigned long long g_icp_nn_ct[8];
 __global__ __launch_bounds__(64 * ICP_NNW, ICP_NN_WPS) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2, int max_iter) {
     constexpr int SB = ICP_SB, SR = ICP_SB + 2;                       // staged targets per lane group and batch; slice stride
                                                                       // (+2: the four groups' equal slots fall into different LDS banks)
@@ -1420,6 +1425,7 @@ __global__ __launch_bounds__(64 * ICP_NNW, ICP_NN_WPS) void k_icp_nn(IcpLarge P,
 #endif
     };
     constexpr int EPL = SB / ICP_SPW;                                 // staged entries per lane and batch
+    int ct_f32 = 0, ct_f64 = 0, ct_tie = 0;                           // (wave-uniform: the trips' branches are ballots)
     double best = seed; int bslot = -1, bj = 0x7fffffff;
     double bx = 0, by = 0, bz = 0;                                    // the best target's coordinates
     bool tief = false;
@@ -1487,6 +1493,7 @@ __global__ __launch_bounds__(64 * ICP_NNW, ICP_NN_WPS) void k_icp_nn(IcpLarge P,
                             ef[u] = e.x; ef[u + 1] = e.y;
                             mf = fminf(mf, fminf(e.x, e.y));
                         }
+                        ++ct_f32;
                         if (!__ballot(mf <= thr)) continue;
                         int own = 0;                                      // bit u: entry u is this source's previous match (pass 0 starts from it)
                         {
@@ -1495,6 +1502,7 @@ __global__ __launch_bounds__(64 * ICP_NNW, ICP_NN_WPS) void k_icp_nn(IcpLarge P,
                             for (int u = 0; u < 8; ++u) { const bool mine = pj[t + u] == pmv; own |= mine ? 1 << u : 0; cand |= ef[u] <= thr && !mine; }
                             if (!__ballot(cand)) continue;            // only previous matches came through
                         }
+                        ++ct_f64;
                         // the fp64 evaluation of the trip, exactly as in the other path, operands from the pool
                         double d[8];
 #pragma unroll
@@ -1558,6 +1566,7 @@ __global__ __launch_bounds__(64 * ICP_NNW, ICP_NN_WPS) void k_icp_nn(IcpLarge P,
           }
           if (pass == 0) {
               if (!__ballot(tief)) break;
+              ++ct_tie;
               best = 1e299; bslot = -1; bj = 0x7fffffff;
           }
         }
@@ -1624,8 +1633,10 @@ __global__ __launch_bounds__(64 * ICP_NNW, ICP_NN_WPS) void k_icp_nn(IcpLarge P,
                             const nn_f2 e = __builtin_elementwise_fma(fz, fz, __builtin_elementwise_fma(fy, fy, fx * fx));
                             mf = fminf(mf, fminf(e.x, e.y));
                         }
+                        ++ct_f32;
                         if (!__ballot(mf <= thr_f)) continue;             // no lane has a target that could matter in this trip
                     }
+                    ++ct_f64;
                     double d[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -1657,9 +1668,18 @@ __global__ __launch_bounds__(64 * ICP_NNW, ICP_NN_WPS) void k_icp_nn(IcpLarge P,
       }
         if (pass == 0) {
             if (!__ballot(tief)) break;
+            ++ct_tie;
             best = 1e299; bslot = -1; bj = 0x7fffffff;
         }
     }
+    }
+    if (any) {
+        const int nlive = __popcll(__ballot(live && g == 0));
+        if (lane == 0) {
+            atomicAdd(&g_icp_nn_ct[0], 1ull); atomicAdd(&g_icp_nn_ct[1], (unsigned long long)ct_f32); atomicAdd(&g_icp_nn_ct[2], (unsigned long long)ct_f64);
+            atomicAdd(&g_icp_nn_ct[3], (unsigned long long)nlive);
+            if (ct_tie) atomicAdd(&g_icp_nn_ct[4], (unsigned long long)ct_tie);
+        }
     }
 #ifdef CREG_ICP_BLK
     if (tid == 0 && blk_rec) { g_icp_blk[0][blockIdx.x] = blk_t0; g_icp_blk[5][blockIdx.x] = gridDim.x;
@@ -1793,6 +1813,11 @@ extern "C" size_t creg_icp_batch_workspace_bytes(int64_t n, int64_t nf, int32_t 
 
 // One problem through the multi-launch path.  The host follows the device one batch of iterations behind (no stream synchronisation;
 // it returns when the convergence it has read back says so, with the last launches and k_icp_finish still in the queue).
+// creg_icp_nn_counters (measurement hook): while `g_icp_nn_timing` is set every k_icp_nn launch is bracketed by two HIP events on the
+// launch stream and the call ends with a stream synchronisation that adds their elapsed times to the two host tallies.
+static bool g_icp_nn_timing = false;
+static double g_icp_nn_us = 0.0;
+static long long g_icp_nn_launches = 0;
 static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_t nf, double scale, double th,
                          int32_t max_iteration, int32_t keep_translation, char* ws, hipStream_t s) {
     const IcpLargeLayout L = icp_large_layout(n, nf, k);
@@ -1829,13 +1854,16 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
     if (h_last) { (void)hipEventSynchronize(h_last); (void)hipEventDestroy(h_last); h_last = nullptr; }
     hipEvent_t ev[ICP_LAG_RING];
     for (auto& e : ev) CREG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    std::vector<hipEvent_t> tev;                                      // (timing mode only)
     int grid = nblk, rc_loop = CREG_OK;                              // live chunks as of the last batch whose counters were read
     bool converged = false;
     int64_t done = 0;
     for (int b = 0; !converged && done <= (int64_t)max_iteration; ++b) {
         const int batch = 16;
         for (int q = 0; q < batch; ++q, ++done) {
+            if (g_icp_nn_timing) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, s); tev.push_back(e); } }
             hipLaunchKernelGGL(k_icp_nn, dim3(grid), dim3(64 * ICP_NNW), nn_smem, s, P, (int)n, k, (int)nf, th * th, max_iteration);
+            if (g_icp_nn_timing) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, s); tev.push_back(e); } }
 #ifdef CREG_STAMPS
             hipLaunchKernelGGL(k_icp_wall_fold, dim3(1), dim3(1), 0, s);
 #endif
@@ -1862,6 +1890,30 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
     if (rc_loop != CREG_OK) { set_error("creg_masked_icp: HIP error in the iteration loop: %s", hipGetErrorString(hipGetLastError())); return rc_loop; }
     hipLaunchKernelGGL(k_icp_finish, dim3(k), dim3(256), 0, s, P, keep_translation);
     CREG_LAUNCH_CHECK();
+    if (!tev.empty()) {
+        (void)hipStreamSynchronize(s);
+        for (size_t i = 0; i + 1 < tev.size(); i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, tev[i], tev[i + 1]) == hipSuccess) { g_icp_nn_us += 1e3 * ms; ++g_icp_nn_launches; }
+        }
+        for (auto e : tev) (void)hipEventDestroy(e);
+    }
+    return CREG_OK;
+}
+
+extern "C" int creg_icp_nn_counters(double* out8, int32_t reset, int32_t timing) {
+    if (out8) {
+        unsigned long long c[8];
+        CREG_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(creg::g_icp_nn_ct), sizeof(c)));
+        for (int i = 0; i < 5; ++i) out8[i] = (double)c[i];
+        out8[5] = g_icp_nn_us; out8[6] = (double)g_icp_nn_launches; out8[7] = 0.0;
+    }
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_icp_nn_ct), z, sizeof(z)));
+        g_icp_nn_us = 0.0; g_icp_nn_launches = 0;
+    }
+    if (timing >= 0) g_icp_nn_timing = timing != 0;
     return CREG_OK;
 }
 

@@ -1584,6 +1584,8 @@ struct Plan {
     hipEvent_t cfork, cjoin[8];
     hipStream_t cal_stream;   // the caller's stream the chain streams were picked against (pick_chain_streams)
     bool cal_done;
+    int probe_us;             // pick_chain_streams: the slowest ACCEPTED joint spin of the chain streams with the caller's (150 us kernels: < 250 = concurrent); -1: a chain had to
+                              //   take a stream that shares a hardware queue; 0: not probed (one chain, or the probe is switched off)
     bool target_blocks_valid; // ys4 / ybox hold the k-d leaves of every problem's last run_batch frame (probe / profile overwrite them)
 };
 
@@ -1977,6 +1979,7 @@ static double spin_together_us(hipStream_t* st, int n, unsigned long long ticks)
 static int pick_chain_streams(Plan* P, hipStream_t s) {
     static const bool probe = !(getenv("CREG_NO_QUEUE_PROBE") && getenv("CREG_NO_QUEUE_PROBE")[0] == '1');
     const unsigned long long ticks = 15000;                 // wall_clock64 runs at 100 MHz: 150 us
+    P->probe_us = 0;
     for (int gi = 1; gi < P->branches; ++gi) {
         hipStream_t set[9], rejected[8];
         int ns = 0, nr = 0;
@@ -1988,7 +1991,7 @@ static int pick_chain_streams(Plan* P, hipStream_t s) {
             double t = spin_together_us(set, ns + 1, ticks);
             const double t2 = t < 0 || t >= 250.0 ? spin_together_us(set, ns + 1, ticks) : t;
             if (t2 >= 0 && (t < 0 || t2 < t)) t = t2;
-            if (!probe || (t >= 0 && t < 250.0)) chosen = P->cst[gi];
+            if (!probe || (t >= 0 && t < 250.0)) { chosen = P->cst[gi]; if (probe && P->probe_us >= 0 && (int)t > P->probe_us) P->probe_us = (int)t; }
             else { (void)hipStreamSynchronize(P->cst[gi]); rejected[nr++] = P->cst[gi]; P->cst[gi] = nullptr; }
         }
         for (int attempt = 0; !chosen && attempt < 7; ++attempt) {
@@ -2001,11 +2004,11 @@ static int pick_chain_streams(Plan* P, hipStream_t s) {
                 const double t2 = spin_together_us(set, ns + 1, ticks);
                 if (t2 >= 0 && (t < 0 || t2 < t)) t = t2;
             }
-            if (t >= 0 && t < 250.0) chosen = cs;
+            if (t >= 0 && t < 250.0) { chosen = cs; if (P->probe_us >= 0 && (int)t > P->probe_us) P->probe_us = (int)t; }
             else if (nr < 8) rejected[nr++] = cs;
             else (void)hipStreamDestroy(cs);
         }
-        if (!chosen && nr) chosen = rejected[--nr];          // every queue is shared with somebody: any stream is as good as another
+        if (!chosen && nr) { chosen = rejected[--nr]; P->probe_us = -1; }      // every queue is shared with somebody: any stream is as good as another
         for (int i = 0; i < nr; ++i) (void)hipStreamDestroy(rejected[i]);
         if (!chosen) {
             (void)hipGetLastError();
@@ -2097,7 +2100,7 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
     if (P->branches > P->B) P->branches = P->B;
     if (P->branches > 8) P->branches = 8;
     P->gexec = nullptr; P->graph_ready = false; P->target_blocks_valid = false;
-    P->cfork = nullptr; P->cal_stream = nullptr; P->cal_done = false;
+    P->cfork = nullptr; P->cal_stream = nullptr; P->cal_done = false; P->probe_us = 0;
     for (int i = 0; i < 8; ++i) { P->cst[i] = nullptr; P->cexec[i] = nullptr; P->cjoin[i] = nullptr; }
     {   // the dynamic LDS of k_bd is the B role's (71 KB at K = 20, hidden 512: its 48 KB slab of W2 + 23 KB; the D role uses none)
         P->smem_bd = (int)(sizeof(float) * b2_smem_floats(D.K, D.IN, D.H2));
@@ -2654,6 +2657,7 @@ extern "C" int creg_train_plan_info(const creg_train_plan* plan, creg_train_plan
     info->nn_points_per_lane = P->D.ppl;
     info->nn_boxes_target = P->D.nbt;
     info->nn_boxes_predicted = P->D.nbp;
+    info->chain_probe_us = P->probe_us;
     return CREG_OK;
 }
 

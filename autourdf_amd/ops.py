@@ -538,6 +538,15 @@ _TWO_DECODER = {0: (56, 4), 2: (72, 6), 3: (48, 3)}
 TRAIN_HIDDEN_TILES = (64, 128, 256, 512)      # widths the train kernels are instantiated for
 
 
+def icp_nn_counters(reset: bool = False, timing=None) -> dict:
+    """Work counters / launch timing of the many-workgroup ICP search (creg_icp_nn_counters; a measurement hook, synchronises)."""
+    out = (ctypes.c_double * 8)()
+    L = _lib.load()
+    _lib.check(L.creg_icp_nn_counters(out, 1 if reset else 0, -1 if timing is None else int(bool(timing))), "creg_icp_nn_counters")
+    keys = ("waves", "f32_trips", "f64_trips", "source_iterations", "tie_rescans", "nn_launch_us_total", "nn_launches_timed")
+    return dict(zip(keys, [float(v) for v in out]))
+
+
 class TrainPlan:
     """Device-resident `train` loop (mlp_reg.py:17-152) for one (rot, K, hidden, N) shape.
 
@@ -573,7 +582,7 @@ class TrainPlan:
         _lib.check(self.L.creg_train_plan_create(ctypes.byref(self.shape), ctypes.c_void_p(base), need,
                                                  ctypes.byref(self.plan)), "creg_train_plan_create")
         self.k, self.n_pred, self.n_tgt, self.epochs, self.hidden = k, n_pred, n_tgt, epochs, hidden
-        info = (ctypes.c_int32 * 8)()
+        info = (ctypes.c_int32 * 9)()
         _lib.check(self.L.creg_train_plan_info(self.plan, info), "creg_train_plan_info")
         #: what the plan chose from its shape (never a result): searches, graph branches, problems per launch, epochs per graph
         self.info = {"pruned_target_search": bool(info[0]), "pruned_predicted_search": bool(info[1]), "graph_branches": int(info[2]),
@@ -587,6 +596,13 @@ class TrainPlan:
                           f"{' and '.join(which)} direction(s) -- the shape is beyond the block-pruned search's limits "
                           "(n_tgt <= 65536: four chunks of k-d leaves built in LDS; n_pred < 65535 and at most 512 blocks of the padded "
                           "predicted cloud); same results, several times the launch time", RuntimeWarning, stacklevel=2)
+
+    def chain_probe_us(self) -> int:
+        """creg_train_plan_info_t.chain_probe_us AFTER a run: < 250 = the chain streams ran concurrently with the caller's (own hardware queues),
+        -1 = a chain shares a queue, 0 = not probed (one chain / no run yet)."""
+        info = (ctypes.c_int32 * 9)()
+        _lib.check(self.L.creg_train_plan_info(self.plan, info), "creg_train_plan_info")
+        return int(info[8])
 
     def __del__(self):
         plan = getattr(self, "plan", None)

@@ -235,6 +235,15 @@ int creg_icp_p2p_f64(const double* src, int64_t n_src, const int32_t* src_offset
                      double* T_out, double* src_out, int32_t* n_iter_out,
                      void* workspace, size_t workspace_bytes, creg_stream_t stream);
 
+/* Measurement hook of the many-workgroup ICP regime (the frame of BASELINE configs[4]; bench.py's roofline of that leg): work counters
+ * of the search kernel k_icp_nn, always on (wave-uniform tallies, one atomic per counter and wave), and -- while `timing` is set -- a
+ * pair of HIP events around every k_icp_nn launch on the launch stream (the call then ends with a stream synchronisation).
+ * out8 (HOST, 8 doubles, may be NULL): [0] waves that searched, [1] float32 screen trips (a trip = 8 staged targets x 64 lanes = 512
+ * pair evaluations), [2] trips that went on to the fp64 evaluation, [3] source-iterations (live sources summed over launches),
+ * [4] tie rescans, [5] summed k_icp_nn launch time in microseconds, [6] launches timed, [7] 0.  reset != 0: zero all of it afterwards.
+ * timing: 1 / 0 switches the event bracketing on / off, < 0 leaves it.  Synchronises the device (hipMemcpyFromSymbol). */
+int creg_icp_nn_counters(double* out8, int32_t reset, int32_t timing);
+
 /* ------------------------------------------------------------------------------------------
  * N2  pose-sequence distance maps, fp64: the consumer of match()'s matrix/NNNN.npy files.  Replaces the
  * Python loops of CoordMap.coord_dist_map (coord_map.py:230-307; roma rotmat_to_rotvec,
@@ -385,6 +394,10 @@ typedef struct creg_train_plan_info_t {
     int32_t nn_points_per_lane;       /* points per lane and block visit of the pruned search (1: 64-point blocks, 4: 256-point blocks) */
     int32_t nn_boxes_target;          /* boxes per lane of the search over the target frame (the k_nn_plan instance) */
     int32_t nn_boxes_predicted;       /* ... and over the predicted cloud */
+    int32_t chain_probe_us;           /* chain streams (graph_branches <= 0, more than one chain), after the first run: the slowest joint run of two 150 us spin
+                                         kernels on the caller's stream + the accepted chain streams, in us (< 250: they ran CONCURRENTLY, i.e. sit in different
+                                         hardware queues); -1: no such stream was found and a chain shares a queue (its epochs then run after the other chain's);
+                                         0: not probed (one chain, no run yet, or CREG_NO_QUEUE_PROBE=1) */
 } creg_train_plan_info_t;
 
 size_t creg_train_workspace_bytes(const creg_train_shape* shape);   /* covers shape.batch problems */

@@ -255,3 +255,60 @@ def test_bench_plain_single_process_creates_its_own_world_one_rccl_group():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["rccl_world1_gather_us"] > 0 and d["rccl_gather"]["backend"] == "nccl", d.get("rccl_gather")
     assert "created by bench.py" in d["rccl_gather"]["group"]
+
+
+_TWO_PROC_CHILD = r"""
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+import numpy as np, torch
+from autourdf_amd.engine import BatchRegistrar
+from autourdf_amd.synthetic import initial_segmentation, make_sequence
+dev = torch.device("cuda:0")
+seq = [make_sequence("wx200_5", s, 4, 1024) for s in range(5)]
+mats0, clusters0, _ = initial_segmentation(seq[0][0], 8, seed=0)
+reg = BatchRegistrar(mats0, clusters0, 1024, 5, "q", 64, 40, True, dev)
+torch.cuda.synchronize()
+open(sys.argv[2] + ".ready", "w").close()
+t0 = time.time()
+while not os.path.exists(sys.argv[3] + ".ready") and time.time() - t0 < 120:      # both processes hold a context before either picks its chain streams
+    time.sleep(0.01)
+out = None
+for f in range(1, 4):
+    out = reg.step([torch.as_tensor(s[f], dtype=torch.float64, device=dev) for s in seq])
+torch.cuda.synchronize()
+print(json.dumps({"probe_us": reg.plan.chain_probe_us(), "chains": reg.plan.info["graph_branches"],
+                  "checksum": float(sum(o[0].double().abs().sum() for o in out))}))
+"""
+
+
+def test_chain_stream_probe_with_two_processes_sharing_the_device(tmp_path):
+    """the closest single-GPU stand-in for the runtime state of an 8-rank node -- two PROCESSES drive plans of five
+    sequences (two chain streams each) on the one device at the same time.  The chain-stream pick (a 150 us spin kernel per candidate
+    stream, accepted only if it overlaps the caller's: train_engine.hip pick_chain_streams) must still end with a verdict in each
+    process -- concurrent streams found (0 < probe < 250 us) or, when the other process's queues make every candidate look shared, the
+    documented fallback (-1) -- and whatever it picks, the poses are those of a process that has the device to itself."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_PROC_CHILD, root, me, other], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for me, other in ((a, b), (b, a))]
+    outs = [p.communicate(timeout=600) for p in procs]
+    res = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-1000:] + se[-2000:]
+        res.append(json.loads([l for l in so.splitlines() if l.startswith("{")][0]))
+    open(a + ".ready", "w").close(); open(b + ".ready", "w").close()
+    alone = subprocess.run([sys.executable, "-c", _TWO_PROC_CHILD, root, str(tmp_path / "c"), a], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert alone.returncode == 0, alone.stderr[-2000:]
+    solo = json.loads([l for l in alone.stdout.splitlines() if l.startswith("{")][0])
+    assert solo["chains"] == 2 and 0 < solo["probe_us"] < 250, solo            # a process alone on the device always finds a queue of its own
+    for r in res:
+        assert r["chains"] == 2
+        assert r["probe_us"] == -1 or 0 < r["probe_us"] < 250, r
+        assert r["checksum"] == solo["checksum"], (r, solo)                     # results never depend on the streams picked
+    print("chain probe with two processes on the device:", [r["probe_us"] for r in res], "alone:", solo["probe_us"])
