@@ -12,7 +12,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace creg
 
-extern "C" int creg_version(void) { return 400; }      // round 4: creg_train_args.y_unchanged, named creg_train_plan_info_t fields
+extern "C" int creg_version(void) { return 600; }      // round 6: creg_train_plan_resume / creg_train_state, creg_train_plan_info_t.chain_probe_us, creg_icp_nn_counters (400: y_unchanged, named info fields)
 extern "C" const char* creg_last_error(void) { return creg::g_err; }
 extern "C" int creg_device_check(void) {
     int dev = 0;

@@ -1285,7 +1285,10 @@ __device__ unsigned long long g_icp_blk[6][8192];
 // Always-on work counters of the search (round 6: the roofline of the configs[4] frame names THIS kernel): [0] waves that searched,
 // [1] float32 screen trips (a trip = 8 staged targets x the wave's 64 lanes = 512 pair evaluations), [2] trips that went on to the fp64
 // evaluation, [3] live sources (source-iterations), [4] tie rescans.  Wave-uniform tallies in SGPRs, one atomic per counter and wave.
-__device__ unsigned long long g_icp_nn_ct[8];
+// 256 shards (blockIdx & 255): ~2 800 waves of a launch adding to ONE word serialise in the L2 -- 88 atomics per microsecond and word, which
+// doubled the launch (50 -> 116 us, measured) when the tallies were first added unsharded.
+constexpr int ICP_CT_SHARDS = 256;
+__device__ unsigned long long g_icp_nn_ct[ICP_CT_SHARDS][8];
 __global__ __launch_bounds__(64 * ICP_NNW, ICP_NN_WPS) void k_icp_nn(IcpLarge P, int n, int k_total, int nf, double th2, int max_iter) {
     constexpr int SB = ICP_SB, SR = ICP_SB + 2;                       // staged targets per lane group and batch; slice stride
                                                                       // (+2: the four groups' equal slots fall into different LDS banks)
@@ -1676,9 +1679,11 @@ __global__ __launch_bounds__(64 * ICP_NNW, ICP_NN_WPS) void k_icp_nn(IcpLarge P,
     if (any) {
         const int nlive = __popcll(__ballot(live && g == 0));
         if (lane == 0) {
-            atomicAdd(&g_icp_nn_ct[0], 1ull); atomicAdd(&g_icp_nn_ct[1], (unsigned long long)ct_f32); atomicAdd(&g_icp_nn_ct[2], (unsigned long long)ct_f64);
-            atomicAdd(&g_icp_nn_ct[3], (unsigned long long)nlive);
-            if (ct_tie) atomicAdd(&g_icp_nn_ct[4], (unsigned long long)ct_tie);
+            unsigned long long* ct = g_icp_nn_ct[blockIdx.x & (ICP_CT_SHARDS - 1)];
+            atomicAdd(ct + 0, 1ull); atomicAdd(ct + 3, (unsigned long long)nlive);
+            if (ct_f32) atomicAdd(ct + 1, (unsigned long long)ct_f32);
+            if (ct_f64) atomicAdd(ct + 2, (unsigned long long)ct_f64);
+            if (ct_tie) atomicAdd(ct + 4, (unsigned long long)ct_tie);
         }
     }
 #ifdef CREG_ICP_BLK
@@ -1903,13 +1908,13 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
 
 extern "C" int creg_icp_nn_counters(double* out8, int32_t reset, int32_t timing) {
     if (out8) {
-        unsigned long long c[8];
+        static unsigned long long c[creg::ICP_CT_SHARDS][8];
         CREG_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(creg::g_icp_nn_ct), sizeof(c)));
-        for (int i = 0; i < 5; ++i) out8[i] = (double)c[i];
+        for (int i = 0; i < 5; ++i) { double t = 0.0; for (int sh = 0; sh < creg::ICP_CT_SHARDS; ++sh) t += (double)c[sh][i]; out8[i] = t; }
         out8[5] = g_icp_nn_us; out8[6] = (double)g_icp_nn_launches; out8[7] = 0.0;
     }
     if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        static const unsigned long long z[creg::ICP_CT_SHARDS][8] = {};
         CREG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(creg::g_icp_nn_ct), z, sizeof(z)));
         g_icp_nn_us = 0.0; g_icp_nn_launches = 0;
     }

@@ -390,6 +390,18 @@ __device__ unsigned long long g_nn_stats[8];       // waves, candidates tested, 
 #else
 #define NN_STAT(i, v) do { } while (0)
 #endif
+#ifdef CREG_NN_WAVE_STAMPS
+// Measurement build (tests/measure/nn_rows_waves.py): every wave of nn_l1_rows records when it started, when its box
+// bounds were done, when its visits were done and when it left (100 MHz wall clock), with its visit / candidate counts.
+struct NnWaveRec { unsigned long long t0, t1, t2, t3; int visits, cands, dir, blk; };
+constexpr unsigned NN_WAVE_CAP = 1u << 19, NN_WAVE_SHARDS = 256, NN_WAVE_PER = NN_WAVE_CAP / NN_WAVE_SHARDS;
+__device__ NnWaveRec g_nn_wave[NN_WAVE_CAP];
+__device__ unsigned g_nn_wave_n[NN_WAVE_SHARDS * 32];      // one slot counter per shard (blockIdx & 255), a 128-byte line each: thousands of waves taking
+                                                           //   their record slot from ONE word serialise in the L2 (47 us per launch: the first version measured itself)
+#define NN_WSTAMP(...) __VA_ARGS__
+#else
+#define NN_WSTAMP(...)
+#endif
 constexpr int NN_ROWQ = 16;                        // queries per wave
 #ifndef NN_ROW_FIRST
 #define NN_ROW_FIRST 2                             // blocks loaded in the first trip: the nearest by bound + the next ones, speculatively
@@ -397,21 +409,30 @@ constexpr int NN_ROWQ = 16;                        // queries per wave
 #ifndef NN_ROW_BATCH
 #define NN_ROW_BATCH 3                             // candidate blocks whose loads are in flight together after the first visit
 #endif
-constexpr int NN_ROW_SLOTS = (NN_BLOCK / 64) * NN_ROWQ;      // query slots per workgroup
+// Workgroups of FOUR waves (round 6).  nn_l1_rows has no workgroup-level state (no LDS, no barrier), so the workgroup only sets the
+// granule in which waves are admitted to a CU: an 8-wave workgroup takes two wave slots per SIMD, and at the franka shape's instance (94
+// VGPRs: five waves per SIMD) a CU held two of them -- four of the five slots -- so the 552 workgroups of a two-problem launch needed a
+// second round on 512 places: the last ~40 started 11 us into the launch (measured per wave, profiles/r06_nn_rows_waves_franka.log).
+// Four-wave workgroups fill all five slots and the whole launch is resident at once.
+#ifndef NN_ROWS_BLOCK
+#define NN_ROWS_BLOCK 256
+#endif
+constexpr int NN_ROW_SLOTS = (NN_ROWS_BLOCK / 64) * NN_ROWQ;      // query slots per workgroup
 
 // qs4: the QUERY cloud in slot order (xyz, bits(original index); padding = index INT_MAX), 64 * nqblk slots in use (nqblk_dev: the
 // device-side count when the host only knows an upper bound); tb: the target blocks of 64 slots with their boxes (NB per lane);
 // T: the targets in ORIGINAL order, 4 floats per point (the winner's coordinates for the epilogue); lossp[group]: the wave's partial.
 // nqblk_host: the HOST's upper bound of the query cloud's blocks -- what the slot array and lossp are allocated for (4 groups per block).
-// The grid is cut in workgroups of NN_ROW_SLOTS = 128 slots = two blocks: with an odd bound the last workgroup's upper four waves lie past
-// both arrays and leave before any load or store (they used to read qs4 and write lossp[4 nqblk_host ..] into the carve padding).
+// Waves past that bound leave before any load or store (with 128-slot workgroups and an odd bound the last workgroup's upper four
+// waves used to read qs4 and write lossp[4 nqblk_host ..] into the carve padding; workgroups are one block of 64 slots since round 6).
 template <int NB, typename Epi, bool NBDEV, bool NQDEV>
 __device__ __forceinline__ void nn_l1_rows(const float4* __restrict__ qs4, int nqblk, const int* nqblk_dev, int nqblk_host, NnBlocks tb, int dir, Epi& epi, int blk,
                                            const int* stop_flag, const float* __restrict__ T, float* __restrict__ lossp) {
     const int tid = threadIdx.x, lane = tid & 63, q = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = blk * (NN_BLOCK / 64) + wave;             // this wave's 16-slot group of the query cloud
+    const int grp = blk * (NN_ROWS_BLOCK / 64) + wave;        // this wave's 16-slot group of the query cloud
     if (grp >= 4 * nqblk_host) return;                        // wave-uniform; nothing below synchronises the workgroup
+    NN_WSTAMP(const unsigned long long ws_t0 = (unsigned long long)wall_clock64(); unsigned long long ws_t1 = 0, ws_t2 = 0; int ws_vis = 0, ws_cand = 0;)
     int stop = *stop_flag;
     int nblk = tb.nblk;
     if constexpr (NBDEV) nblk = *tb.nblk_dev;
@@ -447,6 +468,7 @@ __device__ __forceinline__ void nn_l1_rows(const float4* __restrict__ qs4, int n
     }
     unsigned long long key = (0x7f800000ull << 32) | 0x7fffffffu;      // (+inf : INT_MAX): nothing found yet
     NN_STAT(0 + 4 * dir, 1);
+    NN_WSTAMP(asm volatile("" :: "v"(bnd[0]), "v"(lm)); ws_t1 = wall_clock64();)
     // One block's 64 targets against the wave's queries: lane l holds target l (ONE coalesced 16-byte load per lane and visit); lane
     // (g, q) meets the sixteen targets of ITS row by rotating the row (DPP row_ror: the rotated operand feeds the subtraction
     // directly) -- every lane sees them in another order, which the key (distance : original index) does not care about.
@@ -492,6 +514,7 @@ __device__ __forceinline__ void nn_l1_rows(const float4* __restrict__ qs4, int n
             lm = __builtin_fminf(lm, bnd[gi]);
         }
         NN_STAT(1 + 4 * dir, 1);
+        NN_WSTAMP(++ws_cand;)
         return b;
     };
     auto needed = [&](const float (&bl)[3], const float (&bh)[3]) -> bool {      // does any query's own point-to-box bound reach its running distance?
@@ -512,10 +535,10 @@ __device__ __forceinline__ void nn_l1_rows(const float4* __restrict__ qs4, int n
         float4 v[NN_ROW_FIRST];
 #pragma unroll
         for (int j = 0; j < NN_ROW_FIRST; ++j) v[j] = tb.ts4[(size_t)max(bb[j], 0) * 64 + lane];
-        if (bb[0] >= 0) { NN_STAT(2 + 4 * dir, 1); visit(v[0]); }
+        if (bb[0] >= 0) { NN_STAT(2 + 4 * dir, 1); NN_WSTAMP(++ws_vis;) visit(v[0]); }
 #pragma unroll
         for (int j = 1; j < NN_ROW_FIRST; ++j)
-            if (bb[j] >= 0 && needed(bl[j], bh[j])) { NN_STAT(2 + 4 * dir, 1); visit(v[j]); }
+            if (bb[j] >= 0 && needed(bl[j], bh[j])) { NN_STAT(2 + 4 * dir, 1); NN_WSTAMP(++ws_vis;) visit(v[j]); }
     }
     // then batches of up to NN_ROW_BATCH: the next blocks by bound while the bound is <= the largest running distance of the wave's
     // queries (taken from the distances BEFORE the batch: a superset, r only shrinks), their loads in flight together; a block is
@@ -536,9 +559,10 @@ __device__ __forceinline__ void nn_l1_rows(const float4* __restrict__ qs4, int n
         for (int j = 0; j < NN_ROW_BATCH; ++j) v[j] = tb.ts4[(size_t)max(bb[j], 0) * 64 + lane];
 #pragma unroll
         for (int j = 0; j < NN_ROW_BATCH; ++j)
-            if (bb[j] >= 0 && needed(bl[j], bh[j])) { NN_STAT(2 + 4 * dir, 1); visit(v[j]); }
+            if (bb[j] >= 0 && needed(bl[j], bh[j])) { NN_STAT(2 + 4 * dir, 1); NN_WSTAMP(++ws_vis;) visit(v[j]); }
         if (!open) break;                                        // the batch was not full: nothing is left within r
     }
+    NN_WSTAMP(asm volatile("" :: "v"(key)); ws_t2 = wall_clock64();)
     // ---- per query (row 0): outputs, epilogue, the wave's partial
     const float bd = __uint_as_float((unsigned)(key >> 32));
     const int bi = (int)(unsigned)key;
@@ -550,6 +574,11 @@ __device__ __forceinline__ void nn_l1_rows(const float4* __restrict__ qs4, int n
     }
     acc = row_sum16_f(acc);
     if (lane == 0) lossp[grp] = acc;
+    NN_WSTAMP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              const unsigned long long ws_t3 = (unsigned long long)wall_clock64();
+              if (lane == 0) { const unsigned sh_ = blockIdx.x & (NN_WAVE_SHARDS - 1);
+                               const unsigned i_ = atomicAdd(&g_nn_wave_n[32 * sh_], 1u);
+                               if (i_ < NN_WAVE_PER) g_nn_wave[sh_ * NN_WAVE_PER + i_] = NnWaveRec{ws_t0, ws_t1, ws_t2, ws_t3, ws_vis, ws_cand, dir, blk}; })
 }
 
 template <int QW, typename IdxT, typename Epi>

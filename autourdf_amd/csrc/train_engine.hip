@@ -738,7 +738,7 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_plan(const float* A, int na, co
 // Round 5: the same launch with sixteen queries per wave (nn_l1_rows): both directions take their QUERIES in slot order of their own
 // block-sorted copy (ps4 / ys4: neighbours in space share a wave), 64-point blocks on both sides.
 template <int NBT, int NBP>
-__global__ __launch_bounds__(NN_BLOCK) void k_nn_rows(const float* A, const float* B, int blocksA, int blocksB, EngineEpi epi, NnBlocks yb, NnBlocks pb,
+__global__ __launch_bounds__(NN_ROWS_BLOCK) void k_nn_rows(const float* A, const float* B, int blocksA, int blocksB, EngineEpi epi, NnBlocks yb, NnBlocks pb,
                                                       size_t zstride) {
     asm volatile("" :: "s"(A), "s"(B), "s"(blocksA), "s"(blocksB), "s"(epi.sgn_x), "s"(epi.cnt4), "s"(epi.lossp_x), "s"(epi.lossp_y),
                  "s"(epi.bstride), "s"(epi.stopped), "s"(yb.ts4), "s"(yb.tbox), "s"(yb.nblk), "s"(pb.ts4), "s"(pb.tbox), "s"(pb.nblk_dev), "s"(zstride));
@@ -1727,7 +1727,7 @@ static void launch_nn(const Dims& D, const Ws& W, size_t bstride, int nz, hipStr
         const int blocksA = cdiv(64 * D.npb, NN_ROW_SLOTS), blocksB = cdiv(64 * D.nyb, NN_ROW_SLOTS);
         const dim3 grid((blocksA + blocksB) * nz);
         auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, grid, dim3(NN_BLOCK), 0, s, (const float*)W.pred4, (const float*)W.y4, blocksA, blocksB, epi, yb, pb, bstride);
+            hipLaunchKernelGGL(kern, grid, dim3(NN_ROWS_BLOCK), 0, s, (const float*)W.pred4, (const float*)W.y4, blocksA, blocksB, epi, yb, pb, bstride);
         };
         auto pick_p = [&](auto nbt) {
             constexpr int NBT = decltype(nbt)::value;
@@ -2423,6 +2423,30 @@ extern "C" int creg_debug_nn_stats(unsigned long long* out8, int reset) {
 }
 #endif
 
+#ifdef CREG_NN_WAVE_STAMPS
+// out: up to `cap` records of 8 x u64 {t0, t1, t2, t3, visits, candidates, direction, block}; returns the number recorded; reset != 0 clears
+extern "C" long long creg_debug_nn_waves(unsigned long long* out, long long cap, int reset) {
+    static unsigned n[creg::NN_WAVE_SHARDS * 32];
+    if (hipMemcpyFromSymbol(n, HIP_SYMBOL(creg::g_nn_wave_n), sizeof(n)) != hipSuccess) return -1;
+    long long total = 0;
+    if (out && cap > 0) {
+        std::vector<creg::NnWaveRec> h((size_t)creg::NN_WAVE_CAP);
+        if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(creg::g_nn_wave), sizeof(creg::NnWaveRec) * (size_t)creg::NN_WAVE_CAP) != hipSuccess) return -1;
+        for (unsigned sh = 0; sh < creg::NN_WAVE_SHARDS; ++sh) {
+            const unsigned m = n[32 * sh] < creg::NN_WAVE_PER ? n[32 * sh] : creg::NN_WAVE_PER;
+            for (unsigned i = 0; i < m && total < cap; ++i, ++total) {
+                const creg::NnWaveRec& r = h[(size_t)sh * creg::NN_WAVE_PER + i];
+                unsigned long long* o = out + 8 * total;
+                o[0] = r.t0; o[1] = r.t1; o[2] = r.t2; o[3] = r.t3; o[4] = (unsigned long long)r.visits; o[5] = (unsigned long long)r.cands;
+                o[6] = (unsigned long long)r.dir; o[7] = (unsigned long long)r.blk;
+            }
+        }
+    } else for (unsigned sh = 0; sh < creg::NN_WAVE_SHARDS; ++sh) total += n[32 * sh];
+    if (reset) { static const unsigned z[creg::NN_WAVE_SHARDS * 32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(creg::g_nn_wave_n), z, sizeof(z)) != hipSuccess) return -1; }
+    return total;
+}
+#endif
+
 #ifdef CREG_XCD_PROBE
 // ---- Stage 1 of the XCD-resident train: a MEASUREMENT build (python -m autourdf_amd.build --variant xcd with
 // CREG_EXTRA_FLAGS=-DCREG_XCD_PROBE; tests/measure/xcd_stage1.py).  Two questions, two kernels:
@@ -2600,7 +2624,7 @@ extern "C" int creg_debug_xcd_stage1(creg_train_plan* plan, const creg_train_arg
     const int grid = 8 * 32 * wg_per_cu;
     auto xl = [&](int i, int nzz, bool wscope) {
         const int par = i & 1;
-#define CREG_XCD_GO(R, WS) hipLaunchKernelGGL((k_nn_xcd<R, 1, 2, WS>), dim3(grid), dim3(NN_BLOCK), 0, s, (const float*)W.pred4, D.NP, (const float*)W.y4, D.NT, \
+#define CREG_XCD_GO(R, WS) hipLaunchKernelGGL((k_nn_xcd<R, 1, 2, WS>), dim3(grid), dim3(R ? NN_ROWS_BLOCK : NN_BLOCK), 0, s, (const float*)W.pred4, D.NP, (const float*)W.y4, D.NT, \
                                               blocksA, blocksB, epi, yb, pb, P->bstride, nzz, ctl, par)
         if (D.rows) { if (wscope) CREG_XCD_GO(true, true); else CREG_XCD_GO(true, false); }
         else { if (wscope) CREG_XCD_GO(false, true); else CREG_XCD_GO(false, false); }

@@ -46,7 +46,11 @@ N_PARAMS = (56 * HIDDEN + HIDDEN) + (HIDDEN * (HIDDEN // 2) + HIDDEN // 2) + (3 
 WORKLOADS = {"wx200_5": ("wx200_5", 4096, 20, "BASELINE configs[1]"),
              "franka": ("franka", 16384, 40, "BASELINE configs[2] shape"),
              "allegro": ("allegro_hand", 4096, 30, "BASELINE configs[3] shape"),
-             "c5": ("chain32", 262144, 128, "BASELINE configs[4] shape (ICP-style frame: assign + fit kernels)")}
+             "c5": ("chain32", 262144, 128, "BASELINE configs[4] shape (ICP-style frame: assign + fit kernels)"),
+             # round 6: frames of the REAL robots (the reference's URDFs + meshes through the sim_data path, minted in the build container by
+             # tests/golden/make_golden_real_frames.py: 2 sequences x 10 frames x 4096 points each) instead of the capsule chains of synthetic.py
+             "wx200_5_real": ("wx200_5_real", 4096, 20, "BASELINE configs[1] on real wx200 geometry: tests/golden/frames_wx200_5_real.npz"),
+             "franka_real": ("franka_real", 4096, 20, "real franka_panda geometry at N=4096 / num_seg 20: tests/golden/frames_franka_real.npz")}
 HBM_PEAK_GBPS = 8000.0
 STUB = os.environ.get("CREG_BENCH_STUB") == "1"      # CPU plumbing test: gloo + a stand-in registrar (tests/test_bench_cpu.py)
 
@@ -114,11 +118,11 @@ def _all_threads_probe(m, y, cl0, ncpu, cap_s=3.0):
 
 
 def cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters, budget_frames=2, budget_s=25.0):
-    """The oracle (CPU port of the reference path, `kind: "port"`) on the host cores.  First the team sizes 1 / 8 / 16 / 32 / 64 are
-    timed (one untimed epoch, then three); `value` is then measured at the FASTEST of them (it used to be a
-    hard-coded 16 although 32 measured faster): TWO full registered frames (2 x 600 Adam epochs + 2 resamples) unless the
-    box is so slow that a 25 s budget runs out first, in which case the rest is extrapolated from the per-epoch time and the sample says
-    so.  The all-threads point runs in a child process under a 3 s cap."""
+    """The oracle (CPU port of the reference path, `kind: "port"`) on the host cores.  The team sizes 1 / 8 / 16 / 32 are sampled (one untimed
+    epoch, then three); the two fastest each register FULL frames (2 x 300 Adam epochs + the resample, SURVEY 8(d): two frames for the
+    fastest by sample, one for the runner-up, inside a 25 s budget) and `value` is the faster sustained rate -- VERDICT r5 weak 6: the divisor
+    is the fastest configuration observed, never a hard-coded team.  64 threads are sampled afterwards, all threads in a child process under
+    a 3 s cap."""
     from oracle import _clib, models, registration
     torch.manual_seed(0)
     ncpu = os.cpu_count() or 1
@@ -135,37 +139,54 @@ def cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters, budget_frames=2, 
     team(min(16, ncpu))
     registration.train(m, y1, models.QRegMLP(True, HIDDEN), cl, rot="q", epochs=2)   # warm caches / build the C lib
     team_points = {}
-    for nt in (1, 8, 16, 32, 64):
-        if nt > ncpu:
-            continue
+
+    def time_team(nt):
         team(nt)
         registration.train(m, y1, models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=1)
         tt = time.perf_counter()
         n_ep = 3 if nt > 1 else 6
         registration.train(m, y1, models.QRegMLP(True, HIDDEN), cl0, rot="q", epochs=n_ep)
         team_points[nt] = (time.perf_counter() - tt) / n_ep
-    threads = min(team_points, key=team_points.get)
+
+    for nt in (1, 8, 16, 32):                              # (ascending; 64 and all threads come after `value` is measured)
+        if nt <= ncpu:
+            time_team(nt)
+    # `value` = SUSTAINED full frames, at the fastest team.  A 3-epoch sample does not predict a 600-epoch frame (32 threads sampled 4.8 ms per
+    # epoch and then ran two frames at 10.9 on the GPU box), so the two fastest teams by sample each register full frames and the faster one is
+    # `value` (the divisor must be the fastest configuration observed, not a hard-coded 16).
+    def full_frames(nt, n_frames):
+        team(nt)
+        model, model_rf = models.QRegMLP(True, HIDDEN), models.QRegMLP(True, HIDDEN)
+        mm, cc = torch.tensor(mats0, dtype=torch.float32), [c.clone() for c in cl0]
+        t0 = time.perf_counter()
+        ep_done, fr_done, t_km = 0, 0, 0.0
+        for f in range(n_frames):
+            y = torch.tensor(seq0[f + 1], dtype=torch.float32)
+            if f > 0 and budget_s / 2 - (time.perf_counter() - t0) < (time.perf_counter() - t0) / max(fr_done, 1):
+                break
+            _, m1, _, h1 = registration.train(mm, y, model, cc, rot="q", epochs=EPOCHS)
+            _, m2, _, h2 = registration.train(m1.detach(), y, model_rf, cl0, rot="q", epochs=EPOCHS, learning_rate=1e-4)
+            ep_done += len(h1["loss"]) + len(h2["loss"])
+            tk = time.perf_counter()
+            new, _ = registration.resample_cluster(seq0[f + 1], k_clusters, m2.detach().numpy())
+            t_km += time.perf_counter() - tk
+            mm, cc = m2.detach(), [torch.tensor(c, dtype=torch.float32) for c in new]
+            fr_done += 1
+        el = time.perf_counter() - t0
+        return {"threads": nt, "elapsed": el, "frames": fr_done, "epochs": ep_done, "t_km": t_km, "frame_s": el / max(fr_done, 1)}
+
+    ranked = sorted((nt for nt in team_points if nt > 1), key=team_points.get)[:2] or [1]
+    runs = [full_frames(nt, budget_frames if i == 0 else 1) for i, nt in enumerate(ranked)]
+    best = min(runs, key=lambda r: r["frame_s"])
+    threads, elapsed, frames_done, epochs_done, t_km = best["threads"], best["elapsed"], best["frames"], best["epochs"], best["t_km"]
     team(threads)
-    model, model_rf = models.QRegMLP(True, HIDDEN), models.QRegMLP(True, HIDDEN)
-    t0 = time.perf_counter()
-    epochs_done, frames_done, t_km = 0, 0, 0.0
-    for f in range(budget_frames):
-        y = torch.tensor(seq0[f + 1], dtype=torch.float32)
-        left = budget_s - (time.perf_counter() - t0)
-        if f > 0 and left < (time.perf_counter() - t0) / max(frames_done, 1):
-            break
-        _, m1, _, h1 = registration.train(m, y, model, cl, rot="q", epochs=EPOCHS)
-        _, m2, _, h2 = registration.train(m1.detach(), y, model_rf, cl0, rot="q", epochs=EPOCHS, learning_rate=1e-4)
-        epochs_done += len(h1["loss"]) + len(h2["loss"])
-        tk = time.perf_counter()
-        new, _ = registration.resample_cluster(seq0[f + 1], k_clusters, m2.detach().numpy())
-        t_km += time.perf_counter() - tk
-        m, cl = m2.detach(), [torch.tensor(c, dtype=torch.float32) for c in new]
-        frames_done += 1
-    elapsed = time.perf_counter() - t0
     per_epoch = (elapsed - t_km) / max(epochs_done, 1)
-    frame_s = elapsed / frames_done if frames_done else float("nan")
+    frame_s = best["frame_s"]
     km_s = t_km / max(frames_done, 1)
+    sustained = {str(r["threads"]): round((r["elapsed"] - r["t_km"]) / max(r["epochs"], 1) * 1e3, 2) for r in runs}
+    if ncpu >= 64:
+        time_team(64)                                    # reported, after the fact (never the fastest on this class of host: 30 ms per epoch)
+        team(threads)
     all_cores = None
     if ncpu > max(team_points):
         per_all, what = _all_threads_probe(torch.tensor(mats0, dtype=torch.float32), y1, cl0, ncpu)
@@ -186,8 +207,10 @@ def cpu_baseline(seq0, mats0, clusters0, n_points, k_clusters, budget_frames=2, 
                            "sample": "6 epochs, extrapolated to 600 + the measured resample"},
             "all_cores": all_cores,
             "ms_per_epoch_by_threads": by,
-            "cores_note": f"`value` is taken at {threads} threads, the FASTEST of the team sizes timed in this run (1 / 8 / 16 / 32 / 64: one untimed epoch, "
-                          "then three); the all-threads point runs in a child process under a 3 s cap; the port's OpenMP C search is also faster than "
+            "ms_per_epoch_sustained_full_frames": sustained,
+            "cores_note": f"`value` = full registered frames at {threads} threads: the faster of the two fastest teams by 3-epoch sample (1 / 8 / 16 / 32 timed "
+                          f"first, 64 after), each run through whole frames ({sustained} ms per epoch sustained -- a short sample does not predict a 600-epoch "
+                          "frame); the all-threads point runs in a child process under a 3 s cap; the port's OpenMP C search is also faster than "
                           "pytorch3d's single-threaded knn_cpu, so the GPU / CPU ratio is conservative",
             "host": {"cpu_model": cpu_model, "os_cpu_count": os.cpu_count()},
             "sample": f"{frames_done} full registered frame(s) of sequence 0 (N={n_points}, K={k_clusters}, hidden {HIDDEN}): {epochs_done} Adam "
@@ -313,6 +336,20 @@ class _Mark:
 
     def elapsed_time(self, other):
         return self.ev.elapsed_time(other.ev) if self.ev is not None else (other.t - self.t) * 1e3
+
+
+def frames_of(robot, sid, n_frames, n_points):
+    """The frames of sequence `sid`: synthetic capsule chains (autourdf_amd.synthetic.make_sequence) or, for a `*_real` workload, the
+    committed frames of the real robot (2 sequences x 10 frames; sequence ids wrap)."""
+    if robot.endswith("_real"):
+        d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", f"frames_{robot}.npz"))
+        f = d["frames"]
+        if n_frames > f.shape[1] or n_points != f.shape[2]:
+            raise SystemExit(f"--workload {robot}: the fixture holds {f.shape[0]} sequences x {f.shape[1]} frames x {f.shape[2]} points "
+                             f"(asked for {n_frames} frames of {n_points}): e.g. --sequences 2 --steps 12 --warmup 4")
+        return [f[sid % f.shape[0], i].astype(np.float64) for i in range(n_frames)]
+    from autourdf_amd.synthetic import make_sequence
+    return make_sequence(robot, sid, n_frames, n_points)
 
 
 def _registrar_cls():
@@ -866,6 +903,8 @@ def main(argv=None):
         raise SystemExit(self_launch(args.gpus, sys.argv[1:] if argv is None else argv))
     ctx = init_world(args)
     robot, n_points, k_clusters, wl_tag = WORKLOADS[args.workload]
+    if robot.endswith("_real") and (args.steps, args.warmup, args.sequences) == (ap.get_default("steps"), ap.get_default("warmup"), ap.get_default("sequences")):
+        args.steps, args.warmup, args.sequences = 12, 4, 2          # what the fixture holds: 2 sequences x 9 registrations
     if args.workload == "c5":
         args.mode = "replay"
         out = run_c5(args, ctx, robot, n_points, k_clusters, wl_tag)
@@ -1006,9 +1045,10 @@ def run_registration(args, ctx):
         timed_rounds = (args.steps + S - 1) // S
         n_frames = warm_rounds + timed_rounds + 1
         seq_ids = [args.seed_offset + rank * 1000 + s for s in range(S)]
-    seq0 = make_sequence(robot, 0, max(n_frames, FRAMES_PER_SEQ), n_points)
+    n_gen = n_frames if robot.endswith("_real") else max(n_frames, FRAMES_PER_SEQ)
+    seq0 = frames_of(robot, 0, n_gen, n_points)
     mats0, clusters0, _ = initial_segmentation(seq0[0], k_clusters, seed=0)      # shared frame-0 state (mlp_reg.py:242-253)
-    seqs = [make_sequence(robot, sid, max(n_frames, FRAMES_PER_SEQ), n_points) for sid in seq_ids]
+    seqs = [frames_of(robot, sid, n_gen, n_points) for sid in seq_ids]
     frames64 = [[torch.as_tensor(f, dtype=torch.float64, device=dev) for f in s[1:n_frames]] for s in seqs]
     frames32 = [[f.to(torch.float32) for f in s] for s in frames64]
     hidden = 3 if args.r == "rpy" else HIDDEN            # (the reference builds RegMLP(6, 3), mlp_reg.py:285)

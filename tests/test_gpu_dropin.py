@@ -312,3 +312,82 @@ def test_chain_stream_probe_with_two_processes_sharing_the_device(tmp_path):
         assert r["probe_us"] == -1 or 0 < r["probe_us"] < 250, r
         assert r["checksum"] == solo["checksum"], (r, solo)                     # results never depend on the streams picked
     print("chain probe with two processes on the device:", [r["probe_us"] for r in res], "alone:", solo["probe_us"])
+
+
+@pytest.mark.parametrize("robot", ["wx200_5", "franka"])
+def test_real_robot_geometry_frames(robot, tmp_path, monkeypatch, golden):
+    """VERDICT r5 item 6 / SURVEY N4: frames of the REAL robots -- the reference's URDF + meshes (Robot/interbotix_descriptions wx200,
+    Robot/franka) posed along the reference's joint trajectories, seen through its camera ring, noise and farthest-point down-sampling as
+    Sim/sim_data.py does it (tests/golden/make_golden_real_frames.py, minted in the build container: 2 sequences x 10 frames x 4096 points,
+    num_seg 20) -- instead of the capsule chains every other test runs on:
+      * k-means labels of a frame (Segments' seeding path: k-means++ + Lloyd on the GPU, then the frame-to-frame resample) bit-exact
+        against the oracle; the nearest-neighbour search bit-exact;
+      * train(): the forward of the entering parameters and teacher-forced single epochs (e = 0, 3, 7) within 1e-6 (loss) / 1e-5 (pose),
+        lr and counters exact -- a free-running 8-epoch bound does not exist on these frames (see below);
+      * match() on the PLY files writes the reference's file layout, and its clusters are inv(M) . the frame's points."""
+    import os as _os
+    if not _os.path.exists(_os.path.join(_os.path.dirname(__file__), "golden", f"frames_{robot}_real.npz")):
+        pytest.skip(f"frames_{robot}_real.npz not minted")
+    from autourdf_amd import mlp_reg, ops
+    from autourdf_amd.synthetic import initial_segmentation
+    from oracle import chamfer, kmeans as okm, models as omodels, registration as oreg
+    dev = torch.device("cuda:0")
+    g = golden(f"frames_{robot}_real.npz")
+    frames = g["frames"].astype(np.float64)
+    K = int(g["num_seg"])
+    assert frames.shape == (2, 10, 4096, 3) and K == 20
+    mats, clusters, _ = initial_segmentation(frames[0, 0], K, seed=0)
+    # --- K2: the frame-to-frame re-segmentation seeded at the poses' translations, labels bit-exact; its iteration count
+    f1 = torch.as_tensor(frames[0, 1], device=dev)
+    seeds = torch.as_tensor(mats[:, :3, 3].copy(), device=dev)
+    _, lab, _, n_it = ops.kmeans_lloyd(f1, seeds)
+    _, olab, _, on_it = okm.k_means(frames[0, 1], mats[:, :3, 3])
+    assert (lab.cpu().numpy() == olab).all() and int(n_it) == int(on_it)
+    # --- K1: nearest neighbours between the predicted cloud (frame 0) and frame 1, indices and distances bit-exact
+    x, y = frames[0, 0].astype(np.float32), frames[0, 1].astype(np.float32)
+    dx, ix, dy, iy = ops.nn_l1_bidir(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+    odx, oix = chamfer.nn_l1(x, y)
+    ody, oiy = chamfer.nn_l1(y, x)
+    assert (ix.cpu().numpy() == oix).all() and (dx.cpu().numpy() == odx).all() and (iy.cpu().numpy() == oiy).all() and (dy.cpu().numpy() == ody).all()
+    # --- A1: train() at the reference's model (hidden 512) from the frame-0 state.  On these frames -- as on the allegro shape -- NO second
+    #     float32 evaluation follows the reference for even one free-running step: the oracle with its GEMMs summed in another order is 1.1e-3
+    #     away in pose after ONE epoch, 1.2e-2 after four (measured in the build container, DESIGN section 2: the first Adam step turns every
+    #     gradient into +-lr, and sums of +-1/N signs sit next to zero), so the 8-epoch free-running bound of the capsule chains does not
+    #     exist here.  What does: the forward of the entering parameters, and single epochs teacher-forced from the oracle's state.
+    import _teacher as T
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone() for k, v in omodels.QRegMLP(True, 512).state_dict().items()}
+    off_np = np.cumsum([0] + [len(c) for c in clusters])
+    case = {"m": mats.astype(np.float32), "y": y, "local": np.concatenate(clusters).astype(np.float32), "offsets": off_np}
+    snaps, hist = T.oracle_snapshots(case, sd, K, (0, 3, 7))
+    m_d, y_d = torch.from_numpy(case["m"]).to(dev), torch.from_numpy(y).to(dev)
+    pts, off = ops.pack_clusters([torch.from_numpy(c) for c in T.split(case["local"], off_np)], dev)
+    plan = ops.TrainPlan("q", K, 512, pts.shape[0], 4096, epochs=300, use_graph=False, device=dev)
+    probe_plan = ops.TrainPlan("q", K, 512, pts.shape[0], 4096, epochs=2, use_graph=False, device=dev)
+    for e in (0, 3, 7):
+        r = T.compare(ops.Q_PARAM_ORDER, snaps[e], snaps[e + 1], *T.plan_epoch(plan, probe_plan, dev, ops.Q_PARAM_ORDER, m_d, y_d, pts, off, snaps[e]))
+        assert r["loss_rel"] <= 1e-6 and r["pose"] <= 1e-5, (e, r)
+        assert r["lr_used_exact"] and r["lr"][0] == r["lr"][1] and all(a == b for a, b in r["exact"].values()), (e, r)
+        if e > 0:
+            assert r["upd"] <= 3e-6, (e, r["upd"], r["upd_worst_tensor"])
+    # --- F1: match() on the PLY files of two sequences x three frames
+    for v in range(2):
+        for t in range(3):
+            _write_ply(str(tmp_path / f"data/raw/{robot}/4_deg_20_cams/V{v:04}/{t:04}/robot.ply"), frames[v, t])
+    json.dump({robot: {"num_seg": K, "dof": 5}}, open(tmp_path / "parameters.json", "w"))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(mlp_reg, "EPOCHS", 12)
+    mlp_reg._PLANS.clear()
+    mlp_reg.main(["--robot", robot, "--num_video", "2", "--loss"])
+    base = tmp_path / f"data/part/{robot}_{K}_seg/4_deg_20_cams"
+    for v in range(2):
+        for t in range(3):
+            mm = np.load(base / f"V{v:04}" / "matrix" / f"{t:04}.npy")
+            assert mm.shape == (K, 4, 4) and np.isfinite(mm).all()
+            with np.load(base / f"V{v:04}" / "cluster" / f"{t:04}.npz") as z:
+                assert list(z.keys()) == [str(i) for i in range(K)] and sum(len(z[k]) for k in z.keys()) == 4096
+    mm = np.load(base / "V0001/matrix/0002.npy").astype(np.float64)
+    with np.load(base / "V0001/cluster/0002.npz") as z:
+        world = np.concatenate([z[str(i)] @ mm[i, :3, :3].T + mm[i, :3, 3] for i in range(K)])
+    assert np.abs(np.sort(world, 0) - np.sort(frames[1, 2], 0)).max() < 1e-6
+    assert np.loadtxt(base / "V0000/loss.txt").shape == (2,)
