@@ -104,6 +104,9 @@ def main(src, tag, dst="profiles"):
     cp("km_quick.log", f"{tag}_kmeans_lloyd_iteration.log")
     cp("headline_repeats.log", f"{tag}_headline_repeats.log")
     cp("divergence_envelope_gpu.log", f"{tag}_divergence_envelope_gpu.log")
+    cp("nn_rows_waves.log", f"{tag}_nn_rows_waves.log")
+    cp("teacher_forced.log", f"{tag}_teacher_forced.log")
+    cp("bench_wx200_5_real.log", f"{tag}_final_bench_wx200_5_real.log")
     print("\n".join(lines))
     if os.path.exists(f"{src}/stats_kernel_stats.csv"):
         for r in list(csv.DictReader(open(f"{src}/stats_kernel_stats.csv")))[:8]:
