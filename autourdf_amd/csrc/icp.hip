@@ -922,6 +922,13 @@ __global__ __launch_bounds__(1024) void k_icp_mask(IcpLarge P, int nf, float hal
         const int d = tid;
         float l = wl[0][d], h = wh[0][d];
         for (int w = 1; w < 16; ++w) { l = fminf(l, wl[w][d]); h = fmaxf(h, wh[w][d]); }
+        if (toff) {
+            //  point-to-point mode: l / h are float32 ROUNDINGS of the fp64 targets, which can lie half an ulp outside them -- the
+            // float32 screen of k_icp_nn takes its length bound from this box ("the box holds the targets"): one ulp outwards makes that true;
+            // an EMPTY target segment (+inf / -inf) would give a NaN centre and an infinite bound: a point box at the origin instead
+            if (!(l <= h)) { l = 0.f; h = 0.f; }
+            else { l = nextafterf(l, -INFINITY); h = nextafterf(h, INFINITY); }
+        }
         const float c = (l + h) / 2.0f, sz = h - l;
         s_lo[d] = toff ? l : c - half_scale * sz; s_hi[d] = toff ? h : c + half_scale * sz;
         if (P.box) { P.box[6 * k + d] = s_lo[d]; P.box[6 * k + 3 + d] = s_hi[d]; }

@@ -211,20 +211,16 @@ constexpr int L2_THREADS = 512;
 constexpr int L2_RB = 32;             // pose rows per pass (two M-tiles)
 constexpr int L2_SMEM = (L2_THREADS / 64) * L2_RB * 16 * 4;
 template <int NC>
-__global__ __launch_bounds__(L2_THREADS) void k_l2(Dims D, Ws W0, int par, size_t bstride) {
+__device__ __forceinline__ void l2_body(const Dims& D, const Ws& W, int par, int blk) {
     constexpr int KW = 8 * NC, NS = KW / 4;
     constexpr bool V4 = KW % 16 == 0;
     constexpr int NL = V4 ? NS / 4 : NS;           // loads per operand tile and lane
     __shared__ __attribute__((aligned(16))) float red[(L2_THREADS / 64) * L2_RB * 16];
-    // every kernel argument in the entry block, one wait (see k_bd)
-    asm volatile("" :: "s"(W0.P), "s"(W0.P1), "s"(W0.x1[0]), "s"(W0.x1[1]), "s"(W0.h2[0]), "s"(W0.h2[1]), "s"(W0.state), "s"(D.K), "s"(D.H),
-                 "s"(D.H2), "s"(D.oW2), "s"(D.ob2), "s"(D.slope), "s"(par), "s"(bstride));
-    const Ws W = ws_shift(W0, blockIdx.z * bstride);
     const float* Pc = par ? W.P1 : W.P;
     const float* x1cur = par ? W.x1[1] : W.x1[0];     // (a runtime index into the shifted struct would go to scratch)
     float* h2out = par ? W.h2[1] : W.h2[0];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lj = lane & 15, kk = lane >> 4;
-    const int u0 = blockIdx.x * 16, H = D.H;         // grid covers H2 exactly (H2 % 32 == 0)
+    const int u0 = blk * 16, H = D.H;                // grid covers H2 exactly (H2 % 32 == 0)
     auto load_t = [&](const float* rowp, float* dst) {     // one operand tile of this lane: its wave's KW inputs of row `rowp`
         const float* p = rowp + wv * KW + (V4 ? 4 * kk : kk);
 #pragma unroll
@@ -276,6 +272,14 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2(Dims D, Ws W0, int par, size_
             h2out[(size_t)(r0 + (tid >> 4)) * D.H2 + u0 + (tid & 15)] = act_f(sum + bias, D.slope);
         }
     }
+}
+template <int NC>
+__global__ __launch_bounds__(L2_THREADS) void k_l2(Dims D, Ws W0, int par, size_t bstride) {
+    // every kernel argument in the entry block, one wait (see k_bd)
+    asm volatile("" :: "s"(W0.P), "s"(W0.P1), "s"(W0.x1[0]), "s"(W0.x1[1]), "s"(W0.h2[0]), "s"(W0.h2[1]), "s"(W0.state), "s"(D.K), "s"(D.H),
+                 "s"(D.H2), "s"(D.oW2), "s"(D.ob2), "s"(D.slope), "s"(par), "s"(bstride));
+    const Ws W = ws_shift(W0, blockIdx.z * bstride);
+    l2_body<NC>(D, W, par, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------ head + transform
@@ -2554,6 +2558,25 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_xcd(const float* A, int na, con
         }
     }
 }
+// Stage 2 pre-check: the hidden-layer launch (k_l2) with one problem's H2 / 16 workgroups confined to ONE XCD (problem = XCC_ID, blocks from the
+// per-XCD queue) -- what the W2 slabs (1.5 MB per problem, written through by k_bd a launch earlier) cost through one XCD's fabric port.
+template <int NC>
+__global__ __launch_bounds__(L2_THREADS) void k_l2_xcd(Dims D, Ws W0, int par, size_t bstride, int nz, int* ctl, int cpar) {
+    __shared__ int s_bx;
+    const int x = xcc_id();
+    int* mine = ctl + 32 * (16 * cpar + x);
+    if (threadIdx.x == 0) ctl[32 * (16 * (cpar ^ 1) + x)] = 0;
+    if (x >= nz) return;
+    const Ws W = ws_shift(W0, x * bstride);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_bx = __hip_atomic_fetch_add(mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int bx = s_bx;
+        if (bx >= D.H2 / 16) return;
+        l2_body<NC>(D, W, par, bx);
+    }
+}
 }  // namespace creg
 
 // out (HOST, 64 doubles):
@@ -2562,6 +2585,7 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_xcd(const float* A, int na, con
 //  [16] the plan's NN launch, one problem on the whole chip (us, 200 back to back)   [17] the same with `nz` problems in grid.z
 //  [18] XCD-confined, nz problems, agent-scope queue   [19] workgroup-scope queue   [20] 1 problem confined   [21] outputs identical to the plan's launch (1 / 0)
 //  [22] workgroups per XCD used   [24..31] workgroups that landed on XCD 0..7 in the last confined launch
+//  [32] k_l2 chip-wide, nz problems (us, 200 back to back)   [33] k_l2 confined, problem = XCC_ID   [34] h2 identical (1 / 0)   [35] k_l2 chip-wide, 1 problem   [36] confined, 1 problem
 extern "C" int creg_debug_xcd_stage1(creg_train_plan* plan, const creg_train_args* a, int32_t nz, int32_t wg_per_cu, double* out, creg_stream_t stream) {
     Plan* P = (Plan*)plan;
     CREG_REQUIRE(P && a && out && nz >= 1 && nz <= 8 && nz <= P->B && wg_per_cu >= 1 && wg_per_cu <= 8, "creg_debug_xcd_stage1: bad argument");
@@ -2663,6 +2687,33 @@ extern "C" int creg_debug_xcd_stage1(creg_train_plan* plan, const creg_train_arg
     }
     out[22] = 32 * wg_per_cu;
     CREG_LAUNCH_CHECK();
+    if (D.H == 512) {   // ---- Stage 2 pre-check: k_l2
+        const int l2grid = 8 * (D.H2 / 16);
+        auto l2x = [&](int i, int nzz) { hipLaunchKernelGGL((k_l2_xcd<8>), dim3(l2grid), dim3(L2_THREADS), 0, s, D, W, 0, P->bstride, nzz, ctl, i & 1); };
+        P->nz = nz;
+        if (int r2 = timed([&](int) { launch_l2(P, 0, s); }, out + 32)) return r2;
+        CREG_HIP(hipMemsetAsync(ctl, 0, 4 * 32 * 32, s));
+        if (int r2 = timed([&](int i) { l2x(i, nz); }, out + 33)) return r2;
+        P->nz = 1;
+        if (int r2 = timed([&](int) { launch_l2(P, 0, s); }, out + 35)) return r2;
+        CREG_HIP(hipMemsetAsync(ctl, 0, 4 * 32 * 32, s));
+        if (int r2 = timed([&](int i) { l2x(i, 1); }, out + 36)) return r2;
+        P->nz = nz;
+        const size_t nh = (size_t)D.KP * D.H2;
+        std::vector<float> h0(nh * nz), h1(nh * nz);
+        launch_l2(P, 0, s);
+        CREG_HIP(hipStreamSynchronize(s));
+        for (int z = 0; z < nz; ++z) CREG_HIP(hipMemcpy(h0.data() + nh * z, ws_shift(W, (size_t)z * P->bstride).h2[0], 4 * nh, hipMemcpyDeviceToHost));
+        for (int z = 0; z < nz; ++z) CREG_HIP(hipMemsetAsync(ws_shift(W, (size_t)z * P->bstride).h2[0], 0xff, 4 * (size_t)D.K * D.H2, s));
+        CREG_HIP(hipMemsetAsync(ctl, 0, 4 * 32 * 32, s));
+        l2x(0, nz);
+        CREG_HIP(hipStreamSynchronize(s));
+        for (int z = 0; z < nz; ++z) CREG_HIP(hipMemcpy(h1.data() + nh * z, ws_shift(W, (size_t)z * P->bstride).h2[0], 4 * nh, hipMemcpyDeviceToHost));
+        bool same = true;
+        for (int z = 0; z < nz && same; ++z) same = memcmp(h0.data() + nh * z, h1.data() + nh * z, 4 * (size_t)D.K * D.H2) == 0;
+        out[34] = same ? 1.0 : 0.0;
+        CREG_LAUNCH_CHECK();
+    }
     P->nz = nz_keep;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(ctl); (void)hipFree(payload); (void)hipFree(ticks); (void)hipFree(errs);

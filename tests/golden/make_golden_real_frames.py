@@ -30,6 +30,13 @@ REF = "/root/reference"
 N_SEQ, N_FRAMES, N_POINTS = 2, 10, 4096
 
 
+POOL = None
+
+
+def _one_camera(job):
+    return osim.visibility(*job)[0]
+
+
 def cpu_env(env):
     """The three kernel calls of SimEnv / data_collection on the host (oracle restatements)."""
     r = env.robot
@@ -40,9 +47,15 @@ def cpu_env(env):
         return torch.as_tensor(out)
 
     def visible(joint_positions, pts, width=800, height=800, eps=0.004):
+        # a point is visible when SOME camera sees it and every camera has its own depth buffer: one oracle call per camera, in a process
+        # pool, OR-ed (the same result as one call over the ring; the per-triangle rasteriser is a Python loop: 126 586 triangles for franka)
         T = r.fk(joint_positions, env.base)
         c = env.cameras[0]
-        vis, _ = osim.visibility(r.tri, r.tri_link, T, env.cam_frames, pts.numpy(), c["fov"], c["aspect"], c["near_val"], c["far_val"], width, height, eps)
+        jobs = [(r.tri, r.tri_link, T, env.cam_frames[i:i + 1], pts.numpy(), c["fov"], c["aspect"], c["near_val"], c["far_val"], width, height, eps)
+                for i in range(len(env.cam_frames))]
+        vis = np.zeros(len(pts), bool)
+        for v in POOL.map(_one_camera, jobs):
+            vis |= v
         return torch.as_tensor(vis)
 
     env.sample_surface, env.visible = sample_surface, visible
@@ -70,6 +83,8 @@ def mint(robot, width):
 
 
 if __name__ == "__main__":
+    import multiprocessing
+    POOL = multiprocessing.Pool(min(8, os.cpu_count() or 1))
     for rb in (sys.argv[1:] or ["wx200_5", "franka"]):
         # (franka: 126 586 triangles x 20 cameras through the oracle's per-triangle rasteriser -- a 400 x 400 depth buffer keeps it to minutes)
         mint(rb, 800 if rb != "franka" else 400)

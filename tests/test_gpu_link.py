@@ -173,3 +173,30 @@ def test_icp_point_to_point_in_the_many_workgroup_regime_vs_oracle():
         assert int(it3[i]) == n_ref == int(it1[i])
     np.testing.assert_allclose(T3.cpu().numpy(), T1.cpu().numpy(), atol=1e-12)
     np.testing.assert_allclose(m3.cpu().numpy(), m1.cpu().numpy(), atol=1e-12)
+
+
+def test_icp_point_to_point_large_regime_empty_target_segment_and_far_coordinates():
+    """ADVICE r5 (icp.hip, many-workgroup point-to-point mode): (a) a pair whose TARGET segment is empty used to give a NaN box centre and an
+    infinite screen bound -- it must leave its pose at the initial one, 0 iterations' worth of change, and not disturb its neighbours;
+    (b) targets far from the origin relative to their extent (|coordinate| / extent ~ 1e6: the float32 box is a rounding of the fp64
+    targets, now widened by one ulp) still match the oracle."""
+    from autourdf_amd import ops
+    from oracle import icp as oicp
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rng = np.random.default_rng(5)
+    base = rng.uniform(-0.05, 0.05, size=(3000, 3)) * np.array([1.0, 0.7, 0.2])
+    far = np.array([1.0e4, -2.0e4, 5.0e3])
+    srcs = [base[:2600] + 1e-3, rng.uniform(size=(1500, 3)), (base + far)[:2800] + np.array([8e-4, -5e-4, 3e-4])]
+    tgts = [base, np.zeros((0, 3)), base + far]
+    so = torch.tensor(np.cumsum([0] + [len(a) for a in srcs]), dtype=torch.int32, device=dev)
+    to = torch.tensor(np.cumsum([0] + [len(a) for a in tgts]), dtype=torch.int32, device=dev)
+    T, moved, it = ops.icp_p2p(torch.as_tensor(np.concatenate(srcs), device=dev), so, torch.as_tensor(np.concatenate(tgts), device=dev), to,
+                               torch.eye(4, dtype=torch.float64, device=dev).repeat(3, 1, 1), th=0.05, max_iteration=200)
+    T = T.cpu().numpy()
+    assert np.isfinite(T).all() and np.isfinite(moved.cpu().numpy()).all()
+    np.testing.assert_allclose(T[1], np.eye(4), atol=0)                                   # nothing to register to: the pose stays
+    for i in (0, 2):
+        T_ref, _, _, n_ref = oicp.registration_icp(srcs[i], tgts[i], 0.05, np.eye(4), 200)
+        np.testing.assert_allclose(T[i][:3, :3], T_ref[:3, :3], atol=1e-8)
+        np.testing.assert_allclose(T[i][:3, 3], T_ref[:3, 3], atol=1e-8 if i == 0 else 2e-7)    # (translations of 1e4: fp64 ulp 2e-12 x the rotation's lever)
+        assert int(it[i]) == n_ref
