@@ -30,6 +30,10 @@
 #include "creg_common.h"
 #include "nn_l1.h"
 
+#ifndef CREG_L2_IN_BD_DEFAULT
+#define CREG_L2_IN_BD_DEFAULT false        // (until measured faster)
+#endif
+
 namespace creg {
 
 struct Dims {
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(256) void k_prep(Dims D, Ws W0, size_t bstride, Pre
             s.bc2_sqrt = 1.f; s.last_loss = NAN;
             s.next_bc1 = 1.0 - 0.9; s.next_bc2s = (float)sqrt(1.0 - 0.999);         // step 1 (the tables are filled by this launch)
             W.state[0] = s; W.state[1] = s;
+            for (int i = 0; i < 64; ++i) W.sync[i] = 0;          // [1]: arrivals of the backward launch's B role since the train began (k_bd with the next hidden activation inside)
         }
     }
 }
@@ -1087,7 +1092,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 // those lines before, MI355X_MICROARCH.md "valid forms").  One polling lane per workgroup; the poll is bounded (a few hundred
 // milliseconds): a launch whose producers never arrive -- which cannot happen while workgroups are dispatched in index order, the
 // gradient role owning the lowest indices -- ends as a stopped train instead of hanging the queue.
-struct GbdRecord { int stopped; float step_size, bc2_sqrt; };
+struct GbdRecord { int stopped; float step_size, bc2_sqrt; int step; };
 __device__ __forceinline__ bool gbd_wait(const Ws& W, int K) {
     __shared__ int s_ok;
     if (threadIdx.x == 0) {
@@ -1105,7 +1110,10 @@ __device__ __forceinline__ GbdRecord gbd_record(const Ws& W, bool ok) {
     return r;
 }
 
-template <int KW, bool X, bool FUSED = false>              // W2 rows per wave: H2 = 8 KW; X: more than 64 input features ('6d': 72) -- lanes i4 < 2 of a row take a second float4
+// L2IN (round 6): the D role of the SAME launch goes on to the next hidden activation (what k_l2 computed a launch later) and needs the next
+// encoder activation this role produces: the tile leaves as 16-byte write-through stores, the wave drains them, and the workgroup counts
+// itself in W.sync[1] -- a monotonic count of B-role arrivals since the train began (nB per optimizer step; k_prep / k_set_state set it).
+template <int KW, bool X, bool FUSED = false, bool L2IN = false>              // W2 rows per wave: H2 = 8 KW; X: more than 64 input features ('6d': 72) -- lanes i4 < 2 of a row take a second float4
 __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch, int blk, float* sh, unsigned long long bd_entry) {
     constexpr int NS = KW / 4;                 // k-steps of a wave
     constexpr bool V4 = KW % 16 == 0;          // A operand as 16-byte loads
@@ -1297,7 +1305,17 @@ __device__ __forceinline__ void bwd2_role(const Dims& D, const Ws& W, int epoch,
         if (i4 == 0) xt[r * B2_CB + row] = act_f(v, D.slope);
     }
     __syncthreads();
-    if (live)                                   // the tile goes out as 64-byte row segments, 8 bytes per lane
+    if constexpr (L2IN) {
+        if (live) {                             // 64-byte row segments as four 16-byte write-through stores: the D role reads them in this launch
+            for (int t = tid; t < D.K * (B2_CB / 4); t += B2_THREADS) {
+                const int r = t >> 2, c4 = 4 * (t & 3);
+                st4_wt(x1next, r * D.H + c0 + c4, *(const float4*)(xt + r * B2_CB + c4));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's write-through stores have been acknowledged ...
+            __syncthreads();                                       // ... every thread's
+            if (tid == 0) __hip_atomic_fetch_add(W.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (live)                            // the tile goes out as 64-byte row segments, 8 bytes per lane
         for (int t = tid; t < D.K * (B2_CB / 2); t += B2_THREADS) {
             const int r = t >> 3, c2 = 2 * (t & 7);
             *(nn_f2*)(x1next + (size_t)r * D.H + c0 + c2) = nn_f2{xt[r * B2_CB + c2], xt[r * B2_CB + c2 + 1]};
@@ -1324,8 +1342,8 @@ constexpr int DW_TILES = 4;           // 16-input tiles per wave: 8 waves x 64 i
 constexpr int DW_KC = 5;              // k-steps (4 pose rows each) per chunk of operand loads: K = 20 is one chunk
 __host__ __device__ inline int dw_blocks(const Dims& D) { return D.H2 / DW_UNITS + 2; }
 
-template <bool FUSED = false>
-__device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, int blk, unsigned long long bd_entry) {
+template <bool FUSED = false, bool L2IN = false>
+__device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, int blk, unsigned long long bd_entry, float* sh = nullptr) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lj = lane & 15, q = lane >> 4;
     __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): see bwd2_role
     const int par = epoch & 1;
@@ -1414,7 +1432,7 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
     __builtin_amdgcn_sched_barrier(0);              // (the scheduler otherwise interleaves requests with the MFMAs and their waits)
     if constexpr (!FUSED) {
         const TrainState St = W.state[(epoch + 1) & 1];
-        S.stopped = St.stopped; S.step_size = St.step_size; S.bc2_sqrt = St.bc2_sqrt;
+        S.stopped = St.stopped; S.step_size = St.step_size; S.bc2_sqrt = St.bc2_sqrt; S.step = St.step;
     }
     float pb = Pc[ob + unit], mb = W.AM[ob + unit], vb = W.AV[ob + unit];
     __builtin_amdgcn_sched_barrier(0);
@@ -1450,6 +1468,7 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
         nw.z = adam_value(pw[v].z, pm[v].z, pv[v].z, acc[2][v], S.step_size, S.bc2_sqrt);
         nw.w = adam_value(pw[v].w, pm[v].w, pv[v].w, acc[3][v], S.step_size, S.bc2_sqrt);
         if (vl[v]) { const int e = po / 4 + 16 * v; st4_wt(Pn, e, nw); st4_wt(W.AM, e, pm[v]); st4_wt(W.AV, e, pv[v]); }
+        if constexpr (L2IN) pw[v] = nw;             // the updated rows stay in registers: the B operands of the next hidden activation below
     }
     if (wv == 0) {                                  // the units' biases: gradient = sum over the pose rows of g[r][u], the four lane groups q in order
         float sum = gb;
@@ -1457,6 +1476,63 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
         sum += __shfl_xor(sum, 32, 64);             // ((0,1), (2,3))
         pb = adam_value(pb, mb, vb, sum, S.step_size, S.bc2_sqrt);
         if (q == 0 && ulive) { Pn[ob + unit] = pb; W.AM[ob + unit] = mb; W.AV[ob + unit] = vb; }
+    }
+    if constexpr (L2IN) {
+        // ---- the NEXT hidden activation of this block's 16 units, h2' = act(x1' . W2'^T + b2'), inside the backward launch (round 6): what k_l2
+        // computed a launch later -- from the updated rows this wave still holds (the very B operands k_l2 loaded back: lane (q, unit) holds
+        // inputs i0 + 16 v + 4 q + t as component t of float4 v, k_l2's k order) and the next encoder activation x1' of the B role of THIS launch
+        // (write-through stores there, sc1 loads here, one counter in between).  Same tiles, same k order, same cross-wave sum in wave order:
+        // bit for bit k_l2's result.  Only the hidden blocks take part (the output rows' blocks have left), all eight waves of them (H = 512).
+        if (blk < nb2) {                            // block-uniform
+            float* red = sh;                        // [8 waves][32 rows][16 units] partial tiles, then the 16 new biases
+            float* sbias = red + (BD_THREADS / 64) * L2_RB * 16;
+            if (wv == 0 && q == 0) sbias[lj] = pb;
+            const int nB = D.H / B2_CB;
+            if (threadIdx.x == 0) {                 // the B role's workgroups of this problem have counted themselves in: nB per optimizer step
+                int it = 0;
+                const int want = nB * S.step;
+                while (__hip_atomic_load(W.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++it < (1 << 20)) __builtin_amdgcn_s_sleep(2);
+            }
+            __syncthreads();
+            const float* x1n = par ? W.x1[0] : W.x1[1];
+            float* h2n = par ? W.h2[0] : W.h2[1];
+            const __amdgpu_buffer_rsrc_t rX = buf_rsrc(x1n, D.KP * D.H * 4);
+            const int tid = threadIdx.x;
+            for (int r0 = 0; r0 < D.K; r0 += L2_RB) {
+                const int nr = min(L2_RB, D.K - r0);
+                const bool two = nr > 16;           // block-uniform
+                u32x4v xa[DW_TILES], xb[DW_TILES];
+                const int o0 = (min(r0 + lj, D.K - 1) * D.H + i0 + 4 * q) * 4, o1 = (min(r0 + 16 + lj, D.K - 1) * D.H + i0 + 4 * q) * 4;
+#pragma unroll
+                for (int v = 0; v < DW_TILES; ++v) {
+                    xa[v] = __builtin_amdgcn_raw_buffer_load_b128(rX, o0 + 64 * v, 0, 16);      // sc1: written through by the B role of this launch
+                    if (two) xb[v] = __builtin_amdgcn_raw_buffer_load_b128(rX, o1 + 64 * v, 0, 16);
+                }
+                f32x4 c0v = {0.f, 0.f, 0.f, 0.f}, c1v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int v = 0; v < DW_TILES; ++v) {
+                    const float bq[4] = {pw[v].x, pw[v].y, pw[v].z, pw[v].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        c0v = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa[v][t]), bq[t], c0v, 0, 0, 0);
+                        if (two) c1v = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xb[v][t]), bq[t], c1v, 0, 0, 0);
+                    }
+                }
+                if (r0) __syncthreads();            // the previous pass has read red
+                {
+                    float* o = red + (wv * L2_RB + 4 * q) * 16 + lj;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { o[v * 16] = c0v[v]; if (two) o[(16 + v) * 16] = c1v[v]; }
+                }
+                __syncthreads();
+                if (tid < nr * 16) {
+                    float sum = red[tid];
+#pragma unroll
+                    for (int w2 = 1; w2 < BD_THREADS / 64; ++w2) sum += red[w2 * L2_RB * 16 + tid];
+                    h2n[(size_t)(r0 + (tid >> 4)) * D.H2 + u0 + (tid & 15)] = act_f(sum + sbias[tid & 15], D.slope);
+                }
+            }
+        }
     }
     BD_TEND(1, epoch);                              // D3: Adam, the write-through stores acknowledged
 }
@@ -1470,7 +1546,7 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
 // side the launch takes what the longer role takes, and the next hidden activation, the one thing that needs BOTH results (the
 // next encoder activation from B, the updated hidden rows from D), is k_l2 again, a launch boundary later.
 // grid.x = (H / 16 + H2 / 8 + 1) * problems: the B blocks of ALL problems first (the longer chain of dependent phases).
-template <int NC, int KW, bool X = false>
+template <int NC, int KW, bool X = false, bool L2IN = false>
 __global__ __launch_bounds__(BD_THREADS, 4) void k_bd(Dims D, Ws W0, int epoch, size_t bstride, int nz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef CREG_BD_STAMPS
@@ -1496,8 +1572,8 @@ __global__ __launch_bounds__(BD_THREADS, 4) void k_bd(Dims D, Ws W0, int epoch, 
 #ifdef CREG_BD_ONLY                                   // measurement build: one role alone (1: backward to the encoder, 2: dW + Adam)
     if ((CREG_BD_ONLY == 1) != roleB) return;
 #endif
-    if (roleB) bwd2_role<KW, X>(D, W, epoch, blk, (float*)smem, bd_entry);
-    else dw_role<false>(D, W, epoch, blk, bd_entry);
+    if (roleB) bwd2_role<KW, X, false, L2IN>(D, W, epoch, blk, (float*)smem, bd_entry);
+    else dw_role<false, L2IN>(D, W, epoch, blk, bd_entry, (float*)smem);
 }
 
 // ------------------------------------------------------------------------------------------ the fused backward launch: k_gbd (round 5)
@@ -1554,6 +1630,7 @@ __global__ void k_set_state(Dims D, Ws W, ResumeState rs) {
     s.min_loss = rs.min_loss; s.epochs_run = rs.epochs_run; s.best_epoch = rs.best_epoch;
     s.next_bc1 = W.bc1[min(rs.step + 1, D.epochs)]; s.next_bc2s = W.bc2s[min(rs.step + 1, D.epochs)];       // (k_prep, the launch before, filled the tables)
     W.state[0] = s; W.state[1] = s;
+    W.sync[1] = (D.H / B2_CB) * rs.step;          // (k_bd with the next hidden activation inside: B-role arrivals so far = nB per optimizer step)
     W.result[0] = s.min_loss; W.result[1] = (float)s.epochs_run; W.result[2] = (float)s.lr; W.result[3] = (float)s.best_epoch;
 }
 __global__ void k_get_state(Ws W, int sidx, double* out) {
@@ -1578,6 +1655,7 @@ struct Plan {
     size_t bstride;           // bytes between consecutive problems' workspaces
     int smem_bd;
     bool fused;               // gradient reduction + backward as ONE launch (k_gbd)
+    bool l2in;                // the next hidden activation inside the backward launch (k_bd<.., true>): no k_l2 launch per epoch
     int branches;             // parallel chains in the captured graph (groups of problems)
     // chain-stream mode (creg_train_shape.graph_branches < 0): every chain is its OWN linear graph on its OWN stream, forked from /
     // joined to the caller's stream once per train by events -- the chains' hardware queues are then the streams', not what the
@@ -1708,6 +1786,11 @@ static void by_bd(const Dims& D, F f) {
 static void launch_bd(Plan* P, int epoch, hipStream_t s) {
     const Dims& D = P->D; const Ws& W = P->W;
     const int per = D.H / B2_CB + dw_blocks(D);
+    if (P->l2in) {                                   // (hidden 512, 'q' / 'rpy' / 'dq' widths: see creg_train_plan_create)
+        if (D.HA) hipLaunchKernelGGL((k_bd<8, 96, false, true>), dim3(per * P->nz), dim3(BD_THREADS), P->smem_bd, s, D, W, epoch, P->bstride, P->nz);
+        else hipLaunchKernelGGL((k_bd<8, 64, false, true>), dim3(per * P->nz), dim3(BD_THREADS), P->smem_bd, s, D, W, epoch, P->bstride, P->nz);
+        return;
+    }
     by_bd(D, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(per * P->nz), dim3(BD_THREADS), P->smem_bd, s, D, W, epoch, P->bstride, P->nz); });
 }
 template <typename F>
@@ -1799,7 +1882,8 @@ static void enqueue_epoch(Plan* P, int epoch, hipStream_t s, hipEvent_t* ev = nu
         hipLaunchKernelGGL(k_gradc, dim3(D.K, 1, P->nz), dim3(256), 0, s, D, W, epoch, D.nbx, D.nby, P->bstride); mark(3);
         launch_bd(P, epoch, s); mark(4);
     }
-    launch_l2(P, par ^ 1, s); mark(5);        // the next epoch's hidden activation: next encoder activation (B) x updated hidden rows (D)
+    if (!P->l2in) launch_l2(P, par ^ 1, s);   // the next epoch's hidden activation: next encoder activation (B) x updated hidden rows (D)
+    mark(5);                                  //   (l2in: computed at the end of k_bd's D role)
 }
 
 // One launch copies up to 16 (source, destination, dword count) ranges: a problem's 10 parameter tensors + offsets in,
@@ -2122,6 +2206,15 @@ extern "C" int creg_train_plan_create(const creg_train_shape* shape, void* works
         // MFMAs, the cross-wave sum, dW1, Adam, the next activation: ~7 us of dependent phases) is the critical path, not the intake
         // the prefetch hides, and the hand-off costs what the boundary did.  Off unless CREG_FUSED_GBD=1 (kept as a tested experiment).
         P->fused = (fe ? fe[0] == '1' : false) && P->smem_bd + 4608 <= 160 * 1024;
+        // Round 6: the next hidden activation inside the backward launch (no k_l2 launch per epoch).  Hidden 512 without the '6d' input width;
+        // CREG_L2_IN_BD=0 / 1 overrides (A/B).  Not together with the fused gradient launch.
+        const char* le = getenv("CREG_L2_IN_BD");
+        P->l2in = !P->fused && D.H == 512 && D.IN <= 64 && (le ? le[0] == '1' : CREG_L2_IN_BD_DEFAULT);
+        if (P->l2in) {
+            if (D.HA) e2 = hipFuncSetAttribute((const void*)k_bd<8, 96, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            else e2 = hipFuncSetAttribute((const void*)k_bd<8, 64, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e2 != hipSuccess) { (void)hipGetLastError(); P->l2in = false; }
+        }
         if (P->fused) {
             by_gbd(D, [&](auto kern) { e2 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4608); });
             if (e2 != hipSuccess) { (void)hipGetLastError(); P->fused = false; }

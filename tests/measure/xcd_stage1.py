@@ -53,7 +53,7 @@ for rows in ("0", "1"):
             print(f"    confined, problem = XCC_ID: {nz} problems {v[18]:.2f} us (agent-scope queue) / {v[19]:.2f} us (workgroup-scope queue); 1 problem {v[20]:.2f} us; "
                   f"outputs identical to the plan's launch: {bool(v[21])}; workgroups per XCD seen {[int(x) for x in v[24:32]]}")
     if rows == "0":
-        print(f"(Stage 2 pre-check) k_l2 (the next hidden activation, H2 / 16 = 48 workgroups per problem), 200 back to back: chip-wide {v[32]:.2f} us for {nz} problem(s) / "
-              f"{v[35]:.2f} us for one; every problem confined to one XCD {v[33]:.2f} us / {v[36]:.2f} us; h2 identical: {bool(v[34])}")
+        print(f"(Stage 2 pre-check) k_l2 (the next hidden activation, H2 / 16 = 48 workgroups per problem), 200 back to back, ONE problem (two measurements): chip-wide {v[32]:.2f} / "
+              f"{v[35]:.2f} us; its 48 workgroups confined to one XCD {v[33]:.2f} / {v[36]:.2f} us; h2 identical: {bool(v[34])}")
     del reg
     torch.cuda.synchronize()

@@ -884,6 +884,7 @@ def test_train_resume_continues_a_run(dev):
     m = torch.tensor(mats, dtype=torch.float32, device=dev)
     pts, off = ops.pack_clusters([torch.tensor(c, dtype=torch.float32) for c in cl], dev)
     y = torch.tensor(seq[1], dtype=torch.float32, device=dev)
+    lr0 = float(np.float32(2e-4))        # creg_train_args.lr is a float: the plain run's double lr is its widening; the state's lr is a double of its own
     for rot, ctor, order in (("q", lambda: models.QRegMLP(True, 64), ops.Q_PARAM_ORDER), ("dq", lambda: models.DQRegMLP(64), ops.DQ_PARAM_ORDER)):
         torch.manual_seed(3)
         sd = ctor().state_dict()
@@ -891,9 +892,9 @@ def test_train_resume_continues_a_run(dev):
         zeros = lambda ps: [torch.zeros_like(p) for p in ps]
         plan = ops.TrainPlan(rot, 7, 64, pts.shape[0], y.shape[0], epochs=12, use_graph=False, device=dev)
         pa = fresh()
-        bm_a, bp_a, res_a, lh_a, lrh_a, st_a = plan.resume(m, y, pts, off, pa, {"exp_avg": zeros(pa), "exp_avg_sq": zeros(pa), "lr": 2e-4}, 12, patience=1)
+        bm_a, bp_a, res_a, lh_a, lrh_a, st_a = plan.resume(m, y, pts, off, pa, {"exp_avg": zeros(pa), "exp_avg_sq": zeros(pa), "lr": lr0}, 12, patience=1)
         pb = fresh()
-        bm_1, bp_1, _, lh_1, _, st_1 = plan.resume(m, y, pts, off, pb, {"exp_avg": zeros(pb), "exp_avg_sq": zeros(pb), "lr": 2e-4}, 5, patience=1)
+        bm_1, bp_1, _, lh_1, _, st_1 = plan.resume(m, y, pts, off, pb, {"exp_avg": zeros(pb), "exp_avg_sq": zeros(pb), "lr": lr0}, 5, patience=1)
         assert st_1["step"] == 5 and st_1["epochs_run"] == 5
         pb5 = [p.clone() for p in pb]
         bm_b, bp_b, res_b, lh_b, lrh_b, st_b = plan.resume(m, y, pts, off, pb, st_1, 7, patience=1, best=(bm_1, bp_1))
@@ -1256,6 +1257,61 @@ def test_train_fused_backward_launch_is_bit_identical(dev, golden, rot, hidden, 
         assert int(outs[0][3][1]) < 40                      # it did stop early
     for o in outs[1:]:
         assert all(torch.equal(a, b, ) or (torch.isnan(a) == torch.isnan(b)).all() and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)) for a, b in zip(o, outs[0]))
+
+
+@pytest.mark.parametrize("rot,k,lr,stop,batch", [("q", None, 2e-4, 200, 1), ("dq", None, 2e-4, 200, 3), ("q", 40, 2e-4, 200, 2), ("q", None, 0.2, 3, 1)])
+def test_train_next_hidden_activation_inside_the_backward_launch_is_bit_identical(dev, golden, rot, k, lr, stop, batch, monkeypatch):
+    """CREG_L2_IN_BD (round 6): the D role of k_bd goes on to the next hidden activation from the updated rows it still holds and the next
+    encoder activation the B role of the same launch hands over (write-through stores, one arrival counter, sc1 loads) -- the k_l2 launch
+    of every epoch disappears.  Same tiles, same k order, same cross-wave sums: every output bit equals the five-launch plan's, eager and
+    captured, single and batched, more than 32 pose rows (two passes of the row loop), also when the train stops early and when a train is
+    resumed from a state (the arrival count follows the step count)."""
+    from autourdf_amd import ops
+    g, _, _ = _train_case(golden, "q")
+    torch.manual_seed(5)
+    hidden = 512
+    models = [_oracle_model(rot, hidden) for _ in range(batch)]
+    if lr > 0.1:
+        for mdl in models:
+            for p in mdl.parameters():
+                p.data.mul_(0.2)
+    order = _order(rot)
+    m, y = torch.from_numpy(g["q_m"]).to(dev), torch.from_numpy(g["q_y"]).to(dev)
+    clusters = [torch.from_numpy(c) for c in _split(g["q_local"], g["q_offsets"])]
+    if k is not None:                                       # more pose rows than one pass of the row loop (32): every cluster cut in pieces
+        per = -(-k // len(clusters))
+        pieces, rows = [], []
+        for c, mrow in zip(clusters, m):
+            for part in torch.chunk(c, per):
+                pieces.append(part); rows.append(mrow)
+        clusters, m = pieces, torch.stack(rows)
+        assert len(clusters) > 32
+    pts, off = ops.pack_clusters(clusters, dev)
+    outs = []
+    for l2in, graph in (("0", True), ("1", False), ("1", True)):
+        monkeypatch.setenv("CREG_L2_IN_BD", l2in)
+        params = [[mdl.state_dict()[kk].clone().to(dev) for kk in order] for mdl in models]
+        plan = ops.TrainPlan(rot, len(clusters), hidden, pts.shape[0], y.shape[0], epochs=40, use_graph=graph, device=dev, batch=batch)
+        res = plan.run_batch([(m, y, pts, off, pr) for pr in params], lr=lr, patience=1 if lr > 0.1 else 5, stop=stop)
+        outs.append([t.cpu() for r in res for t in (r[0], r[3], r[2], r[4])] + [torch.cat([p.flatten() for pr in params for p in pr]).cpu()])
+    if lr > 0.1:
+        assert int(outs[0][2][1]) < 40                      # it did stop early
+    same = lambda a, b: torch.equal(a, b) or ((torch.isnan(a) == torch.isnan(b)).all() and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)))
+    for o in outs[1:]:
+        assert all(same(a, b) for a, b in zip(o, outs[0]))
+    if batch == 1 and lr < 0.1 and k is None:               # resumed: 40 epochs == 15 + 25 in this mode too (control exact, numbers to rounding -- see test_train_resume_continues_a_run)
+        monkeypatch.setenv("CREG_L2_IN_BD", "1")
+        lr0 = float(np.float32(lr))
+        plan = ops.TrainPlan(rot, len(clusters), hidden, pts.shape[0], y.shape[0], epochs=40, use_graph=False, device=dev)
+        pa = [models[0].state_dict()[kk].clone().to(dev) for kk in order]
+        z = lambda ps: [torch.zeros_like(p) for p in ps]
+        bm_a, _, _, lh_a, _, st_a = plan.resume(m, y, pts, off, pa, {"exp_avg": z(pa), "exp_avg_sq": z(pa), "lr": lr0}, 40)
+        assert torch.equal(bm_a.cpu(), outs[0][0]) and same(lh_a.cpu(), outs[0][1])
+        pb = [models[0].state_dict()[kk].clone().to(dev) for kk in order]
+        bm_1, bp_1, _, _, _, st_1 = plan.resume(m, y, pts, off, pb, {"exp_avg": z(pb), "exp_avg_sq": z(pb), "lr": lr0}, 15)
+        bm_b, _, _, lh_b, _, st_b = plan.resume(m, y, pts, off, pb, st_1, 25, best=(bm_1, bp_1))
+        assert st_b["step"] == 40 and st_b["lr"] == st_a["lr"] and st_b["best_epoch"] == st_a["best_epoch"]
+        np.testing.assert_allclose(lh_b[15:40].cpu().numpy(), lh_a[15:40].cpu().numpy(), rtol=1e-4)
 
 
 @pytest.mark.parametrize("lr,stop,expect_stop", [(0.2, 3, True), (5e-2, 4, False)])
