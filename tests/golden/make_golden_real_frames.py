@@ -88,3 +88,5 @@ if __name__ == "__main__":
     for rb in (sys.argv[1:] or ["wx200_5", "franka"]):
         # (franka: 126 586 triangles x 20 cameras through the oracle's per-triangle rasteriser -- a 400 x 400 depth buffer keeps it to minutes)
         mint(rb, 800 if rb != "franka" else 400)
+    POOL.close()
+    POOL.join()
