@@ -1505,46 +1505,49 @@ __global__ __launch_bounds__(64 * ICP_NNW, ICP_NN_WPS) void k_icp_nn(IcpLarge P,
                         }
                         ++ct_f32;
                         if (!__ballot(mf <= thr)) continue;
-                        int own = 0;                                      // bit u: entry u is this source's previous match (pass 0 starts from it)
-                        {
-                            bool cand = false;
+                        // Round 6: only the entries that PASSED the screen are evaluated in fp64 -- a lane's candidates of a trip (usually one), two
+                        // at a time, their pool coordinates requested together and kept: ONE dependent L2 round trip per passing trip where there were
+                        // three (operands of entries 0-3, of 4-7, then the winner's coordinates again).  An entry the screen rejects has D > best, so it
+                        // can neither win nor tie: the minimum, the tie flag and the slot are what the eight-entry evaluation gave.
+                        unsigned cm = 0;                                  // bit u: entry u passed this lane's screen and is not its previous match
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) { const bool mine = pj[t + u] == pmv; own |= mine ? 1 << u : 0; cand |= ef[u] <= thr && !mine; }
-                            if (!__ballot(cand)) continue;            // only previous matches came through
-                        }
+                        for (int u = 0; u < 8; ++u) cm |= (ef[u] <= thr && pj[t + u] != pmv) ? 1u << u : 0u;
+                        if (!__ballot(cm != 0)) continue;                 // only previous matches came through
                         ++ct_f64;
-                        // the fp64 evaluation of the trip, exactly as in the other path, operands from the pool
-                        double d[8];
+                        bool any_lt = false;
+                        while (__ballot(cm != 0)) {                        // four candidates per round: one round unless a lane has more
+                            int uu[4]; double X[4], Y[4], Z[4], dd[4];
 #pragma unroll
-                        for (int h = 0; h < 8; h += 4) {                  // four entries' operands at a time (registers: the kernel must keep three waves per SIMD)
-                            double X[4], Y[4], Z[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int pq = t0 + t + h + u;
-                                const bool in = pq < L;
+                            for (int c4 = 0; c4 < 4; ++c4) {
+                                uu[c4] = cm ? __builtin_ctz(cm) : -1; cm &= cm - 1;
+                                const int pq = t0 + t + max(uu[c4], 0);
+                                const bool in = uu[c4] >= 0 && pq < L;
                                 const int tp = in ? seqpos(pq) : 0;
-                                const double x = gx[tp], y = gy[tp], z = gz[tp];
-                                X[u] = in ? x : 1e150; Y[u] = in ? y : 1e150; Z[u] = in ? z : 1e150;
+                                X[c4] = gx[tp]; Y[c4] = gy[tp]; Z[c4] = gz[tp];
+                                if (!in) uu[c4] = -1;
                             }
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const double dx = s0 - X[u], dy = s1 - Y[u], dz = s2 - Z[u];
-                                d[h + u] = (own >> (h + u)) & 1 ? 1e300 : (dx * dx + dy * dy) + dz * dz;
+                            for (int c4 = 0; c4 < 4; ++c4) {
+                                const double dx = s0 - X[c4], dy = s1 - Y[c4], dz = s2 - Z[c4];
+                                dd[c4] = uu[c4] >= 0 ? (dx * dx + dy * dy) + dz * dz : 1e300;
                             }
-                            asm volatile("" ::: "memory");
+                            // the earliest of the smallest, by selects (an index into the register arrays would send them to scratch)
+                            const bool s01 = dd[1] < dd[0], s23 = dd[3] < dd[2];
+                            const double m01 = s01 ? dd[1] : dd[0], m23 = s23 ? dd[3] : dd[2];
+                            const int u01 = s01 ? uu[1] : uu[0], u23 = s23 ? uu[3] : uu[2];
+                            const double x01 = s01 ? X[1] : X[0], y01 = s01 ? Y[1] : Y[0], z01 = s01 ? Z[1] : Z[0];
+                            const double x23 = s23 ? X[3] : X[2], y23 = s23 ? Y[3] : Y[2], z23 = s23 ? Z[3] : Z[2];
+                            const bool sh = m23 < m01;
+                            const double m = sh ? m23 : m01;
+                            const int eq = (dd[0] == m) + (dd[1] == m) + (dd[2] == m) + (dd[3] == m);
+                            const bool lt = m < best;
+                            tief |= m == best || (lt && eq > 1);
+                            bm = lt ? t + (sh ? u23 : u01) : bm;
+                            bx = lt ? (sh ? x23 : x01) : bx; by = lt ? (sh ? y23 : y01) : by; bz = lt ? (sh ? z23 : z01) : bz;
+                            best = lt ? m : best;
+                            any_lt |= lt;
                         }
-                        const double m = vmin_f64(vmin_f64(vmin_f64(d[0], d[1]), vmin_f64(d[2], d[3])), vmin_f64(vmin_f64(d[4], d[5]), vmin_f64(d[6], d[7])));
-                        int first = 7, eq = 0;
-#pragma unroll
-                        for (int u = 7; u >= 0; --u) { const bool e = d[u] == m; first = e ? u : first; eq += e ? 1 : 0; }
-                        const bool lt = m < best;
-                        tief |= m == best || (lt && eq > 1);
-                        bm = lt ? t + first : bm;
-                        best = lt ? m : best;
-                        if (__ballot(lt)) {
-                            if (lt) { const int tp = seqpos(t0 + t + first); bx = gx[tp]; by = gy[tp]; bz = gz[tp]; }   // (a winner is a real entry)
-                        }
-                        if (__ballot(lt)) thr = thr_of(best);
+                        if (__ballot(any_lt)) thr = thr_of(best);
                     }
                     if (bm >= 0) { bj = pj[bm]; bslot = bm; }
                 } else {
