@@ -824,6 +824,7 @@ __device__ __forceinline__ void gradc_role(const Dims& D, const Ws& W, int epoch
     // operands of the last phase (this thread's hidden units of pose row k and their output-layer weights) -- round 2
     // waited for the state first (the early exit of a stopped train) and then for the table entries it indexes
     const TrainState S = W.state[epoch & 1];
+    const int handoff_err = W.sync[3];                  // an in-launch hand-off of an earlier epoch timed out (the opt-in fused launches only): see below
     const int b0 = W.off[k], e0 = W.off[k + 1];
     const Hyper hy = *W.hyper;
     float a = tid < nbx ? W.lossp_x[tid] : 0.f, b = tid < nby ? W.lossp_y[tid] : 0.f;
@@ -852,9 +853,11 @@ __device__ __forceinline__ void gradc_role(const Dims& D, const Ws& W, int epoch
     for (int q = 0; q < GC_QMAX; ++q)
         asm volatile("" :: "v"(h2v[q]), "v"(w3v[q][0]), "v"(w3v[q][1]), "v"(w3v[q][2]), "v"(w3v[q][3]), "v"(w3v[q][4]), "v"(w3v[q][5]), "v"(w3v[q][6]),
                      "v"(w3v[q][7]));
-    if (S.stopped) {
+    if (S.stopped || handoff_err) {                     // (a failed hand-off stops the train and poisons what it returns: loud, not silently inconsistent)
         if (k == 0 && tid == 0) {
-            W.state[(epoch + 1) & 1] = S;
+            TrainState E = S; E.stopped = 1;
+            if (handoff_err) { E.min_loss = NAN; W.result[0] = NAN; }
+            W.state[(epoch + 1) & 1] = E;
             if constexpr (FUSED) st4_wt((float*)W.sync, 32, make_float4(__int_as_float(1), 0.f, 0.f, 0.f));
         }
         if constexpr (FUSED) gradc_arrive(W);
@@ -992,7 +995,7 @@ __global__ __launch_bounds__(256) void k_gradc(Dims D, Ws W0, int epoch, int nbx
     // every kernel argument in the entry block, one wait (see k_bd)
     asm volatile("" :: "s"(W0.P), "s"(W0.P1), "s"(W0.h2[0]), "s"(W0.h2[1]), "s"(W0.head_save), "s"(W0.m2), "s"(W0.gm2), "s"(W0.pts4), "s"(W0.pred4),
                  "s"(W0.sgn_x), "s"(W0.cnt4), "s"(W0.lossp_x), "s"(W0.lossp_y), "s"(W0.g_out), "s"(W0.g_h2), "s"(W0.state), "s"(W0.bc1), "s"(W0.bc2s),
-                 "s"(W0.best_m), "s"(W0.best_pred), "s"(W0.loss_hist), "s"(W0.lr_hist), "s"(W0.result), "s"(W0.off), "s"(W0.hyper),
+                 "s"(W0.best_m), "s"(W0.best_pred), "s"(W0.loss_hist), "s"(W0.lr_hist), "s"(W0.result), "s"(W0.off), "s"(W0.hyper), "s"(W0.sync),
                  "s"(D.rot), "s"(D.K), "s"(D.H2), "s"(D.HA), "s"(D.HB), "s"(D.OA), "s"(D.OB), "s"(D.NP), "s"(D.NT), "s"(D.epochs), "s"(D.slope),
                  "s"(D.oW3A), "s"(D.oW3B), "s"(epoch), "s"(nbx), "s"(nby), "s"(bstride));
     const Ws W = ws_shift(W0, blockIdx.z * bstride);
@@ -1099,7 +1102,8 @@ __device__ __forceinline__ bool gbd_wait(const Ws& W, int K) {
         int it = 0, seen = __hip_atomic_load(W.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (seen < K && ++it < (1 << 19)) { __builtin_amdgcn_s_sleep(16); seen = __hip_atomic_load(W.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         s_ok = seen >= K;
-    }
+        if (!s_ok) __hip_atomic_store(W.sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      //  a hand-off that timed out is an ERROR of the train:
+    }                                                                                                     //   k_gradc of the next epoch / k_params_home stop it and return NaN as its min_loss
     __syncthreads();
     return s_ok != 0;
 }
@@ -1492,6 +1496,7 @@ __device__ __forceinline__ void dw_role(const Dims& D, const Ws& W, int epoch, i
                 int it = 0;
                 const int want = nB * S.step;
                 while (__hip_atomic_load(W.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++it < (1 << 20)) __builtin_amdgcn_s_sleep(2);
+                if (it >= (1 << 20)) __hip_atomic_store(W.sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (cannot happen while workgroups are dispatched in index order: see gbd_wait)
             }
             __syncthreads();
             const float* x1n = par ? W.x1[0] : W.x1[1];
