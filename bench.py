@@ -870,6 +870,7 @@ def build_parser():
     ap.add_argument("--no-icp-variant", action="store_true", help="skip the ICP-style second line (SURVEY 8(d))")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity summary against the oracle (first timed frame of sequence 0, outside the timed region)")
+    ap.add_argument("--force-strong-scaling", action="store_true", help="run the strong-scaling legs at world 1 too (the single-GPU divisors of the N > 1 line, and a test of that path)")
     ap.add_argument("--no-strong-scaling", action="store_true",
                     help="world > 1: skip the strong-scaling legs (BASELINE configs[3]: 50 allegro-shaped frames, configs[4]: 200 frames of N=262144 / K=128, both dealt over the ranks)")
     ap.add_argument("--no-other-workloads", action="store_true",
@@ -919,7 +920,7 @@ def main(argv=None):
         # world > 1 (the driver's `--gpus N` line): the north star's strong-scaling questions answered by the same command -- BASELINE
         # configs[3] (50 allegro-shaped frames) and configs[4] (200 frames of N=262144 / K=128) dealt over the N ranks.  EVERY rank takes part
         # (the legs hold barriers and the gather); the weak-scaling line above stays the headline.
-        strong = (args.workload == "wx200_5" and args.mode == "sequences" and args.r == "q" and ctx.world > 1 and not args.no_strong_scaling
+        strong = (args.workload == "wx200_5" and args.mode == "sequences" and args.r == "q" and (ctx.world > 1 or args.force_strong_scaling) and not args.no_strong_scaling
                   and not args.eager and args.graph_branches == 0)
         if strong:
             legs = strong_scaling_legs(ap, ctx)
