@@ -1,7 +1,7 @@
 """Where does a launch of the sixteen-queries-per-wave search (k_nn_rows) spend its time?  (the franka shape's dominant
 kernel shows a VALU instruction active in 0.30 of the chip's SIMD-cycles.)  Measurement build:
 
-    CREG_EXTRA_FLAGS=-DCREG_NN_WAVE_STAMPS python -m autourdf_amd.build --variant wstamp       # build container
+    CREG_EXTRA_FLAGS=-DCREG_NN_WAVE_STAMPS python -m autourdf_amd.build --variant wstamp       # on the GPU box (hipcc is there; .gpurunignore keeps variant libraries out of the snapshot)
     CREG_LIB_VARIANT=wstamp python tests/measure/nn_rows_waves.py [franka|wx200_5]             # GPU box
 
 Every wave records start / box bounds done / visits done / end on the 100 MHz wall clock, with its visit and candidate counts; the

@@ -1,6 +1,6 @@
 """Stage 1 of the XCD-resident train, a MEASUREMENT build:
 
-    CREG_EXTRA_FLAGS=-DCREG_XCD_PROBE python -m autourdf_amd.build --variant xcd        # in the build container
+    CREG_EXTRA_FLAGS=-DCREG_XCD_PROBE python -m autourdf_amd.build --variant xcd        # on the GPU box (hipcc is there; .gpurunignore keeps variant libraries out of the snapshot)
     CREG_LIB_VARIANT=xcd python tests/measure/xcd_stage1.py                              # on the GPU box
 
 (a) a barrier among the workgroups of ONE XCD (members found at run time through HW_REG_XCC_ID + a per-XCD ticket) with a 4 KB

@@ -74,6 +74,7 @@ python $R/bench.py --workload c5 --steps 12 --warmup 2 > $O/bench_c5.log 2>/dev/
 python $R/tests/measure/divergence_envelope.py gpu $O/divergence.json 2>/dev/null | grep -v amdgpu.ids > $O/divergence_envelope_gpu.log
 python $R/tests/measure/bench_c5_resegment.py > $O/c5_resegment.log 2>/dev/null
 python $R/tests/measure/profile_icp_frame.py both 2>/dev/null | grep -v amdgpu.ids > $O/icp_frame_phases.log
+(cd $R && CREG_EXTRA_FLAGS=-DCREG_NN_WAVE_STAMPS python -m autourdf_amd.build --variant wstamp > $O/wstamp_build.log 2>&1)      # (the measurement build is made here: .gpurunignore keeps variant libraries out of the snapshot)
 (CREG_LIB_VARIANT=wstamp python $R/tests/measure/nn_rows_waves.py franka; CREG_LIB_VARIANT=wstamp python $R/tests/measure/nn_rows_waves.py wx200_5) 2>/dev/null | grep -v "amdgpu.ids\|Warn\|ret = ret" > $O/nn_rows_waves.log
 python $R/tests/measure/teacher_forced.py 2>/dev/null | grep -v "amdgpu.ids\|Warn\|current =\|Consider" > $O/teacher_forced.log
 python $R/bench.py --workload wx200_5_real --no-cpu-baseline > $O/bench_wx200_5_real.log 2>/dev/null
