@@ -1712,6 +1712,31 @@ __global__ __launch_bounds__(64 * ICP_NNW, ICP_NN_WPS) void k_icp_nn(IcpLarge P,
         if (od < best || (od == best && oj < bj)) { best = od; bj = oj; bx = ox; by = oy; bz = oz; }
     }
     NN_STAMP(12);
+#ifdef CREG_ICP_RECT_STATS
+    {   // measurement build (tests/measure/icp_rect_stats.py): the entries of the cell rectangle this wave SCANNED (from the distances to the
+        // previous matches) against those of the rectangle its FINAL nearest distances would have needed -- what a centre-out scan with a
+        // shrinking radius could save at most
+        double fal = INFINITY, fah = -INFINITY, fbl = INFINITY, fbh = -INFINITY;
+        if (live) {
+            const double sa = axa == 0 ? s0 : (axa == 1 ? s1 : s2), sb = axb == 0 ? s0 : (axb == 1 ? s1 : s2);
+            if (bj != 0x7fffffff) { const double r1 = sqrt(best) * (1.0 + 1e-12) + 1e-300; fal = sa - r1; fah = sa + r1; fbl = sb - r1; fbh = sb + r1; }
+            else { fal = -INFINITY; fah = INFINITY; fbl = -INFINITY; fbh = INFINITY; }
+        }
+        const int fa0 = __builtin_amdgcn_readfirstlane(icp_bin(wave_min_fast(fal), x0a, inv_a, gd)), fa1 = __builtin_amdgcn_readfirstlane(icp_bin(wave_max_fast(fah), x0a, inv_a, gd));
+        const int fb0 = __builtin_amdgcn_readfirstlane(icp_bin(wave_min_fast(fbl), x0b, inv_b, gd)), fb1 = __builtin_amdgcn_readfirstlane(icp_bin(wave_max_fast(fbh), x0b, inv_b, gd));
+        int e1 = 0, e0 = 0;
+        if (any) {
+            if (lane <= fa1 - fa0) e1 = tst[(fa0 + lane) * gd + fb1 + 1] - tst[(fa0 + lane) * gd + fb0];
+            if (lane <= ra1 - ra0) e0 = tst[(ra0 + lane) * gd + cb1 + 1] - tst[(ra0 + lane) * gd + cb0];
+            for (int o = 32; o >= 1; o >>= 1) { e1 += __shfl_xor(e1, o, 64); e0 += __shfl_xor(e0, o, 64); }
+            if (lane == 0) {
+                unsigned long long* ct = g_icp_nn_ct[blockIdx.x & (ICP_CT_SHARDS - 1)];
+                atomicAdd(ct + 5, (unsigned long long)e1); atomicAdd(ct + 6, (unsigned long long)e0);
+                atomicAdd(ct + 7, (unsigned long long)((ra1 - ra0 + 1) * (cb1 - cb0 + 1)) | ((unsigned long long)((fa1 - fa0 + 1) * (fb1 - fb0 + 1)) << 32));
+            }
+        }
+    }
+#endif
     double cm[ICP_NM];
     for (int a = 0; a < ICP_NM; ++a) cm[a] = 0;
     if (live && g == 0) {
@@ -1916,6 +1941,15 @@ static int icp_large_run(const creg_icp_problem& q, int64_t n, int32_t k, int64_
     return CREG_OK;
 }
 
+#ifdef CREG_ICP_RECT_STATS
+extern "C" int creg_debug_icp_rect(double* out4) {      // entries of the final-distance rectangles, of the scanned ones, cells scanned, cells needed (sums over waves)
+    static unsigned long long c[creg::ICP_CT_SHARDS][8];
+    CREG_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(creg::g_icp_nn_ct), sizeof(c)));
+    out4[0] = out4[1] = out4[2] = out4[3] = 0.0;
+    for (int sh = 0; sh < creg::ICP_CT_SHARDS; ++sh) { out4[0] += (double)c[sh][5]; out4[1] += (double)c[sh][6]; out4[2] += (double)(c[sh][7] & 0xffffffffull); out4[3] += (double)(c[sh][7] >> 32); }
+    return CREG_OK;
+}
+#endif
 extern "C" int creg_icp_nn_counters(double* out8, int32_t reset, int32_t timing) {
     if (out8) {
         static unsigned long long c[creg::ICP_CT_SHARDS][8];
